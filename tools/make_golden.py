@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the reference itself (build container only).
+
+Imports /root/reference through tools/ref_loader.py (in-memory PEP-695 de-sugaring; no reference
+source is stored), drives the reference's own classes on seeded inputs and writes ONLY numbers:
+inputs, consumed random draws and the reference's outputs.  Re-run:  python tools/make_golden.py
+
+Outputs
+  reference_kats.json   numbers the reference's own tests hold (self_sampling.py:57-82,
+                        self_scheduling.py:30-45, miscellaneous.py:11), extracted from the test text
+  tables.json           wrapper timesteps / sigmas / schedule_np, Gamma/Delta/zeta, effective_order,
+                        RK all_points, every built-in tableau
+  steps_cfg{1..5}.npz   per-step (x_t, model_out, noise) -> (prev_sample, pred_original_sample)
+                        through SkrampleWrapperScheduler.step / RKUltraWrapperScheduler.step
+  steps_extra.npz       same for further sampler/model/eta combinations
+  noise.npz             Offset / Pyramid / Colored outputs with the raw draws they consumed
+"""
+
+from __future__ import annotations
+
+import ast
+import json
+import math
+import os
+import re
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, HERE)
+
+import ref_loader  # noqa: E402
+
+ref_loader.install()
+
+import skrample.diffusers as RD  # noqa: E402
+import skrample.pytorch.noise as RN  # noqa: E402
+import skrample.scheduling as RS  # noqa: E402
+from skrample.common import DeltaPoint, Step, bashforth  # noqa: E402
+from skrample.sampling import functional, models, structured, tableaux  # noqa: E402
+
+REF = ref_loader.REFERENCE_ROOT
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    "lossless numpy view (bf16 -> int16 bit pattern)"
+    if t.dtype == torch.bfloat16:
+        return t.contiguous().view(torch.int16).numpy().copy()
+    return t.contiguous().numpy().copy()
+
+
+# ---------------------------------------------------------------------------------------------------
+def kats() -> None:
+    out: dict = {}
+    text = open(os.path.join(REF, "tests", "self_sampling.py"), encoding="utf-8").read()
+    rows = re.findall(r"\((\w+)\.(\w+), scheduling\.(\w+), models\.(\w+)\): (\[[^\]]*\])", text)
+    out["sampler_trajectories"] = {f"{s}/{sch}/{m}": ast.literal_eval(v) for _, s, sch, m, v in rows}
+    assert len(out["sampler_trajectories"]) == 24
+    text = open(os.path.join(REF, "tests", "self_scheduling.py"), encoding="utf-8").read()
+    rows = re.findall(r"^    ([A-Za-z()]+\(\)\)+): (\[\[.*\]\]),", text, flags=re.M)
+    out["schedule_points"] = {k: ast.literal_eval(v) for k, v in rows}
+    assert len(out["schedule_points"]) == 14, len(out["schedule_points"])
+    out["bashforth"] = [[1], [3 / 2, -1 / 2], [23 / 12, -4 / 3, 5 / 12], [55 / 24, -59 / 24, 37 / 24, -3 / 8]]  # miscellaneous.py:11
+    out["measured_steps"] = 7
+    out["measured_seed"] = 42
+    json.dump(out, open(os.path.join(OUT, "reference_kats.json"), "w"), indent=0)
+
+
+# ---------------------------------------------------------------------------------------------------
+CFG_SCHEDULES = {
+    "scaled": lambda: RS.Scaled(),
+    "karras_scaled": lambda: RS.Karras(RS.Scaled()),
+    "linear": lambda: RS.Linear(),
+    "zsnr": lambda: RS.ZSNR(),
+    "flowshift_linear": lambda: RS.FlowShift(RS.Linear()),
+    "beta_zsnr_flowshift": lambda: RS.FlowShift(RS.Beta(RS.ZSNR())),
+    "hyper_scaled": lambda: RS.Hyper(RS.Scaled()),
+    "exponential_scaled": lambda: RS.Exponential(RS.Scaled()),
+    "sinner_linear": lambda: RS.Sinner(RS.Linear()),
+    "probit_linear": lambda: RS.Probit(RS.Linear()),
+    "linear_vp14": lambda: RS.Linear(sigma_start=14.6),
+    "scaled_neg_b1": lambda: RS.Scaled(base_timesteps=-1000, beta_scale=1),
+}
+MODELS = {"data": models.DataModel(), "eps": models.NoiseModel(), "flow": models.FlowModel(), "v": models.VelocityModel(), "scalex": models.ScaleX()}
+
+
+def tables() -> None:
+    out: dict = {"wrapper": {}, "gdz": [], "effective_order": [], "tableaux": {}, "rk_points": {}}
+    for name, mk in CFG_SCHEDULES.items():
+        for n in (1, 2, 7, 20, 50):
+            w = RD.SkrampleWrapperScheduler(structured.Euler(), mk())
+            w.set_timesteps(n)
+            out["wrapper"][f"{name}/{n}"] = {
+                "timesteps": w.timesteps.tolist(),
+                "sigmas": w.sigmas.tolist(),
+                "schedule_np": w.schedule_np.tolist(),
+                "point_0": list(w.schedule.point(0)),
+                "point_1": list(w.schedule.point(1)),
+                "ipoint_0.37": list(w.schedule.ipoint(0.37)),
+            }
+    for sname in ("scaled", "linear", "zsnr", "karras_scaled"):
+        sch = CFG_SCHEDULES[sname]()
+        for mname, m in MODELS.items():
+            for eta in (-1.5, 0, 0.5, 1):
+                for a, b in ((0.0, 0.05), (0.4, 0.45), (0.9, 1.0), (0.35, 0.7)):
+                    dp = DeltaPoint(*sch.ipoints([a, b]))
+                    try:
+                        row = [m.gamma(dp, eta), m.delta(dp, eta), m.zeta(dp, eta)]
+                    except ZeroDivisionError:
+                        row = None
+                    if row is not None and not all(math.isfinite(v) for v in row):
+                        row = [repr(v) for v in row]
+                    out["gdz"].append({"schedule": sname, "model": mname, "eta": eta, "step": [a, b], "gdz": row})
+    for cls, order in ((structured.DPM, 3), (structured.Adams, 4), (structured.UniP, 9), (structured.UniPC, 3)):
+        for steps in (1, 2, 5, 20):
+            for nprev in (0, 1, 3, 12):
+                s = cls(order=order)
+                out["effective_order"].append(
+                    {
+                        "sampler": cls.__name__,
+                        "order": order,
+                        "steps": steps,
+                        "n_previous": nprev,
+                        "eo": [s.effective_order(Step.from_int(i, steps), [None] * nprev) for i in range(steps)],
+                        "require_previous": s.require_previous,
+                    }
+                )
+    for group in (tableaux.RK1, tableaux.RK2, tableaux.RK3, tableaux.RK4, tableaux.RKZ, tableaux.RKE2, tableaux.RKE3, tableaux.RKE5, tableaux.SSP, tableaux.WSO, tableaux.Shanks1965):
+        for member in group:
+            tab = member.tableau()
+            out["tableaux"][f"{group.__name__}.{member.name}"] = {
+                "c": [float(s.c) for s in tab.stages],
+                "a": [[float(v) for v in s.a] for s in tab.stages],
+                "b": [float(v) for v in tab.weights],
+                **({"e": [float(v) for v in tab.error_weights]} if hasattr(tab, "error_weights") else {}),
+            }
+    out["default_providers"] = {str(k): f"{type(v).__name__}.{v.name}" for k, v in functional.DEFAULT_PROVIDERS.items()}
+    out["stable_providers"] = {str(k): f"{type(v).__name__}.{v.name}" for k, v in functional.STABLE_PROVIDERS.items()}
+    for x in (0.1, 0.25, 0.4):
+        out["tableaux"][f"gen.rk2({x})"] = _tab(tableaux.providers.rk2_tableau(x))
+        out["tableaux"][f"gen.ees25({x})"] = _tab(tableaux.providers.ees25_tableau(x))
+        out["tableaux"][f"gen.ees27({x})"] = _tab(tableaux.providers.ees27_tableau(x))
+    out["tableaux"]["gen.rk3(0.5,0.75)"] = _tab(tableaux.providers.rk3_tableau(0.5, 0.75))
+    out["tableaux"]["gen.rk4(0.4,0.6)"] = _tab(tableaux.providers.rk4_tableau(0.4, 0.6))
+    for sname in ("scaled", "linear", "sinner_linear"):
+        for order in (1, 2, 3, 4, 5, 6, 99):
+            for steps in (1, 3, 7):
+                w = RD.RKUltraWrapperScheduler(CFG_SCHEDULES[sname](), sampler_order=order)
+                w.set_timesteps(steps)
+                out["rk_points"][f"rku/{sname}/{order}/{steps}"] = {"all": [list(p) for p in w.all_points], "timesteps": w.timesteps.tolist(), "order": w.order}
+        for order in (2, 3, 4):
+            for steps in (1, 3, 7):
+                w = RD.DynasauRKWrapperScheduler(CFG_SCHEDULES[sname](), sampler_order=order, model=models.FlowModel() if "linear" in sname else models.NoiseModel())
+                w.set_timesteps(steps)
+                out["rk_points"][f"dyn/{sname}/{order}/{steps}"] = {"all": [list(p) for p in w.all_points], "timesteps": w.timesteps.tolist(), "order": w.order}
+    json.dump(out, open(os.path.join(OUT, "tables.json"), "w"))
+
+
+def _tab(tab) -> dict:
+    return {"c": [float(s.c) for s in tab.stages], "a": [[float(v) for v in s.a] for s in tab.stages], "b": [float(v) for v in tab.weights]}
+
+
+# ---------------------------------------------------------------------------------------------------
+class _Injected:
+    "stands in for BatchTensorNoise: hands back pre-drawn noise so the fixture knows what was consumed"
+
+    def __init__(self, draws):
+        self.draws = list(draws)
+
+    def generate(self, step):
+        return self.draws.pop(0)
+
+
+def run_wrapper(w, B, unit, steps, dtype, seed, noise_fn=None):
+    g = torch.Generator().manual_seed(seed)
+    w.set_timesteps(steps)
+    n_calls = len(w.timesteps)
+    x = torch.randn([B, *unit], generator=g).to(dtype)
+    outs = [torch.randn([B, *unit], generator=g).to(dtype) for _ in range(n_calls)]
+    noises = [(noise_fn(i, g) if noise_fn else torch.randn([B, *unit], generator=g)) for i in range(n_calls)]
+    w._noise_generator = _Injected(noises)
+    rec = {"x0": bits(x), "outs": np.stack([bits(o) for o in outs]), "noises": np.stack([n.numpy() for n in noises]), "timesteps": w.timesteps.numpy().copy()}
+    prevs, preds = [], []
+    for t, o in zip(w.timesteps, outs):
+        prev, pred = w.step(o, t, x, return_dict=False)
+        prevs.append(bits(prev))
+        preds.append(bits(pred))
+        x = prev
+    rec["prev"] = np.stack(prevs)
+    rec["pred"] = np.stack(preds)
+    rec["noise_used"] = np.asarray(n_calls - len(w._noise_generator.draws))
+    if int(rec["noise_used"]) == 0:
+        rec["noises"] = np.zeros((0,), dtype=np.float32)  # deterministic sampler: nothing was consumed
+    return rec
+
+
+def steps() -> None:
+    bf16, f32 = torch.bfloat16, torch.float32
+    cases = {
+        # the five BASELINE.json configs at reduced shape
+        "cfg1": (lambda: RD.SkrampleWrapperScheduler(structured.Euler(), RS.Scaled()), 1, (4, 64, 64), 5, f32),
+        "cfg2": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2, stochasticity=1), RS.Karras(RS.Scaled())), 2, (4, 16, 16), 8, bf16),
+        "cfg3": (lambda: RD.SkrampleWrapperScheduler(structured.UniPC(order=3, stochasticity=1), RS.Linear(), models.FlowModel()), 2, (16, 16, 16), 8, bf16),
+        "cfg4": (lambda: RD.SkrampleWrapperScheduler(structured.Adams(order=4), RS.ZSNR(), models.VelocityModel()), 2, (4, 16, 16), 8, bf16),
+        "cfg5": (lambda: RD.RKUltraWrapperScheduler(RS.Scaled(), sampler_order=6, stochasticity=1), 2, (4, 16, 16), 3, bf16),
+    }
+    for name, (mk, B, unit, n, dt) in cases.items():
+        np.savez_compressed(os.path.join(OUT, f"steps_{name}.npz"), **run_wrapper(mk(), B, unit, n, dt, seed=1000 + len(name)))
+
+    extra = {
+        "euler_sde_v_zsnr": (lambda: RD.SkrampleWrapperScheduler(structured.Euler(stochasticity=1), RS.ZSNR(), models.VelocityModel()), bf16),
+        "dpm1_ode_eps": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=1), RS.Scaled()), bf16),
+        "dpm3_sde_eps": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=3, stochasticity=0.5), RS.Scaled()), f32),
+        "dpm2_flow_shift": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2), RS.FlowShift(RS.Linear()), models.FlowModel()), bf16),
+        "adams9_data": (lambda: RD.SkrampleWrapperScheduler(structured.Adams(order=9), RS.Scaled(), models.DataModel()), f32),
+        "unip4_eps": (lambda: RD.SkrampleWrapperScheduler(structured.UniP(order=4, stochasticity=-1.5), RS.Scaled()), f32),
+        "unipc2_fast_v": (lambda: RD.SkrampleWrapperScheduler(structured.UniPC(order=2, fast_solve=True), RS.Scaled(), models.VelocityModel()), bf16),
+        "unipc3_adams_pred": (lambda: RD.SkrampleWrapperScheduler(structured.UniPC(order=3, predictor=structured.Adams(order=2)), RS.Linear(), models.FlowModel()), f32),
+        "dpm2_deriv_v": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2, derivative_transform=models.VelocityModel()), RS.Scaled()), f32),
+        "adams3_noderiv": (lambda: RD.SkrampleWrapperScheduler(structured.Adams(order=3, derivative_transform=None), RS.Scaled()), f32),
+        "euler_invert": (lambda: RD.SkrampleWrapperScheduler(structured.Euler(), RS.Scaled(), invert_prediction=True), bf16),
+        "dpm2_f16": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2, stochasticity=1), RS.Scaled()), torch.float16),
+        "dpm2_f64": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2, stochasticity=1), RS.Scaled(), compute_scale=torch.float64), torch.float64),
+        "rku2_ode_flow": (lambda: RD.RKUltraWrapperScheduler(RS.Linear(), sampler_order=2, model=models.FlowModel()), bf16),
+        "rku4_sde_v": (lambda: RD.RKUltraWrapperScheduler(RS.Scaled(), sampler_order=4, stochasticity=0.5, model=models.VelocityModel()), f32),
+        "rku5_noderiv": (lambda: RD.RKUltraWrapperScheduler(RS.Scaled(), sampler_order=5, derivative_transform=None), f32),
+    }
+    blob = {}
+    for i, (name, (mk, dt)) in enumerate(extra.items()):
+        rec = run_wrapper(mk(), 2, (4, 8, 8), 7 if "rku" not in name else 3, dt, seed=2000 + i)
+        if dt == torch.float16:
+            rec = {k: (v.view(np.int16) if v.dtype == np.float16 else v) for k, v in rec.items()}
+        for k, v in rec.items():
+            blob[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "steps_extra.npz"), **blob)
+
+
+# ---------------------------------------------------------------------------------------------------
+class _RecGen:
+    "torch.Generator stand-in is impossible (C++ type); instead patch torch.randn/rand inside the noise module"
+
+
+def noise() -> None:
+    blob: dict = {}
+    real_randn, real_rand = torch.randn, torch.rand
+
+    def record(fn):
+        normals, uniforms = [], []
+
+        def randn(*a, **k):
+            v = real_randn(*a, **k)
+            normals.append(v.clone())
+            return v
+
+        def rand(*a, **k):
+            v = real_rand(*a, **k)
+            uniforms.append(v.item())
+            return v
+
+        RN.torch.randn, RN.torch.rand = randn, rand
+        try:
+            result = fn()
+        finally:
+            RN.torch.randn, RN.torch.rand = real_randn, real_rand
+        return result, normals, uniforms
+
+    def put(tag, result, normals, uniforms):
+        blob[f"{tag}/out"] = result.numpy()
+        blob[f"{tag}/uniforms"] = np.asarray(uniforms, dtype=np.float64)
+        blob[f"{tag}/n_normals"] = np.asarray(len(normals))
+        for i, n in enumerate(normals):
+            blob[f"{tag}/normal{i}"] = n.numpy()
+
+    g = lambda s: torch.Generator().manual_seed(s)  # noqa: E731
+    for unit in ((4, 16, 16), (4, 32, 24), (16, 16, 16)):
+        u = "x".join(map(str, unit))
+        gen = RN.Offset.from_inputs(unit, g(11))
+        put(f"offset/{u}", *record(lambda: gen.generate(None)))
+        gen = RN.Offset.from_inputs(unit, g(12), RN.OffsetProps(dims=(0, 2), strength=0.5))
+        put(f"offset_d02/{u}", *record(lambda: gen.generate(None)))
+        gen = RN.Pyramid.from_inputs(unit, g(13))
+        put(f"pyramid/{u}", *record(lambda: gen.generate(None)))
+        gen = RN.Pyramid.from_inputs(unit, g(14), RN.PyramidProps(strength=0.6, depth=1))
+        put(f"pyramid_depth1/{u}", *record(lambda: gen.generate(None)))
+        for j, st in enumerate((None, Step(0.0, 0.05), Step(0.45, 0.5), Step(0.95, 1.0))):
+            gen = RN.Colored.from_inputs(unit, g(15 + j))
+            put(f"colored{j}/{u}", *record(lambda: gen.generate(st)))
+        gen = RN.Colored.from_inputs(unit, g(20), RN.ColoredProps(energy=2.5, color_start=1.5, color_end=-3, color_curve=0))
+        put(f"colored_energy/{u}", *record(lambda: gen.generate(Step(0.3, 0.4))))
+        blob[f"radial/{u}"] = RN.Colored._radial_freq_grid(torch.Size(unit), torch.device("cpu")).numpy()
+    gen = RN.Pyramid.from_inputs((4, 128, 128), g(21))
+    r, nn, uu = record(lambda: gen.generate(None))
+    blob["pyramid_levels/4x128x128/uniforms"] = np.asarray(uu)
+    blob["pyramid_levels/4x128x128/shapes"] = np.asarray([list(n.shape) for n in nn])
+    blob["colored_exponents"] = np.asarray(
+        [[a, b, _exp(Step(a, b))] for a, b in ((0, 0.05), (0.2, 0.25), (0.45, 0.5), (0.95, 1.0), (1.0, 0.9))], dtype=np.float64
+    )
+    np.savez_compressed(os.path.join(OUT, "noise.npz"), **blob)
+
+
+def _exp(step) -> float:
+    seen = {}
+    orig = RN.Colored.colorize_noise
+    RN.Colored.colorize_noise = staticmethod(lambda white, exponent=0.0, energy=None: seen.setdefault("e", exponent) and white)
+    try:
+        RN.Colored.from_inputs((2, 2), torch.Generator().manual_seed(0)).generate(step)
+    finally:
+        RN.Colored.colorize_noise = orig
+    return seen["e"]
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    kats()
+    tables()
+    steps()
+    noise()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
