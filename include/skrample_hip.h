@@ -1,0 +1,115 @@
+/*
+ * skrample_hip.h -- C ABI of the MI355X (gfx950) sampler-step engine.
+ *
+ * This is the drop-in boundary for the per-step hot path of Beinsezii/skrample.  The reference is
+ * pure Python and has no FFI of its own; each entry point below names the reference interface whose
+ * tensor arithmetic it replaces (file:line under the reference tree).  The Python side
+ * (skrample_amd/_hip.py) binds these with ctypes; INTEGRATION.md shows the binding a reference
+ * maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; every buffer is caller-owned device memory; launches
+ * are asynchronous on the caller's hipStream_t (passed as void*); every function returns an int
+ * status (0 = SKR_OK) and never throws; no hidden global state except the loaded code object.
+ * Thread-safe for concurrent callers on distinct streams.
+ */
+#ifndef SKRAMPLE_HIP_H
+#define SKRAMPLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKR_ABI_VERSION 2
+#define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
+
+enum skr_status {
+  SKR_OK = 0,
+  SKR_ERR_NULL = 1,        /* required pointer is NULL */
+  SKR_ERR_DTYPE = 2,       /* dtype combination has no kernel */
+  SKR_ERR_TERMS = 3,       /* n_terms out of range or terms not grouped by dtype */
+  SKR_ERR_ALIGN = 4,       /* a buffer is not 16-byte aligned */
+  SKR_ERR_SHAPE = 5,       /* numel / sample_numel / shape arguments inconsistent */
+  SKR_ERR_LAUNCH = 6,      /* hipLaunchKernel failed (see skr_last_hip_error) */
+  SKR_ERR_UNSUPPORTED = 7, /* valid request outside what the kernels cover */
+};
+
+enum skr_dtype { SKR_BF16 = 0, SKR_F16 = 1, SKR_F32 = 2, SKR_F64 = 3, SKR_NONE = -1 };
+
+/*
+ * One fused solver step:
+ *
+ *     out0[e] = sum_k coef0[k] * in_k[e]  + zeta0 * N(seed[s(e)], stream0, e)
+ *     out1[e] = chain * out0[e] + sum_k coef1[k] * in_k[e] + zeta1 * N(seed[s(e)], stream1, e)
+ *
+ * evaluated in fp32 (fp64 if acc_f64) registers and rounded once per output, in a single pass over
+ * HBM.  `chain` uses out0 before its rounding to out0_dtype.  N() is the Philox4x32-10 / Box-Muller
+ * normal of oracle/skr_oracle/noise.py::philox_normal, keyed by the per-sample seed (s(e) =
+ * e / sample_numel), so results do not depend on how a batch is sharded over GPUs.
+ *
+ * Replaces, per sampler (coefficients are computed on the host in fp64 by skrample_amd.sampling):
+ *   - DiffusionModel.to_x / from_x / ModelConvert.output_to   skrample/sampling/models.py:92-224
+ *   - DiffusionModel.forward (sample*G + output*D + noise*z)   skrample/sampling/models.py:53-67
+ *   - Euler / DPM / Adams / UniP._sample_packed tensor math    skrample/sampling/structured.py:167-436
+ *   - UniPC.sample_packed (corrector out0 + predictor out1)    skrample/sampling/structured.py:469-497
+ *   - RKWrapperCore.step_tableau_inside_out (one stage)        skrample/diffusers.py:746-796
+ *   - the dtype casts around them                              skrample/diffusers.py:575-599
+ *
+ * Inputs must be grouped by dtype: terms [0, n_group_a) have dtype_a, the rest dtype_b.
+ */
+typedef struct skr_step_plan {
+  int32_t n_terms;     /* 0..SKR_MAX_TERMS */
+  int32_t n_group_a;   /* terms [0,n_group_a) are dtype_a, [n_group_a,n_terms) dtype_b */
+  int32_t dtype_a;     /* skr_dtype */
+  int32_t dtype_b;     /* skr_dtype; ignored when n_group_a == n_terms */
+  int32_t out0_dtype;  /* skr_dtype, SKR_NONE if out0 is not stored */
+  int32_t out1_dtype;  /* skr_dtype, SKR_NONE if there is no second output */
+  int32_t acc_f64;     /* 1 = accumulate in double (compute_scale=float64), else float */
+  int32_t noise_mode;  /* 0 = none, 1 = in-kernel Philox normals */
+  double coef0[SKR_MAX_TERMS];
+  double coef1[SKR_MAX_TERMS];
+  double chain;
+  double zeta0, zeta1;
+  uint64_t stream0, stream1; /* Philox stream id of the draw feeding out0 / out1 */
+  int64_t sample_numel;      /* elements per batch item (prod(shape[1:])) */
+  /* Optional rounded pair conversion (Runge-Kutta wrapper, skrample/diffusers.py:819-834): when
+   * convert_to or convert_from is non-zero, out0 is NOT the coef0 combination but
+   *     out0 = from_x(s, to_x(s, o)),  s = inputs[0], o = inputs[1]  (both of dtype_a)
+   * evaluated one rounded op at a time in dtype_a's arithmetic, exactly as the reference's tensor ops:
+   *   to_x   1: (s - k0*o)/k1   2: k1*s - k0*o   3: o*k0        (0: o)
+   *   from_x 1: (s - k2*x)/k3   2: (k2*s - x)/k3 3: x/k2        (0: x)
+   * out1 = chain*out0 + sum_k coef1[k]*in_k (+ noise) as usual.  Requires out1. */
+  int32_t convert_to, convert_from;
+  double convert_k[4];
+} skr_step_plan;
+
+int skr_step_launch(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
+                    const uint64_t* seeds_dev /* [batch] device, may be NULL if noise_mode==0 */,
+                    int64_t numel, void* stream);
+
+/*
+ * Noise generators -- replace skrample/pytorch/noise.py behind BatchTensorNoise.generate
+ * (noise.py:438-446) / SkrampleWrapperCore.get_step_noise (diffusers.py:312-346).
+ * One launch (or a short fixed chain of launches) produces the whole [batch, *unit] tensor; every
+ * reduction is per sample.  `seeds_dev` holds one 64-bit seed per batch item; `stream` numbers the
+ * draw (the wrapper passes the step index) so repeated calls give fresh, reproducible noise.
+ */
+
+/* Random.generate (noise.py:58-74): out = N() */
+int skr_noise_random(void* out, int32_t out_dtype, const uint64_t* seeds_dev, uint64_t stream_id,
+                     int64_t batch, int64_t sample_numel, void* stream);
+
+/* raw generator outputs, for parity tests of the RNG itself */
+int skr_philox_u32(uint32_t* out /* [n_blocks*4] device */, uint64_t seed, uint64_t stream_id,
+                   uint64_t first_block, int64_t n_blocks, void* stream);
+
+int skr_abi_version(void);
+const char* skr_strerror(int status);
+int skr_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */
+const char* skr_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKRAMPLE_HIP_H */

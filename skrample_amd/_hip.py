@@ -1,0 +1,140 @@
+"""ctypes binding of libskrample_hip.so (include/skrample_hip.h).
+
+The HIP library is the product: there is no CPU or eager-PyTorch fallback anywhere in this
+package.  If the library is missing or a launch fails, `SkrampleHipError` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+MAX_TERMS = 80
+ABI_VERSION = 2
+
+BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
+DTYPE_CODE = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32, torch.float64: F64}
+CODE_DTYPE = {v: k for k, v in DTYPE_CODE.items()}
+
+LIB_NAME = "libskrample_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
+
+EXPORTS = (
+    "skr_step_launch",
+    "skr_noise_random",
+    "skr_philox_u32",
+    "skr_abi_version",
+    "skr_strerror",
+    "skr_last_hip_error",
+    "skr_build_info",
+)
+
+
+class SkrampleHipError(RuntimeError):
+    "The HIP engine is unavailable or rejected a request.  Never silently degraded."
+
+
+class StepPlanC(ctypes.Structure):
+    "mirror of `skr_step_plan`"
+
+    _fields_ = [
+        ("n_terms", ctypes.c_int32),
+        ("n_group_a", ctypes.c_int32),
+        ("dtype_a", ctypes.c_int32),
+        ("dtype_b", ctypes.c_int32),
+        ("out0_dtype", ctypes.c_int32),
+        ("out1_dtype", ctypes.c_int32),
+        ("acc_f64", ctypes.c_int32),
+        ("noise_mode", ctypes.c_int32),
+        ("coef0", ctypes.c_double * MAX_TERMS),
+        ("coef1", ctypes.c_double * MAX_TERMS),
+        ("chain", ctypes.c_double),
+        ("zeta0", ctypes.c_double),
+        ("zeta1", ctypes.c_double),
+        ("stream0", ctypes.c_uint64),
+        ("stream1", ctypes.c_uint64),
+        ("sample_numel", ctypes.c_int64),
+        ("convert_to", ctypes.c_int32),
+        ("convert_from", ctypes.c_int32),
+        ("convert_k", ctypes.c_double * 4),
+    ]
+
+
+_lock = threading.Lock()
+_lib: ctypes.CDLL | None = None
+
+
+def load() -> ctypes.CDLL:
+    "dlopen the engine (once) and declare the prototypes"
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise SkrampleHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "skrample_amd has no CPU fallback."
+            )
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as exc:  # pragma: no cover - depends on the box
+            raise SkrampleHipError(f"cannot load {LIB_PATH}: {exc}") from exc
+        vp, i64, u64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32
+        lib.skr_step_launch.argtypes = [ctypes.POINTER(StepPlanC), ctypes.POINTER(vp), vp, vp, vp, i64, vp]
+        lib.skr_step_launch.restype = ctypes.c_int
+        lib.skr_noise_random.argtypes = [vp, i32, vp, u64, i64, i64, vp]
+        lib.skr_noise_random.restype = ctypes.c_int
+        lib.skr_philox_u32.argtypes = [vp, u64, u64, u64, i64, vp]
+        lib.skr_philox_u32.restype = ctypes.c_int
+        lib.skr_abi_version.restype = ctypes.c_int
+        lib.skr_strerror.argtypes = [ctypes.c_int]
+        lib.skr_strerror.restype = ctypes.c_char_p
+        lib.skr_last_hip_error.restype = ctypes.c_int
+        lib.skr_build_info.restype = ctypes.c_char_p
+        if lib.skr_abi_version() != ABI_VERSION:
+            raise SkrampleHipError(f"ABI mismatch: library {lib.skr_abi_version()} != binding {ABI_VERSION}; rebuild")
+        _lib = lib
+        return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        lib = load()
+        msg = lib.skr_strerror(status).decode()
+        extra = f" (hipError {lib.skr_last_hip_error()})" if status == 6 else ""
+        raise SkrampleHipError(f"{what}: {msg}{extra}")
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise SkrampleHipError(
+            f"{what} must be a torch tensor on a HIP device; skrample_amd executes on the GPU only "
+            "(no CPU path). Got " + (f"{t.device}" if isinstance(t, torch.Tensor) else type(t).__name__)
+        )
+
+
+def current_stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def launch_step(plan: StepPlanC, inputs: list[torch.Tensor], out0, out1, seeds, numel: int, device: torch.device) -> None:
+    "one fused kernel launch on torch's current stream of `device`"
+    lib = load()
+    n = len(inputs)
+    arr = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in inputs])
+    status = lib.skr_step_launch(
+        ctypes.byref(plan),
+        arr,
+        out0.data_ptr() if out0 is not None else None,
+        out1.data_ptr() if out1 is not None else None,
+        seeds.data_ptr() if seeds is not None else None,
+        numel,
+        current_stream_ptr(device),
+    )
+    check(status, "skr_step_launch")

@@ -1,0 +1,84 @@
+// C-ABI odds and ends: version / error strings, the stand-alone Random generator and the raw
+// Philox dump used by the parity tests.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/skrample_hip.h"
+#include "skr_philox.h"
+
+extern "C" int skr_abi_version(void) { return SKR_ABI_VERSION; }
+
+extern "C" const char* skr_build_info(void) { return "skrample_hip gfx950 (wave64), built " __DATE__ " " __TIME__; }
+
+extern "C" const char* skr_strerror(int status) {
+  switch (status) {
+    case SKR_OK: return "ok";
+    case SKR_ERR_NULL: return "required pointer is NULL";
+    case SKR_ERR_DTYPE: return "dtype combination has no kernel";
+    case SKR_ERR_TERMS: return "term count out of range or terms not grouped by dtype";
+    case SKR_ERR_ALIGN: return "buffer not 16-byte aligned";
+    case SKR_ERR_SHAPE: return "inconsistent numel / sample_numel / shape";
+    case SKR_ERR_LAUNCH: return "hip kernel launch failed";
+    case SKR_ERR_UNSUPPORTED: return "request outside kernel coverage";
+    default: return "unknown status";
+  }
+}
+
+// Random.generate (reference noise.py:58-74) for ANY per-sample size: one lane per Philox block of
+// a sample (4 elements), so ragged sizes need no special casing.  Shapes with sample_numel % 8 == 0
+// normally never get here -- their noise is drawn inside the fused step kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void random_kernel(T* out, const uint64_t* seeds, uint64_t stream_id, int64_t sample_numel, int64_t blocks_per_sample, int64_t total_blocks) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_blocks; i += (int64_t)gridDim.x * 256) {
+    const int64_t smp = i / blocks_per_sample;
+    const int64_t blk = i - smp * blocks_per_sample;
+    float z[4];
+    skr::normal4(seeds[smp], stream_id, (uint64_t)blk, z);
+    const int64_t r0 = blk * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (r0 + j < sample_numel) out[smp * sample_numel + r0 + j] = (T)z[j];
+    }
+  }
+}
+
+extern "C" int skr_noise_random(void* out, int32_t out_dtype, const uint64_t* seeds_dev, uint64_t stream_id,
+                                int64_t batch, int64_t sample_numel, void* stream) {
+  if (batch < 0 || sample_numel < 0) return SKR_ERR_SHAPE;
+  if (batch == 0 || sample_numel == 0) return SKR_OK;
+  if (!out || !seeds_dev) return SKR_ERR_NULL;
+  const int64_t bps = (sample_numel + 3) / 4, total = bps * batch;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (out_dtype) {
+    case SKR_BF16: hipLaunchKernelGGL(random_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (__bf16*)out, seeds_dev, stream_id, sample_numel, bps, total); break;
+    case SKR_F16: hipLaunchKernelGGL(random_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (_Float16*)out, seeds_dev, stream_id, sample_numel, bps, total); break;
+    case SKR_F32: hipLaunchKernelGGL(random_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)out, seeds_dev, stream_id, sample_numel, bps, total); break;
+    case SKR_F64: hipLaunchKernelGGL(random_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (double*)out, seeds_dev, stream_id, sample_numel, bps, total); break;
+    default: return SKR_ERR_DTYPE;
+  }
+  return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}
+
+__global__ void philox_dump_kernel(uint32_t* out, uint64_t seed, uint64_t stream_id, uint64_t first, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t blk = first + (uint64_t)i;
+  skr::u32x4 c{(uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  c = skr::philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  out[4 * i + 0] = c.x;
+  out[4 * i + 1] = c.y;
+  out[4 * i + 2] = c.z;
+  out[4 * i + 3] = c.w;
+}
+
+extern "C" int skr_philox_u32(uint32_t* out, uint64_t seed, uint64_t stream_id, uint64_t first_block, int64_t n_blocks, void* stream) {
+  if (!out) return SKR_ERR_NULL;
+  if (n_blocks < 0) return SKR_ERR_SHAPE;
+  if (n_blocks == 0) return SKR_OK;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((n_blocks + threads - 1) / threads);
+  hipLaunchKernelGGL(philox_dump_kernel, dim3(blocks), dim3(threads), 0, reinterpret_cast<hipStream_t>(stream), out, seed, stream_id, first_block, n_blocks);
+  return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}

@@ -1,0 +1,531 @@
+// Fused solver-step kernel for MI355X (gfx950): one coalesced HBM round trip per step.
+//
+//   out0 = sum_k c0[k]*in_k + zeta0*N(stream0)            (fp32 / fp64 registers)
+//   out1 = chain*out0 + sum_k c1[k]*in_k + zeta1*N(stream1)
+//
+// Memory-bound by construction (<= ~1.5 flop/byte without noise): no LDS, no MFMA.  Each lane owns
+// 8 consecutive elements per trip (16 B of bf16, 32 B of fp32), inputs are issued in batches of four
+// independent 16-byte loads before any FMA so every wave keeps >= 4 KiB in flight, coefficients
+// live in SGPRs (kernarg), outputs use non-temporal stores (they are next read by the model, not
+// by us).  The reference equivalent is ~16 separate aten passes + 17 copies per step
+// (SURVEY.md section 8a, rows S2-S12).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/skrample_hip.h"
+#include "skr_philox.h"
+
+namespace skr {
+
+constexpr int VEC = 8;       // elements per lane per trip
+constexpr int BLOCK = 256;   // 4 waves
+constexpr int UV = 2;        // vectors per lane per trip (spaced BLOCK apart: every wave access stays 1 KiB contiguous)
+constexpr int MAXK = SKR_MAX_TERMS;
+
+struct bf16_t { uint16_t v; };
+struct f16_t { _Float16 v; };
+
+template <typename Acc>
+struct StepArgs {
+  const void* in[MAXK];
+  Acc c0[MAXK];
+  Acc c1[MAXK];
+  void* out0;
+  void* out1;
+  const uint64_t* seeds;
+  Acc chain, zeta0, zeta1;
+  uint64_t stream0, stream1;
+  int64_t numel;
+  int64_t sample_numel;
+  double inv_sample_numel;
+  int64_t vps;          // vectors per sample (per-sample grid only)
+  int32_t n_a, n_terms;
+  int32_t grid_mode;    // 0 flat grid, 1 per-sample grid (noise kernels, sample_numel % 8 == 0)
+  int32_t aligned;      // sample_numel % 8 == 0
+  int32_t conv_to, conv_from;  // rounded pair conversion (CONV kernels): see convert_rounded()
+  double ck[4];
+};
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---- 8-element loads (widening to Acc) ---------------------------------------------------------
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Raw;  // raw register image of 8 elements
+template <> struct Raw<bf16_t> { u32x4_t q; };
+template <> struct Raw<f16_t> { u32x4_t q; };
+template <> struct Raw<float> { f32x4_t q[2]; };
+template <> struct Raw<double> { f64x2_t q[4]; };
+
+template <typename T>
+__device__ __forceinline__ Raw<T> load_raw(const void* base, int64_t vec) {
+  Raw<T> r;
+  if constexpr (sizeof(T) == 2) {
+    r.q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(base) + vec);
+  } else if constexpr (sizeof(T) == 4) {
+    const f32x4_t* p = reinterpret_cast<const f32x4_t*>(base) + vec * 2;
+    r.q[0] = __builtin_nontemporal_load(p);
+    r.q[1] = __builtin_nontemporal_load(p + 1);
+  } else {
+    const f64x2_t* p = reinterpret_cast<const f64x2_t*>(base) + vec * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.q[i] = __builtin_nontemporal_load(p + i);
+  }
+  return r;
+}
+
+template <typename T, typename Acc>
+__device__ __forceinline__ void widen(const Raw<T>& r, Acc v[VEC]) {
+  if constexpr (std::is_same<T, bf16_t>::value) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = (Acc)__uint_as_float(r.q[i] << 16);
+      v[2 * i + 1] = (Acc)__uint_as_float(r.q[i] & 0xFFFF0000u);
+    }
+  } else if constexpr (std::is_same<T, f16_t>::value) {
+    // (bit_cast of a dword to a _Float16x2 vector is mis-compiled by ROCm 7.2 hipcc for lanes 1..3 of a
+    //  dwordx4: go through scalar 16-bit halves instead)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t w = r.q[i];
+      v[2 * i] = (Acc)(float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu));
+      v[2 * i + 1] = (Acc)(float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+    }
+  } else if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (Acc)r.q[i >> 2][i & 3];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (Acc)r.q[i >> 1][i & 1];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ float load_scalar(const void* base, int64_t i) {
+  if constexpr (std::is_same<T, bf16_t>::value)
+    return __uint_as_float((uint32_t) reinterpret_cast<const uint16_t*>(base)[i] << 16);
+  else if constexpr (std::is_same<T, f16_t>::value)
+    return (float)reinterpret_cast<const _Float16*>(base)[i];
+  else
+    return (float)reinterpret_cast<const T*>(base)[i];
+}
+template <typename T>
+__device__ __forceinline__ double load_scalar_d(const void* base, int64_t i) {
+  if constexpr (std::is_same<T, double>::value) return reinterpret_cast<const double*>(base)[i];
+  else return (double)load_scalar<T>(base, i);
+}
+
+// ---- stores (single rounding from Acc) --------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  f32x2_t f = {a, b};
+  bf16x2_t h = __builtin_convertvector(f, bf16x2_t);  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  const uint32_t lo = __builtin_bit_cast(uint16_t, (_Float16)a);
+  const uint32_t hi = __builtin_bit_cast(uint16_t, (_Float16)b);
+  return lo | (hi << 16);
+}
+
+template <typename T, typename Acc>
+__device__ __forceinline__ void store8(void* base, int64_t vec, const Acc v[VEC]) {
+  if constexpr (sizeof(T) == 2) {
+    u32x4_t q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (std::is_same<T, bf16_t>::value) q[i] = pack_bf16((float)v[2 * i], (float)v[2 * i + 1]);
+      else q[i] = pack_f16((float)v[2 * i], (float)v[2 * i + 1]);
+    }
+    __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t*>(base) + vec);
+  } else if constexpr (sizeof(T) == 4) {
+    f32x4_t* p = reinterpret_cast<f32x4_t*>(base) + vec * 2;
+    f32x4_t a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    f32x4_t b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    __builtin_nontemporal_store(a, p);
+    __builtin_nontemporal_store(b, p + 1);
+  } else {
+    f64x2_t* p = reinterpret_cast<f64x2_t*>(base) + vec * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f64x2_t a = {(double)v[2 * i], (double)v[2 * i + 1]};
+      __builtin_nontemporal_store(a, p + i);
+    }
+  }
+}
+
+template <typename T, typename Acc>
+__device__ __forceinline__ void store_scalar(void* base, int64_t i, Acc v) {
+  if constexpr (std::is_same<T, bf16_t>::value) reinterpret_cast<uint16_t*>(base)[i] = (uint16_t)(pack_bf16((float)v, 0.f) & 0xFFFFu);
+  else if constexpr (std::is_same<T, f16_t>::value) reinterpret_cast<_Float16*>(base)[i] = (_Float16)(float)v;
+  else reinterpret_cast<T*>(base)[i] = (T)v;
+}
+
+// ---- accumulate one dtype group: N terms x UV vectors of independent 16-byte loads, then FMAs --------
+template <typename T, typename Acc, bool HAS1, int N>
+__device__ __forceinline__ void acc_batch(const StepArgs<Acc>& a, int k, int64_t v0, int64_t vhi, Acc s0[UV][VEC], Acc s1[UV][VEC]) {
+  Raw<T> raw[UV][N];
+#pragma unroll
+  for (int u = 0; u < UV; ++u) {
+    const int64_t v = v0 + u * BLOCK;
+    if (v < vhi) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) raw[u][j] = load_raw<T>(a.in[k + j], v);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UV; ++u) {
+    if (v0 + u * BLOCK >= vhi) continue;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      Acc v[VEC];
+      widen<T, Acc>(raw[u][j], v);
+      const Acc w0 = a.c0[k + j];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s0[u][i] = fma_(w0, v[i], s0[u][i]);
+      if constexpr (HAS1) {
+        const Acc w1 = a.c1[k + j];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s1[u][i] = fma_(w1, v[i], s1[u][i]);
+      }
+    }
+  }
+}
+
+template <typename T, typename Acc, bool HAS1>
+__device__ __forceinline__ void acc_group(const StepArgs<Acc>& a, int k, int kend, int64_t v0, int64_t vhi, Acc s0[UV][VEC], Acc s1[UV][VEC]) {
+  for (; k + 4 <= kend; k += 4) acc_batch<T, Acc, HAS1, 4>(a, k, v0, vhi, s0, s1);
+  if (k + 2 <= kend) { acc_batch<T, Acc, HAS1, 2>(a, k, v0, vhi, s0, s1); k += 2; }
+  if (k < kend) acc_batch<T, Acc, HAS1, 1>(a, k, v0, vhi, s0, s1);
+}
+
+// ---- rounded pair conversion (Runge-Kutta wrapper) ---------------------------------------------------
+// The reference's RK wrapper converts the network output to derivative space in the INPUT dtype,
+// one rounded tensor op at a time, before any cast to compute_scale (skrample/diffusers.py:819-834 with
+// models.py:92-224).  out0 = from_x(s, to_x(s, o)) is reproduced here op for op with the same roundings,
+// so the stored derivative tensor is bit-identical to the reference's.
+//   to_x   kinds: 0 o | 1 ((s - k0*o) / k1) | 2 (k1*s - k0*o) | 3 (o * k0)
+//   from_x kinds: 0 x | 1 ((s - k2*x) / k3) | 2 ((k2*s - x) / k3) | 3 (x / k2)
+template <typename T> struct OpMath { using type = float; };
+template <> struct OpMath<double> { using type = double; };
+
+template <typename T> __device__ __forceinline__ float rnd(float v) {
+  if constexpr (std::is_same<T, bf16_t>::value) return __uint_as_float(pack_bf16(v, 0.f) << 16);
+  else if constexpr (std::is_same<T, f16_t>::value) return (float)(_Float16)v;
+  else return v;
+}
+__device__ __forceinline__ double rnd_d(double v) { return v; }
+
+__device__ __forceinline__ float mul_(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float sub_(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float div_(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ double mul_(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double sub_(double a, double b) { return __dsub_rn(a, b); }
+__device__ __forceinline__ double div_(double a, double b) { return __ddiv_rn(a, b); }
+
+template <typename T, typename M>
+__device__ __forceinline__ M convert_rounded(M s, M o, int to_kind, int from_kind, const M k[4]) {
+  auto R = [](M v) -> M { if constexpr (std::is_same<M, double>::value) return v; else return rnd<T>(v); };
+  M x;
+  switch (to_kind) {
+    case 1: x = R(div_(R(sub_(s, R(mul_(k[0], o)))), k[1])); break;
+    case 2: x = R(sub_(R(mul_(k[1], s)), R(mul_(k[0], o)))); break;
+    case 3: x = R(mul_(o, k[0])); break;
+    default: x = o; break;
+  }
+  switch (from_kind) {
+    case 1: return R(div_(R(sub_(s, R(mul_(k[2], x)))), k[3]));
+    case 2: return R(div_(R(sub_(R(mul_(k[2], s)), x)), k[3]));
+    case 3: return R(div_(x, k[2]));
+    default: return x;
+  }
+}
+
+// ---- noise ---------------------------------------------------------------------------------------
+// element e of the whole tensor -> sample s = e / sample_numel, r = e % sample_numel,
+// Philox block r >> 2, lane r & 3 (oracle/skr_oracle/noise.py::philox_normal).
+template <typename Acc>
+__device__ __forceinline__ void fma_noise8(Acc zeta, const float z[VEC], Acc s[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = fma_(zeta, (Acc)z[i], s[i]);
+}
+
+// generic placement: any sample_numel.  `smp`/`r` locate element e0 (first of the 8).
+template <typename Acc>
+__device__ __forceinline__ void locate(const StepArgs<Acc>& a, int64_t e0, int64_t& smp, int64_t& r) {
+  smp = (int64_t)((double)e0 * a.inv_sample_numel);  // fp64 reciprocal, exact after one fix-up below 2^52
+  r = e0 - smp * a.sample_numel;
+  if (r < 0) { --smp; r += a.sample_numel; }
+  else if (r >= a.sample_numel) { ++smp; r -= a.sample_numel; }
+}
+
+template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bool ST0, bool HAS1, bool NOISE, bool CONV>
+__global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
+  // Geometry.  mode 1 (per-sample grid): blockIdx.y/z pick the sample, so the seed is one scalar
+  // load per block and no division is needed.  mode 0: flat grid over all vectors.
+  int64_t vlo = 0, vhi = a.numel / VEC;
+  uint64_t seed_u = 0;
+  if constexpr (NOISE) {
+    if (a.grid_mode == 1) {
+      const int64_t smp = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+      vlo = smp * a.vps;
+      vhi = vlo + a.vps;
+      seed_u = a.seeds[smp];
+    }
+  }
+  const int64_t stride = (int64_t)gridDim.x * (BLOCK * UV);
+  for (int64_t v0 = vlo + (int64_t)blockIdx.x * (BLOCK * UV) + threadIdx.x; v0 < vhi; v0 += stride) {
+    // flat-grid noise needs a per-lane seed: fetch it BEFORE the data loads so that waiting for it
+    // (vmcnt counts in order) does not drain the whole load batch ahead of the Philox rounds.
+    uint64_t seed_l[UV];
+    int64_t r_l[UV];
+    if constexpr (NOISE) {
+      if (a.grid_mode == 0) {
+#pragma unroll
+        for (int u = 0; u < UV; ++u) {
+          const int64_t v = v0 + u * BLOCK;
+          seed_l[u] = 0; r_l[u] = 0;
+          if (v < vhi) { int64_t smp; locate(a, v * VEC, smp, r_l[u]); seed_l[u] = a.seeds[smp]; }
+        }
+      }
+    }
+    Acc s0[UV][VEC], s1[UV][VEC];
+#pragma unroll
+    for (int u = 0; u < UV; ++u)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s0[u][i] = 0; s1[u][i] = 0; }
+
+    // first load batch of group A is issued here; Philox (pure VALU) runs while it is in flight
+    float z0[UV][VEC], z1[UV][VEC];
+    if constexpr (NOISE) {
+#pragma unroll
+      for (int u = 0; u < UV; ++u) {
+        const int64_t v = v0 + u * BLOCK;
+        if (v >= vhi) continue;
+        const uint64_t seed = a.grid_mode == 1 ? seed_u : seed_l[u];
+        const uint64_t blk = a.grid_mode == 1 ? (uint64_t)(v - vlo) * 2 : (uint64_t)r_l[u] >> 2;
+        if (a.zeta0 != (Acc)0) { normal4(seed, a.stream0, blk, z0[u]); normal4(seed, a.stream0, blk + 1, z0[u] + 4); }
+        if constexpr (HAS1) {
+          if (a.zeta1 != (Acc)0) { normal4(seed, a.stream1, blk, z1[u]); normal4(seed, a.stream1, blk + 1, z1[u] + 4); }
+        }
+      }
+    }
+
+    acc_group<TA, Acc, HAS1>(a, 0, a.n_a, v0, vhi, s0, s1);
+    if constexpr (!std::is_same<TA, TB>::value) acc_group<TB, Acc, HAS1>(a, a.n_a, a.n_terms, v0, vhi, s0, s1);
+    if constexpr (CONV) {
+      // out0 = rounded conversion of (in[0], in[1]); the host zeroes coef0 so s0 is still 0 here
+      using M = typename OpMath<TA>::type;
+      const M k[4] = {(M)a.ck[0], (M)a.ck[1], (M)a.ck[2], (M)a.ck[3]};
+#pragma unroll
+      for (int u = 0; u < UV; ++u) {
+        const int64_t v = v0 + u * BLOCK;
+        if (v >= vhi) continue;
+        M sv[VEC], ov[VEC];
+        widen<TA, M>(load_raw<TA>(a.in[0], v), sv);
+        widen<TA, M>(load_raw<TA>(a.in[1], v), ov);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s0[u][i] = (Acc)convert_rounded<TA, M>(sv[i], ov[i], a.conv_to, a.conv_from, k);
+      }
+    }
+
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int64_t v = v0 + u * BLOCK;
+      if (v >= vhi) continue;
+      if constexpr (NOISE) { if (a.zeta0 != (Acc)0) fma_noise8<Acc>(a.zeta0, z0[u], s0[u]); }
+      if constexpr (HAS1) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s1[u][i] = fma_(a.chain, s0[u][i], s1[u][i]);
+        if constexpr (NOISE) { if (a.zeta1 != (Acc)0) fma_noise8<Acc>(a.zeta1, z1[u], s1[u]); }
+        store8<TO1, Acc>(a.out1, v, s1[u]);
+      }
+      if constexpr (ST0) store8<TO0, Acc>(a.out0, v, s0[u]);
+    }
+  }
+
+  // ragged tail (< 8 elements at the very end of the tensor): one lane, scalar.  In-kernel noise
+  // requires sample_numel % 8 == 0 (checked on the host), so a noisy launch never has a tail.
+  const int64_t tail0 = (a.numel / VEC) * VEC;
+  if (!NOISE && tail0 < a.numel && blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = 0; tail0 + i < a.numel; ++i) {
+      const int64_t e = tail0 + i;
+      Acc t0 = 0, t1 = 0;
+      for (int k = 0; k < a.n_terms; ++k) {
+        Acc v;
+        if (k < a.n_a) v = std::is_same<Acc, double>::value ? (Acc)load_scalar_d<TA>(a.in[k], e) : (Acc)load_scalar<TA>(a.in[k], e);
+        else v = std::is_same<Acc, double>::value ? (Acc)load_scalar_d<TB>(a.in[k], e) : (Acc)load_scalar<TB>(a.in[k], e);
+        t0 = fma_(a.c0[k], v, t0);
+        if constexpr (HAS1) t1 = fma_(a.c1[k], v, t1);
+      }
+      if constexpr (CONV) {
+        using M = typename OpMath<TA>::type;
+        const M k[4] = {(M)a.ck[0], (M)a.ck[1], (M)a.ck[2], (M)a.ck[3]};
+        M sv, ov;
+        if constexpr (std::is_same<M, double>::value) { sv = load_scalar_d<TA>(a.in[0], e); ov = load_scalar_d<TA>(a.in[1], e); }
+        else { sv = load_scalar<TA>(a.in[0], e); ov = load_scalar<TA>(a.in[1], e); }
+        t0 = (Acc)convert_rounded<TA, M>(sv, ov, a.conv_to, a.conv_from, k);
+      }
+      if constexpr (HAS1) {
+        t1 = fma_(a.chain, t0, t1);
+        store_scalar<TO1, Acc>(a.out1, e, t1);
+      }
+      if constexpr (ST0) store_scalar<TO0, Acc>(a.out0, e, t0);
+    }
+  }
+}
+
+// ---- host-side dispatch ------------------------------------------------------------------------------
+static thread_local int g_last_hip_error = 0;
+
+template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bool ST0, bool HAS1, bool NOISE, bool CONV>
+static int launch(StepArgs<Acc>& args, hipStream_t stream) {
+  const int64_t nvec = args.numel / VEC;
+  const int64_t per_block = BLOCK * UV;
+  dim3 grid(1, 1, 1);
+  args.grid_mode = 0;
+  args.aligned = (args.sample_numel % VEC) == 0;
+  args.vps = args.sample_numel / VEC;
+  const int64_t batch = args.numel / args.sample_numel;
+  if (NOISE && args.aligned && args.vps >= per_block && batch <= 65535ll * 65535ll) {
+    // per-sample grid: x covers one sample's vectors, (y,z) enumerate samples
+    int64_t bx = (args.vps + per_block - 1) / per_block;
+    const int64_t want = (256 * 16 + batch - 1) / batch;  // keep >= ~16 blocks per CU in total, no more per sample
+    if (bx > want) bx = want < 1 ? 1 : want;
+    const int64_t gy = batch < 65535 ? batch : 65535;
+    const int64_t gz = (batch + gy - 1) / gy;
+    if (gy * gz == batch) {
+      grid = dim3((unsigned)bx, (unsigned)gy, (unsigned)gz);
+      args.grid_mode = 1;
+    }
+  }
+  if (args.grid_mode == 0) {
+    int64_t blocks = (nvec + per_block - 1) / per_block;
+    const int64_t cap = NOISE ? 256 * 16 : 256 * 4;  // grid-stride beyond: 4 (16 with Philox) blocks per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    grid = dim3((unsigned)blocks, 1, 1);
+  }
+  hipLaunchKernelGGL((step_kernel<TA, TB, TO0, TO1, Acc, ST0, HAS1, NOISE, CONV>), grid, dim3(BLOCK), 0, stream, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_last_hip_error = (int)e; return SKR_ERR_LAUNCH; }
+  return SKR_OK;
+}
+
+template <typename TA, typename TB, typename TO0, typename TO1, typename Acc>
+static int pick_flags(StepArgs<Acc>& a, bool st0, bool has1, bool noise, bool conv, hipStream_t s) {
+#define SKR_GO(ST0, HAS1, NOISE, CONV) return launch<TA, TB, TO0, TO1, Acc, ST0, HAS1, NOISE, CONV>(a, s)
+  if (!has1) {
+    if (!st0 || conv) return conv ? SKR_ERR_UNSUPPORTED : SKR_ERR_NULL;
+    if (noise) SKR_GO(true, false, true, false);
+    SKR_GO(true, false, false, false);
+  }
+  if (conv) {
+    if (st0) { if (noise) SKR_GO(true, true, true, true); SKR_GO(true, true, false, true); }
+    if (noise) SKR_GO(false, true, true, true);
+    SKR_GO(false, true, false, true);
+  }
+  if (st0) { if (noise) SKR_GO(true, true, true, false); SKR_GO(true, true, false, false); }
+  if (noise) SKR_GO(false, true, true, false);
+  SKR_GO(false, true, false, false);
+#undef SKR_GO
+}
+
+// outputs: each of out0/out1 is either the group-A dtype or fp32 (fp64 when accumulating in double)
+template <typename TA, typename TB, typename Acc>
+static int pick_out(StepArgs<Acc>& a, int dt_a, int o0, int o1, bool noise, bool conv, hipStream_t s) {
+  using Wide = typename std::conditional<std::is_same<Acc, double>::value, double, float>::type;
+  const int wide = std::is_same<Acc, double>::value ? SKR_F64 : SKR_F32;
+  const bool st0 = o0 != SKR_NONE, has1 = o1 != SKR_NONE;
+  const int e0 = st0 ? o0 : dt_a, e1 = has1 ? o1 : dt_a;
+  if ((e0 != dt_a && e0 != wide) || (e1 != dt_a && e1 != wide)) return SKR_ERR_DTYPE;
+  if (e0 == dt_a && e1 == dt_a) return pick_flags<TA, TB, TA, TA, Acc>(a, st0, has1, noise, conv, s);
+  if (e0 == wide && e1 == dt_a) return pick_flags<TA, TB, Wide, TA, Acc>(a, st0, has1, noise, conv, s);
+  if (e0 == dt_a && e1 == wide) return pick_flags<TA, TB, TA, Wide, Acc>(a, st0, has1, noise, conv, s);
+  return pick_flags<TA, TB, Wide, Wide, Acc>(a, st0, has1, noise, conv, s);
+}
+
+template <typename Acc>
+static int pick_in(StepArgs<Acc>& a, const skr_step_plan& p, hipStream_t s) {
+  const bool noise = p.noise_mode == 1 && (p.zeta0 != 0.0 || (p.out1_dtype != SKR_NONE && p.zeta1 != 0.0));
+  const int da = p.dtype_a, db = (p.n_group_a == p.n_terms) ? p.dtype_a : p.dtype_b;
+  const bool conv = p.convert_to != 0 || p.convert_from != 0;
+  if constexpr (std::is_same<Acc, double>::value) {
+    if (da == SKR_F64 && db == SKR_F64) return pick_out<double, double, double>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    if (da == SKR_F32 && (db == SKR_F32 || db == SKR_F64)) return pick_out<float, double, double>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    return SKR_ERR_DTYPE;
+  } else {
+    if (da == SKR_BF16 && db == SKR_BF16) return pick_out<bf16_t, bf16_t, float>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    if (da == SKR_BF16 && db == SKR_F32) return pick_out<bf16_t, float, float>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    if (da == SKR_F16 && db == SKR_F16) return pick_out<f16_t, f16_t, float>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    if (da == SKR_F16 && db == SKR_F32) return pick_out<f16_t, float, float>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    if (da == SKR_F32 && db == SKR_F32) return pick_out<float, float, float>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    return SKR_ERR_DTYPE;
+  }
+}
+
+template <typename Acc>
+static int run(const skr_step_plan& p, const void* const* inputs, void* out0, void* out1, const uint64_t* seeds, int64_t numel, hipStream_t s) {
+  StepArgs<Acc> a;
+  for (int k = 0; k < p.n_terms; ++k) {
+    a.in[k] = inputs[k];
+    a.c0[k] = (Acc)p.coef0[k];
+    a.c1[k] = (Acc)p.coef1[k];
+  }
+  for (int k = p.n_terms; k < MAXK; ++k) { a.in[k] = nullptr; a.c0[k] = 0; a.c1[k] = 0; }
+  a.out0 = out0; a.out1 = out1; a.seeds = seeds;
+  a.chain = (Acc)p.chain; a.zeta0 = (Acc)p.zeta0; a.zeta1 = (Acc)p.zeta1;
+  a.stream0 = p.stream0; a.stream1 = p.stream1;
+  a.numel = numel;
+  a.sample_numel = p.sample_numel > 0 ? p.sample_numel : (numel > 0 ? numel : 1);
+  a.inv_sample_numel = 1.0 / (double)a.sample_numel;
+  a.n_a = p.n_group_a; a.n_terms = p.n_terms;
+  a.conv_to = p.convert_to; a.conv_from = p.convert_from;
+  for (int i = 0; i < 4; ++i) a.ck[i] = p.convert_k[i];
+  if (a.conv_to != 0 || a.conv_from != 0) {
+    for (int k = 0; k < p.n_terms; ++k) a.c0[k] = 0;  // out0 is the conversion alone
+  }
+  return pick_in<Acc>(a, p, s);
+}
+
+}  // namespace skr
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int skr_step_launch(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
+                               const uint64_t* seeds_dev, int64_t numel, void* stream) {
+  if (!plan) return SKR_ERR_NULL;
+  const skr_step_plan& p = *plan;
+  if (p.n_terms < 0 || p.n_terms > SKR_MAX_TERMS || p.n_group_a < 0 || p.n_group_a > p.n_terms) return SKR_ERR_TERMS;
+  if (p.n_terms > 0 && !inputs) return SKR_ERR_NULL;
+  if (numel < 0) return SKR_ERR_SHAPE;
+  if (numel == 0) return SKR_OK;  // empty batch: nothing to do (the reference returns empty tensors)
+  const bool st0 = p.out0_dtype != SKR_NONE, has1 = p.out1_dtype != SKR_NONE;
+  if ((st0 && !out0) || (has1 && !out1) || (!st0 && !has1)) return SKR_ERR_NULL;
+  for (int k = 0; k < p.n_terms; ++k) {
+    if (!inputs[k]) return SKR_ERR_NULL;
+    if (!aligned16(inputs[k])) return SKR_ERR_ALIGN;
+  }
+  if ((st0 && !aligned16(out0)) || (has1 && !aligned16(out1))) return SKR_ERR_ALIGN;
+  const bool wants_noise = p.noise_mode == 1 && (p.zeta0 != 0.0 || (has1 && p.zeta1 != 0.0));
+  if (p.noise_mode != 0 && p.noise_mode != 1) return SKR_ERR_UNSUPPORTED;
+  if (p.convert_to < 0 || p.convert_to > 3 || p.convert_from < 0 || p.convert_from > 3) return SKR_ERR_UNSUPPORTED;
+  if ((p.convert_to || p.convert_from) && (p.n_group_a < 2 || !has1)) return SKR_ERR_TERMS;
+  if (wants_noise) {
+    if (!seeds_dev) return SKR_ERR_NULL;
+    if (p.sample_numel <= 0 || numel % p.sample_numel != 0) return SKR_ERR_SHAPE;
+    // fused Philox needs every 8-element lane group inside one sample; other shapes draw the noise
+    // with skr_noise_random (any shape) and pass it as an ordinary input term.
+    if (p.sample_numel % 8 != 0) return SKR_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return p.acc_f64 ? skr::run<double>(p, inputs, out0, out1, seeds_dev, numel, s)
+                   : skr::run<float>(p, inputs, out0, out1, seeds_dev, numel, s);
+}
+
+extern "C" int skr_last_hip_error(void) { return skr::g_last_hip_error; }

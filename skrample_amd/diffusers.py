@@ -1,0 +1,769 @@
+"""Scheduler-shaped wrappers: the outer drop-in boundary (what a diffusers pipeline calls).
+
+Same classes, dataclass fields, properties and methods as reference `skrample/diffusers.py`
+(parse_diffusers_config :112-196, as_diffusers_config :206-230, SkrampleWrapperCore :233-388,
+SkrampleWrapperScheduler :390-599, RKWrapperCore :602-873, RKUltraWrapperScheduler :876-963,
+DynasauRKWrapperScheduler :966-1041).  Like the reference, `diffusers` itself is never imported.
+
+What `step()` does differently from the reference (diffusers.py:550-599):
+  * no `.to(compute_scale)` / `.to(out dtype)` passes: bf16/fp16 inputs are widened in registers and
+    the result is rounded once inside the single fused kernel;
+  * history holds aliases of the caller's tensors, not deep copies (structured.py:113-125 deep-copies
+    every tensor field through dataclasses.asdict);
+  * white noise is drawn inside the step kernel (Philox), other noise types by one batched launch;
+  * a device-resident `timestep` tensor is not `.item()`-synchronised: steps are assumed to arrive in
+    schedule order from `set_begin_index` (host numbers / CPU tensors are looked up by value exactly
+    as in the reference, raising ValueError when absent).
+"""
+
+from __future__ import annotations
+
+import abc
+import contextlib
+import dataclasses
+import functools
+import math
+from collections import OrderedDict
+from collections.abc import Hashable, Mapping, Sequence
+from types import MappingProxyType
+from typing import Any
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import scheduling
+from .common import DeltaPoint, MergeStrategy, Point, Step
+from .pytorch.noise import BatchTensorNoise, Random, TensorNoiseCommon, TensorNoiseProps
+from .sampling import functional, interface, lazy, models, tableaux, traits
+from .sampling import structured as sampling
+from .sampling.lazy import LazyTensor, Lin, lift
+from .sampling.models import DataModel, DiffusionModel, FlowModel, NoiseModel, VelocityModel
+from .sampling.structured import SampleInput, SKSamples, StructuredSampler
+from .scheduling import ScheduleCommon, ScheduleModifier, SkrampleSchedule, SubSchedule
+
+DIFFUSERS_CLASS_MAP: dict[str, tuple[type[StructuredSampler], dict[str, Any]]] = {
+    "DDIMScheduler": (sampling.Euler, {}),
+    "DDPMScheduler": (sampling.Euler, {"stochasticity": True}),
+    "DPMSolverMultistepScheduler": (sampling.DPM, {}),
+    "DPMSolverSDEScheduler": (sampling.DPM, {"stochasticity": True, "order": 1}),
+    "EulerAncestralDiscreteScheduler": (sampling.Euler, {"stochasticity": True}),
+    "EulerDiscreteScheduler": (sampling.Euler, {}),
+    "FlowMatchEulerDiscreteScheduler": (sampling.Euler, {}),
+    "IPNDMScheduler": (sampling.Adams, {"order": 4}),
+    "MiniMaxH3Scheduler": (sampling.Euler, {}),
+    "UniPCMultistepScheduler": (sampling.UniPC, {}),
+}
+
+DIFFUSERS_KEY_MAP: dict[str, str] = {
+    "shift": "shift",
+    "flow_shift": "shift",
+    "solver_order": "order",
+    "num_train_timesteps": "base_timesteps",
+}
+DIFFUSERS_KEY_MAP_REV: dict[str, str] = {v: k for k, v in DIFFUSERS_KEY_MAP.items()}
+
+DIFFUSERS_VALUE_MAP: dict[tuple[str, Any], tuple[str, Any]] = {
+    ("beta_schedule", "linear"): ("beta_scale", 1),
+    ("beta_schedule", "scaled_linear"): ("beta_scale", 2),
+    ("algorithm_type", "dpmsolver"): ("stochasticity", False),
+    ("algorithm_type", "dpmsolver++"): ("stochasticity", False),
+    ("algorithm_type", "sde-dpmsolver"): ("stochasticity", True),
+    ("algorithm_type", "sde-dpmsolver++"): ("stochasticity", True),
+    ("prediction_type", "epsilon"): ("skrample_predictor", NoiseModel()),
+    ("prediction_type", "flow"): ("skrample_predictor", FlowModel()),
+    ("prediction_type", "sample"): ("skrample_predictor", DataModel()),
+    ("prediction_type", "v_prediction"): ("skrample_predictor", VelocityModel()),
+    # later entries win
+    ("use_flow_sigmas", True): ("skrample_subschedule", None),
+    ("use_beta_sigmas", True): ("skrample_subschedule", scheduling.Beta),
+    ("use_exponential_sigmas", True): ("skrample_subschedule", scheduling.Exponential),
+    ("use_karras_sigmas", True): ("skrample_subschedule", scheduling.Karras),
+}
+DIFFUSERS_VALUE_MAP_REV: dict[tuple[str, Any], tuple[str, Any]] = {v: k for k, v in DIFFUSERS_VALUE_MAP.items()}
+
+DEFAULT_FAKE_CONFIG = {
+    "base_image_seq_len": 256,
+    "base_shift": 0.5,
+    "max_image_seq_len": 4096,
+    "max_shift": 1.15,
+    "use_dynamic_shifting": True,
+}
+
+
+@dataclasses.dataclass(frozen=True)
+class ParsedDiffusersConfig:
+    sampler: type[StructuredSampler]
+    sampler_props: dict[str, Any]
+    schedule: type[SkrampleSchedule]
+    schedule_props: dict[str, Any]
+    subschedule: type[SubSchedule] | None
+    subschedule_props: dict[str, Any]
+    schedule_modifiers: list[tuple[type[ScheduleModifier], dict[str, Any]]]
+    model: DiffusionModel
+    invert_prediction: bool
+
+
+def _field_names(cls) -> list[str]:
+    return [f.name for f in dataclasses.fields(cls)]
+
+
+def parse_diffusers_config(config, sampler: type[StructuredSampler] | None = None, schedule: type[SkrampleSchedule] | None = None) -> ParsedDiffusersConfig:
+    "translate a diffusers scheduler (or its config dict) into skrample classes + keyword props"
+    class_name = config.get("_class_name", "") if isinstance(config, dict) else type(config).__name__
+    if not isinstance(config, dict):
+        config = dict(config.config)
+
+    mapped: dict[str, Any] = {dst: config[src] for src, dst in DIFFUSERS_KEY_MAP.items() if src in config}
+    for (src, src_value), (dst, dst_value) in DIFFUSERS_VALUE_MAP.items():
+        if src in config and config[src] == src_value:
+            mapped[dst] = dst_value
+
+    if "skrample_predictor" in mapped:
+        model: DiffusionModel = mapped.pop("skrample_predictor")
+    elif "shift" in mapped:
+        model = FlowModel()
+    else:
+        model = NoiseModel()
+
+    sampler_props: dict[str, Any] = {}
+    if not sampler:
+        sampler, sampler_props = DIFFUSERS_CLASS_MAP.get(class_name, (sampling.DPM, {}))
+
+    if not schedule:
+        if isinstance(model, FlowModel):
+            schedule = scheduling.Linear
+        elif config.get("rescale_betas_zero_snr", False):
+            schedule = scheduling.ZSNR
+        else:
+            schedule = scheduling.Scaled
+
+    # a Linear schedule for a non-flow model starts at the sigma the beta schedule would reach
+    if "sigma_start" not in mapped and not isinstance(model, FlowModel) and issubclass(schedule, scheduling.Linear):
+        beta = scheduling.Scaled(**{k: v for k, v in mapped.items() if k in _field_names(scheduling.Scaled)})
+        mapped["sigma_start"] = beta.space.regularize(beta.point_1.sigma).item()
+
+    modifiers: list[tuple[type[ScheduleModifier], dict[str, Any]]] = []
+    subschedule: type[SubSchedule] | None = None
+    subschedule_props: dict[str, Any] = {}
+    if "skrample_subschedule" in mapped:
+        subschedule = mapped.pop("skrample_subschedule")
+        if config.get("use_flow_sigmas", False) is True and subschedule in (scheduling.Karras, scheduling.Exponential):
+            subschedule = None  # flow sigmas + karras/exponential flags: flow wins
+        if subschedule:
+            subschedule_props = {k: v for k, v in mapped.items() if k in _field_names(subschedule)}
+
+    if isinstance(model, FlowModel) and not subschedule:
+        modifiers.append((scheduling.FlowShift, {k: v for k, v in mapped.items() if k in _field_names(scheduling.FlowShift)}))
+
+    invert = class_name == "MiniMaxH3Scheduler"
+    if invert and "base_timesteps" not in mapped:
+        mapped["base_timesteps"] = -1
+
+    return ParsedDiffusersConfig(
+        sampler=sampler,
+        sampler_props=sampler_props | {k: v for k, v in mapped.items() if k in _field_names(sampler)},
+        schedule=schedule,
+        schedule_props={k: v for k, v in mapped.items() if k in _field_names(schedule)},
+        subschedule=subschedule,
+        subschedule_props=subschedule_props,
+        schedule_modifiers=modifiers,
+        model=model,
+        invert_prediction=invert,
+    )
+
+
+def attr_dict(**kwargs) -> OrderedDict:
+    "OrderedDict whose items are also attributes (what diffusers' BaseOutput looks like to callers)"
+    od = OrderedDict(**kwargs)
+    for k, v in od.items():
+        setattr(od, k, v)
+    return od
+
+
+def as_diffusers_config(sampler: StructuredSampler, schedule: SkrampleSchedule, model: DiffusionModel) -> dict[str, Any]:
+    "best-effort inverse of parse_diffusers_config"
+    cfg = dataclasses.asdict(sampler)
+    cfg["skrample_predictor"] = model
+    if isinstance(schedule, ScheduleModifier):
+        sub = schedule.all_split[1]
+        if sub is not None:
+            cfg["skrample_subschedule"] = type(sub)
+    else:
+        cfg |= dataclasses.asdict(schedule)
+    renamed = {DIFFUSERS_KEY_MAP_REV[k]: v for k, v in cfg.items() if k in DIFFUSERS_KEY_MAP_REV}
+    revalued = {}
+    for k, v in cfg.items():
+        if isinstance(v, Hashable) and (k, v) in DIFFUSERS_VALUE_MAP_REV:
+            dk, dv = DIFFUSERS_VALUE_MAP_REV[(k, v)]
+            revalued[dk] = dv
+    return cfg | renamed | revalued
+
+
+def _build_schedule(parsed: ParsedDiffusersConfig, schedule, subschedule, schedule_modifiers, schedule_props, subschedule_props, merge: MergeStrategy):
+    built = (schedule or parsed.schedule)(**parsed.schedule_props | schedule_props)
+    sub = subschedule or parsed.subschedule
+    if sub is not None and isinstance(built, ScheduleCommon):
+        built = sub(built, **parsed.subschedule_props | subschedule_props)
+    if isinstance(built, (ScheduleCommon, SubSchedule, ScheduleModifier)):
+        for modifier, props in merge.merge(ours=schedule_modifiers, theirs=parsed.schedule_modifiers, cmp=lambda a, b: a[0] is b[0]):
+            built = modifier(base=built, **props)
+    return built
+
+
+def _apply_dynamic(schedule: SkrampleSchedule, steps: int, mu: float | None) -> SkrampleSchedule:
+    "per-run schedule tweaks: FlowShift.shift = exp(mu); Karras/Exponential.steps = steps"
+    if mu is not None and isinstance(schedule, ScheduleModifier):
+        found = schedule.find_split(scheduling.FlowShift)
+        if found is not None:
+            before, flow, after, sub, base = found
+            schedule = schedule.stack([*before, dataclasses.replace(flow, shift=math.exp(mu)), *after], sub, base)
+    ramped = (scheduling.Karras, scheduling.Exponential)
+    if isinstance(schedule, ramped):
+        schedule = dataclasses.replace(schedule, steps=steps)
+    elif isinstance(schedule, ScheduleModifier):
+        mods, sub, base = schedule.all_split
+        if isinstance(sub, ramped):
+            schedule = schedule.stack(mods, dataclasses.replace(sub, steps=steps), base)
+    return schedule
+
+
+def _host_number(timestep) -> float | None:
+    "python number for host scalars / CPU tensors; None for device tensors (no sync)"
+    if isinstance(timestep, (int, float)):
+        return timestep
+    if isinstance(timestep, Tensor):
+        return None if timestep.is_cuda else timestep.item()
+    return float(timestep)
+
+
+@dataclasses.dataclass
+class SkrampleWrapperCore(abc.ABC):
+    def __post_init__(self) -> None:
+        self._steps: int = 50
+        self._index: int = 0
+        self._device: torch.device = torch.device("cpu")
+        self._noise_generator: BatchTensorNoise | None = None
+
+    @property
+    @abc.abstractmethod
+    def sigma_space(self) -> scheduling.SigmaSpace: ...
+
+    @property
+    @abc.abstractmethod
+    def schedule_np(self) -> np.ndarray: ...
+
+    @property
+    @abc.abstractmethod
+    def config(self) -> OrderedDict: ...
+
+    @property
+    def schedule_pt(self) -> Tensor:
+        return torch.from_numpy(self.schedule_np).to(self._device)
+
+    @property
+    def timesteps(self) -> Tensor:
+        return torch.from_numpy(self.schedule_np[:, 0]).to(self._device)
+
+    @property
+    def sigmas(self) -> Tensor:
+        regular = torch.from_numpy(self.sigma_space.regularize(self.schedule_np[:, 1])).to(self._device)
+        return torch.cat([regular, torch.zeros([1], device=regular.device, dtype=regular.dtype)])  # diffusers wants the trailing 0
+
+    @property
+    def init_noise_sigma(self) -> float:
+        return 1
+
+    @property
+    def order(self) -> int:
+        return 1
+
+    @abc.abstractmethod
+    def functional_interface(self): ...
+
+    def functional_sample_model(self, sample, model, steps: int, include: slice = slice(None), rng=None, callback=None):
+        sampler, schedule, transform = self.functional_interface()
+        return sampler.sample_model(sample, model, transform, schedule, steps, include, rng, callback)
+
+    def functional_generate_model(self, model, rng, steps: int, include: slice = slice(None), initial=None, callback=None):
+        sampler, schedule, transform = self.functional_interface()
+        return sampler.generate_model(model, transform, schedule, rng, steps, include, initial, callback)
+
+    def _make_noise_generator(self, step: Step, sample: Tensor, noise_type, noise_props, generator) -> BatchTensorNoise:
+        if isinstance(generator, list) and len(generator) == sample.shape[0]:
+            seeds: list = generator
+        elif isinstance(generator, torch.Generator) and sample.shape[0] == 1:
+            seeds = [generator]
+        else:
+            # fallback: seed from each item's middle element (one small gather + sync, first step only)
+            flat = sample.reshape(sample.shape[0], -1)
+            mids = flat[:, flat.shape[1] // 2].to(torch.float64).cpu().tolist()
+            seeds = [int(v * 1e4 * (step.position() + 1)) for v in mids]
+        return BatchTensorNoise.from_batch_inputs(noise_type, unit_shape=tuple(sample.shape[1:]), seeds=seeds, props=noise_props, dtype=sample.dtype)
+
+    def get_step_noise(self, step: Step, sample: Tensor, noise_type, noise_props, generator=None, dtype: torch.dtype | None = None, lazy_ok: bool = False):
+        """noise for this step: [B, *unit].  With `lazy_ok` plain white noise comes back symbolic
+        (drawn inside the step kernel); otherwise a tensor of `dtype or sample.dtype`."""
+        if self._noise_generator is None:
+            self._noise_generator = self._make_noise_generator(step, sample, noise_type, noise_props, generator)
+        if lazy_ok:
+            return self._noise_generator.generate_lazy(step)
+        noise = self._noise_generator.generate(step)
+        return lazy.cast(noise, dtype or sample.dtype)
+
+    @abc.abstractmethod
+    def scale_noise(self, sample: Tensor, timestep: Tensor, noise: Tensor) -> Tensor: ...
+
+    @abc.abstractmethod
+    def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None, sigmas=None, mu=None) -> None: ...
+
+    @abc.abstractmethod
+    def step(self, model_output, timestep, sample, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict=True): ...
+
+    def set_begin_index(self, begin_index: int = 0) -> None:
+        self._index = begin_index
+
+    def add_noise(self, original_samples: Tensor, noise: Tensor, timesteps: Tensor) -> Tensor:
+        if len(timesteps) == 0:
+            return original_samples
+        return self.scale_noise(original_samples, timesteps[0], noise)
+
+    def scale_model_input(self, sample: Tensor, timestep) -> Tensor:
+        return sample
+
+    def time_shift(self, mu: float, sigma: float, t: Tensor) -> Tensor:
+        return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+
+    # ---- shared helpers ---------------------------------------------------------------------------
+    def _resolve_steps(self, num_inference_steps, timesteps, sigmas) -> int | None:
+        if num_inference_steps is not None:
+            return num_inference_steps
+        if timesteps is not None:
+            return len(timesteps)
+        if sigmas is not None:
+            return len(sigmas)
+        return None
+
+    def _lookup(self, table: Sequence[float], timestep, expected: int) -> int:
+        value = _host_number(timestep)
+        if value is None:  # device tensor: trust the schedule order, no sync
+            if not 0 <= expected < len(table):
+                raise ValueError(f"step {expected} is outside the {len(table)}-step schedule")
+            return expected
+        return table.index(value)
+
+    @staticmethod
+    def _finish(prev, pred, like: Tensor, return_dict: bool):
+        def conv(v):
+            if isinstance(v, LazyTensor):
+                return v if v.dtype == like.dtype else LazyTensor(v.form, like.dtype)
+            return lazy.cast(v, like.dtype) if isinstance(v, Tensor) else v
+
+        prev, pred = conv(prev), conv(pred)
+        return attr_dict(prev_sample=prev, pred_original_sample=pred) if return_dict else (prev, pred)
+
+
+@dataclasses.dataclass
+class SkrampleWrapperScheduler(SkrampleWrapperCore):
+    sampler: StructuredSampler
+    schedule: SkrampleSchedule
+    model: DiffusionModel = NoiseModel()  # noqa: RUF009
+    noise_type: type[TensorNoiseCommon] = Random
+    noise_props: TensorNoiseProps | None = None
+    compute_scale: torch.dtype | None = torch.float32
+    allow_dynamic: bool = True
+    invert_prediction: bool = False
+    fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
+
+    def __post_init__(self) -> None:
+        super().__post_init__()
+        self._previous: list[SKSamples] = []
+        self._schedule = self.schedule  # pristine copy restored by set_timesteps
+        self._calls = 0
+
+    @classmethod
+    def from_diffusers_config(
+        cls,
+        config,
+        sampler: type[StructuredSampler] | None = None,
+        schedule: type[SkrampleSchedule] | None = None,
+        subschedule: type[SubSchedule] | None = None,
+        schedule_modifiers: list[tuple[type[ScheduleModifier], dict[str, Any]]] = [],  # noqa: B006
+        model: DiffusionModel | None = None,
+        noise_type: type[TensorNoiseCommon] = Random,
+        compute_scale: torch.dtype | None = torch.float32,
+        sampler_props: dict[str, Any] = {},  # noqa: B006
+        noise_props: TensorNoiseProps | None = None,
+        schedule_props: dict[str, Any] = {},  # noqa: B006
+        subschedule_props: dict[str, Any] = {},  # noqa: B006
+        modifier_merge_strategy: MergeStrategy = MergeStrategy.UniqueBefore,
+        allow_dynamic: bool = True,
+        invert_prediction: bool | None = None,
+    ) -> "SkrampleWrapperScheduler":
+        parsed = parse_diffusers_config(config=config, sampler=sampler, schedule=schedule)
+        return cls(
+            (sampler or parsed.sampler)(**parsed.sampler_props | sampler_props),
+            _build_schedule(parsed, schedule, subschedule, schedule_modifiers, schedule_props, subschedule_props, modifier_merge_strategy),
+            model or parsed.model,
+            noise_type=noise_type,
+            noise_props=noise_props,
+            compute_scale=compute_scale,
+            fake_config=config.copy() if isinstance(config, dict) else dict(config.config),
+            allow_dynamic=allow_dynamic,
+            invert_prediction=parsed.invert_prediction if invert_prediction is None else invert_prediction,
+        )
+
+    def functional_interface(self):
+        return interface.StructuredFunctionalAdapter(self.sampler), self._schedule, self.model
+
+    @property
+    def sigma_space(self) -> scheduling.SigmaSpace:
+        return self.schedule.space
+
+    @property
+    def schedule_np(self) -> np.ndarray:
+        return scheduling.np_schedule_lru(self.schedule, self._steps)
+
+    @property
+    def init_noise_sigma(self) -> float:
+        return self.sampler.scale_input(1, Point(*self.schedule_np[0]))
+
+    @property
+    def order(self) -> int:
+        return 1
+
+    @property
+    def config(self) -> OrderedDict:
+        return attr_dict(**(self.fake_config | as_diffusers_config(self.sampler, self._schedule, self.model)))
+
+    def set_begin_index(self, begin_index: int = 0) -> None:
+        super().set_begin_index(begin_index)
+        self._calls = 0
+        self.fake_config["begin_index"] = begin_index
+
+    def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None, sigmas=None, mu=None) -> None:
+        self._index = 0
+        self._calls = 0
+        self.schedule = self._schedule
+        steps = self._resolve_steps(num_inference_steps, timesteps, sigmas)
+        if steps is None:
+            return
+        self._steps = steps
+        if self.allow_dynamic:
+            self.schedule = _apply_dynamic(self.schedule, steps, mu)
+        self._previous = []
+        self._noise_generator = None
+        self._timestep_list = None
+        if device is not None:
+            self._device = torch.device(device)
+
+    def _timestep_table(self) -> list[float]:
+        key = (self.schedule, self._steps)
+        if getattr(self, "_timestep_list", None) is None or self._timestep_key != key:
+            self._timestep_list = self.schedule_np[:, 0].tolist()
+            self._timestep_key = key
+        return self._timestep_list
+
+    def scale_noise(self, sample: Tensor, timestep: Tensor, noise: Tensor) -> Tensor:
+        idx = self._lookup(self._timestep_table(), timestep, self._index)
+        return self.sampler.add_noise(sample, noise, Point(*self.schedule_np[idx]))
+
+    def scale_model_input(self, sample: Tensor, timestep) -> Tensor:
+        idx = self._lookup(self._timestep_table(), timestep, self._index + self._calls)
+        return self.sampler.scale_input(sample, Point(*self.schedule_np[idx]))
+
+    def step(self, model_output: Tensor, timestep, sample: Tensor, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict: bool = True):
+        table = self._timestep_table()
+        idx = self._lookup(table, timestep, self._index + self._calls)
+        self._calls += 1
+        step = Step.from_int(idx, len(table))
+
+        prediction = LazyTensor(-Lin.leaf(model_output), model_output.dtype) if self.invert_prediction else model_output
+        noise = None
+        if self.sampler.require_noise:
+            noise = self.get_step_noise(step, sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
+
+        with lazy.compute_scale(self.compute_scale):
+            record = self.sampler.sample_packed(
+                SampleInput(sample=sample, prediction=prediction, step=step, noise=noise),
+                model_transform=self.model,
+                schedule=self.schedule,
+                previous=self._previous,
+            )
+        self._previous.append(record)
+        self._previous = self._previous[max(len(self._previous) - self.sampler.require_previous, 0) :]
+        return self._finish(record.final, record.prediction, model_output, return_dict)
+
+
+@dataclasses.dataclass
+class RKWrapperCore(SkrampleWrapperCore):
+    """Runge-Kutta samplers turned inside out: the pipeline calls `step()` once per *stage* and
+    receives the next stage input (or, after the last stage, the step result)."""
+
+    schedule: SkrampleSchedule
+    sampler_order: int = traits.UnifiedModelling.order
+    stochasticity: float = 0
+    model: DiffusionModel = NoiseModel()  # noqa: RUF009
+    derivative_transform: DiffusionModel | None = traits.UnifiedModelling.derivative_transform
+    noise_type: type[TensorNoiseCommon] = Random
+    noise_props: TensorNoiseProps | None = None
+    compute_scale: torch.dtype | None = torch.float32
+    allow_dynamic: bool = True
+    invert_prediction: bool = False
+    fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
+
+    def __post_init__(self) -> None:
+        super().__post_init__()
+        self._index = 0
+        self._derivatives: list = []  # lazy derivative forms of the stages of the current step
+        self._sample = None  # base sample of the current step (alias of the caller's tensor)
+        self._schedule = self.schedule
+
+    @abc.abstractmethod
+    def functional_sampler(self): ...
+
+    def functional_interface(self):
+        return self.functional_sampler(), self._schedule, self.model
+
+    @abc.abstractmethod
+    def tableau(self) -> tableaux.Tableau: ...
+
+    def adjust_steps(self, steps: int) -> int:
+        return self.functional_interface()[0].adjust_steps(steps)
+
+    @abc.abstractmethod
+    def _schedule_full(self, steps: int) -> Sequence[Point]: ...
+
+    @functools.cached_property
+    def all_points(self) -> Sequence[Point]:
+        "every point a stage is evaluated at, clean-end stages included"
+        return self._schedule_full(self._steps)
+
+    @functools.cached_property
+    def schedule_np_trim(self) -> np.ndarray:
+        "all_points without the stages that sit on the clean end (the network is never called there)"
+        clean = self.schedule.point_0
+        kept = [p for p in self.all_points if abs(p.timestep - clean.timestep) > 1e-8 and abs(p.sigma - clean.sigma) > 1e-8]
+        return np.asarray(kept if kept else self.all_points, dtype=np.float64)
+
+    @property
+    def sigma_space(self) -> scheduling.SigmaSpace:
+        return self.schedule.space
+
+    @property
+    def schedule_np(self) -> np.ndarray:
+        return self.schedule_np_trim
+
+    @property
+    def order(self) -> int:
+        return len(self.tableau().stages)
+
+    @property
+    def config(self) -> OrderedDict:
+        return attr_dict(**self.fake_config)
+
+    def set_begin_index(self, begin_index: int = 0) -> None:
+        assert begin_index % self.order == 0, f"Expected {begin_index=} to be multiple of {self.order=}!"
+        super().set_begin_index(begin_index)
+        self.fake_config["begin_index"] = begin_index
+
+    def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None, sigmas=None, mu=None) -> None:
+        self._index = 0
+        self._derivatives.clear()
+        self._sample = None
+        with contextlib.suppress(AttributeError):
+            del self.all_points
+        with contextlib.suppress(AttributeError):
+            del self.schedule_np_trim
+        self.schedule = self._schedule
+        steps = self._resolve_steps(num_inference_steps, timesteps, sigmas)
+        if steps is None:
+            return
+        self._steps = steps
+        if self.allow_dynamic:
+            self.schedule = _apply_dynamic(self.schedule, steps, mu)
+        self._noise_generator = None
+        if device is not None:
+            self._device = torch.device(device)
+
+    def scale_noise(self, sample: Tensor, timestep: Tensor, noise: Tensor) -> Tensor:
+        idx = self._lookup(self.schedule_np[:, 0].tolist(), timestep, 0)
+        return Point(*self.schedule_np[idx]).add_noise(sample, noise)
+
+    def _stage_form(self, sample, derivative, space: DiffusionModel, s0: Point, s1: Point, sn: Point, generator):
+        """append this stage's derivative; return the lazy form of the next stage input, or of the step
+        result when all stages are in (reference step_tableau_inside_out, diffusers.py:746-796)"""
+        nodes, weights = self.tableau()
+        self._derivatives.append(derivative)
+        if self._sample is None:
+            self._sample = sample
+        base = lift(self._sample)
+        if len(self._derivatives) == len(weights):
+            noise = None
+            if abs(self.stochasticity) > 1e-8:
+                noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), self._sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
+            mix = sum((d * w for d, w in zip(self._derivatives[1:], weights[1:])), self._derivatives[0] * weights[0])
+            form = space.update_form(base, mix, DeltaPoint(s0, s1), noise, self.stochasticity)
+            self._derivatives = []
+            self._sample = None
+            return form
+        row = nodes[len(self._derivatives)][1]
+        if row:
+            mix = sum((d * w for d, w in zip(self._derivatives[1:], row[1:])), self._derivatives[0] * row[0]) / math.fsum(row)
+            return space.update_form(base, mix, DeltaPoint(s0, sn))
+        raise ValueError
+
+    def step(self, model_output: Tensor, timestep, sample: Tensor, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict: bool = True):
+        value = _host_number(timestep)
+        expected = self.all_points[self._index].timestep
+        if value is not None:
+            assert value == expected, f"Expected timestep {expected} for step {self._index}, got {timestep=}!"
+
+        points = [*self.all_points, Point(0, 0, 1)]
+        conv = None
+        if self.derivative_transform:
+            space = self.derivative_transform
+            convert = models.ModelConvert(self.model, self.derivative_transform)
+            program = convert.rounded_program(points[self._index], negate_output=self.invert_prediction)
+            if program is not None and program[:2] != (0, 0):
+                # the reference converts in the input dtype, op by op, BEFORE widening (diffusers.py:819-834)
+                conv = lazy.RoundedConversion(sample, model_output, *program)
+                derivative = conv.node()
+            else:
+                output = -Lin.leaf(model_output) if self.invert_prediction else lift(model_output)
+                ws, wo = convert.weights_to(points[self._index])
+                derivative = lift(sample) * ws + output * wo if ws != 0 else output * wo
+        else:
+            derivative, space = (-Lin.leaf(model_output) if self.invert_prediction else lift(model_output)), self.model
+
+        held = len(self._derivatives)
+        i0 = self._index - held
+        i1 = self._index + self.order - held
+        form = self._stage_form(sample, derivative, space, points[i0], points[i1], points[self._index + 1], generator)
+        self._index += 1
+
+        clean = self.schedule.point_0
+        while self._index < len(self.all_points) and (
+            abs(self.all_points[self._index].timestep - clean.timestep) < 1e-8 or abs(self.all_points[self._index].sigma - clean.sigma) < 1e-8
+        ):
+            # stage on the clean end: synthesise the derivative that reproduces the pending stage input
+            base = lift(sample if self._sample is None else self._sample)
+            delta = DeltaPoint(points[i0], points[i1])
+            synth = (form - base * space.gamma(delta)) / space.delta(delta)
+            form = self._stage_form(sample, synth, space, points[i0], points[i1], points[self._index + 1], generator)
+            self._index += 1
+
+        with lazy.compute_scale(self.compute_scale):
+            if conv is not None:
+                converted, result = lazy.evaluate([conv, form], [None, model_output.dtype])
+                self._derivatives = [d.substitute(conv, converted) for d in self._derivatives]
+                pred = converted
+            else:
+                result = lazy.evaluate([form], [model_output.dtype])[0]
+                pred = LazyTensor(derivative, model_output.dtype) if (self.derivative_transform or self.invert_prediction) else model_output
+        return self._finish(result, pred, model_output, return_dict)
+
+
+def _rk_from_config(cls, config, schedule, subschedule, schedule_modifiers, schedule_props, subschedule_props, merge, model, invert_prediction, **fields):
+    parsed = parse_diffusers_config(config=config, sampler=None, schedule=schedule)
+    return cls(
+        _build_schedule(parsed, schedule, subschedule, schedule_modifiers, schedule_props, subschedule_props, merge),
+        model=model or parsed.model,
+        fake_config=config.copy() if isinstance(config, dict) else dict(config.config),
+        invert_prediction=parsed.invert_prediction if invert_prediction is None else invert_prediction,
+        **fields,
+    )
+
+
+@dataclasses.dataclass
+class RKUltraWrapperScheduler(RKWrapperCore):
+    providers: Mapping[int, Any] = functional.RKUltra.providers
+
+    @classmethod
+    def from_diffusers_config(
+        cls,
+        config,
+        schedule: type[SkrampleSchedule] | None = None,
+        sampler_order: int = functional.RKUltra.order,
+        stochasticity: float = 0,
+        subschedule: type[SubSchedule] | None = None,
+        schedule_modifiers: list[tuple[type[ScheduleModifier], dict[str, Any]]] = [],  # noqa: B006
+        providers: Mapping[int, Any] = functional.RKUltra.providers,
+        model: DiffusionModel | None = None,
+        noise_type: type[TensorNoiseCommon] = Random,
+        derivative_transform: DiffusionModel | None = functional.RKUltra.derivative_transform,
+        compute_scale: torch.dtype | None = torch.float32,
+        schedule_props: dict[str, Any] = {},  # noqa: B006
+        subschedule_props: dict[str, Any] = {},  # noqa: B006
+        noise_props: TensorNoiseProps | None = None,
+        modifier_merge_strategy: MergeStrategy = MergeStrategy.UniqueBefore,
+        allow_dynamic: bool = True,
+        invert_prediction: bool | None = None,
+    ) -> "RKUltraWrapperScheduler":
+        return _rk_from_config(
+            cls, config, schedule, subschedule, schedule_modifiers, schedule_props, subschedule_props, modifier_merge_strategy, model, invert_prediction,
+            sampler_order=sampler_order, stochasticity=stochasticity, providers=providers, derivative_transform=derivative_transform,
+            noise_type=noise_type, noise_props=noise_props, compute_scale=compute_scale, allow_dynamic=allow_dynamic,
+        )  # fmt: skip
+
+    def functional_sampler(self) -> functional.RKUltra:
+        return functional.RKUltra(order=self.sampler_order, stochasticity=self.stochasticity, derivative_transform=self.derivative_transform, providers=MappingProxyType(dict(self.providers)))
+
+    def tableau(self) -> tableaux.Tableau:
+        return self.functional_sampler().tableau()
+
+    def _schedule_full(self, steps: int) -> Sequence[Point]:
+        "stage times are c_j fractions of each step: read the points straight off the schedule"
+        nodes = self.tableau().stages
+        seen: list[Point] = []
+        for n in range(steps):
+            t0, t1 = Step.from_int(n, steps)
+            seen.extend(self.schedule.ipoints([t0 + c * (t1 - t0) for c, _ in nodes]))
+        return seen
+
+
+@dataclasses.dataclass
+class DynasauRKWrapperScheduler(RKWrapperCore):
+    @classmethod
+    def from_diffusers_config(
+        cls,
+        config,
+        schedule: type[SkrampleSchedule] | None = None,
+        sampler_order: int = functional.RKUltra.order,
+        stochasticity: float = 0,
+        subschedule: type[SubSchedule] | None = None,
+        schedule_modifiers: list[tuple[type[ScheduleModifier], dict[str, Any]]] = [],  # noqa: B006
+        model: DiffusionModel | None = None,
+        noise_type: type[TensorNoiseCommon] = Random,
+        derivative_transform: DiffusionModel | None = functional.RKUltra.derivative_transform,
+        compute_scale: torch.dtype | None = torch.float32,
+        schedule_props: dict[str, Any] = {},  # noqa: B006
+        subschedule_props: dict[str, Any] = {},  # noqa: B006
+        noise_props: TensorNoiseProps | None = None,
+        modifier_merge_strategy: MergeStrategy = MergeStrategy.UniqueBefore,
+        allow_dynamic: bool = True,
+        invert_prediction: bool | None = None,
+    ) -> "DynasauRKWrapperScheduler":
+        return _rk_from_config(
+            cls, config, schedule, subschedule, schedule_modifiers, schedule_props, subschedule_props, modifier_merge_strategy, model, invert_prediction,
+            sampler_order=sampler_order, stochasticity=stochasticity, derivative_transform=derivative_transform,
+            noise_type=noise_type, noise_props=noise_props, compute_scale=compute_scale, allow_dynamic=allow_dynamic,
+        )  # fmt: skip
+
+    def functional_sampler(self) -> functional.DynasauRK:
+        return functional.DynasauRK(order=self.sampler_order, stochasticity=self.stochasticity, derivative_transform=self.derivative_transform)
+
+    def tableau(self) -> tableaux.Tableau:
+        fs = self.functional_sampler()
+        stages = len(fs.tableau(Step(0, 1)).stages)
+        return fs.tableau(Step.from_int(self._index // stages, self._steps))
+
+    def _schedule_full(self, steps: int) -> Sequence[Point]:
+        fs = self.functional_sampler()
+        seen: list[Point] = []
+        for n in range(steps):
+            step = Step.from_int(n, steps)
+            t0, t1 = step
+            seen.extend(self.schedule.ipoints([t0 + c * (t1 - t0) for c, _ in fs.tableau(step).stages]))
+        assert len(seen) == self.order * steps
+        return seen

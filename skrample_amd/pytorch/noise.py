@@ -1,0 +1,225 @@
+"""Device noise generators behind skrample's noise protocol.
+
+Class names, constructor fields and `generate(step)` follow reference `skrample/pytorch/noise.py`
+(SkrampleTensorNoise :17-24, TensorNoiseCommon :27-55, Random :58-74, Offset :77-113,
+Pyramid :116-207, Colored :255-435, BatchTensorNoise :438-466).  What differs:
+
+* Randomness is counter-based Philox4x32-10 keyed by a 64-bit per-sample seed (taken from
+  `torch.Generator.initial_seed()` or an int), never a torch generator stream.  Draw `n` of a
+  generator uses Philox stream id n*256 + k (k numbers the independent normals one draw needs), so
+  any draw can be re-created later from (seed, stream) alone, results do not depend on batch
+  sharding, and plain `Random` noise never has to exist in memory: `generate_lazy()` returns a
+  symbolic `PhiloxNoise` that the step kernel draws in registers.
+* A whole batch is one launch (`BatchTensorNoise` holds a device seed vector), not a Python loop
+  over per-sample generators followed by `torch.stack`.
+* Bit-level agreement with torch's CPU mt19937 / CUDA Philox streams is impossible by construction;
+  the deterministic stages (offset broadcast, pyramid up-sampling, spectral colouring, per-sample
+  normalisation) are parity-tested on injected draws (tests/test_noise_gpu.py).
+
+`Brownian` (torchsde-backed in the reference) is out of scope for this engine.
+"""
+
+from __future__ import annotations
+
+import math
+from abc import ABC, abstractmethod
+from dataclasses import dataclass, field
+from typing import Any, Sequence
+
+import torch
+
+from .. import _hip
+from .._hip import SkrampleHipError
+from ..common import Step, divf, rescale_positive
+from ..sampling.lazy import PhiloxNoise
+
+SUBSTREAMS = 256  # Philox stream ids per draw
+
+
+@dataclass(frozen=True)
+class TensorNoiseProps:
+    "configuration of a generator; reuse this, not the (stateful) generator"
+
+
+def seed_value(seed) -> int:
+    "64-bit key from a torch.Generator (its initial seed) or an int"
+    if isinstance(seed, torch.Generator):
+        return seed.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    return int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
+def seed_device(seed) -> torch.device:
+    if isinstance(seed, torch.Generator) and seed.device.type == "cuda":
+        return seed.device
+    if not torch.cuda.is_available():
+        raise SkrampleHipError("no HIP device available: skrample_amd noise generators run on the GPU only")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def seeds_tensor(values: Sequence[int], device: torch.device) -> torch.Tensor:
+    signed = [v - (1 << 64) if v >= (1 << 63) else v for v in values]
+    return torch.tensor(signed, dtype=torch.int64, device=device)
+
+
+@dataclass
+class SkrampleTensorNoise(ABC):
+    @abstractmethod
+    def generate(self, step: Step | None) -> torch.Tensor:
+        "next noise tensor; stateful (advances the draw counter)"
+
+
+@dataclass
+class TensorNoiseCommon(SkrampleTensorNoise):
+    shape: tuple[int, ...]
+    seed: Any  # torch.Generator | int
+    dtype: torch.dtype
+    props: Any
+
+    def __post_init__(self) -> None:
+        self._draws = 0
+        self._seeds_cache = None
+        self._setup()
+
+    @property
+    def _device(self) -> torch.device:
+        return seed_device(self.seed)
+
+    @property
+    def _seeds(self) -> torch.Tensor:
+        "device seed vector (length 1), created on first single-generator use"
+        if self._seeds_cache is None:
+            self._seeds_cache = seeds_tensor([seed_value(self.seed)], self._device)
+        return self._seeds_cache
+
+    def _setup(self) -> None: ...
+
+    def _next_stream(self) -> int:
+        n = self._draws
+        self._draws += 1
+        return n * SUBSTREAMS
+
+    @classmethod
+    @abstractmethod
+    def from_inputs(cls, shape, seed, props=None, dtype: torch.dtype = torch.float32): ...
+
+    # batched core: every generator implements the whole-batch form; a single generator is batch 1
+    @classmethod
+    @abstractmethod
+    def _batch(cls, unit_shape, seeds: torch.Tensor, stream: int, step: Step | None, props, dtype, state: dict) -> torch.Tensor: ...
+
+    @classmethod
+    def _batch_lazy(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        "symbolic result when the generator is plain white noise, else the realised tensor"
+        return cls._batch(unit_shape, seeds, stream, step, props, dtype, state)
+
+    def generate(self, step: Step | None) -> torch.Tensor:
+        if not hasattr(self, "_state"):
+            self._state = {}
+        return self._batch(tuple(self.shape), self._seeds, self._next_stream(), step, self.props, self.dtype, self._state)[0]
+
+
+@dataclass
+class Random(TensorNoiseCommon):
+    "plain standard-normal noise"
+
+    @classmethod
+    def from_inputs(cls, shape, seed, props=None, dtype=torch.float32):
+        return cls(tuple(shape), seed, dtype, props)
+
+    @classmethod
+    def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        return cls._batch_lazy(unit_shape, seeds, stream, step, props, dtype, state).realize(dtype)
+
+    @classmethod
+    def _batch_lazy(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        return PhiloxNoise(seeds, stream, (seeds.shape[0], *unit_shape), seeds.device)
+
+
+@dataclass(frozen=True)
+class OffsetProps(TensorNoiseProps):
+    dims: tuple[int, ...] = (0,)
+    strength: float = 0.2
+    static: bool = False
+
+
+@dataclass(frozen=True)
+class PyramidProps(OffsetProps):
+    dims: tuple[int, ...] = (-1, -2)
+    strength: float = 0.3
+    depth: int = 99
+
+
+@dataclass(frozen=True)
+class BrownianProps(TensorNoiseProps):
+    max_steps: int = 10_000
+
+
+@dataclass(frozen=True)
+class ColoredProps(TensorNoiseProps):
+    energy: float | None = None
+    color_start: float = 1 / 4
+    color_end: float = -2
+    color_curve: float = 2
+
+
+def colored_exponent(step: Step | None, props: ColoredProps) -> float:
+    "power-law exponent for this step: color_start at the beginning, color_end at time_to = 1"
+    if step is None:
+        return props.color_start
+    if props.color_curve == math.inf:
+        return props.color_end
+    t = step.normal().clamp().time_to
+    shift = rescale_positive(-props.color_curve)
+    t = shift / (shift + (divf(1, t) - 1))
+    return (1 - t) * props.color_start + t * props.color_end
+
+
+@dataclass
+class Brownian(TensorNoiseCommon):
+    def _setup(self) -> None:
+        raise SkrampleHipError("Brownian noise (torchsde BrownianInterval in the reference) is outside this engine's scope")
+
+    @classmethod
+    def from_inputs(cls, shape, seed, props=BrownianProps(), dtype=torch.float32):
+        return cls(tuple(shape), seed, dtype, props)
+
+    @classmethod
+    def _batch(cls, *a, **k):
+        raise SkrampleHipError("Brownian noise is outside this engine's scope")
+
+
+@dataclass
+class BatchTensorNoise(SkrampleTensorNoise):
+    """One logical generator per batch item, executed as a single launch.  `generators` is kept for
+    API compatibility (len == batch); the batch shares one draw counter."""
+
+    generators: list[TensorNoiseCommon]
+    _draws: int = field(default=0, repr=False)
+
+    def __post_init__(self) -> None:
+        if not self.generators:
+            raise ValueError("BatchTensorNoise needs at least one generator")
+        first = self.generators[0]
+        self._kind = type(first)
+        self._device = first._device
+        self._seeds = seeds_tensor([seed_value(g.seed) for g in self.generators], self._device)
+        self._state: dict = {}
+
+    def _stream(self) -> int:
+        n = self._draws
+        self._draws += 1
+        return n * SUBSTREAMS
+
+    def generate(self, step: Step | None) -> torch.Tensor:
+        g = self.generators[0]
+        return self._kind._batch(tuple(g.shape), self._seeds, self._stream(), step, g.props, g.dtype, self._state)
+
+    def generate_lazy(self, step: Step | None):
+        "PhiloxNoise (drawn inside the step kernel) for white noise, a realised tensor otherwise"
+        g = self.generators[0]
+        return self._kind._batch_lazy(tuple(g.shape), self._seeds, self._stream(), step, g.props, g.dtype, self._state)
+
+    @classmethod
+    def from_batch_inputs(cls, subclass, unit_shape, seeds: list, props=None, dtype: torch.dtype = torch.float32) -> "BatchTensorNoise":
+        unit_shape = tuple(unit_shape)
+        return cls([subclass.from_inputs(unit_shape, s, props, dtype) if props is not None else subclass.from_inputs(unit_shape, s, dtype=dtype) for s in seeds])

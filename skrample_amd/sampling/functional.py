@@ -1,0 +1,214 @@
+"""Closure-driven (functional) samplers: the sampler owns the loop and calls the model itself.
+
+Public surface follows reference `skrample/sampling/functional.py`: step_tableau (:55-105),
+FunctionalSampler.sample_model / generate_model (:108-149), RKUltra (:217-268), DynasauRK (:271-349)
+and the provider maps (:18-52).  The adaptive RKMoire (:352-472) is out of scope (needs a global
+error reduction and a host round-trip per step).
+
+One Runge-Kutta step with s stages costs exactly s fused launches: every stage input
+X_j = Gamma*x0 + Delta * (sum_i a_ji d_i)/sum_i a_ji and the final combination are single lazy
+forms over the *aliased* pairs (X_i, model(X_i)) -- the derivative conversions d_i = ws*X_i + wo*out_i
+are folded into the coefficients instead of being materialised.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import math
+from abc import ABC, abstractmethod
+from types import MappingProxyType
+from typing import Any, Callable, Mapping
+
+from .. import common, scheduling
+from ..common import DeltaPoint, Point, Step
+from . import lazy, models, tableaux, traits
+from .lazy import Lin, lift
+
+SampleCallback = Callable[[Any, int, DeltaPoint], Any]
+SampleableModel = Callable[[Any, float, float, float], Any]
+
+DEFAULT_PROVIDERS: Mapping[int, Any] = {
+    1: tableaux.RK1.Euler,
+    2: tableaux.RK2.Mid,
+    3: tableaux.RK2.EES5_MIN,
+    4: tableaux.RK2.EES7_MIN,
+    5: tableaux.SSP.RK4_5,
+    6: tableaux.RKE5.CashKarp,
+    7: tableaux.RKZ.Butcher6,
+    8: tableaux.SSP.RK3_8,
+    10: tableaux.SSP.RK5_10,
+    11: tableaux.RKZ.CV8,
+    15: tableaux.RKZ_UNAVAILABLE["Stepanov10"],
+}
+"default tableau per *stage count* (not mathematical order)"
+
+STABLE_PROVIDERS: Mapping[int, Any] = {
+    2: tableaux.RKE2.Heun,
+    3: tableaux.SSP.RK3_3,
+    4: tableaux.RKE3.SSPRK3_4,
+    5: tableaux.SSP.RK3_5,
+    6: tableaux.SSP.RK3_6,
+    7: tableaux.SSP.RK3_7,
+}
+
+DEFAULT_EMBEDDED_PROVIDERS: Mapping[int, Any] = {
+    2: tableaux.RKE2.Heun,
+    4: tableaux.RKE3.BogackiShampine,
+    6: tableaux.RKE5.Fehlberg,
+}
+
+
+def _materialise(value, like):
+    return lazy.settle(value, like=like) if isinstance(value, Lin) else value
+
+
+def step_tableau(
+    tableau,
+    sample,
+    model: SampleableModel,
+    model_transform: models.DiffusionModel,
+    schedule: scheduling.SkrampleSchedule,
+    step: Step,
+    derivative_transform: models.DiffusionModel | None = None,
+    noise=None,
+    stochasticity: float = 0,
+    epsilon: float = 1e-8,
+) -> tuple:
+    """One explicit Runge-Kutta step in derivative space; returns one result per weight row."""
+    nodes, weight_rows = tableau[0], tableau[1:]
+    convert = models.ModelConvert(model_transform, derivative_transform) if derivative_transform else None
+    space = derivative_transform or model_transform
+
+    t0, t1 = step
+    p0, p1, *stage_points = schedule.ipoints([t0, t1, *(t0 + c * (t1 - t0) for c, _ in nodes)])
+    delta = DeltaPoint(p0, p1)
+    base = lift(sample)
+    derivs: list = []
+    for point, (_, row) in zip(stage_points, nodes):
+        if row:
+            mix = common.sumprod(derivs, row) / math.fsum(row)
+            stage_in = _materialise(space.update_form(base, mix, DeltaPoint(p0, point)), sample)
+        else:
+            stage_in = sample
+        if abs(point.timestep) < epsilon or abs(point.sigma) < epsilon:
+            # never evaluate the network at the clean end: use the derivative that would reproduce X
+            g, d = space.gamma(delta), space.delta(delta)
+            derivs.append((lift(stage_in) - base * g) / d)
+        else:
+            out = model(stage_in, *point)
+            derivs.append(convert.form_to(stage_in, out, point) if convert else lift(out))
+    return tuple(
+        _materialise(space.update_form(base, common.sumprod(derivs, row), delta, noise, stochasticity), sample) for row in weight_rows
+    )
+
+
+@dataclasses.dataclass(frozen=True)
+class FunctionalSampler(ABC, traits.SamplingCommon):
+    @abstractmethod
+    def sample_model(self, sample, model, model_transform, schedule, steps: int, include: slice = slice(None), rng=None, callback=None):
+        "run the steps selected by `include` (of `steps` total) on an already-noised sample"
+
+    def generate_model(self, model, model_transform, schedule, rng, steps: int, include: slice = slice(None), initial=None, callback=None):
+        "like sample_model, but draws (and scales) the starting noise itself"
+        if initial is None and include.start is None:
+            sample = rng(None)
+        else:
+            start = schedule.ipoint((include.start or 0) / steps)
+            noise = rng(None)
+            mixed = lift(noise) * start.sigma if initial is None else lift(initial) * start.alpha + lift(noise) * start.sigma
+            full = schedule.point_1
+            sample = lazy.settle(mixed / (0.0 * full.alpha + 1.0 * full.sigma), like=noise)
+        return self.sample_model(sample, model, model_transform, schedule, steps, include, rng, callback)
+
+
+@dataclasses.dataclass(frozen=True)
+class FunctionalHigher(traits.HigherOrder, FunctionalSampler):
+    def adjust_steps(self, steps: int) -> int:
+        return round(steps / self.order)
+
+
+@dataclasses.dataclass(frozen=True)
+class FunctionalUnified(traits.UnifiedModelling, FunctionalHigher): ...
+
+
+@dataclasses.dataclass(frozen=True)
+class FunctionalSinglestep(FunctionalSampler):
+    @abstractmethod
+    def step(self, sample, model, model_transform, schedule, step: Step, rng=None): ...
+
+    def sample_model(self, sample, model, model_transform, schedule, steps, include=slice(None), rng=None, callback=None):
+        for n in list(range(steps))[include]:
+            step = Step.from_int(n, steps)
+            sample = self.step(sample, model, model_transform, schedule, step, rng)
+            if callback:
+                callback(sample, n, schedule.istep(step))
+        return sample
+
+
+@dataclasses.dataclass(frozen=True)
+class RKUltra(FunctionalUnified, FunctionalSinglestep):
+    "fixed-tableau explicit Runge-Kutta; `order` selects the tableau with the most stages <= order"
+
+    providers: Mapping[int, Any] = MappingProxyType(DEFAULT_PROVIDERS)
+
+    @staticmethod
+    def max_order() -> int:
+        return 99
+
+    def tableau(self, order: int | None = None) -> tableaux.Tableau:
+        order = self.order if order is None else order
+        usable = [k for k in self.providers if k <= order]
+        if order >= min(self.providers) and usable and max(usable):
+            tab = self.providers[max(usable)].tableau()
+            return tableaux.Tableau(tab.stages, tab.weights)
+        return tableaux.RK1.Euler.value
+
+    def adjust_steps(self, steps: int) -> int:
+        "steps that spend about the same number of model calls (stages at c = 1 are free on the last step)"
+        stages = self.tableau()[0]
+        return max(round(steps / len(stages) + sum(abs(1 - c) < 1e-8 for c, _ in stages) / len(stages)), 1)
+
+    def step(self, sample, model, model_transform, schedule, step, rng=None):
+        return step_tableau(self.tableau(), sample, model, model_transform, schedule, step, self.derivative_transform, rng(step) if rng else None, self.stochasticity)[0]
+
+
+@dataclasses.dataclass(frozen=True)
+class DynasauRK(FunctionalUnified, FunctionalSinglestep):
+    """Runge-Kutta with a tableau generated per step: starts at the most stable member of a
+    one-parameter family and decays exponentially towards the most convergent one
+    (gradient = exp(-(S*T + s*t) * stages), T = total steps, t = current step)."""
+
+    per_step_decay: float = math.log(0.5) / -2
+    total_step_decay: float = math.log(0.5) / -20
+    invert: bool = False
+
+    @staticmethod
+    def min_order() -> int:
+        return 2
+
+    @staticmethod
+    def max_order() -> int:
+        return 4
+
+    def adjust_steps(self, steps: int) -> int:
+        return max(round(steps / self.order), 1)
+
+    def _family(self):
+        if self.order >= 4:
+            return 1 / 4 * (2 - math.sqrt(2)), 1 / 14 * (5 - 3 * math.sqrt(2)), tableaux.ees27_tableau
+        if self.order >= 3:
+            return 0.25, 0.1, tableaux.ees25_tableau
+        return 1, 0.5, tableaux.rk2_tableau
+
+    def gradient(self, step: Step, stages: int) -> float:
+        step = step.normal().clamp()
+        g = math.exp((-self.total_step_decay * step.amount() - self.per_step_decay * step.position()) * stages)
+        return abs(self.invert - min(max(g, 0), 1))
+
+    def tableau(self, step: Step) -> tableaux.Tableau:
+        stable, convergent, make = self._family()
+        g = self.gradient(step, len(make((stable + convergent) / 2).stages))
+        return make(g * stable + (1 - g) * convergent)
+
+    def step(self, sample, model, model_transform, schedule, step, rng=None):
+        return step_tableau(self.tableau(step), sample, model, model_transform, schedule, step, self.derivative_transform, rng(step) if rng else None, self.stochasticity)[0]

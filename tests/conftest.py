@@ -1,0 +1,50 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    try:
+        import torch
+
+        have_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def kats():
+    return json.load(open(os.path.join(GOLDEN, "reference_kats.json")))
+
+
+@pytest.fixture(scope="session")
+def tables():
+    return json.load(open(os.path.join(GOLDEN, "tables.json")))
+
+
+def load_npz(name: str) -> dict:
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def eq_nan(a, b) -> bool:
+    return np.array_equal(np.asarray(a, dtype=float), np.asarray(b, dtype=float), equal_nan=True)

@@ -1,0 +1,331 @@
+"""Host-side logic of the product (skrample_amd): schedules, coefficient algebra, sampler step
+plans -- exercised on Python scalars and symbolic operands, no GPU.  Written to read like the
+reference's own tests (tests/self_sampling.py, tests/self_scheduling.py, tests/miscellaneous.py)."""
+
+import itertools
+import math
+import random
+
+import numpy as np
+import pytest
+import torch
+from cases import MODELS, SAMPLERS, SCHEDULES, fake_model
+from conftest import eq_nan
+
+import skrample_amd.diffusers as PD
+import skrample_amd.scheduling as PS
+from skr_oracle import rk as OK
+from skr_oracle import samplers as OA
+from skr_oracle import schedules as OS
+from skrample_amd.common import DeltaPoint, MergeStrategy, Point, Step, bashforth, sigmoid, softmax, spowf
+from skrample_amd.sampling import functional as PF
+from skrample_amd.sampling import interface as PI
+from skrample_amd.sampling import lazy
+from skrample_amd.sampling import models as PM
+from skrample_amd.sampling import structured as PT
+from skrample_amd.sampling import tableaux as PTab
+
+
+def product_trajectory(sampler, schedule, model, steps=7, seed=42):
+    out = []
+    random.seed(seed)
+    (PI.StructuredFunctionalAdapter(sampler) if isinstance(sampler, PT.StructuredSampler) else sampler).generate_model(
+        fake_model, model, PS.Hyper(schedule), lambda _: random.random(), steps, callback=lambda x, i, d: out.append(x)
+    )
+    return out
+
+
+def oracle_trajectory(cfg, sched, pred, steps=7, seed=42):
+    out = []
+    random.seed(seed)
+    hs = OS.hyper(sched)
+    loop = lambda x: OA.adapter_loop(cfg, x, fake_model, pred, hs, steps, rng=lambda _: random.random(), callback=lambda x, i, d: out.append(x))  # noqa: E731
+    OA.generate(loop, None, lambda _: random.random(), hs, steps)
+    return out
+
+
+def test_reference_sampler_goldens(kats):
+    "the 24 committed reference trajectories (reference tests/self_sampling.py:57-104, tolerance 1e-3 %)"
+    mk = {"RKUltra": lambda: PF.RKUltra(providers={2: PTab.RKE2.Heun}), "DynasauRK": PF.DynasauRK, "Adams": PT.Adams, "SPC": PT.SPC}
+    for key, ref in kats["sampler_trajectories"].items():
+        s, sch, m = key.split("/")
+        got = product_trajectory(mk[s](), getattr(PS, sch)(), getattr(PM, m)())
+        np.testing.assert_allclose(got, ref, rtol=1e-9, err_msg=key)
+
+
+def test_reference_schedule_goldens(kats):
+    env = {k: getattr(PS, k) for k in ("Linear", "Scaled", "Karras", "Beta", "Exponential", "Probit", "Hyper", "Sinner")}
+    for label, ref in kats["schedule_points"].items():
+        got = eval(label, {"__builtins__": {}}, env).points_np(np.linspace(1, 0, 7))  # noqa: S307
+        np.testing.assert_allclose(got, np.asarray(ref), rtol=1e-5, err_msg=label)
+
+
+@pytest.mark.parametrize("name", SCHEDULES)
+def test_schedules_equal_oracle(name):
+    o, p = SCHEDULES[name][0](), SCHEDULES[name][1]()
+    t = [0, 1, *np.random.default_rng(0).random(30)]
+    assert eq_nan(o.points_np(t), p.points_np(t))
+    assert eq_nan(o.schedule_np(13), p.schedule_np(13))
+    assert tuple(o.ipoint(0.3)) == tuple(p.ipoint(0.3))
+    hash(p)  # schedules key LRU caches
+    if "zsnr" not in name and "neg" not in name:
+        assert p.point(0) == (0, 0, 1)  # reference test_zero_point (Linear / Scaled bases)
+
+
+def test_wrapper_tables(tables):
+    for key, ref in tables["wrapper"].items():
+        name, n = key.split("/")
+        w = PD.SkrampleWrapperScheduler(PT.Euler(), SCHEDULES[name][1]())
+        w.set_timesteps(int(n))
+        assert eq_nan(w.timesteps.tolist(), ref["timesteps"]), key
+        assert eq_nan(w.sigmas.tolist(), ref["sigmas"]), key
+        assert eq_nan(w.schedule_np.tolist(), ref["schedule_np"]), key
+
+
+def test_gamma_delta_zeta(tables):
+    for row in tables["gdz"]:
+        sched = SCHEDULES[row["schedule"]][1]()
+        dp = DeltaPoint(*sched.ipoints(row["step"]))
+        m = MODELS[row["model"]][1]
+        try:
+            got = [m.gamma(dp, row["eta"]), m.delta(dp, row["eta"]), m.zeta(dp, row["eta"])]
+        except ZeroDivisionError:
+            got = None
+        ref = row["gdz"]
+        if ref is None or got is None:
+            assert ref is None and got is None, row
+        elif isinstance(ref[0], str):
+            assert [repr(v) for v in got] == ref, row
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-15, atol=0, err_msg=str(row))
+
+
+def test_effective_order(tables):
+    kind = {"DPM": PT.DPM, "Adams": PT.Adams, "UniP": PT.UniP, "UniPC": PT.UniPC}
+    for row in tables["effective_order"]:
+        s = kind[row["sampler"]](order=row["order"])
+        got = [s.effective_order(Step.from_int(i, row["steps"]), [None] * row["n_previous"]) for i in range(row["steps"])]
+        assert got == row["eo"] and s.require_previous == row["require_previous"], row
+
+
+def test_tableaux(tables):
+    groups = (PTab.RK1, PTab.RK2, PTab.RK3, PTab.RK4, PTab.RKZ, PTab.RKE2, PTab.RKE3, PTab.RKE5, PTab.SSP)
+    for grp in groups:
+        for member in grp:
+            ref = tables["tableaux"][f"{grp.__name__}.{member.name}"]
+            tab = member.tableau()
+            assert PTab.validate_tableau(tab) is None, member  # reference test_tableau_providers
+            flat_ref = [*ref["c"], *(v for r in ref["a"] for v in r), *ref["b"]]
+            np.testing.assert_allclose(PTab.serialize(tab), flat_ref, rtol=0, atol=1e-15, err_msg=str(member))
+    for k, v in tables["default_providers"].items():
+        if int(k) <= 11:
+            grp, name = v.split(".")
+            assert PF.DEFAULT_PROVIDERS[int(k)] is getattr(getattr(PTab, grp), name)
+            assert int(k) == len(PF.DEFAULT_PROVIDERS[int(k)].tableau()[0])  # reference test_tableau_preset_stages
+    for k, v in tables["stable_providers"].items():
+        grp, name = v.split(".")
+        assert PF.STABLE_PROVIDERS[int(k)] is getattr(getattr(PTab, grp), name)
+    with pytest.raises(NotImplementedError):
+        PF.RKUltra(order=99).tableau()
+
+
+def test_rk_points(tables):
+    for key, ref in tables["rk_points"].items():
+        kind, name, order, steps = key.split("/")
+        if kind == "rku":
+            if int(order) > 11:
+                continue
+            w = PD.RKUltraWrapperScheduler(SCHEDULES[name][1](), sampler_order=int(order))
+        else:
+            w = PD.DynasauRKWrapperScheduler(SCHEDULES[name][1](), sampler_order=int(order), model=PM.FlowModel() if "linear" in name else PM.NoiseModel())
+        w.set_timesteps(int(steps))
+        np.testing.assert_allclose([list(p) for p in w.all_points], ref["all"], rtol=0, atol=1e-12, err_msg=key)
+        np.testing.assert_allclose(w.timesteps.tolist(), ref["timesteps"], rtol=0, atol=1e-9)
+        assert w.order == ref["order"] and len(w.timesteps) <= int(steps) * w.order
+
+
+@pytest.mark.parametrize("sampler", SAMPLERS)
+def test_samplers_equal_oracle_on_scalars(sampler):
+    "every sampler x schedule x model: product step algebra == oracle (== reference), 9-step trajectories"
+    mk_o, mk_p = SAMPLERS[sampler]
+    for sname in ("linear", "scaled", "zsnr", "karras_scaled"):
+        for mname in ("data", "flow", "v", "eps", "scalex"):
+            if mname == "eps" and sname in ("linear", "zsnr"):
+                continue  # alpha = 0 at t = 1: division by zero in the reference too
+            a = oracle_trajectory(mk_o(), SCHEDULES[sname][0](), MODELS[mname][0], steps=9)
+            b = product_trajectory(mk_p(), SCHEDULES[sname][1](), MODELS[mname][1], steps=9)
+            np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-12, err_msg=f"{sampler}/{sname}/{mname}")
+    assert OA.require_noise(mk_o()) == mk_p().require_noise
+    assert OA.require_previous(mk_o()) == mk_p().require_previous
+
+
+def test_spc_power_scalar():
+    a = oracle_trajectory(OA.make("spc", power=2), OS.scaled(), "v", steps=9)
+    b = product_trajectory(PT.SPC(power=2), PS.Scaled(), PM.VelocityModel(), steps=9)
+    np.testing.assert_allclose(b, a, rtol=1e-9)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6])
+def test_rkultra_equals_oracle(order):
+    for (so, sp), (po, pp), eta in itertools.product([SCHEDULES["linear"], SCHEDULES["scaled"]], [MODELS["data"], MODELS["flow"], MODELS["v"]], (0, 0.7)):
+        random.seed(1)
+        a = OK.rk_loop(lambda st: OK.pick_tableau(order), 0.7, fake_model, po, OS.hyper(so()), 5, rng=lambda _: random.random(), eta=eta)
+        random.seed(1)
+        b = PF.RKUltra(order=order, stochasticity=eta).sample_model(0.7, fake_model, pp, PS.Hyper(sp()), 5, rng=lambda _: random.random())
+        assert abs(a - b) < 1e-10 * max(1, abs(a))
+
+
+# ---- identities the reference tests pin (tests/self_sampling.py:107-171, 332-414) ----------------------
+@pytest.mark.parametrize(("model", "schedule", "eta"), itertools.product([PM.DataModel, PM.NoiseModel, PM.FlowModel, PM.VelocityModel], [PS.Linear, PS.Scaled], [-1.5, 0, 0.5, 1]))
+def test_model_transforms(model, schedule, eta):
+    m = model()
+    sample, output, noise = 0.8, 0.3, 0.6
+    p0 = schedule().point(0.6)
+    x = m.to_x(sample, output, p0)
+    assert abs(output - m.from_x(sample, x, p0)) < 1e-12
+    for t_next in (0.05, 0):
+        delta = DeltaPoint(p0, schedule().point(t_next))
+        f = m.forward(sample, output, delta, noise, eta)
+        assert abs(f - PM.DataModel().forward(sample, x, delta, noise, eta)) < 1e-12
+        assert abs(output - m.backward(sample, f, delta, noise, eta)) < 1e-12
+
+
+@pytest.mark.parametrize(
+    ("m_from", "m_to", "schedule", "sigma_to"),
+    itertools.product([PM.DataModel, PM.NoiseModel, PM.FlowModel, PM.VelocityModel], [PM.DataModel, PM.NoiseModel, PM.FlowModel, PM.VelocityModel, PM.ScaleX], [PS.Linear, PS.Scaled], (0.05, 0.0)),
+)
+def test_model_convert(m_from, m_to, schedule, sigma_to):
+    conv = PM.ModelConvert(m_from(), m_to())
+    delta = DeltaPoint(schedule().point(0.2), schedule().point(sigma_to))
+    model = lambda x, t, s, a: 0.3  # noqa: E731
+    a = conv.transform_from.forward(0.8, model(0.8, *delta.point_from), delta)
+    b = conv.transform_to.forward(0.8, conv.wrap_model_call(model)(0.8, *delta.point_from), delta)
+    assert abs(a - b) < 1e-12
+
+
+@pytest.mark.parametrize(("sigma", "alpha", "sample", "noise"), itertools.product([1, 0.65, 0], [1, 0.35, 0], [-1.5, 0, 0.5, 1.5], [-1.5, 0, 0.5, 1.5]))
+def test_point(sigma, alpha, sample, noise):
+    p = Point(sigma, sigma, alpha)
+    noisy = p.add_noise(sample, noise)
+    clean = p.remove_noise(noisy, noise)
+    assert abs((sample if alpha != 0 else noisy) - clean) < 1e-15
+
+
+@pytest.mark.parametrize(("model", "schedule", "noise"), itertools.product([PM.DataModel, PM.NoiseModel, PM.VelocityModel, PM.FlowModel], [PS.Sinner(PS.Linear()), PS.Scaled()], [False, True]))
+def test_maruyama(model, schedule, noise):
+    "DPM(order=1, eta) == Euler(eta) step for step (reference test_maruyama)"
+    if model is PM.NoiseModel and isinstance(schedule.space, PS.FlowMatching):
+        return
+    dpm = PI.StructuredFunctionalAdapter(PT.DPM(order=1, stochasticity=noise))
+    eul = PI.StructuredFunctionalAdapter(PT.Euler(stochasticity=int(noise)))
+    f = lambda x, t, s, a: x + math.sin(x) * s  # noqa: E731
+    random.seed(0)
+    a = dpm.sample_model(1.7, f, model(), schedule, 23, rng=lambda _: random.random())
+    random.seed(0)
+    b = eul.sample_model(1.7, f, model(), schedule, 23, rng=lambda _: random.random())
+    assert abs(a - b) < 1e-12
+
+
+@pytest.mark.parametrize(("sampler", "steps"), itertools.product([PT.DPM(o, n) for o in range(1, 4) for n in (False, True)], [1, 3, 4, 9, 512]))
+def test_functional_adapter(sampler, steps):
+    "adapter loop == manual sampler.sample loop, exactly (reference test_functional_adapter)"
+    f = lambda x, t, s, a: x + math.sin(x) * s  # noqa: E731
+    schedule, transform = PS.Scaled(), PM.FlowModel()
+    noise = [random.random() for _ in range(steps)]
+    rng = iter(noise)
+    via_adapter = PI.StructuredFunctionalAdapter(sampler).sample_model(1.5, f, transform, schedule, steps, rng=lambda _: next(rng))
+    rng = iter(noise)
+    x, prev = 1.5, []
+    for n, (t, s, a) in enumerate(schedule.schedule(steps)):
+        rec = sampler.sample(x, f(x, t, s, a), Step.from_int(n, steps), transform, schedule, next(rng), prev)
+        prev.append(rec)
+        x = rec.final
+    assert x == via_adapter
+
+
+def test_require_previous_and_noise():
+    "history may be trimmed to require_previous; noise matters iff require_noise (reference :227-329)"
+    previous = tuple(PT.SKSamples(n / 2, n * 2, Step.from_int(n, 100), 1 / (n + 1), n * 1.5) for n in range(31))
+    samplers = [mk() for _, mk in SAMPLERS.values()]
+    for s in samplers:
+        a = s.sample(1.5, 0.5, Step.from_int(31, 100), PM.DataModel(), PS.Linear(), None, previous)
+        b = s.sample(1.5, 0.5, Step.from_int(31, 100), PM.DataModel(), PS.Linear(), None, previous[len(previous) - s.require_previous :])
+        assert a.final == b.final, s
+        c = s.sample(1.5, 0.5, Step.from_int(31, 100), PM.DataModel(), PS.Linear(), -0.5, previous)
+        d = s.sample(1.5, 0.5, Step.from_int(31, 100), PM.DataModel(), PS.Linear(), None, [PT.SKSamples(p.sample, p.prediction, p.step, None, p.final) for p in previous])
+        assert (c.final == d.final) ^ s.require_noise, s
+
+
+def test_misc_common():
+    "reference tests/miscellaneous.py"
+    for n, coeffs in enumerate(((1,), (3 / 2, -1 / 2), (23 / 12, -4 / 3, 5 / 12), (55 / 24, -59 / 24, 37 / 24, -3 / 8))):
+        assert np.allclose(coeffs, bashforth(n + 1), atol=1e-12, rtol=1e-12)
+    items = [spowf(v, 2) for v in np.linspace(-2, 2, 9).tolist()]
+    assert np.allclose([sigmoid(v) for v in items], torch.sigmoid(torch.tensor(items, dtype=torch.float64)).tolist(), atol=1e-12)
+    assert np.allclose(softmax(tuple(items)), torch.softmax(torch.tensor(items, dtype=torch.float64), 0).tolist(), atol=1e-12)
+    a, b = list(range(0, 11)), list(range(0, 15, 2))
+    assert MergeStrategy.UniqueBefore.merge(a, b) == b + list(range(1, 10, 2))
+    assert MergeStrategy.UniqueAfter.merge(a, b) == a + list(range(12, 15, 2))
+    assert MergeStrategy.Before.merge(a, b) == b + a and MergeStrategy.Ours.merge(a, b) == a
+    for n in range(32):
+        st = Step.from_int(n, 31)
+        assert abs(st.amount() - 31) < 1e-8 and abs(st.position() - n) < 1e-8 and Step(*reversed(st)).normal() == st
+        assert abs(st.offset(-4).position() - (n - 4)) < 1e-8
+        assert st.offset(15.5).clamp().position() + 1 <= 31 + 1e-8 and st.offset(-15.5).clamp().position() >= 0
+    for cls, data in PD.DIFFUSERS_CLASS_MAP.values():
+        cls(**data)
+
+
+def test_config_parsing():
+    "reference tests/diffusers_map.py (the cases that need no diffusers install)"
+    flow = {"base_shift": 0.5, "flow_shift": 3.0, "num_train_timesteps": 1000, "prediction_type": "flow_prediction", "shift": 3.0, "use_dynamic_shifting": True}
+    w = PD.SkrampleWrapperScheduler.from_diffusers_config(flow)
+    assert w.sampler == PT.DPM() and w.model == PM.FlowModel() and w.schedule == PS.FlowShift(PS.Linear(), shift=3.0)
+    scaled = {"beta_end": 0.012, "beta_schedule": "scaled_linear", "beta_start": 0.00085, "num_train_timesteps": 1000, "prediction_type": "epsilon", "use_karras_sigmas": True, "_class_name": "EulerAncestralDiscreteScheduler"}
+    w = PD.SkrampleWrapperScheduler.from_diffusers_config(scaled)
+    assert w.sampler == PT.Euler(stochasticity=True) and w.model == PM.NoiseModel() and w.schedule == PS.Karras(PS.Scaled(beta_scale=2))
+    w = PD.SkrampleWrapperScheduler.from_diffusers_config({"_class_name": "UniPCMultistepScheduler", "solver_order": 3, "prediction_type": "v_prediction", "rescale_betas_zero_snr": True})
+    assert w.sampler == PT.UniPC(order=3) and w.model == PM.VelocityModel() and isinstance(w.schedule, PS.ZSNR)
+    w = PD.SkrampleWrapperScheduler.from_diffusers_config({"_class_name": "MiniMaxH3Scheduler", "shift": 12})
+    assert w.invert_prediction and w.schedule.lowest.base_timesteps == -1
+    assert w.config["shift"] == 12 and w.config.prediction_type == "flow"
+    a = PD.SkrampleWrapperScheduler(PT.DPM(), PS.Hyper(PS.FlowShift(PS.Hyper(PS.Linear()))))
+    a.set_timesteps(123, mu=1.2345)  # reference test_mu_set
+    assert a.schedule == PS.Hyper(PS.FlowShift(PS.Hyper(PS.Linear()), shift=math.exp(1.2345)))
+    k = PD.SkrampleWrapperScheduler(PT.DPM(), PS.Karras(PS.Scaled()))
+    k.set_timesteps(31)
+    assert k.schedule == PS.Karras(PS.Scaled(), steps=31) and len(k.timesteps) == 31 and len(k.sigmas) == 32
+    r = PD.RKUltraWrapperScheduler.from_diffusers_config(flow, sampler_order=6)
+    r.set_timesteps(4)
+    assert r.order == 6 and isinstance(r.model, PM.FlowModel)
+
+
+def test_lazy_algebra_is_symbolic():
+    "the sampler algebra never touches tensor data: forms over opaque leaves just accumulate coefficients"
+
+    class Opaque(lazy.PhiloxNoise):  # any leaf object works; reuse the symbolic-noise leaf type
+        def __init__(self, tag):
+            super().__init__(None, 0, (2, 8), torch.device("cpu"))
+            self.tag = tag
+
+    x, o, xp, op_, n = (lazy.Lin.leaf(Opaque(t)) for t in "x o xp op n".split())
+    sched, model = PS.Karras(PS.Scaled()), PM.NoiseModel()
+    prev = [PT.SKSamples(xp, op_, Step.from_int(4, 20), None, None)]
+    form = PT.DPM(order=2, stochasticity=1)._form(PT.SampleInput(x, o, Step.from_int(5, 20), n), model, sched, prev)
+    coef = {leaf.tag: c for leaf, c in form.terms.values()}
+    assert set(coef) == {"x", "o", "xp", "op", "n"}
+    # same numbers from the oracle on unit "tensors": coefficient of leaf k = f(e_k)
+    from skr_oracle import schedules as OS
+
+    osched = OS.karras(OS.scaled())
+    cfg = OA.make("dpm", 2, eta=1)
+    for k, tag in enumerate(("x", "o", "xp", "op", "n")):
+        e = [1.0 if i == k else 0.0 for i in range(5)]
+        rec = OA.sample_packed(cfg, OA.Rec(e[0], e[1], (5 / 20, 6 / 20), e[4]), "eps", osched, [OA.Rec(e[2], e[3], (4 / 20, 5 / 20))])
+        assert abs(rec.final - coef[tag]) < 1e-12 * max(1, abs(coef[tag])), tag
+    with pytest.raises(lazy.SkrampleHipError):
+        x * o
+    with pytest.raises(lazy.SkrampleHipError):
+        lazy.lift(np.ones(3))
+    with pytest.raises(lazy.SkrampleHipError):
+        lazy.lift(torch.ones(3))  # CPU tensor: refused, there is no CPU tensor path

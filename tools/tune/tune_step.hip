@@ -1,0 +1,203 @@
+// Stand-alone tuning harness for the fused step kernel structure (not part of the product).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tune_step tune_step.hip && ./tune_step
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "../../skrample_amd/csrc/skr_philox.h"
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  f32x2_t f = {a, b};
+  bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+struct Args {
+  const u32x4_t* in[4];
+  u32x4_t* out;
+  const uint64_t* seeds;
+  float c[4];
+  float zeta;
+  uint64_t stream;
+  int64_t nvec;
+  int64_t vps;  // vectors per sample
+};
+
+template <bool NT>
+__device__ __forceinline__ u32x4_t ld(const u32x4_t* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st(u32x4_t* p, u32x4_t v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+__device__ __forceinline__ void noise8(const Args& a, int64_t vec, float z[8]) {
+  const int64_t smp = vec / a.vps;
+  const int64_t r = (vec - smp * a.vps) * 8;
+  const uint64_t seed = a.seeds[smp];
+  skr::normal4(seed, a.stream, (uint64_t)r >> 2, z);
+  skr::normal4(seed, a.stream, ((uint64_t)r >> 2) + 1, z + 4);
+}
+
+template <int K, bool NT_LD, bool NT_ST, int UV, bool NOISE, bool NOISE_FIRST, bool MEM>
+__global__ __launch_bounds__(256) void k(const Args a) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * UV;
+  for (int64_t v0 = ((int64_t)blockIdx.x * 256) * UV + threadIdx.x; v0 < a.nvec; v0 += stride) {
+    u32x4_t raw[UV][K];
+    if constexpr (MEM) {
+#pragma unroll
+      for (int u = 0; u < UV; ++u)
+#pragma unroll
+        for (int j = 0; j < K; ++j) raw[u][j] = ld<NT_LD>(a.in[j] + v0 + u * 256);
+    }
+    float z[UV][8];
+    if constexpr (NOISE && NOISE_FIRST) {
+#pragma unroll
+      for (int u = 0; u < UV; ++u) noise8(a, v0 + u * 256, z[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      float s[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = 0.f;
+      if constexpr (MEM) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s[2 * i] = __builtin_fmaf(a.c[j], __uint_as_float(raw[u][j][i] << 16), s[2 * i]);
+            s[2 * i + 1] = __builtin_fmaf(a.c[j], __uint_as_float(raw[u][j][i] & 0xFFFF0000u), s[2 * i + 1]);
+          }
+        }
+      }
+      if constexpr (NOISE) {
+        if constexpr (!NOISE_FIRST) noise8(a, v0 + u * 256, z[u]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.zeta, z[u][i], s[i]);
+      }
+      u32x4_t q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = pack_bf16(s[2 * i], s[2 * i + 1]);
+      if (MEM || q[0] == 0x12345678u) st<NT_ST>(a.out + v0 + u * 256, q);
+    }
+  }
+}
+
+template <int K, bool NT_LD, bool NT_ST, int UV, bool NOISE, bool NOISE_FIRST, bool MEM>
+void run(const char* name, std::vector<Args>& sets, int blocks_cap, int iters = 200) {
+  int64_t nvec = sets[0].nvec;
+  int64_t blocks = (nvec + 256 * UV - 1) / (256 * UV);
+  if (blocks_cap > 0 && blocks > blocks_cap) blocks = blocks_cap;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<K, NT_LD, NT_ST, UV, NOISE, NOISE_FIRST, MEM>), dim3(blocks), dim3(256), 0, 0, sets[i % sets.size()]);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k<K, NT_LD, NT_ST, UV, NOISE, NOISE_FIRST, MEM>), dim3(blocks), dim3(256), 0, 0, sets[i % sets.size()]);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  double us = ms * 1e3 / iters;
+  double bytes = (double)nvec * 16 * (K + 1);
+  printf("%-46s blocks=%6lld  %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, (long long)blocks, us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
+}
+
+template <int K, int UV>
+__global__ __launch_bounds__(256) void k_read(const Args a) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * UV;
+  u32x4_t acc = {0, 0, 0, 0};
+  for (int64_t v0 = ((int64_t)blockIdx.x * 256) * UV + threadIdx.x; v0 < a.nvec; v0 += stride) {
+#pragma unroll
+    for (int u = 0; u < UV; ++u)
+#pragma unroll
+      for (int j = 0; j < K; ++j) acc ^= __builtin_nontemporal_load(a.in[j] + v0 + u * 256);
+  }
+  if (acc[0] == 0x12345678u && acc[1] == 0x9abcdef0u) a.out[0] = acc;
+}
+template <int UV>
+__global__ __launch_bounds__(256) void k_write(const Args a) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * UV;
+  for (int64_t v0 = ((int64_t)blockIdx.x * 256) * UV + threadIdx.x; v0 < a.nvec; v0 += stride) {
+#pragma unroll
+    for (int u = 0; u < UV; ++u) { u32x4_t q = {(uint32_t)v0, 1, 2, 3}; __builtin_nontemporal_store(q, a.out + v0 + u * 256); }
+  }
+}
+template <typename F>
+void timeit(const char* name, F launch, double bytes, int iters = 200) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 10; ++i) launch(i);
+  CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) launch(i);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / iters;
+  printf("%-46s %7.2f us  %6.3f TB/s\n", name, us, bytes / us / 1e6);
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 256;
+  const int64_t stagger = argc > 2 ? atoll(argv[2]) : 0;
+  const int64_t sample = 4 * 128 * 128;
+  const int64_t n = (int64_t)B * sample;
+  const int NS = 4;
+  std::vector<Args> sets(NS);
+  uint64_t* seeds; CK(hipMalloc(&seeds, B * 8));
+  std::vector<uint64_t> hs(B); for (int i = 0; i < B; ++i) hs[i] = 42 + i;
+  CK(hipMemcpy(seeds, hs.data(), B * 8, hipMemcpyHostToDevice));
+  std::vector<uint16_t> host(n);
+  for (int64_t i = 0; i < n; ++i) host[i] = 0x3f80 + (rand() & 0x7f);
+  char* slab; const int64_t pitch = n * 2 + (4 << 20); CK(hipMalloc((void**)&slab, pitch * 5 * NS + (64 << 20)));
+  printf("stagger=%lld bytes\n", (long long)stagger);
+  for (int s = 0; s < NS; ++s) {
+    for (int j = 0; j < 4; ++j) { void* p = slab + pitch * (s * 5 + j) + stagger * j; CK(hipMemcpy(p, host.data(), n * 2, hipMemcpyHostToDevice)); sets[s].in[j] = (const u32x4_t*)p; }
+    void* o = slab + pitch * (s * 5 + 4) + stagger * 4; sets[s].out = (u32x4_t*)o;
+    sets[s].seeds = seeds; sets[s].c[0] = 1.01f; sets[s].c[1] = -0.53f; sets[s].c[2] = 0.12f; sets[s].c[3] = 0.43f;
+    sets[s].zeta = 0.3f; sets[s].stream = 1; sets[s].nvec = n / 8; sets[s].vps = sample / 8;
+  }
+  printf("B=%d n=%lld\n", B, (long long)n);
+  {
+    double rb = (double)n * 2 * 4, wb = (double)n * 2;
+    timeit("read-only 4 streams uv1 grid2048", [&](int i) { hipLaunchKernelGGL((k_read<4, 1>), dim3(2048), dim3(256), 0, 0, sets[i % NS]); }, rb);
+    timeit("read-only 4 streams uv4 grid2048", [&](int i) { hipLaunchKernelGGL((k_read<4, 4>), dim3(2048), dim3(256), 0, 0, sets[i % NS]); }, rb);
+    timeit("read-only 1 stream  uv4 grid2048", [&](int i) { hipLaunchKernelGGL((k_read<1, 4>), dim3(2048), dim3(256), 0, 0, sets[i % NS]); }, rb / 4);
+    timeit("write-only uv1 grid2048", [&](int i) { hipLaunchKernelGGL((k_write<1>), dim3(2048), dim3(256), 0, 0, sets[i % NS]); }, wb);
+    timeit("write-only uv4 grid2048", [&](int i) { hipLaunchKernelGGL((k_write<4>), dim3(2048), dim3(256), 0, 0, sets[i % NS]); }, wb);
+    timeit("hipMemcpyAsync D2D (1R+1W)", [&](int i) { CK(hipMemcpyAsync((void*)sets[i % NS].out, (const void*)sets[i % NS].in[0], n * 2, hipMemcpyDeviceToDevice, 0)); }, wb * 2);
+  }
+  //                 K  NTLD  NTST  UV NOISE NFIRST MEM
+  run<4, true, true, 1, false, false, true>("nt/nt uv1 cap2048", sets, 2048);
+  run<4, true, true, 1, false, false, true>("nt/nt uv1 cap1024", sets, 1024);
+  run<4, true, true, 1, false, false, true>("nt/nt uv1 cap4096", sets, 4096);
+  run<4, true, true, 1, false, false, true>("nt/nt uv1 nocap", sets, 0);
+  run<4, false, true, 1, false, false, true>("plain/nt uv1 cap2048", sets, 2048);
+  run<4, false, false, 1, false, false, true>("plain/plain uv1 cap2048", sets, 2048);
+  run<4, false, false, 1, false, false, true>("plain/plain uv1 nocap", sets, 0);
+  run<4, true, false, 1, false, false, true>("nt/plain uv1 cap2048", sets, 2048);
+  run<4, true, true, 2, false, false, true>("nt/nt uv2 cap2048", sets, 2048);
+  run<4, true, true, 2, false, false, true>("nt/nt uv2 cap1024", sets, 1024);
+  run<4, true, true, 2, false, false, true>("nt/nt uv2 nocap", sets, 0);
+  run<4, false, false, 2, false, false, true>("plain/plain uv2 nocap", sets, 0);
+  run<4, true, true, 4, false, false, true>("nt/nt uv4 cap1024", sets, 1024);
+  run<4, true, true, 4, false, false, true>("nt/nt uv4 nocap", sets, 0);
+  printf("-- with noise\n");
+  run<4, true, true, 1, true, false, true>("noise last  nt/nt uv1 cap2048", sets, 2048);
+  run<4, true, true, 1, true, true, true>("noise first nt/nt uv1 cap2048", sets, 2048);
+  run<4, true, true, 1, true, true, true>("noise first nt/nt uv1 nocap", sets, 0);
+  run<4, true, true, 1, true, true, true>("noise first nt/nt uv1 cap4096", sets, 4096);
+  run<4, true, true, 2, true, true, true>("noise first nt/nt uv2 cap2048", sets, 2048);
+  run<4, true, true, 2, true, true, true>("noise first nt/nt uv2 nocap", sets, 0);
+  run<4, false, false, 1, true, true, true>("noise first plain uv1 nocap", sets, 0);
+  printf("-- VALU only (no memory)\n");
+  run<4, true, true, 1, true, true, false>("philox+boxmuller only uv1 cap2048", sets, 2048);
+  run<4, true, true, 1, true, true, false>("philox+boxmuller only uv1 nocap", sets, 0);
+  return 0;
+}
