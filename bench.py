@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused DPM-2 SDE sampler step (eps-prediction, Karras(Scaled) sigmas) over
+B x 4 x 128 x 128 bf16 latents -- BASELINE.json `metric`, north-star shape B = 256 per GPU.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one solver step over one B=256 batch resident in HBM: exactly one launch of the fused
+kernel through the C ABI (skr_step_launch).  The launch plans are not hand-written here: the real
+scheduler wrapper (skrample_amd.diffusers.SkrampleWrapperScheduler) is run once over a 20-step
+schedule with launch tracing on, and the plans it emitted for the steady-state steps 5..14 are
+replayed on >= 4 rotating buffer sets (footprint > 256 MB Infinity Cache).  Multi-GPU = batch shards
+with no collective (weak scaling, B = 256 per GPU); noise seeds are indexed by global sample id.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+B_PER_GPU, C, H, W = 256, 4, 128, 128
+SCHEDULE_STEPS = 20
+STEADY = list(range(5, 15))  # steady-state (order-2) step indices that are cycled
+ALGO_BYTES_PER_ELEM = 10  # x 2 + model_out 2 + history pair 4 + y 2 (in-kernel noise 0)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def parse() -> argparse.Namespace:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="samples per GPU (default: the north-star 256)")
+    ap.add_argument("--sets", type=int, default=6, help="rotating buffer sets (>= 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def make_wrapper():
+    import skrample_amd.diffusers as PD
+    import skrample_amd.scheduling as PS
+    from skrample_amd.sampling import structured as PT
+
+    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))
+    w.set_timesteps(SCHEDULE_STEPS)
+    return w
+
+
+def capture_plans(dev: torch.device, batch: int, first_sample: int):
+    """Run the real wrapper once with tracing and return, per steady-state step, the emitted plan and
+    the role of each input pointer (x, out, x_prev, out_prev)."""
+    from skrample_amd import _hip
+
+    w = make_wrapper()
+    g = torch.Generator(device=dev).manual_seed(1234 + first_sample)
+    shape = (batch, C, H, W)
+    gens = [42 + first_sample + i for i in range(batch)]  # per-sample seeds by GLOBAL sample index
+    x = torch.randn(shape, device=dev, generator=g).to(torch.bfloat16)
+    plans = {}
+    prev_pair = None
+    _hip.trace = []
+    try:
+        for i, t in enumerate(w.timesteps):
+            out = torch.randn(shape, device=dev, generator=g).to(torch.bfloat16)
+            _hip.trace.clear()
+            # seeds are plain ints (the generator protocol only needs initial_seed())
+            nxt = w.step(out, t, x, generator=[_Seed(s) for s in gens], return_dict=False)[0]
+            assert len(_hip.trace) == 1, "a solver step must be exactly one fused launch"
+            plan, inputs, _, _, seeds, numel = _hip.trace[0]
+            roles = []
+            for tin in inputs:
+                if tin.data_ptr() == x.data_ptr():
+                    roles.append("x")
+                elif tin.data_ptr() == out.data_ptr():
+                    roles.append("out")
+                elif prev_pair and tin.data_ptr() == prev_pair[0].data_ptr():
+                    roles.append("x_prev")
+                elif prev_pair and tin.data_ptr() == prev_pair[1].data_ptr():
+                    roles.append("out_prev")
+                else:
+                    raise RuntimeError("unexpected operand in the traced launch")
+            plans[i] = (plan, roles, seeds, numel)
+            prev_pair = (x, out)
+            x = nxt
+    finally:
+        _hip.trace = None
+    torch.cuda.synchronize(dev)
+    return plans
+
+
+class _Seed:
+    "minimal stand-in for torch.Generator as a seed carrier (initial_seed only)"
+
+    def __init__(self, s: int):
+        self.s = s
+
+    def initial_seed(self) -> int:
+        return self.s
+
+
+def cpu_baseline(seconds: float) -> dict:
+    """The oracle (reference-order torch CPU port, incl. the reference's deep copies and per-sample randn +
+    stack) timed on this box's host cores on a bounded sample: a slice of the batch, scaled to B=256."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from skr_oracle import samplers as OA
+    from skr_oracle import schedules as OS
+    from skr_oracle import wrapper as OW
+
+    threads = torch.get_num_threads()
+    sub = 16
+    drv = OW.StepDriver(OA.make("dpm", 2, eta=1), OS.karras(OS.scaled(), steps=SCHEDULE_STEPS), "eps", mimic_copies=True)
+    drv.set_timesteps(SCHEDULE_STEPS)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(sub, C, H, W, generator=g).bfloat16()
+    seeds = [42 + i for i in range(sub)]
+    times = []
+    t_start = time.perf_counter()
+    for i, t in enumerate(drv.timesteps):
+        out = torch.randn(sub, C, H, W, generator=g).bfloat16()
+        t0 = time.perf_counter()
+        x = drv.step(out, t, x, seeds=seeds)[0]
+        dt = time.perf_counter() - t0
+        if i in STEADY:
+            times.append(dt)
+        if time.perf_counter() - t_start > seconds and len(times) >= 3:
+            break
+    per_step_full = (sum(times) / len(times)) * (B_PER_GPU / sub)
+    return {
+        "value": 1.0 / per_step_full,
+        "unit": "steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle StepDriver (reference op order, fp32 compute, per-sample randn+stack, deep copies) on {sub} of {B_PER_GPU} samples, "
+        f"{len(times)} steady-state steps of a {SCHEDULE_STEPS}-step schedule, time scaled x{B_PER_GPU // sub} to B={B_PER_GPU}; {threads} torch threads",
+    }
+
+
+def load_traffic() -> float | None:
+    "HBM bytes per launch from the committed PMC pass (profiles/r01_pmc_traffic.json), corrected per the guide"
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return float(json.load(open(path))["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def main() -> None:
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from skrample_amd import _hip
+
+    lib = _hip.load()
+    batch = args.batch
+    numel = batch * C * H * W
+    plans = capture_plans(dev, batch, first_sample=rank * batch)
+
+    # rotating buffer sets: (x, out, x_prev, out_prev, y) each 2 B/elem -> 168 MB per set at B=256
+    nsets = max(args.sets, 4)
+    g = torch.Generator(device=dev).manual_seed(99 + rank)
+    sets = []
+    for _ in range(nsets):
+        bufs = {r: torch.randn(numel, device=dev, generator=g).to(torch.bfloat16) for r in ("x", "out", "x_prev", "out_prev")}
+        bufs["y"] = torch.empty(numel, device=dev, dtype=torch.bfloat16)
+        sets.append(bufs)
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    calls = []
+    for k in range(len(STEADY) * nsets):
+        plan, roles, seeds, n = plans[STEADY[k % len(STEADY)]]
+        assert n == numel and roles == ["x", "out", "x_prev", "out_prev"], roles
+        bufs = sets[k % nsets]
+        ptrs = (ctypes.c_void_p * len(roles))(*[bufs[r].data_ptr() for r in roles])
+        calls.append((ctypes.byref(plan), ptrs, bufs["y"].data_ptr(), seeds.data_ptr()))
+
+    def run(count: int, offset: int = 0) -> None:
+        launch = lib.skr_step_launch
+        ncalls = len(calls)
+        for i in range(count):
+            p, ptrs, y, sd = calls[(offset + i) % ncalls]
+            status = launch(p, ptrs, y, None, sd, numel, stream)
+            if status:
+                _hip.check(status, "skr_step_launch")
+
+    run(args.warmup)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    run(args.steps, offset=args.warmup)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream: average per launch
+
+    elapsed = torch.tensor([wall], dtype=torch.float64, device=dev)
+    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    wall, kernel_ms = elapsed.item(), kms.item()
+
+    # wrapper-level rate (Python scheduler overhead included), for information
+    wrapper_rate = None
+    if rank == 0:
+        w = make_wrapper()
+        shape = (batch, C, H, W)
+        xs = [s["x"].view(shape) for s in sets]
+        outs = [s["out"].view(shape) for s in sets]
+        seeds = [_Seed(42 + i) for i in range(batch)]
+        for rep in range(2):
+            w.set_timesteps(SCHEDULE_STEPS)
+            torch.cuda.synchronize(dev)
+            tw = time.perf_counter()
+            for i, t in enumerate(w.timesteps):
+                w.step(outs[i % nsets], t, xs[i % nsets], generator=seeds, return_dict=False)
+            torch.cuda.synchronize(dev)
+            wrapper_rate = SCHEDULE_STEPS / (time.perf_counter() - tw)
+
+    if rank == 0:
+        steps_per_s = world * args.steps / wall
+        algo_bytes = numel * ALGO_BYTES_PER_ELEM
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "sampler steps/sec (fused DPM-2 SDE step, eps-pred, Karras sigmas, Bx4x128x128 bf16) + achieved HBM GB/s",
+            "value": steps_per_s,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"DPM order-2 SDE (eta=1) + Karras(Scaled) sigmas, eps-pred, B={batch}x{C}x{H}x{W} bf16 latents per GPU "
+                "(BASELINE north-star shape; cfg2 at 4x batch), in-kernel Philox noise, one fused launch per step",
+                "global_batch": batch * world,
+                "per_gpu_batch": batch,
+                "latent_dtype": "bf16",
+                "compute_dtype": "f32 registers, fp64 host coefficients",
+                "schedule_steps": SCHEDULE_STEPS,
+                "steady_state_steps": [STEADY[0], STEADY[-1]],
+                "buffer_sets": nsets,
+                "parallelism": f"batch-shard x{world}, no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": load_traffic(),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_us_per_launch": kernel_ms * 1e3,
+                "kernel": "skr::step_kernel<bf16,bf16,bf16,bf16,float,ST0,!HAS1,NOISE,!CONV>",
+            },
+            "wrapper_steps_per_s": wrapper_rate,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,9 +123,16 @@ def current_stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# When a list is installed here every launch appends (plan, inputs, out0, out1, seeds, numel): used by
+# bench.py to lift the exact plans the samplers emit and replay them through the C ABI.
+trace: list | None = None
+
+
 def launch_step(plan: StepPlanC, inputs: list[torch.Tensor], out0, out1, seeds, numel: int, device: torch.device) -> None:
     "one fused kernel launch on torch's current stream of `device`"
     lib = load()
+    if trace is not None:
+        trace.append((plan, list(inputs), out0, out1, seeds, numel))
     n = len(inputs)
     arr = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in inputs])
     status = lib.skr_step_launch(

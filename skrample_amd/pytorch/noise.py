@@ -43,7 +43,7 @@ class TensorNoiseProps:
 
 def seed_value(seed) -> int:
     "64-bit key from a torch.Generator (its initial seed) or an int"
-    if isinstance(seed, torch.Generator):
+    if hasattr(seed, "initial_seed"):
         return seed.initial_seed() & 0xFFFFFFFFFFFFFFFF
     return int(seed) & 0xFFFFFFFFFFFFFFFF
 
