@@ -19,7 +19,11 @@ namespace skr {
 
 constexpr int VEC = 8;       // elements per lane per trip
 constexpr int BLOCK = 256;   // 4 waves
-constexpr int UV = 2;        // vectors per lane per trip (spaced BLOCK apart: every wave access stays 1 KiB contiguous)
+// vectors per lane per trip (spaced BLOCK apart so every wave access stays 1 KiB contiguous).  Measured on
+// MI355X (tools/tune/tune_step.hip, B=256 DPM-2): without Philox more bytes in flight per lane win
+// (UV 1/2/4 -> 29.3/28.2/27.4 us); with Philox one vector per lane and one trip per lane is best
+// (UV 1/2/4 -> 28.3/29.7/30.9 us): the VALU work then overlaps other waves' loads instead of its own.
+constexpr int uv_for(bool noise, bool has1) { return noise ? 1 : (has1 ? 2 : 4); }
 constexpr int MAXK = SKR_MAX_TERMS;
 
 struct bf16_t { uint16_t v; };
@@ -167,7 +171,7 @@ __device__ __forceinline__ void store_scalar(void* base, int64_t i, Acc v) {
 }
 
 // ---- accumulate one dtype group: N terms x UV vectors of independent 16-byte loads, then FMAs --------
-template <typename T, typename Acc, bool HAS1, int N>
+template <typename T, typename Acc, bool HAS1, int N, int UV>
 __device__ __forceinline__ void acc_batch(const StepArgs<Acc>& a, int k, int64_t v0, int64_t vhi, Acc s0[UV][VEC], Acc s1[UV][VEC]) {
   Raw<T> raw[UV][N];
 #pragma unroll
@@ -197,11 +201,11 @@ __device__ __forceinline__ void acc_batch(const StepArgs<Acc>& a, int k, int64_t
   }
 }
 
-template <typename T, typename Acc, bool HAS1>
+template <typename T, typename Acc, bool HAS1, int UV>
 __device__ __forceinline__ void acc_group(const StepArgs<Acc>& a, int k, int kend, int64_t v0, int64_t vhi, Acc s0[UV][VEC], Acc s1[UV][VEC]) {
-  for (; k + 4 <= kend; k += 4) acc_batch<T, Acc, HAS1, 4>(a, k, v0, vhi, s0, s1);
-  if (k + 2 <= kend) { acc_batch<T, Acc, HAS1, 2>(a, k, v0, vhi, s0, s1); k += 2; }
-  if (k < kend) acc_batch<T, Acc, HAS1, 1>(a, k, v0, vhi, s0, s1);
+  for (; k + 4 <= kend; k += 4) acc_batch<T, Acc, HAS1, 4, UV>(a, k, v0, vhi, s0, s1);
+  if (k + 2 <= kend) { acc_batch<T, Acc, HAS1, 2, UV>(a, k, v0, vhi, s0, s1); k += 2; }
+  if (k < kend) acc_batch<T, Acc, HAS1, 1, UV>(a, k, v0, vhi, s0, s1);
 }
 
 // ---- rounded pair conversion (Runge-Kutta wrapper) ---------------------------------------------------
@@ -266,6 +270,7 @@ __device__ __forceinline__ void locate(const StepArgs<Acc>& a, int64_t e0, int64
 
 template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bool ST0, bool HAS1, bool NOISE, bool CONV>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
+  constexpr int UV = uv_for(NOISE, HAS1);
   // Geometry.  mode 1 (per-sample grid): blockIdx.y/z pick the sample, so the seed is one scalar
   // load per block and no division is needed.  mode 0: flat grid over all vectors.
   int64_t vlo = 0, vhi = a.numel / VEC;
@@ -316,8 +321,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
       }
     }
 
-    acc_group<TA, Acc, HAS1>(a, 0, a.n_a, v0, vhi, s0, s1);
-    if constexpr (!std::is_same<TA, TB>::value) acc_group<TB, Acc, HAS1>(a, a.n_a, a.n_terms, v0, vhi, s0, s1);
+    acc_group<TA, Acc, HAS1, UV>(a, 0, a.n_a, v0, vhi, s0, s1);
+    if constexpr (!std::is_same<TA, TB>::value) acc_group<TB, Acc, HAS1, UV>(a, a.n_a, a.n_terms, v0, vhi, s0, s1);
     if constexpr (CONV) {
       // out0 = rounded conversion of (in[0], in[1]); the host zeroes coef0 so s0 is still 0 here
       using M = typename OpMath<TA>::type;
@@ -383,38 +388,133 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
 // ---- host-side dispatch ------------------------------------------------------------------------------
 static thread_local int g_last_hip_error = 0;
 
-template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bool ST0, bool HAS1, bool NOISE, bool CONV>
-static int launch(StepArgs<Acc>& args, hipStream_t stream) {
-  const int64_t nvec = args.numel / VEC;
-  const int64_t per_block = BLOCK * UV;
-  dim3 grid(1, 1, 1);
-  args.grid_mode = 0;
-  args.aligned = (args.sample_numel % VEC) == 0;
-  args.vps = args.sample_numel / VEC;
-  const int64_t batch = args.numel / args.sample_numel;
-  if (NOISE && args.aligned && args.vps >= per_block && batch <= 65535ll * 65535ll) {
-    // per-sample grid: x covers one sample's vectors, (y,z) enumerate samples
-    int64_t bx = (args.vps + per_block - 1) / per_block;
-    const int64_t want = (256 * 16 + batch - 1) / batch;  // keep >= ~16 blocks per CU in total, no more per sample
-    if (bx > want) bx = want < 1 ? 1 : want;
-    const int64_t gy = batch < 65535 ? batch : 65535;
-    const int64_t gz = (batch + gy - 1) / gy;
-    if (gy * gz == batch) {
-      grid = dim3((unsigned)bx, (unsigned)gy, (unsigned)gz);
-      args.grid_mode = 1;
+// ---- compile-time-K fast path: uniform dtype, one output, no tail -------------------------------------
+// The generic kernel walks a runtime term list (pointer/coefficient fetched from kernarg at a loop-dependent
+// offset, loads in batches of 4).  For the common plans (<= 8 same-dtype operands, out dtype = in dtype) the
+// term count is a template constant: every pointer and coefficient sits in SGPRs before the first load, all K
+// loads are issued back to back, the Philox rounds run while they are in flight, then the FMAs.
+template <typename T, int K, bool NOISE, int UV>
+__global__ __launch_bounds__(BLOCK) void step_kernel_k(const StepArgs<float> a) {
+  int64_t vlo = 0, vhi = a.numel / VEC;
+  uint64_t seed_u = 0;
+  if constexpr (NOISE) {
+    const int64_t smp = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+    vlo = smp * a.vps;
+    vhi = vlo + a.vps;
+    seed_u = a.seeds[smp];
+  }
+  const int64_t stride = (int64_t)gridDim.x * (BLOCK * UV);
+  for (int64_t v0 = vlo + (int64_t)blockIdx.x * (BLOCK * UV) + threadIdx.x; v0 < vhi; v0 += stride) {
+    Raw<T> raw[UV][K];
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      if (v0 + u * BLOCK < vhi) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) raw[u][j] = load_raw<T>(a.in[j], v0 + u * BLOCK);
+      }
+    }
+    float z[UV][VEC];
+    if constexpr (NOISE) {
+#pragma unroll
+      for (int u = 0; u < UV; ++u) {
+        const uint64_t blk = (uint64_t)(v0 + u * BLOCK - vlo) * 2;
+        normal4(seed_u, a.stream0, blk, z[u]);
+        normal4(seed_u, a.stream0, blk + 1, z[u] + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int64_t v = v0 + u * BLOCK;
+      if (v >= vhi) continue;
+      float s[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        float w[VEC];
+        widen<T, float>(raw[u][j], w);
+        const float c = a.c0[j];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] = fma_(c, w[i], s[i]);
+      }
+      if constexpr (NOISE) fma_noise8<float>(a.zeta0, z[u], s);
+      store8<T, float>(a.out0, v, s);
     }
   }
-  if (args.grid_mode == 0) {
-    int64_t blocks = (nvec + per_block - 1) / per_block;
-    const int64_t cap = NOISE ? 256 * 16 : 256 * 4;  // grid-stride beyond: 4 (16 with Philox) blocks per CU
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    grid = dim3((unsigned)blocks, 1, 1);
+}
+
+struct Geometry { dim3 grid; int mode; };
+
+template <int UV, bool NOISE>
+static Geometry geometry(int64_t numel, int64_t sample_numel) {
+  const int64_t nvec = numel / VEC, per_block = BLOCK * UV;
+  const bool aligned = (sample_numel % VEC) == 0;
+  const int64_t vps = sample_numel / VEC, batch = numel / sample_numel;
+  if (NOISE && aligned && vps >= per_block / 2 && batch <= 65535ll * 65535ll) {
+    // per-sample grid: x covers one sample's vectors in ONE trip, (y,z) enumerate samples
+    int64_t bx = (vps + per_block - 1) / per_block;
+    if (bx > 65535) bx = 65535;  // grid-stride beyond (samples of > 134M elements)
+    const int64_t gy = batch < 65535 ? batch : 65535;
+    const int64_t gz = (batch + gy - 1) / gy;
+    if (gy * gz == batch) return {dim3((unsigned)bx, (unsigned)gy, (unsigned)gz), 1};
   }
-  hipLaunchKernelGGL((step_kernel<TA, TB, TO0, TO1, Acc, ST0, HAS1, NOISE, CONV>), grid, dim3(BLOCK), 0, stream, args);
+  int64_t blocks = (nvec + per_block - 1) / per_block;
+  const int64_t cap = NOISE ? 256 * 32 : 256 * 4;  // grid-stride beyond: 4 blocks per CU (32 with Philox)
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return {dim3((unsigned)blocks, 1, 1), 0};
+}
+
+static int finish_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_last_hip_error = (int)e; return SKR_ERR_LAUNCH; }
   return SKR_OK;
+}
+
+template <typename T, bool NOISE, int UV>
+static int launch_k_uv(StepArgs<float>& args, hipStream_t stream, bool& taken) {
+  Geometry g = geometry<UV, NOISE>(args.numel, args.sample_numel);
+  if (NOISE && g.mode != 1) return SKR_OK;  // flat-grid noise (tiny samples): generic kernel
+  args.grid_mode = g.mode;
+  args.aligned = 1;
+  args.vps = args.sample_numel / VEC;
+  taken = true;
+#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_k<T, N, NOISE, UV>), g.grid, dim3(BLOCK), 0, stream, args); break
+  switch (args.n_terms) { SKR_K(1); SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
+#undef SKR_K
+  return finish_launch();
+}
+
+template <typename T, bool NOISE>
+static int launch_k(StepArgs<float>& args, hipStream_t stream, bool& taken) {
+  taken = false;
+  if (args.n_terms < 1 || args.n_terms > 8 || args.numel % VEC != 0) return SKR_OK;
+  if constexpr (NOISE) {
+    return launch_k_uv<T, true, 1>(args, stream, taken);
+  } else {
+    // 4 vectors per lane once that still leaves >= 4 blocks per CU (>= 8M elements), else 1 per lane
+    if (args.numel / VEC >= 4ll * 256 * BLOCK * 4) return launch_k_uv<T, false, 4>(args, stream, taken);
+    return launch_k_uv<T, false, 1>(args, stream, taken);
+  }
+}
+
+template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bool ST0, bool HAS1, bool NOISE, bool CONV>
+static int launch(StepArgs<Acc>& args, hipStream_t stream) {
+  // fast path: uniform 16/32-bit dtype, single output of the same dtype, fp32 accumulate
+  if constexpr (std::is_same<Acc, float>::value && std::is_same<TA, TB>::value && std::is_same<TO0, TA>::value && ST0 && !HAS1 && !CONV) {
+    if (args.n_a == args.n_terms && (!NOISE || args.zeta0 != 0.f)) {
+      bool taken = false;
+      const int rc = launch_k<TA, NOISE>(args, stream, taken);
+      if (taken) return rc;
+    }
+  }
+  constexpr int UV = uv_for(NOISE, HAS1);
+  Geometry g = geometry<UV, NOISE>(args.numel, args.sample_numel);
+  args.grid_mode = g.mode;
+  args.aligned = (args.sample_numel % VEC) == 0;
+  args.vps = args.sample_numel / VEC;
+  hipLaunchKernelGGL((step_kernel<TA, TB, TO0, TO1, Acc, ST0, HAS1, NOISE, CONV>), g.grid, dim3(BLOCK), 0, stream, args);
+  return finish_launch();
 }
 
 template <typename TA, typename TB, typename TO0, typename TO1, typename Acc>

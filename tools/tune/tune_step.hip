@@ -93,6 +93,62 @@ __global__ __launch_bounds__(256) void k(const Args a) {
   }
 }
 
+// per-sample grid: blockIdx.y = sample, scalar seed, no division
+template <int K, int UV, int BLK, bool NOISE_FIRST>
+__global__ __launch_bounds__(BLK) void k2(const Args a) {
+  const int64_t smp = blockIdx.y;
+  const int64_t vlo = smp * a.vps, vhi = vlo + a.vps;
+  const uint64_t seed = a.seeds[smp];
+  const int64_t stride = (int64_t)gridDim.x * BLK * UV;
+  for (int64_t v0 = vlo + ((int64_t)blockIdx.x * BLK) * UV + threadIdx.x; v0 < vhi; v0 += stride) {
+    u32x4_t raw[UV][K];
+#pragma unroll
+    for (int u = 0; u < UV; ++u)
+#pragma unroll
+      for (int j = 0; j < K; ++j) if (v0 + u * BLK < vhi) raw[u][j] = __builtin_nontemporal_load(a.in[j] + v0 + u * BLK);
+    float z[UV][8];
+    if constexpr (NOISE_FIRST) {
+#pragma unroll
+      for (int u = 0; u < UV; ++u) { const uint64_t blk = (uint64_t)(v0 + u * BLK - vlo) * 2; skr::normal4(seed, a.stream, blk, z[u]); skr::normal4(seed, a.stream, blk + 1, z[u] + 4); }
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      if (v0 + u * BLK >= vhi) continue;
+      float s[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s[2 * i] = __builtin_fmaf(a.c[j], __uint_as_float(raw[u][j][i] << 16), s[2 * i]);
+          s[2 * i + 1] = __builtin_fmaf(a.c[j], __uint_as_float(raw[u][j][i] & 0xFFFF0000u), s[2 * i + 1]);
+        }
+      }
+      if constexpr (!NOISE_FIRST) { const uint64_t blk = (uint64_t)(v0 + u * BLK - vlo) * 2; skr::normal4(seed, a.stream, blk, z[u]); skr::normal4(seed, a.stream, blk + 1, z[u] + 4); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.zeta, z[u][i], s[i]);
+      u32x4_t q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = pack_bf16(s[2 * i], s[2 * i + 1]);
+      __builtin_nontemporal_store(q, a.out + v0 + u * BLK);
+    }
+  }
+}
+
+template <int K, int UV, int BLK, bool NF>
+void run2(const char* name, std::vector<Args>& sets, int B, int bx, int iters = 200) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  dim3 grid(bx, B);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k2<K, UV, BLK, NF>), grid, dim3(BLK), 0, 0, sets[i % sets.size()]);
+  CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k2<K, UV, BLK, NF>), grid, dim3(BLK), 0, 0, sets[i % sets.size()]);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / iters;
+  double bytes = (double)sets[0].nvec * 16 * (K + 1);
+  printf("%-46s grid=%dx%d  %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, bx, B, us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
+}
+
 template <int K, bool NT_LD, bool NT_ST, int UV, bool NOISE, bool NOISE_FIRST, bool MEM>
 void run(const char* name, std::vector<Args>& sets, int blocks_cap, int iters = 200) {
   int64_t nvec = sets[0].nvec;
@@ -196,6 +252,21 @@ int main(int argc, char** argv) {
   run<4, true, true, 2, true, true, true>("noise first nt/nt uv2 cap2048", sets, 2048);
   run<4, true, true, 2, true, true, true>("noise first nt/nt uv2 nocap", sets, 0);
   run<4, false, false, 1, true, true, true>("noise first plain uv1 nocap", sets, 0);
+  printf("-- per-sample grid with noise\n");
+  run2<4, 1, 256, true>("k2 uv1 blk256 nf  bx32", sets, B, 32);
+  run2<4, 1, 256, false>("k2 uv1 blk256 nl  bx32", sets, B, 32);
+  run2<4, 1, 256, true>("k2 uv1 blk256 nf  bx16", sets, B, 16);
+  run2<4, 1, 256, true>("k2 uv1 blk256 nf  bx8", sets, B, 8);
+  run2<4, 2, 256, true>("k2 uv2 blk256 nf  bx16", sets, B, 16);
+  run2<4, 2, 256, false>("k2 uv2 blk256 nl  bx16", sets, B, 16);
+  run2<4, 2, 256, true>("k2 uv2 blk256 nf  bx8", sets, B, 8);
+  run2<4, 4, 256, true>("k2 uv4 blk256 nf  bx8", sets, B, 8);
+  run2<4, 4, 256, false>("k2 uv4 blk256 nl  bx8", sets, B, 8);
+  run2<4, 1, 512, true>("k2 uv1 blk512 nf  bx16", sets, B, 16);
+  run2<4, 2, 512, true>("k2 uv2 blk512 nf  bx8", sets, B, 8);
+  run2<4, 1, 1024, true>("k2 uv1 blk1024 nf bx8", sets, B, 8);
+  run2<4, 1, 128, true>("k2 uv1 blk128 nf  bx64", sets, B, 64);
+  run2<4, 1, 64, true>("k2 uv1 blk64 nf  bx128", sets, B, 128);
   printf("-- VALU only (no memory)\n");
   run<4, true, true, 1, true, true, false>("philox+boxmuller only uv1 cap2048", sets, 2048);
   run<4, true, true, 1, true, true, false>("philox+boxmuller only uv1 nocap", sets, 0);
