@@ -100,6 +100,26 @@ int skr_step_launch(const skr_step_plan* plan, const void* const* inputs, void* 
 int skr_noise_random(void* out, int32_t out_dtype, const uint64_t* seeds_dev, uint64_t stream_id,
                      int64_t batch, int64_t sample_numel, void* stream);
 
+/* Offset.generate (noise.py:84-113): out = N(stream_base) + strength^2 * N(stream_offset)[broadcast].
+ * `unit_shape[ndim]` (ndim <= 4) is the per-sample shape; bit k of keep_mask set = dimension k of the unit
+ * shape keeps its size in the offset tensor (reference OffsetProps.dims), otherwise it is broadcast. */
+int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* seeds_dev, uint64_t stream_base,
+                     uint64_t stream_offset, int64_t batch, const int64_t* unit_shape, int32_t ndim,
+                     uint32_t keep_mask, double strength, void* stream);
+
+/* Pyramid.generate (noise.py:146-207) over the last two dims of a [batch][lead][h][w] tensor:
+ *   out = (N(base) + sum_l weight[l] * upsample_bilinear(N(level l)))  /  per-sample unbiased std
+ * Level l >= 1 normals (stream_base+1+l, shape [lead][h_l][w_l]) are generated into LDS and sampled there;
+ * level 0 is full resolution.  `level_hw_dev` = int32 [batch][8][2], `n_levels_dev` = int32 [batch] (level
+ * geometry is drawn per sample on the host from the same Philox key, stream_base+255); `level_weight` = host
+ * double[8] (strength^l, 0 for skipped levels); `max_level_elems` = max over samples of sum_{l>=1} h_l*w_l.
+ * `scratch_f32` [batch*lead*h*w] and `partials_f64` [batch*lead*2] are caller-provided workspaces. */
+int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64,
+                      const uint64_t* seeds_dev, uint64_t stream_base, int64_t batch, int64_t lead, int64_t h,
+                      int64_t w, const int32_t* level_hw_dev, const int32_t* n_levels_dev,
+                      const double* level_weight, int32_t max_level_elems, int32_t with_base,
+                      int32_t normalise, void* stream);
+
 /* raw generator outputs, for parity tests of the RNG itself */
 int skr_philox_u32(uint32_t* out /* [n_blocks*4] device */, uint64_t seed, uint64_t stream_id,
                    uint64_t first_block, int64_t n_blocks, void* stream);

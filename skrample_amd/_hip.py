@@ -25,6 +25,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_
 EXPORTS = (
     "skr_step_launch",
     "skr_noise_random",
+    "skr_noise_offset",
+    "skr_noise_pyramid",
     "skr_philox_u32",
     "skr_abi_version",
     "skr_strerror",
@@ -90,6 +92,10 @@ def load() -> ctypes.CDLL:
         lib.skr_step_launch.restype = ctypes.c_int
         lib.skr_noise_random.argtypes = [vp, i32, vp, u64, i64, i64, vp]
         lib.skr_noise_random.restype = ctypes.c_int
+        lib.skr_noise_offset.argtypes = [vp, i32, vp, u64, u64, i64, ctypes.POINTER(i64), i32, ctypes.c_uint32, ctypes.c_double, vp]
+        lib.skr_noise_offset.restype = ctypes.c_int
+        lib.skr_noise_pyramid.argtypes = [vp, i32, vp, vp, vp, u64, i64, i64, i64, i64, vp, vp, ctypes.POINTER(ctypes.c_double), i32, i32, i32, vp]
+        lib.skr_noise_pyramid.restype = ctypes.c_int
         lib.skr_philox_u32.argtypes = [vp, u64, u64, u64, i64, vp]
         lib.skr_philox_u32.restype = ctypes.c_int
         lib.skr_abi_version.restype = ctypes.c_int

@@ -142,6 +142,42 @@ class OffsetProps(TensorNoiseProps):
     static: bool = False
 
 
+def _launch_ctx(seeds: torch.Tensor):
+    return _hip.load(), _hip.current_stream_ptr(seeds.device)
+
+
+@dataclass
+class Offset(TensorNoiseCommon):
+    "white noise plus a random offset shared along the dimensions NOT listed in `props.dims`"
+
+    @classmethod
+    def from_inputs(cls, shape, seed, props=OffsetProps(), dtype=torch.float32):
+        return cls(tuple(shape), seed, dtype, props)
+
+    @classmethod
+    def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        import ctypes
+
+        if len(unit_shape) > 4:
+            raise SkrampleHipError("Offset noise supports per-sample shapes of up to 4 dimensions")
+        if props.static:  # the offset is drawn once (first call) and reused
+            offset_stream = state.setdefault("offset_stream", stream + 1)
+        else:
+            offset_stream = stream + 1
+        nd = len(unit_shape)
+        mask = 0
+        for d in props.dims:
+            mask |= 1 << (d + nd if d < 0 else d)
+        out = torch.empty((seeds.shape[0], *unit_shape), dtype=dtype, device=seeds.device)
+        lib, hstream = _launch_ctx(seeds)
+        shape_arr = (ctypes.c_int64 * nd)(*unit_shape)
+        _hip.check(
+            lib.skr_noise_offset(out.data_ptr(), _hip.DTYPE_CODE[dtype], seeds.data_ptr(), stream, offset_stream, seeds.shape[0], shape_arr, nd, mask, float(props.strength), hstream),
+            "skr_noise_offset",
+        )
+        return out
+
+
 @dataclass(frozen=True)
 class PyramidProps(OffsetProps):
     dims: tuple[int, ...] = (-1, -2)
@@ -172,6 +208,102 @@ def colored_exponent(step: Step | None, props: ColoredProps) -> float:
     shift = rescale_positive(-props.color_curve)
     t = shift / (shift + (divf(1, t) - 1))
     return (1 - t) * props.color_start + t * props.color_end
+
+
+PYRAMID_MAX_LEVELS = 8
+
+
+def pyramid_level_shapes(unit_hw: tuple[int, int], resize_h: bool, uniforms) -> list[tuple[int, int]]:
+    """(h_l, w_l) of every pyramid level for one sample (reference noise.py:157-162,195-196): level i
+    shrinks the *running* size by r_i**i with r_i = 2 + 2*u_i, and the pyramid ends with the first level
+    that has a resized dimension of 1 (or after 99 levels)."""
+    h, w = unit_hw
+    levels = []
+    for i, u in enumerate(uniforms):
+        r = float(u) * 2 + 2
+        if resize_h:
+            h = max(1, int(h / (r**i)))
+        w = max(1, int(w / (r**i)))
+        levels.append((h, w))
+        if w <= 1 or (resize_h and h <= 1):
+            break
+    return levels
+
+
+@dataclass
+class Pyramid(TensorNoiseCommon):
+    """Multi-resolution noise (white noise + bilinearly up-sampled coarser noise levels), rescaled to unit
+    variance per sample.  Level geometry is random per sample, as in the reference."""
+
+    @classmethod
+    def from_inputs(cls, shape, seed, props=PyramidProps(), dtype=torch.float32):
+        return cls(tuple(shape), seed, dtype, props)
+
+    @staticmethod
+    def _geometry(unit_shape, props) -> tuple[int, int, int, bool]:
+        nd = len(unit_shape)
+        dims = sorted((d + nd if d < 0 else d) for d in props.dims)
+        if dims == [nd - 2, nd - 1] and nd >= 2:
+            return math.prod(unit_shape[:-2]), unit_shape[-2], unit_shape[-1], True
+        if dims == [nd - 1]:
+            return math.prod(unit_shape[:-1]), 1, unit_shape[-1], False
+        raise SkrampleHipError("Pyramid noise resizes the last one or two dimensions (the reference's other `dims` choices fail inside torch.interpolate)")
+
+    @classmethod
+    def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        import ctypes
+
+        import numpy as np
+
+        from ._philox_host import uniform01
+
+        if props.static:
+            stream_levels = state.setdefault("static_stream", stream)  # pyramid component frozen at the first draw
+        else:
+            stream_levels = stream
+        lead, h, w, resize_h = cls._geometry(unit_shape, props)
+        batch = seeds.shape[0]
+        host_seeds = state.get("host_seeds")
+        if host_seeds is None or len(host_seeds) != batch:
+            host_seeds = state["host_seeds"] = seeds.cpu().numpy().astype(np.uint64)
+        uniforms = uniform01(host_seeds, stream_levels + 255, PYRAMID_MAX_LEVELS)
+        table = np.zeros((batch, PYRAMID_MAX_LEVELS, 2), dtype=np.int32)
+        counts = np.zeros(batch, dtype=np.int32)
+        worst = 0
+        for b in range(batch):
+            levels = pyramid_level_shapes((h, w), resize_h, uniforms[b])
+            counts[b] = len(levels)
+            table[b, : len(levels)] = levels
+            worst = max(worst, sum(lh * lw for lh, lw in levels[1:]))
+        n_max = int(counts.max())
+        # depth: keep only the `depth`+1 coarsest levels (reference noise.py:198-200) -- per sample the count can
+        # differ, so the skip is applied through the weights only when every sample agrees; otherwise per level count
+        weights = np.zeros(PYRAMID_MAX_LEVELS, dtype=np.float64)
+        for l in range(n_max):
+            weights[l] = props.strength**l
+        if props.depth < n_max - 1:
+            if len(set(counts.tolist())) != 1:
+                raise SkrampleHipError("Pyramid depth truncation with per-sample level counts that differ is not supported in one launch")
+            for l in range(max(0, (n_max - 1) - props.depth)):
+                weights[l] = 0.0
+        dev = seeds.device
+        out = torch.empty((batch, *unit_shape), dtype=dtype, device=dev)
+        scratch = torch.empty(batch * lead * h * w, dtype=torch.float32, device=dev)
+        partials = torch.empty(batch * lead * 2, dtype=torch.float64, device=dev)
+        table_d = torch.from_numpy(table).to(dev)
+        counts_d = torch.from_numpy(counts).to(dev)
+        lib, hstream = _launch_ctx(seeds)
+        # base normal: this draw's own stream; levels: stream_levels (+1+l)
+        if stream_levels != stream:
+            raise SkrampleHipError("static pyramids are not implemented on this engine yet")
+        _hip.check(
+            lib.skr_noise_pyramid(
+                out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), partials.data_ptr(), seeds.data_ptr(), stream, batch, lead, h, w,
+                table_d.data_ptr(), counts_d.data_ptr(), (ctypes.c_double * PYRAMID_MAX_LEVELS)(*weights.tolist()), int(worst), 1, 1, hstream,
+            ),
+            "skr_noise_pyramid",
+        )
+        return out
 
 
 @dataclass
