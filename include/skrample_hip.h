@@ -120,6 +120,16 @@ int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* 
                       const double* level_weight, int32_t max_level_elems, int32_t with_base,
                       int32_t normalise, void* stream);
 
+/* Colored.generate / colorize_noise (noise.py:337-425): white Philox noise shaped in the Fourier domain by
+ * clamp(radial_frequency, eps)^(-exponent/2) and rescaled per sample to the white noise's std (or `energy`).
+ * The per-sample transform is over (d1, d2, d3) (d1 = 1 for a 2-D unit), each a power of two <= 4096.
+ * Workspaces (caller-provided): spec_c64 = batch*d1*d2*(d3/2+1) complex64, scratch_f32 = batch*d1*d2*d3,
+ * partials_f64 = 4*batch*partial_slots doubles with partial_slots >= ceil(d1*d2 / max(1, 4096/d3)). */
+int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
+                      int64_t partial_slots, const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch,
+                      int32_t d1, int32_t d2, int32_t d3, double exponent, int32_t has_energy, double energy,
+                      void* stream);
+
 /* raw generator outputs, for parity tests of the RNG itself */
 int skr_philox_u32(uint32_t* out /* [n_blocks*4] device */, uint64_t seed, uint64_t stream_id,
                    uint64_t first_block, int64_t n_blocks, void* stream);

@@ -1,0 +1,318 @@
+// Colored (power-law) noise for MI355X -- reference skrample/pytorch/noise.py:284-425.
+//
+//   white = N()  ->  F = rfftn(white)  ->  F *= clamp(radius, eps)^(-exponent/2)  ->  irfftn  ->  rescale so
+//   that std(out) = std(white) (or `energy`), per sample.
+//
+// The per-sample transform is 2-D or 3-D over power-of-two sizes and is done axis by axis with a shared
+// LDS radix-2 FFT (`fft_tile`): a 256-thread block owns a tile of L lines x N points (<= 4096 complex), loads
+// it coalesced whatever the axis stride, transforms all lines together and stores it back.
+//   pass A  last axis, real -> half spectrum; the real input is *drawn in place* (Philox), never read
+//   pass B  middle axis forward                                   (3-D only)
+//   pass C  outermost axis forward, x radial weights, inverse     (fused: the weights need the full transform)
+//   pass D  middle axis inverse                                   (3-D only)
+//   pass E  last axis, half spectrum -> real (fp32 scratch) + per-block sums
+//   pass F  per-sample unbiased std of white (from A) and coloured (from E), rescale, round to out dtype
+// Reductions are per block into fixed slots and summed in a fixed order (bit-reproducible, no atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/skrample_hip.h"
+#include "skr_philox.h"
+
+namespace skr {
+
+constexpr int FFT_THREADS = 256;
+constexpr int FFT_MAX_TILE = 4096;  // complex points per block tile (32 KiB) + twiddles
+
+struct ColoredArgs {
+  float2* spec;         // [batch][d1][d2][d3h]
+  float* real_out;      // [batch][d1][d2][d3] fp32 scratch (pass E)
+  double* partials;     // [2][batch][n_slots][2]  (0: white from pass A, 1: coloured from pass E)
+  const uint64_t* seeds;
+  uint64_t stream;
+  int64_t batch;
+  int32_t d1, d2, d3, d3h;   // d1 = 1 for 2-D
+  int32_t n_slots;
+  float exponent_half_neg;   // -exponent / 2
+  float eps_clip;
+  float inv_rmax;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+__device__ __forceinline__ unsigned brev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
+
+// In-place radix-2 DIT over L lines of N points held in `buf` (line-major, stride N+1), input already in
+// bit-reversed order.  `tw` holds exp(-2 pi i k / N), k < N/2; INVERSE conjugates it.
+template <bool INVERSE>
+__device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, int logN, int L) {
+  const int half_n = N >> 1, ld = N + 1;
+  const int total = L * half_n;
+  for (int s = 0; s < logN; ++s) {
+    const int half = 1 << s;
+    const int tw_step = half_n >> s;
+    __syncthreads();
+    for (int t = threadIdx.x; t < total; t += FFT_THREADS) {
+      const int line = t / half_n, k = t - line * half_n;
+      const int pos = k & (half - 1);
+      const int i0 = ((k >> s) << (s + 1)) + pos;
+      float2 w = tw[pos * tw_step];
+      if (INVERSE) w.y = -w.y;
+      float2* p = buf + line * ld;
+      const float2 a = p[i0], b = cmul(p[i0 + half], w);
+      p[i0] = make_float2(a.x + b.x, a.y + b.y);
+      p[i0 + half] = make_float2(a.x - b.x, a.y - b.y);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void make_twiddles(float2* tw, int N) {
+  for (int k = threadIdx.x; k < N / 2; k += FFT_THREADS) {
+    float s, c;
+    sincospif(-2.0f * (float)k / (float)N, &s, &c);
+    tw[k] = make_float2(c, s);
+  }
+}
+
+__device__ __forceinline__ float axis_freq(int k, int d) { const int m = k < d - k ? k : d - k; return (float)m / (float)d; }
+
+// block-wide sum of two doubles into partial slot (fixed order)
+__device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
+  __shared__ double red[2][FFT_THREADS / 64];
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < FFT_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+    slot[0] = a; slot[1] = b;
+  }
+}
+
+// ---- pass A / E: last axis (contiguous lines of d3 reals <-> d3h complex) -------------------------------------
+template <bool FORWARD>
+__global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredArgs a, int logN, int L) {
+  extern __shared__ float2 smem[];
+  const int N = a.d3, ld = N + 1;
+  float2* tw = smem;
+  float2* buf = smem + N / 2;
+  const int64_t smp = blockIdx.y;
+  const int64_t n_lines = (int64_t)a.d1 * a.d2;
+  const int64_t line0 = (int64_t)blockIdx.x * L;
+  const int lines = (int)((n_lines - line0) < L ? (n_lines - line0) : L);
+  make_twiddles(tw, N);
+  double s1 = 0.0, s2 = 0.0;
+  if (FORWARD) {
+    // draw the white noise straight into LDS (bit-reversed), 4 normals per Philox call
+    const uint64_t seed = a.seeds[smp];
+    for (int q = threadIdx.x; q < lines * (N / 4); q += FFT_THREADS) {
+      const int line = q / (N / 4), n4 = (q - line * (N / 4)) * 4;
+      const int64_t e = (line0 + line) * N + n4;  // element index inside the sample
+      float z[4];
+      normal4(seed, a.stream, (uint64_t)e >> 2, z);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        buf[line * ld + brev(n4 + j, logN)] = make_float2(z[j], 0.f);
+        s1 += (double)z[j];
+        s2 += (double)z[j] * (double)z[j];
+      }
+    }
+    fft_tile<false>(buf, tw, N, logN, lines);
+    float2* dst = a.spec + (smp * n_lines + line0) * a.d3h;
+    for (int q = threadIdx.x; q < lines * a.d3h; q += FFT_THREADS) {
+      const int line = q / a.d3h, k = q - line * a.d3h;
+      dst[(int64_t)line * a.d3h + k] = buf[line * ld + k];
+    }
+    block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + blockIdx.x) * 2);
+  } else {
+    const float2* src = a.spec + (smp * n_lines + line0) * a.d3h;
+    for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
+      const int line = q / N, k = q - line * N;
+      float2 v;
+      if (k < a.d3h) v = src[(int64_t)line * a.d3h + k];
+      else { v = src[(int64_t)line * a.d3h + (N - k)]; v.y = -v.y; }  // Hermitian half
+      buf[line * ld + brev(k, logN)] = v;
+    }
+    fft_tile<true>(buf, tw, N, logN, lines);
+    const float scale = 1.0f / ((float)a.d1 * (float)a.d2 * (float)a.d3);
+    float* dst = a.real_out + (smp * n_lines + line0) * N;
+    for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
+      const int line = q / N, n = q - line * N;
+      const float v = buf[line * ld + n].x * scale;
+      dst[(int64_t)line * N + n] = v;
+      s1 += (double)v;
+      s2 += (double)v * (double)v;
+    }
+    block_sums(s1, s2, a.partials + ((1 * a.batch + smp) * a.n_slots + blockIdx.x) * 2);
+  }
+}
+
+// ---- pass B / C / D: a strided axis of length N; lines start at consecutive complex positions --------------------
+//   element n of line q (within a sample):  (q / inner) * outer + (q % inner) + n * stride
+// MODE 0 forward, 1 inverse, 2 forward + radial weights + inverse (outermost axis)
+template <int MODE>
+__global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const ColoredArgs a, int N, int logN, int L, int64_t n_lines, int64_t inner, int64_t outer, int64_t stride, int axis /*1 or 2*/) {
+  extern __shared__ float2 smem[];
+  const int ld = N + 1;
+  float2* tw = smem;
+  float2* buf = smem + N / 2;
+  const int64_t smp = blockIdx.y;
+  const int64_t line0 = (int64_t)blockIdx.x * L;
+  const int lines = (int)((n_lines - line0) < L ? (n_lines - line0) : L);
+  float2* base = a.spec + smp * (int64_t)a.d1 * a.d2 * a.d3h;
+  make_twiddles(tw, N);
+  // coalesced along the line index j (adjacent lines are adjacent in memory)
+  for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
+    const int n = q / lines, j = q - n * lines;
+    const int64_t ql = line0 + j;
+    buf[j * ld + brev(n, logN)] = base[(ql / inner) * outer + (ql % inner) + (int64_t)n * stride];
+  }
+  fft_tile<MODE == 1>(buf, tw, N, logN, lines);
+  if (MODE == 2) {
+    // natural-order spectrum along this axis: weight, then bit-reverse in place for the inverse transform
+    for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
+      const int j = q / N, k = q - j * N;
+      const int64_t ql = line0 + j;
+      // frequency coordinates of this line's other axes
+      int k2, k3;
+      float f1, f2, f3;
+      if (axis == 1) {  // 3-D: this axis is d1, line position = (k2, k3)
+        k2 = (int)(ql / a.d3h); k3 = (int)(ql - (int64_t)k2 * a.d3h);
+        f1 = axis_freq(k, a.d1); f2 = axis_freq(k2, a.d2);
+      } else {          // 2-D: this axis is d2, line position = k3
+        k3 = (int)ql; f1 = 0.f; f2 = axis_freq(k, a.d2);
+      }
+      f3 = (float)k3 / (float)a.d3;
+      float radius = sqrtf(f1 * f1 + f2 * f2 + f3 * f3) * a.inv_rmax;
+      radius = radius < a.eps_clip ? a.eps_clip : radius;
+      const float wgt = powf(radius, a.exponent_half_neg);
+      float2 v = buf[j * ld + k];
+      buf[j * ld + k] = make_float2(v.x * wgt, v.y * wgt);
+    }
+    __syncthreads();
+    // in-place bit reversal (swap pairs once)
+    for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
+      const int j = q / N, k = q - j * N;
+      const int r = (int)brev(k, logN);
+      if (k < r) { float2 t = buf[j * ld + k]; buf[j * ld + k] = buf[j * ld + r]; buf[j * ld + r] = t; }
+    }
+    fft_tile<true>(buf, tw, N, logN, lines);
+  }
+  for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
+    const int n = q / lines, j = q - n * lines;
+    const int64_t ql = line0 + j;
+    base[(ql / inner) * outer + (ql % inner) + (int64_t)n * stride] = buf[j * ld + n];
+  }
+}
+
+// ---- pass F: rescale per sample ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colored_finish(T* out, const ColoredArgs a, int64_t unit, int has_energy, double energy) {
+  const int64_t smp = blockIdx.y;
+  double w1 = 0, w2 = 0, c1 = 0, c2 = 0;
+  for (int s = 0; s < a.n_slots; ++s) {
+    const double* pw = a.partials + ((0 * a.batch + smp) * a.n_slots + s) * 2;
+    const double* pc = a.partials + ((1 * a.batch + smp) * a.n_slots + s) * 2;
+    w1 += pw[0]; w2 += pw[1]; c1 += pc[0]; c2 += pc[1];
+  }
+  const double n = (double)unit;
+  const double wstd = sqrt((w2 - w1 * w1 / n) / (n - 1.0));
+  const double cstd = sqrt((c2 - c1 * c1 / n) / (n - 1.0));
+  float factor = 1.0f;  // reference: only rescale when the coloured std is not degenerate (noise.py:401-403)
+  if ((float)cstd > 1e-8f) factor = has_energy ? (float)energy / (float)cstd : (float)wstd / (float)cstd;
+  const float* src = a.real_out + smp * unit;
+  T* dst = out + smp * unit;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < unit; i += (int64_t)gridDim.x * 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    dst[i] = (T)(v.x * factor); dst[i + 1] = (T)(v.y * factor); dst[i + 2] = (T)(v.z * factor); dst[i + 3] = (T)(v.w * factor);
+  }
+}
+
+}  // namespace skr
+
+static int ilog2_exact(int64_t v) {
+  if (v < 2 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1ll << l) < v) ++l;
+  return l;
+}
+
+#define SKR_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH; } while (0)
+
+extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64, int64_t partial_slots,
+                                 const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t d1, int32_t d2, int32_t d3,
+                                 double exponent, int32_t has_energy, double energy, void* stream) {
+  using namespace skr;
+  if (batch < 0 || d1 < 1 || d2 < 2 || d3 < 4) return SKR_ERR_SHAPE;
+  if (batch == 0) return SKR_OK;
+  if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || !seeds_dev) return SKR_ERR_NULL;
+  const int l3 = ilog2_exact(d3), l2 = ilog2_exact(d2), l1 = d1 == 1 ? 0 : ilog2_exact(d1);
+  if (l3 < 2 || l2 < 1 || l1 < 0 || d3 > FFT_MAX_TILE || d2 > FFT_MAX_TILE || d1 > FFT_MAX_TILE) return SKR_ERR_UNSUPPORTED;  // power-of-two axes only
+  if (batch > 65535) return SKR_ERR_UNSUPPORTED;
+  ColoredArgs a;
+  a.spec = reinterpret_cast<float2*>(spec_c64); a.real_out = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
+  a.stream = stream_id; a.batch = batch; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
+  a.exponent_half_neg = (float)(-exponent / 2.0);
+  const int nd = d1 > 1 ? 3 : 2;
+  const double n_eff = nd == 3 ? ((double)d1 + d2 + d3) / 3.0 : ((double)d2 + d3) / 2.0;
+  a.eps_clip = (float)(0.5 / (n_eff > 4.0 ? n_eff : 4.0));
+  // r_max over the rfftn grid: every axis reaches floor(d/2)/d
+  auto fmaxf_axis = [](int d) { return (float)(d / 2) / (float)d; };
+  const float m1 = d1 > 1 ? fmaxf_axis(d1) : 0.f, m2 = fmaxf_axis(d2), m3 = fmaxf_axis(d3);
+  const float rmax = sqrtf(m1 * m1 + m2 * m2 + m3 * m3);
+  a.inv_rmax = rmax > 0.f ? 1.0f / rmax : 1.0f;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+  // pass A: last axis forward
+  const int64_t lines_last = (int64_t)d1 * d2;
+  int La = FFT_MAX_TILE / d3; if (La > lines_last) La = (int)lines_last; if (La < 1) La = 1;
+  const int64_t blocks_a = (lines_last + La - 1) / La;
+  if (blocks_a > partial_slots) return SKR_ERR_SHAPE;
+  a.n_slots = (int32_t)blocks_a;
+  const size_t lds_a = sizeof(float2) * ((size_t)d3 / 2 + (size_t)La * (d3 + 1));
+  hipLaunchKernelGGL(colored_last_axis<true>, dim3((unsigned)blocks_a, (unsigned)batch), dim3(FFT_THREADS), lds_a, s, a, l3, La);
+  SKR_CHECK_LAUNCH();
+
+  auto strided = [&](int mode, int N, int logN, int64_t n_lines, int64_t inner, int64_t outer, int64_t stride, int axis) -> int {
+    int L = FFT_MAX_TILE / N; if (L > n_lines) L = (int)n_lines; if (L < 1) L = 1;
+    if (L > 64) L = 64;  // keep the coalesced run per row modest so more blocks are in flight
+    const int64_t blocks = (n_lines + L - 1) / L;
+    const size_t lds = sizeof(float2) * ((size_t)N / 2 + (size_t)L * (N + 1));
+    dim3 grid((unsigned)blocks, (unsigned)batch);
+    if (mode == 0) hipLaunchKernelGGL(colored_strided_axis<0>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, L, n_lines, inner, outer, stride, axis);
+    else if (mode == 1) hipLaunchKernelGGL(colored_strided_axis<1>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, L, n_lines, inner, outer, stride, axis);
+    else hipLaunchKernelGGL(colored_strided_axis<2>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, L, n_lines, inner, outer, stride, axis);
+    return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+  };
+  const int64_t d3h = a.d3h;
+  int rc;
+  if (nd == 3) {
+    // axis 2 (length d2, stride d3h): lines = (i1, k3)
+    if ((rc = strided(0, d2, l2, (int64_t)d1 * d3h, d3h, (int64_t)d2 * d3h, d3h, 2)) != SKR_OK) return rc;
+    // axis 1 (length d1, stride d2*d3h): lines = (k2, k3), fused forward + weights + inverse
+    if ((rc = strided(2, d1, l1, (int64_t)d2 * d3h, (int64_t)d2 * d3h, 0, (int64_t)d2 * d3h, 1)) != SKR_OK) return rc;
+    if ((rc = strided(1, d2, l2, (int64_t)d1 * d3h, d3h, (int64_t)d2 * d3h, d3h, 2)) != SKR_OK) return rc;
+  } else {
+    if ((rc = strided(2, d2, l2, d3h, d3h, 0, d3h, 2)) != SKR_OK) return rc;
+  }
+
+  // pass E: last axis inverse -> real scratch
+  hipLaunchKernelGGL(colored_last_axis<false>, dim3((unsigned)blocks_a, (unsigned)batch), dim3(FFT_THREADS), lds_a, s, a, l3, La);
+  SKR_CHECK_LAUNCH();
+
+  // pass F
+  const int64_t unit = (int64_t)d1 * d2 * d3;
+  int64_t bx = (unit / 4 + 255) / 256; if (bx > 64) bx = 64;
+  dim3 grid((unsigned)bx, (unsigned)batch);
+  switch (out_dtype) {
+    case SKR_BF16: hipLaunchKernelGGL(colored_finish<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, a, unit, has_energy, energy); break;
+    case SKR_F16: hipLaunchKernelGGL(colored_finish<_Float16>, grid, dim3(256), 0, s, (_Float16*)out, a, unit, has_energy, energy); break;
+    case SKR_F32: hipLaunchKernelGGL(colored_finish<float>, grid, dim3(256), 0, s, (float*)out, a, unit, has_energy, energy); break;
+    case SKR_F64: hipLaunchKernelGGL(colored_finish<double>, grid, dim3(256), 0, s, (double*)out, a, unit, has_energy, energy); break;
+    default: return SKR_ERR_DTYPE;
+  }
+  SKR_CHECK_LAUNCH();
+  return SKR_OK;
+}

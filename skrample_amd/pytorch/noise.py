@@ -307,6 +307,62 @@ class Pyramid(TensorNoiseCommon):
 
 
 @dataclass
+class Colored(TensorNoiseCommon):
+    """Power-law coloured noise: white Philox noise shaped in the Fourier domain by f^(-exponent/2), the
+    exponent moving from `color_start` to `color_end` over the schedule; per-sample std preserved (or set to
+    `energy`).  Transform axes must be powers of two (2-D or 3-D per sample after dropping size-1 dims)."""
+
+    @classmethod
+    def from_inputs(cls, shape, seed, props=ColoredProps(), dtype=torch.float32):
+        return cls(tuple(shape), seed, dtype, props)
+
+    @staticmethod
+    def _axes(unit_shape) -> tuple[int, int, int]:
+        dims = [d for d in unit_shape if d != 1]
+        if len(dims) == 2:
+            dims = [1, *dims]
+        if len(dims) != 3 or any(d & (d - 1) for d in dims) or dims[2] < 4 or dims[1] < 2:
+            raise SkrampleHipError(f"Colored noise on this engine needs a 2-D/3-D per-sample shape with power-of-two sizes, got {tuple(unit_shape)}")
+        return dims[0], dims[1], dims[2]
+
+    @classmethod
+    def _batch_lazy(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        if colored_exponent(step, props) == 0.0 and props.energy is None:
+            return PhiloxNoise(seeds, stream, (seeds.shape[0], *unit_shape), seeds.device)  # plain white noise
+        return cls._batch(unit_shape, seeds, stream, step, props, dtype, state)
+
+    @classmethod
+    def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        exponent = colored_exponent(step, props)
+        batch = seeds.shape[0]
+        if exponent == 0.0 and props.energy is None:
+            return PhiloxNoise(seeds, stream, (batch, *unit_shape), seeds.device).realize(dtype)
+        d1, d2, d3 = cls._axes(unit_shape)
+        dev = seeds.device
+        key = ("ws", batch, d1, d2, d3)
+        if key not in state:
+            slots = -(-(d1 * d2) // max(1, 4096 // d3))
+            state.clear()
+            state[key] = (
+                torch.empty(batch * d1 * d2 * (d3 // 2 + 1), dtype=torch.complex64, device=dev),
+                torch.empty(batch * d1 * d2 * d3, dtype=torch.float32, device=dev),
+                torch.empty(4 * batch * slots, dtype=torch.float64, device=dev),
+                slots,
+            )
+        spec, scratch, partials, slots = state[key]
+        out = torch.empty((batch, *unit_shape), dtype=dtype, device=dev)
+        lib, hstream = _launch_ctx(seeds)
+        _hip.check(
+            lib.skr_noise_colored(
+                out.data_ptr(), _hip.DTYPE_CODE[dtype], spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), slots, seeds.data_ptr(), stream,
+                batch, d1, d2, d3, float(exponent), 0 if props.energy is None else 1, 0.0 if props.energy is None else float(props.energy), hstream,
+            ),
+            "skr_noise_colored",
+        )
+        return out
+
+
+@dataclass
 class Brownian(TensorNoiseCommon):
     def _setup(self) -> None:
         raise SkrampleHipError("Brownian noise (torchsde BrownianInterval in the reference) is outside this engine's scope")

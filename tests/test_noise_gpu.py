@@ -137,3 +137,76 @@ def test_pyramid_through_wrapper(dev):
     for t in w.timesteps:
         x = w.step(torch.randn_like(x), t, x, generator=[1, 2], return_dict=False)[0]
     assert torch.isfinite(x.float()).all() and x.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (2, 8, 256)])
+def test_colored(unit, dev):
+    seeds = [31, 32]
+    cases = [
+        (PN.ColoredProps(), [None, Step(0.0, 0.05), Step(0.45, 0.5), Step(0.95, 1.0)]),
+        (PN.ColoredProps(energy=2.5, color_start=1.5, color_end=-3, color_curve=0), [Step(0.3, 0.4)]),
+        (PN.ColoredProps(energy=-1.5, color_start=0.0), [None]),
+    ]
+    for props, steps in cases:
+        g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=props, dtype=torch.float32)
+        kw = dict(energy=props.energy, color_start=props.color_start, color_end=props.color_end, color_curve=props.color_curve)
+        for n, st in enumerate(steps):
+            got = g.generate(st).cpu()
+            ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st, **kw) for s in seeds])
+            assert rel(got, ref) < 5e-5, (unit, props, st, rel(got, ref))
+            if props.energy is not None:
+                assert (got.reshape(2, -1).std(dim=1) - abs(props.energy)).abs().max() < 1e-4
+
+
+def test_colored_spectrum_slope(dev):
+    "reference tests/self_noise.py:63-80: the measured PSD slope follows the requested exponent"
+    from scipy import fft
+    from scipy.stats import linregress
+
+    def slope(data):
+        F = fft.fftshift(fft.fftn(data))
+        psd = np.abs(F) ** 2
+        mesh = np.meshgrid(*[fft.fftshift(fft.fftfreq(s)) for s in data.shape], indexing="ij")
+        r = np.sqrt(sum(m**2 for m in mesh))
+        mask = r > 0
+        rf, pf = r[mask], psd[mask]
+        nb = min(data.shape) // 2
+        edges = np.linspace(rf.min(), rf.max(), nb + 1)
+        idx = np.digitize(rf, edges) - 1
+        centers = 0.5 * (edges[:-1] + edges[1:])
+        power = np.array([pf[idx == i].mean() if (idx == i).any() else 0 for i in range(nb)])
+        ok = (power > 0) & (centers > 0)
+        return -linregress(np.log(centers[ok]), np.log(power[ok])).slope
+
+    for exponent in (-3, -1.5, 1.5, 3):
+        for unit in ((1024, 1024), (128, 128, 128)):
+            g = PN.Colored(unit, 5, torch.float32, PN.ColoredProps(color_curve=0, color_start=exponent, color_end=-exponent))
+            assert abs(exponent - slope(g.generate(None).cpu().numpy())) < 0.1
+            assert abs(-exponent - slope(g.generate(Step(0, 1)).cpu().numpy())) < 0.1
+
+
+def test_colored_with_unipc_wrapper(dev):
+    "cfg3: UniPC-3 SDE + Colored noise through the scheduler wrapper vs the oracle fed the same realised noise"
+    import skrample_amd.diffusers as PD
+    import skrample_amd.scheduling as PS
+    from skr_oracle import samplers as OA
+    from skr_oracle import schedules as OS
+    from skr_oracle import wrapper as OW
+    from skrample_amd.sampling import models as PM
+    from skrample_amd.sampling import structured as PT
+
+    steps, shape, seeds = 6, (2, 16, 16, 16), [41, 42]
+    w = PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), noise_type=PN.Colored, noise_props=PN.ColoredProps())
+    o = OW.StepDriver(OA.make("unipc", 3, eta=1), OS.linear(), "flow")
+    w.set_timesteps(steps)
+    o.set_timesteps(steps)
+    shadow = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, shape[1:], seeds, props=PN.ColoredProps(), dtype=torch.float32)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(shape, generator=g)
+    for i, t in enumerate(w.timesteps):
+        out = torch.randn(shape, generator=g)
+        got = w.step(out.to(dev), t, x.to(dev), generator=seeds, return_dict=False)[0]
+        noise = shadow.generate(Step.from_int(i, steps)).cpu()  # the same draw the wrapper's generator made
+        ref = o.step(out, t, x, noise=noise)[0]
+        assert rel(got, ref) < 1e-5, i
+        x = ref
