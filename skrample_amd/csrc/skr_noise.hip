@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void offset_kernel(const OffsetArgs a) {
 // un-normalised sum in fp32 plus per-block (sum, sum of squares) in double; pass 2 divides by the per-sample
 // unbiased std (fixed summation order => bit-reproducible) and rounds to the output dtype.
 constexpr int PYR_MAX_LEVELS = 8;
-constexpr int PYR_LDS_FLOATS = 12 * 1024;  // 48 KiB of level storage per block
+constexpr int PYR_LDS_FLOATS = 38 * 1024;  // up to 152 KiB of level storage per block (dynamic LDS, 160 KiB per CU)
 
 struct PyramidArgs {
   float* scratch;          // [batch][lead][h][w] fp32
@@ -90,7 +90,7 @@ __device__ __forceinline__ void src_index(int dst, int in_size, int out_size, in
 }
 
 __global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
-  __shared__ float lds[PYR_LDS_FLOATS];
+  extern __shared__ float lds[];  // sum over levels >= 1 of h_l*w_l floats (sized by the host per launch)
   __shared__ double red[2][4];
   const int64_t slice = blockIdx.x;  // smp * lead + c
   const int64_t smp = slice / a.lead, c = slice - smp * a.lead;
@@ -219,7 +219,11 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   a.stream_base = stream_base; a.batch = batch; a.lead = lead; a.h = h; a.w = w; a.with_base = with_base;
   for (int l = 0; l < skr::PYR_MAX_LEVELS; ++l) a.weight[l] = (float)level_weight[l];
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(skr::pyramid_pass1, dim3((unsigned)(batch * lead)), dim3(256), 0, s, a);
+  const size_t lds_bytes = sizeof(float) * (size_t)(max_level_elems > 0 ? max_level_elems : 1);
+  if (lds_bytes > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(skr::pyramid_pass1, dim3((unsigned)(batch * lead)), dim3(256), lds_bytes, s, a);
   if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
   const int64_t unit = lead * h * w;
   int64_t bx = (unit / 4 + 255) / 256;

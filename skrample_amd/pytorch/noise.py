@@ -213,21 +213,31 @@ def colored_exponent(step: Step | None, props: ColoredProps) -> float:
 PYRAMID_MAX_LEVELS = 8
 
 
-def pyramid_level_shapes(unit_hw: tuple[int, int], resize_h: bool, uniforms) -> list[tuple[int, int]]:
-    """(h_l, w_l) of every pyramid level for one sample (reference noise.py:157-162,195-196): level i
-    shrinks the *running* size by r_i**i with r_i = 2 + 2*u_i, and the pyramid ends with the first level
-    that has a resized dimension of 1 (or after 99 levels)."""
-    h, w = unit_hw
-    levels = []
-    for i, u in enumerate(uniforms):
-        r = float(u) * 2 + 2
+def pyramid_level_tables(unit_hw: tuple[int, int], resize_h: bool, uniforms):
+    """Per-sample level geometry, vectorised over the batch.  uniforms: [batch, PYRAMID_MAX_LEVELS] in [0,1).
+    Returns (table int32 [batch][PYRAMID_MAX_LEVELS][2], counts int32 [batch]).  Level i shrinks the *running*
+    size by r_i**i, r_i = 2 + 2*u_i, and the pyramid ends with the first level that has a resized dimension of
+    1 (reference noise.py:157-162,195-196; its 99-level cap cannot be reached: sizes fall super-geometrically)."""
+    import numpy as np
+
+    batch = uniforms.shape[0]
+    h = np.full(batch, unit_hw[0], dtype=np.int64)
+    w = np.full(batch, unit_hw[1], dtype=np.int64)
+    table = np.zeros((batch, PYRAMID_MAX_LEVELS, 2), dtype=np.int32)
+    counts = np.zeros(batch, dtype=np.int32)
+    alive = np.ones(batch, dtype=bool)
+    for i in range(PYRAMID_MAX_LEVELS):
+        shrink = (uniforms[:, i] * 2 + 2) ** i
         if resize_h:
-            h = max(1, int(h / (r**i)))
-        w = max(1, int(w / (r**i)))
-        levels.append((h, w))
-        if w <= 1 or (resize_h and h <= 1):
-            break
-    return levels
+            h = np.where(alive, np.maximum(1, (h / shrink).astype(np.int64)), h)
+        w = np.where(alive, np.maximum(1, (w / shrink).astype(np.int64)), w)
+        table[alive, i, 0] = h[alive]
+        table[alive, i, 1] = w[alive]
+        counts[alive] = i + 1
+        alive &= ~((w <= 1) | (resize_h & (h <= 1)))
+        if not alive.any():
+            return table, counts
+    raise SkrampleHipError("pyramid deeper than PYRAMID_MAX_LEVELS levels (per-sample sizes this large are not supported)")
 
 
 @dataclass
@@ -267,14 +277,8 @@ class Pyramid(TensorNoiseCommon):
         if host_seeds is None or len(host_seeds) != batch:
             host_seeds = state["host_seeds"] = seeds.cpu().numpy().astype(np.uint64)
         uniforms = uniform01(host_seeds, stream_levels + 255, PYRAMID_MAX_LEVELS)
-        table = np.zeros((batch, PYRAMID_MAX_LEVELS, 2), dtype=np.int32)
-        counts = np.zeros(batch, dtype=np.int32)
-        worst = 0
-        for b in range(batch):
-            levels = pyramid_level_shapes((h, w), resize_h, uniforms[b])
-            counts[b] = len(levels)
-            table[b, : len(levels)] = levels
-            worst = max(worst, sum(lh * lw for lh, lw in levels[1:]))
+        table, counts = pyramid_level_tables((h, w), resize_h, uniforms)
+        worst = int((table[:, 1:, 0].astype(np.int64) * table[:, 1:, 1]).sum(axis=1).max())
         n_max = int(counts.max())
         # depth: keep only the `depth`+1 coarsest levels (reference noise.py:198-200) -- per sample the count can
         # differ, so the skip is applied through the weights only when every sample agrees; otherwise per level count

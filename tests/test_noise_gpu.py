@@ -90,6 +90,19 @@ def test_offset_static_and_dtypes(dev):
     assert h.dtype == torch.bfloat16 and (h.cpu().float() - ref.float()).abs().max() <= 2.0**-6
 
 
+def test_pyramid_level_geometry():
+    "vectorised host geometry == the oracle's level rule, sample by sample"
+    seeds = np.arange(40, dtype=np.uint64) + 100
+    u = uniform01(seeds, 3 * 256 + 255, PN.PYRAMID_MAX_LEVELS)
+    for hw, resize_h in (((128, 128), True), ((256, 256), True), ((1, 64), False), ((33, 20), True)):
+        table, counts = PN.pyramid_level_tables(hw, resize_h, u)
+        for b in range(len(seeds)):
+            it = iter(u[b].tolist())
+            shape = (4, *hw) if resize_h else (4, hw[1])
+            want = [run[-2:] if resize_h else (1, run[-1]) for _, run, _ in ON.pyramid_levels(shape, lambda: next(it), (-1, -2) if resize_h else (-1,))]
+            assert counts[b] == len(want) and [tuple(r) for r in table[b, : counts[b]].tolist()] == [tuple(x) for x in want]
+
+
 def pyramid_reference(unit, seed: int, stream: int, **kw) -> torch.Tensor:
     "oracle pyramid fed the draws the specification assigns: base stream+0, level l stream+1+l, uniforms stream+255"
     uniforms = uniform01(np.array([seed], dtype=np.uint64), stream + 255, 8)[0].tolist()
@@ -109,7 +122,7 @@ def pyramid_reference(unit, seed: int, stream: int, **kw) -> torch.Tensor:
 
 @pytest.mark.parametrize(
     ("unit", "kw"),
-    [((4, 16, 16), {}), ((4, 32, 24), {}), ((16, 16, 16), {}), ((4, 128, 128), {}), ((4, 64, 64), dict(strength=0.6, depth=1)), ((8, 64), dict(dims=(-1,)))],  # (4-D unit shapes fail inside the reference itself)
+    [((4, 16, 16), {}), ((4, 32, 24), {}), ((16, 16, 16), {}), ((4, 128, 128), {}), ((4, 256, 256), {}), ((4, 64, 64), dict(strength=0.6, depth=1)), ((8, 64), dict(dims=(-1,)))],  # (4-D unit shapes fail inside the reference itself)
 )
 def test_pyramid(unit, kw, dev):
     seeds = [21, 22, 23]

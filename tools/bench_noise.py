@@ -1,0 +1,19 @@
+"""Generator timings on the MI355X (not the headline metric): per-call time and GB/s of output."""
+import sys, time
+sys.path.insert(0, '.')
+import torch
+from skrample_amd.pytorch import noise as PN
+from skrample_amd.common import Step
+dev = torch.device('cuda:0')
+def timeit(name, gen, step, n=20):
+    for _ in range(3): gen.generate(step)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(n): out = gen.generate(step)
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t)/n
+    print(f"{name:40s} {dt*1e3:8.3f} ms/call  {out.numel()/dt/1e9:7.2f} Gelem/s  out {tuple(out.shape)} {out.dtype}")
+for B, unit in [(256,(16,128,128)), (64,(4,128,128)), (64,(4,256,256)), (256,(4,128,128))]:
+    seeds = list(range(B))
+    timeit(f"Random   B={B} {unit}", PN.BatchTensorNoise.from_batch_inputs(PN.Random, unit, seeds, dtype=torch.bfloat16), None)
+    timeit(f"Offset   B={B} {unit}", PN.BatchTensorNoise.from_batch_inputs(PN.Offset, unit, seeds, props=PN.OffsetProps(), dtype=torch.bfloat16), None)
+    timeit(f"Pyramid  B={B} {unit}", PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=PN.PyramidProps(), dtype=torch.bfloat16), None)
+    timeit(f"Colored  B={B} {unit}", PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.bfloat16), Step(0.45,0.5))
