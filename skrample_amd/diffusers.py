@@ -35,7 +35,8 @@ from torch import Tensor
 from . import scheduling
 from .common import DeltaPoint, MergeStrategy, Point, Step
 from .pytorch.noise import BatchTensorNoise, Random, TensorNoiseCommon, TensorNoiseProps
-from .sampling import functional, interface, lazy, models, tableaux, traits
+from . import _hip
+from .sampling import functional, interface, lazy, models, program, tableaux, traits
 from .sampling import structured as sampling
 from .sampling.lazy import LazyTensor, Lin, lift
 from .sampling.models import DataModel, DiffusionModel, FlowModel, NoiseModel, VelocityModel
@@ -378,6 +379,10 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
     def __post_init__(self) -> None:
         super().__post_init__()
         self._previous: list[SKSamples] = []
+        self._raw_outputs: list[Tensor] = []  # model outputs / inputs of the records in _previous (for step programs)
+        self._raw_samples: list[Tensor] = []
+        self._programs: dict = {}
+        self._programs_for = None
         self._schedule = self.schedule  # pristine copy restored by set_timesteps
         self._calls = 0
 
@@ -452,6 +457,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         if self.allow_dynamic:
             self.schedule = _apply_dynamic(self.schedule, steps, mu)
         self._previous = []
+        self._raw_outputs = []
+        self._raw_samples = []
         self._noise_generator = None
         self._timestep_list = None
         if device is not None:
@@ -483,15 +490,44 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         if self.sampler.require_noise:
             noise = self.get_step_noise(step, sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
 
-        with lazy.compute_scale(self.compute_scale):
-            record = self.sampler.sample_packed(
-                SampleInput(sample=sample, prediction=prediction, step=step, noise=noise),
-                model_transform=self.model,
-                schedule=self.schedule,
-                previous=self._previous,
-            )
+        # step programs (sampling/program.py): lower each distinct step once, then replay by pointer binding
+        owner = (self.sampler, self.model, self.schedule, self._steps, self.compute_scale)
+        if self._programs_for != owner:  # frozen dataclasses: equal configuration <=> equal coefficients
+            self._programs, self._programs_for = {}, owner
+        roles = program.Roles(sample, model_output, noise, self._previous, self._raw_outputs, self._raw_samples)
+        key = (
+            idx, tuple(rec.step for rec in self._previous), sample.dtype, model_output.dtype, tuple(sample.shape),
+            type(noise), getattr(noise, "dtype", None), tuple(type(rec.noise) for rec in self._previous),
+        )  # fmt: skip
+        record = None
+        prog = self._programs.get(key)
+        if prog is not None and prog is not False:
+            record = prog.run(roles, step, prediction, sample.device)
+        if record is None:
+            tracing = prog is None and _hip.trace is None and isinstance(sample, Tensor) and sample.is_cuda
+            if tracing:
+                _hip.trace = []
+            try:
+                with lazy.compute_scale(self.compute_scale):
+                    record = self.sampler.sample_packed(
+                        SampleInput(sample=sample, prediction=prediction, step=step, noise=noise),
+                        model_transform=self.model,
+                        schedule=self.schedule,
+                        previous=self._previous,
+                    )
+                if tracing:
+                    built = program.StepProgram.build(_hip.trace[0], roles, record, prediction) if len(_hip.trace) == 1 else None
+                    self._programs[key] = built if built is not None else False
+            finally:
+                if tracing:
+                    _hip.trace = None
         self._previous.append(record)
-        self._previous = self._previous[max(len(self._previous) - self.sampler.require_previous, 0) :]
+        self._raw_outputs.append(model_output)
+        self._raw_samples.append(sample)
+        keep = self.sampler.require_previous
+        self._previous = self._previous[max(len(self._previous) - keep, 0) :]
+        self._raw_outputs = self._raw_outputs[max(len(self._raw_outputs) - keep, 0) :]
+        self._raw_samples = self._raw_samples[max(len(self._raw_samples) - keep, 0) :]
         return self._finish(record.final, record.prediction, model_output, return_dict)
 
 

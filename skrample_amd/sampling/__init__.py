@@ -1,3 +1,3 @@
 """Sampler layer: fp64 host algebra that compiles every solver step to one fused HIP launch."""
 
-from . import functional, interface, lazy, models, structured, tableaux, traits  # noqa: F401
+from . import functional, interface, lazy, models, program, structured, tableaux, traits  # noqa: F401

@@ -421,16 +421,23 @@ class LazyTensor:
     callers rarely read (e.g. `pred_original_sample`): unused, it costs no HBM traffic; used in any
     torch function or via `.materialize()`, it becomes an ordinary tensor."""
 
-    def __init__(self, form: Lin, dtype: torch.dtype):
-        self.form, self.dtype, self._value = form, dtype, None
+    def __init__(self, form: Lin | None, dtype: torch.dtype, form_fn=None, shape=None, device=None):
+        self._form, self._form_fn, self.dtype, self._value = form, form_fn, dtype, None
+        self._shape, self._device = shape, device
+
+    @property
+    def form(self) -> Lin:
+        if self._form is None:
+            self._form = self._form_fn()
+        return self._form
 
     @property
     def shape(self):
-        return self.form.shape
+        return self._shape if self._form is None and self._shape is not None else self.form.shape
 
     @property
     def device(self):
-        return self.form.device
+        return self._device if self._form is None and self._device is not None else self.form.device
 
     def materialize(self) -> torch.Tensor:
         if self._value is None:

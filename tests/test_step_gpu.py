@@ -382,3 +382,37 @@ def test_full_size_properties(dev):
     e.set_timesteps(steps)
     y2 = e.step(outs[0] * 4, e.timesteps[0], x * 4, return_dict=False)[0]
     assert torch.equal(y2, y1 * 4)
+
+
+def test_step_programs_replay_bitwise(dev):
+    "second pass through a wrapper replays cached step programs: results identical to the first (algebra) pass"
+    from skrample_amd.pytorch import noise as PN
+
+    shape, steps = (3, 4, 32, 32), 8
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps)]
+    wrappers = [
+        PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled())),
+        PD.SkrampleWrapperScheduler(PT.DPM(order=3), PS.Scaled()),
+        PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel()),
+        PD.SkrampleWrapperScheduler(PT.UniPC(order=2, predictor=PT.Adams(order=3)), PS.Scaled(), PM.VelocityModel()),
+        PD.SkrampleWrapperScheduler(PT.Adams(order=4), PS.ZSNR(), PM.VelocityModel()),
+        PD.SkrampleWrapperScheduler(PT.Euler(stochasticity=1), PS.Scaled(), invert_prediction=True),
+        PD.SkrampleWrapperScheduler(PT.SPC(), PS.Scaled()),
+        PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), noise_type=PN.Offset, noise_props=PN.OffsetProps()),
+    ]
+    for w in wrappers:
+        passes = []
+        for rep in range(3):
+            w.set_timesteps(steps)
+            x, traj = x0, []
+            for i, t in enumerate(w.timesteps):
+                prev, pred = w.step(outs[i], t, x, generator=[5, 6, 7], return_dict=False)
+                traj.append((prev, torch.as_tensor(pred.materialize() if isinstance(pred, lazy.LazyTensor) else pred)))
+                x = prev
+            passes.append(traj)
+        cached = [k for k, v in w._programs.items() if v is not False]
+        assert len(cached) >= steps - 1, (type(w.sampler).__name__, len(cached))  # every step got a program
+        for a, b, c in zip(*passes):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0]) and torch.equal(a[1], b[1]) and torch.equal(a[1], c[1]), type(w.sampler).__name__

@@ -1,0 +1,20 @@
+import sys, time, cProfile, pstats
+sys.path.insert(0, '.')
+import torch
+import skrample_amd.diffusers as PD, skrample_amd.scheduling as PS
+from skrample_amd.sampling import structured as PT
+dev = torch.device('cuda:0')
+w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))
+B=256
+x = torch.randn(B,4,128,128, device=dev).bfloat16(); out = torch.randn_like(x)
+seeds = list(range(B))
+def loop(n=3):
+    for _ in range(n):
+        w.set_timesteps(20)
+        for t in w.timesteps:
+            w.step(out, t, x, generator=seeds, return_dict=False)
+    torch.cuda.synchronize()
+loop(2)
+t=time.perf_counter(); loop(5); dt=time.perf_counter()-t; print("us/step", dt/100*1e6)
+pr = cProfile.Profile(); pr.enable(); loop(5); pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
