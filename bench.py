@@ -169,7 +169,7 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torchrun, also for a single rank
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -416,3 +416,21 @@ def test_step_programs_replay_bitwise(dev):
         assert len(cached) >= steps - 1, (type(w.sampler).__name__, len(cached))  # every step got a program
         for a, b, c in zip(*passes):
             assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0]) and torch.equal(a[1], b[1]) and torch.equal(a[1], c[1]), type(w.sampler).__name__
+
+
+def test_sampler_generics_device(dev):
+    "reference test_sampler_generics: a python float and a (device, float64) tensor give the same step result"
+    import random
+
+    rnd = random.Random(0)
+    for name, (_, mk_p) in SAMPLERS.items():
+        sampler = mk_p()
+        for schedule in (PS.Scaled(), PS.FlowShift(PS.Linear())):
+            i, o, n = rnd.random(), rnd.random(), rnd.random()
+            step = PT.Step.from_int(4, 10)
+            prev_f = [PT.SKSamples(rnd.random(), rnd.random(), PT.Step((a := rnd.random()), a * 2), rnd.random(), rnd.random()) for _ in range(9)]
+            f64 = lambda v: torch.tensor([v] * 8, dtype=torch.float64, device=dev)  # noqa: E731
+            prev_t = [PT.SKSamples(f64(p.sample), f64(p.prediction), p.step, f64(p.noise), f64(p.final)) for p in prev_f]
+            scalar = sampler.sample(i, o, step, PM.DataModel(), schedule, n, previous=prev_f).final
+            tensor = sampler.sample(f64(i), f64(o), step, PM.DataModel(), schedule, f64(n), previous=prev_t).final
+            assert tensor.dtype == torch.float64 and abs(tensor[0].item() - scalar) < 1e-12 * max(1.0, abs(scalar)), (name, tensor[0].item(), scalar)
