@@ -38,7 +38,7 @@ DEFAULT_PROVIDERS: Mapping[int, Any] = {
     8: tableaux.SSP.RK3_8,
     10: tableaux.SSP.RK5_10,
     11: tableaux.RKZ.CV8,
-    15: tableaux.RKZ_UNAVAILABLE["Stepanov10"],
+    15: tableaux.RKZ.Stepanov10,
 }
 "default tableau per *stage count* (not mathematical order)"
 

@@ -7,16 +7,18 @@ validate_tableau :145-156; providers.py: generator functions :15-127, provider e
 themselves are the published ones (citations on each family); they are written here as exact
 rationals / surds and evaluated once at import.
 
-Not transcribed in this round: the 10th-14th order tables with 15-35 stages (RKZ.Stepanov10, Ono10,
-Harrier10, Zhang10, Feagin10/12/14).  Asking for them raises NotImplementedError rather than
-silently substituting a lower-order method.
+The 10th-14th order tables with 15-35 stages (RKZ.Stepanov10, Ono10, Harrier10, Zhang10, Feagin10/12/14) are
+pure data: their published coefficients live in `tableaux_high_order.json` (exact float hex; produced by
+tools/make_tableaux_data.py, which also lists the papers they come from).
 """
 
 from __future__ import annotations
 
 import dataclasses
 import enum
+import json
 import math
+import os
 from fractions import Fraction
 from typing import NamedTuple, Protocol, Sequence
 
@@ -303,18 +305,18 @@ def _cv8() -> Tableau:
     return Tableau(stages, (1 / 20, 0, 0, 0, 0, 0, 0, 49 / 180, 16 / 45, 49 / 180, 1 / 20))
 
 
-def _missing(name: str):
-    class _Unavailable:
-        def __init__(self, label: str):
-            self.label = label
+def _high_order() -> dict[str, Tableau]:
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tableaux_high_order.json")
+    with open(path) as fh:
+        raw = json.load(fh)
+    h = float.fromhex
+    return {
+        name: Tableau(tuple(Stage(h(c), tuple(h(v) for v in row)) for c, row in zip(t["c"], t["a"])), tuple(h(v) for v in t["b"]))
+        for name, t in raw.items()
+    }
 
-        def tableau(self):
-            raise NotImplementedError(f"tableau {self.label} (15-35 stages) is not transcribed into skrample_amd yet")
 
-        def __repr__(self) -> str:
-            return f"<unavailable tableau {self.label}>"
-
-    return _Unavailable(name)
+_HIGH = _high_order()
 
 
 class RKZ(_EnumProvider):
@@ -323,9 +325,13 @@ class RKZ(_EnumProvider):
     Nystrom5 = _rational(["", "1/3", "4/25 6/25", "1/4 -3 15/4", "2/27 10/9 -50/81 8/81", "2/25 12/25 2/15 8/75 0"], "23/192 0 125/192 0 -27/64 125/192")
     Butcher6 = _butcher6()
     CV8 = _cv8()
-
-
-RKZ_UNAVAILABLE = {name: _missing(f"RKZ.{name}") for name in ("Stepanov10", "Ono10", "Harrier10", "Zhang10", "Feagin10", "Feagin12", "Feagin14")}
+    Stepanov10 = _HIGH["Stepanov10"]  # arXiv 2504.17329, 15 stages
+    Ono10 = _HIGH["Ono10"]  # H. Ono 2003, 17 stages
+    Harrier10 = _HIGH["Harrier10"]
+    Zhang10 = _HIGH["Zhang10"]  # arXiv 1911.00318, 16 stages
+    Feagin10 = _HIGH["Feagin10"]
+    Feagin12 = _HIGH["Feagin12"]  # T. Feagin 2007, 25 stages
+    Feagin14 = _HIGH["Feagin14"]  # 35 stages
 
 
 @enum.unique

@@ -434,3 +434,55 @@ def test_sampler_generics_device(dev):
             scalar = sampler.sample(i, o, step, PM.DataModel(), schedule, n, previous=prev_f).final
             tensor = sampler.sample(f64(i), f64(o), step, PM.DataModel(), schedule, f64(n), previous=prev_t).final
             assert tensor.dtype == torch.float64 and abs(tensor[0].item() - scalar) < 1e-12 * max(1.0, abs(scalar)), (name, tensor[0].item(), scalar)
+
+
+@pytest.mark.parametrize("wrapper", [PD.RKUltraWrapperScheduler, PD.DynasauRKWrapperScheduler])
+def test_runge_kutta_wrapper_equals_functional(wrapper, dev):
+    """reference test_runge_kutta_diffusers (tests/self_sampling.py:417-500): the inside-out wrapper reproduces the
+    functional sampler model call by model call -- points to 1e-15, samples to 1e-8 -- over models, derivative
+    transforms, orders and stochasticities.  Functional side runs on python floats, wrapper side on float64
+    device tensors (compute_scale=float64), noise injected."""
+    import itertools
+    import math
+    import random
+
+    from skrample_amd.common import Point
+
+    rnd = random.Random(7)
+    combos = itertools.product(
+        [PM.DataModel, PM.VelocityModel, PM.FlowModel],
+        [None, PM.DataModel, PM.VelocityModel, PM.FlowModel, PM.ScaleX],
+        [PS.Sinner(PS.Linear()), PS.Scaled()],
+        [0, 2, 3, 4, 6] if wrapper is PD.RKUltraWrapperScheduler else [2, 3, 4],
+        [0, 0.5, -1.5],
+    )
+    for model, transform, schedule, order, eta in combos:
+        if rnd.random() > 0.2:  # a seeded fifth of the full product keeps this under a few seconds
+            continue
+        w = wrapper(schedule, sampler_order=order, stochasticity=eta, model=model(), derivative_transform=transform() if transform else None, compute_scale=torch.float64)
+        steps = rnd.randint(3, 9)
+        fake = lambda x, t, s, a: x + math.sin(x) * s  # noqa: E731
+        seen_ref, pts_ref = [], []
+
+        def model_ref(x, t, s, a):
+            seen_ref.append(x)
+            pts_ref.append(Point(t, s, a))
+            return fake(x, t, s, a)
+
+        noises = [rnd.gauss(0, 1) for _ in range(steps)]
+        it = iter(noises)
+        x0 = 1 / (rnd.random() + 1e-4) * (rnd.randint(0, 1) * 2 - 1)
+        want = w.functional_sample_model(x0, model_ref, steps, rng=lambda _: next(it))
+
+        w.set_timesteps(steps)
+        w._noise_generator = Injected([torch.full((1, 8), v, dtype=torch.float64) for v in noises], dev)
+        x = x0
+        for n, (t, sg) in enumerate(zip(w.timesteps, w.sigmas)):
+            s_n, a_n = (v.item() for v in w.schedule.space.normalize(sg.item()))
+            np.testing.assert_allclose((t.item(), s_n, a_n), pts_ref[n], rtol=0, atol=1e-12)
+            assert abs(seen_ref[n] - x) < 1e-8 * max(1, abs(x)), (model.__name__, transform, order, eta, n)
+            out = fake(x, t.item(), s_n, a_n)
+            res = w.step(torch.full((1, 8), out, dtype=torch.float64, device=dev), t, torch.full((1, 8), x, dtype=torch.float64, device=dev), return_dict=False)[0]
+            assert res.dtype == torch.float64
+            x = res[0, 0].item()
+        assert abs(want - x) < 1e-8 * max(1, abs(want)), (model.__name__, transform, order, eta)

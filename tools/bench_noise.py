@@ -1,6 +1,6 @@
 """Generator timings on the MI355X (not the headline metric): per-call time and GB/s of output."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from skrample_amd.pytorch import noise as PN
 from skrample_amd.common import Step

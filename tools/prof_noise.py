@@ -1,0 +1,12 @@
+import sys
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from skrample_amd.pytorch import noise as PN
+from skrample_amd.common import Step
+B, unit = 256, (16,128,128)
+seeds = list(range(B))
+g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.bfloat16)
+p = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, (4,256,256), list(range(64)), props=PN.PyramidProps(), dtype=torch.bfloat16)
+for _ in range(10):
+    g.generate(Step(0.45,0.5)); p.generate(None)
+torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 import sys, time, cProfile, pstats
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import skrample_amd.diffusers as PD, skrample_amd.scheduling as PS
 from skrample_amd.sampling import structured as PT
