@@ -107,18 +107,17 @@ int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* seeds_dev, ui
                      uint64_t stream_offset, int64_t batch, const int64_t* unit_shape, int32_t ndim,
                      uint32_t keep_mask, double strength, void* stream);
 
-/* Pyramid.generate (noise.py:146-207) over the last two dims of a [batch][lead][h][w] tensor:
- *   out = (N(base) + sum_l weight[l] * upsample_bilinear(N(level l)))  /  per-sample unbiased std
- * Level l >= 1 normals (stream_base+1+l, shape [lead][h_l][w_l]) are generated into LDS and sampled there;
- * level 0 is full resolution.  `level_hw_dev` = int32 [batch][8][2], `n_levels_dev` = int32 [batch] (level
- * geometry is drawn per sample on the host from the same Philox key, stream_base+255); `level_weight` = host
- * double[8] (strength^l, 0 for skipped levels); `max_level_elems` = max over samples of sum_{l>=1} h_l*w_l.
- * `scratch_f32` [batch*lead*h*w] and `partials_f64` [batch*lead*2] are caller-provided workspaces. */
-int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64,
+/* Pyramid.generate (noise.py:146-207) over the last two dims (resize_h = 1) or the last dim (resize_h = 0,
+ * h must be 1) of a [batch][lead][h][w] tensor:
+ *   out = (N(base) + sum_{l >= skip} strength^l * upsample_bilinear(N(level l)))  /  per-sample unbiased std
+ * The per-sample level geometry is drawn on the device (uniforms = stream_base+255); level l >= 1 normals
+ * (stream_base+1+l, shape [lead][h_l][w_l]) are generated into LDS and sampled there; level 0 is full resolution;
+ * skip = max(0, n_levels-1-depth).  Workspaces: scratch_f32 [batch*lead*h*w], partials_f64 [batch*lead*2],
+ * level_ws int32 [batch*17] (receives the level table, readable for tests).  Limits: w % 4 == 0 and
+ * about h*w <= 380*380 (the level stage must fit 152 KiB of LDS). */
+int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64, int32_t* level_ws,
                       const uint64_t* seeds_dev, uint64_t stream_base, int64_t batch, int64_t lead, int64_t h,
-                      int64_t w, const int32_t* level_hw_dev, const int32_t* n_levels_dev,
-                      const double* level_weight, int32_t max_level_elems, int32_t with_base,
-                      int32_t normalise, void* stream);
+                      int64_t w, int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream);
 
 /* Colored.generate / colorize_noise (noise.py:337-425): white Philox noise shaped in the Fourier domain by
  * clamp(radial_frequency, eps)^(-exponent/2) and rescaled per sample to the white noise's std (or `energy`).

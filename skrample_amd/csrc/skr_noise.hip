@@ -59,11 +59,12 @@ __global__ __launch_bounds__(256) void offset_kernel(const OffsetArgs a) {
 }
 
 // ---- Pyramid ---------------------------------------------------------------------------------------------
-// Per (sample, leading slice) block.  Levels >= 1 are tiny (<= 64x64): their normals are generated straight
-// into LDS and bilinearly sampled from there (torch upsample_bilinear2d, align_corners=False); level 0 is
-// full resolution, i.e. an identity "interpolation" of a second normal tensor.  Pass 1 writes the
-// un-normalised sum in fp32 plus per-block (sum, sum of squares) in double; pass 2 divides by the per-sample
-// unbiased std (fixed summation order => bit-reproducible) and rounds to the output dtype.
+// Per (sample, leading slice) block.  Levels >= 1 are small (<= half size per axis): their normals are generated
+// straight into LDS and bilinearly sampled from there (torch upsample_bilinear2d, align_corners=False);
+// level 0 is full resolution, i.e. an identity "interpolation" of a second normal tensor.  Pass 0 draws the
+// per-sample level geometry on the device (no host round trip); pass 1 writes the un-normalised sum in fp32
+// plus per-block (sum, sum of squares) in double; pass 2 divides by the per-sample unbiased std (fixed
+// summation order => bit-reproducible) and rounds to the output dtype.
 constexpr int PYR_MAX_LEVELS = 8;
 constexpr int PYR_LDS_FLOATS = 38 * 1024;  // up to 152 KiB of level storage per block (dynamic LDS, 160 KiB per CU)
 
@@ -71,17 +72,45 @@ struct PyramidArgs {
   float* scratch;          // [batch][lead][h][w] fp32
   double* partials;        // [batch][lead][2]
   const uint64_t* seeds;
-  const int32_t* level_hw; // [batch][PYR_MAX_LEVELS][2] (h_l, w_l); level 0 is (h, w)
-  const int32_t* n_levels; // [batch]
+  int32_t* level_hw;       // [batch][PYR_MAX_LEVELS][2] (h_l, w_l); level 0 is (h, w)
+  int32_t* n_levels;       // [batch]
   uint64_t stream_base;
-  int64_t batch, lead, h, w;
-  float weight[PYR_MAX_LEVELS];  // strength^l, 0 for skipped levels
-  int32_t with_base;       // 1: add the base normal (stream_base + 0)
+  int64_t batch;
+  int32_t lead, h, w;
+  int32_t resize_h, depth, with_base;
+  float strength;
 };
 
-__device__ __forceinline__ void src_index(int dst, int in_size, int out_size, int& i0, int& i1, float& l1) {
+// level geometry (reference noise.py:157-162,195-196): level i shrinks the RUNNING size by r_i**i,
+// r_i = 2 + 2*u_i, u_i = (philox word i of stream_base+255 >> 8) * 2^-24; stop at the first level with a
+// resized dimension of 1.  Same arithmetic as skrample_amd/pytorch/noise.py::pyramid_level_tables.
+__global__ void pyramid_geometry(const PyramidArgs a) {
+  const int64_t smp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (smp >= a.batch) return;
+  const uint64_t seed = a.seeds[smp];
+  uint32_t words[PYR_MAX_LEVELS];
+  for (int blk = 0; blk < PYR_MAX_LEVELS / 4; ++blk) {
+    u32x4 c{(uint32_t)blk, 0u, (uint32_t)(a.stream_base + 255), (uint32_t)((a.stream_base + 255) >> 32)};
+    c = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    words[blk * 4] = c.x; words[blk * 4 + 1] = c.y; words[blk * 4 + 2] = c.z; words[blk * 4 + 3] = c.w;
+  }
+  int64_t h = a.h, w = a.w;
+  int n = 0;
+  for (int i = 0; i < PYR_MAX_LEVELS; ++i) {
+    const double r = (double)(words[i] >> 8) * 5.9604644775390625e-08 * 2.0 + 2.0;
+    const double shrink = pow(r, (double)i);
+    if (a.resize_h) { h = (int64_t)((double)h / shrink); if (h < 1) h = 1; }
+    w = (int64_t)((double)w / shrink); if (w < 1) w = 1;
+    a.level_hw[(smp * PYR_MAX_LEVELS + i) * 2] = (int32_t)h;
+    a.level_hw[(smp * PYR_MAX_LEVELS + i) * 2 + 1] = (int32_t)w;
+    n = i + 1;
+    if (w <= 1 || (a.resize_h && h <= 1)) break;
+  }
+  a.n_levels[smp] = n;
+}
+
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
   // area_pixel_compute_source_index(scale = in/out, align_corners = false, cubic = false)
-  const float scale = (float)in_size / (float)out_size;
   float src = scale * ((float)dst + 0.5f) - 0.5f;
   src = src < 0.f ? 0.f : src;
   i0 = (int)src;
@@ -90,61 +119,86 @@ __device__ __forceinline__ void src_index(int dst, int in_size, int out_size, in
 }
 
 __global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
-  extern __shared__ float lds[];  // sum over levels >= 1 of h_l*w_l floats (sized by the host per launch)
+  extern __shared__ float lds[];  // levels >= 1, back to back
   __shared__ double red[2][4];
-  const int64_t slice = blockIdx.x;  // smp * lead + c
-  const int64_t smp = slice / a.lead, c = slice - smp * a.lead;
+  __shared__ int s_lh[PYR_MAX_LEVELS], s_lw[PYR_MAX_LEVELS], s_off[PYR_MAX_LEVELS];
+  __shared__ float s_wgt[PYR_MAX_LEVELS], s_sy[PYR_MAX_LEVELS], s_sx[PYR_MAX_LEVELS];
+  const int slice = blockIdx.x;  // smp * lead + c
+  const int smp = slice / a.lead, c = slice - smp * a.lead;
   const uint64_t seed = a.seeds[smp];
   const int nl = a.n_levels[smp];
-  const int32_t* hw = a.level_hw + smp * PYR_MAX_LEVELS * 2;
-
-  // stage levels >= 1 in LDS
-  int base_off[PYR_MAX_LEVELS];
-  int off = 0;
-  for (int l = 1; l < nl; ++l) {
-    base_off[l] = off;
-    const int lh = hw[2 * l], lw = hw[2 * l + 1];
-    const int n = lh * lw;
-    if (a.weight[l] != 0.f) {
-      for (int i = threadIdx.x; i < n; i += 256)
-        lds[off + i] = normal1(seed, a.stream_base + 1 + l, (uint64_t)(c * n + i));  // level tensor is [lead][lh][lw]
+  if (threadIdx.x == 0) {
+    const int32_t* hw = a.level_hw + (int64_t)smp * PYR_MAX_LEVELS * 2;
+    const int skip = (nl - 1) - a.depth > 0 ? (nl - 1) - a.depth : 0;  // keep the depth+1 coarsest levels (noise.py:198-200)
+    int off = 0;
+    float wgt = 1.f;
+    for (int l = 0; l < nl; ++l) {
+      s_lh[l] = hw[2 * l]; s_lw[l] = hw[2 * l + 1];
+      s_off[l] = off;
+      s_wgt[l] = l >= skip ? wgt : 0.f;
+      s_sy[l] = (float)s_lh[l] / (float)a.h;
+      s_sx[l] = (float)s_lw[l] / (float)a.w;
+      if (l >= 1) off += s_lh[l] * s_lw[l];
+      wgt *= a.strength;
     }
-    off += n;
+  }
+  __syncthreads();
+  for (int l = 1; l < nl; ++l) {
+    if (s_wgt[l] == 0.f) continue;
+    const int n = s_lh[l] * s_lw[l];
+    float* g = lds + s_off[l];
+    for (int i4 = threadIdx.x * 4; i4 < n; i4 += 1024) {  // level tensor is [lead][lh][lw]; 4 normals per Philox call
+      const int64_t e = (int64_t)c * n + i4;
+      const int64_t blk = e >> 2;
+      const int lane0 = (int)(e & 3);
+      float z[8];
+      normal4(seed, a.stream_base + 1 + l, (uint64_t)blk, z);
+      if (lane0) normal4(seed, a.stream_base + 1 + l, (uint64_t)blk + 1, z + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (i4 + j < n) g[i4 + j] = z[lane0 + j];
+    }
   }
   __syncthreads();
 
-  const int64_t hwn = a.h * a.w;
+  const int w4 = a.w >> 2;  // w % 4 == 0 (host-checked): 4 consecutive pixels never straddle a row
+  const int n4 = a.h * w4;
+  const float w0 = s_wgt[0];
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t p4 = threadIdx.x; p4 * 4 < hwn; p4 += 256) {
-    const int64_t e0 = c * hwn + p4 * 4;  // element index inside the sample (hwn % 4 == 0 is checked on the host)
+  for (int q = threadIdx.x; q < n4; q += 256) {
+    const int y = q / w4, x0 = (q - y * w4) * 4;
+    const int64_t e0 = ((int64_t)c * a.h + y) * a.w + x0;  // element index inside the sample
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.with_base) normal4(seed, a.stream_base, (uint64_t)e0 >> 2, v);
-    if (a.weight[0] != 0.f) {
+    if (w0 != 0.f) {
       float z[4];
       normal4(seed, a.stream_base + 1, (uint64_t)e0 >> 2, z);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += z[j] * a.weight[0];
+      for (int j = 0; j < 4; ++j) v[j] = fmaf(z[j], w0, v[j]);
+    }
+    for (int l = 1; l < nl; ++l) {
+      const float wl = s_wgt[l];
+      if (wl == 0.f) continue;
+      const int lh = s_lh[l], lw = s_lw[l];
+      const float* g = lds + s_off[l];
+      int y0, y1;
+      float ly;
+      src_index(y, s_sy[l], lh, y0, y1, ly);
+      const float* r0 = g + y0 * lw;
+      const float* r1 = g + y1 * lw;
+      const float sx = s_sx[l];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int xa, xb;
+        float lx;
+        src_index(x0 + j, sx, lw, xa, xb, lx);
+        const float top = (1.f - lx) * r0[xa] + lx * r0[xb];
+        const float bot = (1.f - lx) * r1[xa] + lx * r1[xb];
+        v[j] += wl * ((1.f - ly) * top + ly * bot);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t p = p4 * 4 + j;
-      const int y = (int)(p / a.w), x = (int)(p - (int64_t)y * a.w);
-      for (int l = 1; l < nl; ++l) {
-        if (a.weight[l] == 0.f) continue;
-        const int lh = hw[2 * l], lw = hw[2 * l + 1];
-        int y0, y1, x0, x1;
-        float ly, lx;
-        src_index(y, lh, (int)a.h, y0, y1, ly);
-        src_index(x, lw, (int)a.w, x0, x1, lx);
-        const float* g = lds + base_off[l];
-        const float top = (1.f - lx) * g[y0 * lw + x0] + lx * g[y0 * lw + x1];
-        const float bot = (1.f - lx) * g[y1 * lw + x0] + lx * g[y1 * lw + x1];
-        v[j] += a.weight[l] * ((1.f - ly) * top + ly * bot);
-      }
-      s1 += (double)v[j];
-      s2 += (double)v[j] * (double)v[j];
-    }
-    *reinterpret_cast<float4*>(a.scratch + (smp * a.lead + c) * hwn + p4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int j = 0; j < 4; ++j) { s1 += (double)v[j]; s2 += (double)v[j] * (double)v[j]; }
+    *reinterpret_cast<float4*>(a.scratch + (int64_t)slice * a.h * a.w + (int64_t)q * 4) = make_float4(v[0], v[1], v[2], v[3]);
   }
   // block reduction in a fixed order
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
@@ -152,8 +206,8 @@ __global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
   if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    a.partials[slice * 2 + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-    a.partials[slice * 2 + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    a.partials[(int64_t)slice * 2 + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    a.partials[(int64_t)slice * 2 + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
   }
 }
 
@@ -204,22 +258,28 @@ extern "C" int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* se
   return status_of_launch();
 }
 
-extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64, const uint64_t* seeds_dev,
-                                 uint64_t stream_base, int64_t batch, int64_t lead, int64_t h, int64_t w,
-                                 const int32_t* level_hw_dev, const int32_t* n_levels_dev, const double* level_weight /* host [8] */,
-                                 int32_t max_level_elems, int32_t with_base, int32_t normalise, void* stream) {
-  if (batch < 0 || lead < 1 || h < 1 || w < 1) return SKR_ERR_SHAPE;
+extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64, int32_t* level_ws /* [batch*17] */,
+                                 const uint64_t* seeds_dev, uint64_t stream_base, int64_t batch, int64_t lead, int64_t h, int64_t w,
+                                 int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream) {
+  if (batch < 0 || lead < 1 || h < 1 || w < 1 || depth < 0) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
-  if (!out || !scratch_f32 || !partials_f64 || !seeds_dev || !level_hw_dev || !n_levels_dev || !level_weight) return SKR_ERR_NULL;
-  if ((h * w) % 4 != 0) return SKR_ERR_UNSUPPORTED;
-  if (max_level_elems > skr::PYR_LDS_FLOATS) return SKR_ERR_UNSUPPORTED;  // sum of level >= 1 sizes must fit the LDS stage
+  if (!out || !scratch_f32 || !partials_f64 || !seeds_dev || !level_ws) return SKR_ERR_NULL;
+  if (w % 4 != 0 || h > 32767 || w > 32767) return SKR_ERR_UNSUPPORTED;
+  if (!resize_h && h != 1) return SKR_ERR_SHAPE;
   if (batch * lead > 0x7fffffffll || batch > 65535) return SKR_ERR_UNSUPPORTED;
+  // LDS stage for levels >= 1: every level is at most half the previous size per resized axis (r >= 2, and
+  // level i >= 2 shrinks by r^i >= 4), so sum_{l>=1} h_l*w_l <= h*w/4 * (1 + 1/16 + ...) (1-D: w/2 * (1 + 1/4 + ...))
+  const int64_t bound = resize_h ? (h / 2) * (w / 2) + (h / 8) * (w / 8) + (h / 32) * (w / 32) + 64 : w / 2 + w / 8 + w / 32 + 64;
+  if (bound > skr::PYR_LDS_FLOATS) return SKR_ERR_UNSUPPORTED;
   skr::PyramidArgs a;
-  a.scratch = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev; a.level_hw = level_hw_dev; a.n_levels = n_levels_dev;
-  a.stream_base = stream_base; a.batch = batch; a.lead = lead; a.h = h; a.w = w; a.with_base = with_base;
-  for (int l = 0; l < skr::PYR_MAX_LEVELS; ++l) a.weight[l] = (float)level_weight[l];
+  a.scratch = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
+  a.level_hw = level_ws; a.n_levels = level_ws + batch * skr::PYR_MAX_LEVELS * 2;
+  a.stream_base = stream_base; a.batch = batch; a.lead = (int32_t)lead; a.h = (int32_t)h; a.w = (int32_t)w;
+  a.resize_h = resize_h; a.depth = depth; a.with_base = with_base; a.strength = (float)strength;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t lds_bytes = sizeof(float) * (size_t)(max_level_elems > 0 ? max_level_elems : 1);
+  hipLaunchKernelGGL(skr::pyramid_geometry, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, a);
+  if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
+  const size_t lds_bytes = sizeof(float) * (size_t)bound;
   if (lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
   }
@@ -228,8 +288,6 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   const int64_t unit = lead * h * w;
   int64_t bx = (unit / 4 + 255) / 256;
   if (bx > 64) bx = 64;
-  const double target = normalise ? -1.0 : 0.0;
-  (void)target;
   dim3 grid((unsigned)bx, (unsigned)batch);
   switch (out_dtype) {
     case SKR_BF16: hipLaunchKernelGGL(skr::normalise_pass2<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, scratch_f32, partials_f64, lead, unit, batch, -1.0); break;

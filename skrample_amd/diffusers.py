@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import abc
 import contextlib
+import ctypes
 import dataclasses
 import functools
 import math
@@ -553,6 +554,9 @@ class RKWrapperCore(SkrampleWrapperCore):
         self._index = 0
         self._derivatives: list = []  # lazy derivative forms of the stages of the current step
         self._sample = None  # base sample of the current step (alias of the caller's tensor)
+        self._last_noise = None
+        self._rk_programs: dict = {}
+        self._rk_programs_for = None
         self._schedule = self.schedule
 
     @abc.abstractmethod
@@ -638,6 +642,7 @@ class RKWrapperCore(SkrampleWrapperCore):
             noise = None
             if abs(self.stochasticity) > 1e-8:
                 noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), self._sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
+            self._last_noise = noise
             mix = sum((d * w for d, w in zip(self._derivatives[1:], weights[1:])), self._derivatives[0] * weights[0])
             form = space.update_form(base, mix, DeltaPoint(s0, s1), noise, self.stochasticity)
             self._derivatives = []
@@ -655,15 +660,27 @@ class RKWrapperCore(SkrampleWrapperCore):
         if value is not None:
             assert value == expected, f"Expected timestep {expected} for step {self._index}, got {timestep=}!"
 
+        # stage programs: the same lower-once / replay-by-binding scheme as SkrampleWrapperScheduler.step
+        owner = (self.schedule, self._steps, self.sampler_order, self.stochasticity, self.model, self.derivative_transform, self.compute_scale, self.invert_prediction)
+        if self._rk_programs_for != owner:
+            self._rk_programs, self._rk_programs_for = {}, owner
+        held = len(self._derivatives)
+        key = (self._index, held, sample.dtype, model_output.dtype, tuple(sample.shape))
+        prog = self._rk_programs.get(key)
+        if prog:
+            done = self._replay_stage(prog, model_output, sample, generator)
+            if done is not None:
+                return self._finish(done[0], done[1], model_output, return_dict)
+
         points = [*self.all_points, Point(0, 0, 1)]
         conv = None
         if self.derivative_transform:
             space = self.derivative_transform
             convert = models.ModelConvert(self.model, self.derivative_transform)
-            program = convert.rounded_program(points[self._index], negate_output=self.invert_prediction)
-            if program is not None and program[:2] != (0, 0):
+            rounded = convert.rounded_program(points[self._index], negate_output=self.invert_prediction)
+            if rounded is not None and rounded[:2] != (0, 0):
                 # the reference converts in the input dtype, op by op, BEFORE widening (diffusers.py:819-834)
-                conv = lazy.RoundedConversion(sample, model_output, *program)
+                conv = lazy.RoundedConversion(sample, model_output, *rounded)
                 derivative = conv.node()
             else:
                 output = -Lin.leaf(model_output) if self.invert_prediction else lift(model_output)
@@ -672,32 +689,137 @@ class RKWrapperCore(SkrampleWrapperCore):
         else:
             derivative, space = (-Lin.leaf(model_output) if self.invert_prediction else lift(model_output)), self.model
 
-        held = len(self._derivatives)
+        pending = list(self._derivatives)
+        base_before = self._sample
+        start_index = self._index
+        self._last_noise = None
         i0 = self._index - held
         i1 = self._index + self.order - held
         form = self._stage_form(sample, derivative, space, points[i0], points[i1], points[self._index + 1], generator)
         self._index += 1
 
         clean = self.schedule.point_0
+        synthesised = False
         while self._index < len(self.all_points) and (
             abs(self.all_points[self._index].timestep - clean.timestep) < 1e-8 or abs(self.all_points[self._index].sigma - clean.sigma) < 1e-8
         ):
             # stage on the clean end: synthesise the derivative that reproduces the pending stage input
+            synthesised = True
             base = lift(sample if self._sample is None else self._sample)
             delta = DeltaPoint(points[i0], points[i1])
             synth = (form - base * space.gamma(delta)) / space.delta(delta)
             form = self._stage_form(sample, synth, space, points[i0], points[i1], points[self._index + 1], generator)
             self._index += 1
 
-        with lazy.compute_scale(self.compute_scale):
-            if conv is not None:
-                converted, result = lazy.evaluate([conv, form], [None, model_output.dtype])
-                self._derivatives = [d.substitute(conv, converted) for d in self._derivatives]
-                pred = converted
-            else:
-                result = lazy.evaluate([form], [model_output.dtype])[0]
-                pred = LazyTensor(derivative, model_output.dtype) if (self.derivative_transform or self.invert_prediction) else model_output
+        tracing = prog is None and _hip.trace is None and isinstance(sample, Tensor) and sample.is_cuda and not synthesised
+        if tracing:
+            _hip.trace = []
+        try:
+            with lazy.compute_scale(self.compute_scale):
+                if conv is not None:
+                    converted, result = lazy.evaluate([conv, form], [None, model_output.dtype])
+                    self._derivatives = [d.substitute(conv, converted) for d in self._derivatives]
+                    pred = converted
+                else:
+                    result = lazy.evaluate([form], [model_output.dtype])[0]
+                    pred = LazyTensor(derivative, model_output.dtype) if (self.derivative_transform or self.invert_prediction) else model_output
+            if tracing:
+                built = None
+                if len(_hip.trace) == 1 and (conv is not None or pred is model_output):
+                    built = self._build_stage_program(_hip.trace[0], sample, model_output, base_before, pending, conv is not None, finished=not self._derivatives and self._sample is None)
+                self._rk_programs[(start_index, held, sample.dtype, model_output.dtype, tuple(sample.shape))] = built or False
+        finally:
+            if tracing:
+                _hip.trace = None
         return self._finish(result, pred, model_output, return_dict)
+
+    @staticmethod
+    def _single_tensor(form):
+        "the tensor if `form` is exactly 1.0 * tensor, else None"
+        if isinstance(form, Lin) and len(form.terms) == 1:
+            (leaf, c), = form.terms.values()
+            if isinstance(leaf, Tensor) and c == 1.0:
+                return leaf
+        return None
+
+    def _build_stage_program(self, entry, sample, model_output, base_before, pending, converted: bool, finished: bool):
+        plan, inputs, out0, out1, seeds, numel = entry
+        table: dict[int, tuple] = {}
+        for j, d in enumerate(pending):
+            t = self._single_tensor(d)
+            if t is None:
+                return None
+            table[id(t)] = ("d", j)
+        if base_before is not None:
+            table[id(base_before)] = ("b",)
+        noise = self._last_noise
+        if isinstance(noise, Tensor):
+            table[id(noise)] = ("n",)
+        table[id(model_output)] = ("o",)
+        table[id(sample)] = ("x",)
+        roles = []
+        for t in inputs:
+            if id(t) not in table:
+                return None
+            roles.append(table[id(t)])
+        philox = plan.noise_mode == 1
+        if philox:
+            if not isinstance(noise, lazy.PhiloxNoise) or noise.seeds is not seeds:
+                return None
+            if (converted and plan.zeta0 != 0.0) or (not converted and plan.zeta1 != 0.0):
+                return None  # the draw must feed the step result (out1 when a conversion occupies out0)
+        return {
+            "plan": plan, "roles": roles, "dtypes": [t.dtype for t in inputs], "numel": numel, "shape": tuple(sample.shape),
+            "out_dtypes": (out0.dtype, out1.dtype if out1 is not None else None), "converted": converted, "finished": finished,
+            "noise": "philox" if philox else ("tensor" if isinstance(noise, Tensor) else None), "ptrs": (ctypes.c_void_p * max(len(inputs), 1))(),
+        }  # fmt: skip
+
+    def _replay_stage(self, prog: dict, model_output: Tensor, sample: Tensor, generator):
+        "fast path of step(): bind today's tensors to a recorded stage launch; None -> take the normal path"
+        pending = [self._single_tensor(d) for d in self._derivatives]
+        if any(t is None for t in pending):
+            return None
+        noise = None
+        if prog["noise"] is not None:
+            base = sample if self._sample is None else self._sample
+            noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), base, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
+        ops = []
+        for role, dt in zip(prog["roles"], prog["dtypes"]):
+            kind = role[0]
+            t = sample if kind == "x" else model_output if kind == "o" else self._sample if kind == "b" else noise if kind == "n" else pending[role[1]]
+            if not isinstance(t, Tensor) or t.dtype != dt or t.numel() != prog["numel"] or not t.is_contiguous() or t.data_ptr() % 16:
+                return None
+            ops.append(t)
+        plan = prog["plan"]
+        seeds_ptr = None
+        if prog["noise"] == "philox":
+            if not isinstance(noise, lazy.PhiloxNoise) or not noise.fusable() or noise.shape != prog["shape"]:
+                return None
+            if prog["converted"]:
+                plan.stream1 = noise.stream
+            else:
+                plan.stream0 = noise.stream
+            seeds_ptr = noise.seeds.data_ptr()
+        elif prog["noise"] == "tensor" and not isinstance(noise, Tensor):
+            return None
+        dev = sample.device
+        out0 = torch.empty(prog["shape"], dtype=prog["out_dtypes"][0], device=dev)
+        out1 = torch.empty(prog["shape"], dtype=prog["out_dtypes"][1], device=dev) if prog["out_dtypes"][1] is not None else None
+        arr = prog["ptrs"]
+        for i, t in enumerate(ops):
+            arr[i] = t.data_ptr()
+        status = _hip.load().skr_step_launch(ctypes.byref(plan), arr, out0.data_ptr(), out1.data_ptr() if out1 is not None else None, seeds_ptr, prog["numel"], torch.cuda.current_stream(dev).cuda_stream)
+        _hip.check(status, "skr_step_launch")
+        result = out1 if prog["converted"] else out0
+        pred = out0 if prog["converted"] else model_output
+        if prog["finished"]:
+            self._derivatives, self._sample = [], None
+        else:
+            self._derivatives.append(Lin.leaf(pred))
+            if self._sample is None:
+                self._sample = sample
+        self._index += 1
+        return result, pred
 
 
 def _rk_from_config(cls, config, schedule, subschedule, schedule_modifiers, schedule_props, subschedule_props, merge, model, invert_prediction, **fields):

@@ -261,52 +261,30 @@ class Pyramid(TensorNoiseCommon):
 
     @classmethod
     def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
-        import ctypes
-
-        import numpy as np
-
-        from ._philox_host import uniform01
-
         if props.static:
-            stream_levels = state.setdefault("static_stream", stream)  # pyramid component frozen at the first draw
-        else:
-            stream_levels = stream
+            raise SkrampleHipError("static pyramids are not implemented on this engine yet")
         lead, h, w, resize_h = cls._geometry(unit_shape, props)
         batch = seeds.shape[0]
-        host_seeds = state.get("host_seeds")
-        if host_seeds is None or len(host_seeds) != batch:
-            host_seeds = state["host_seeds"] = seeds.cpu().numpy().astype(np.uint64)
-        uniforms = uniform01(host_seeds, stream_levels + 255, PYRAMID_MAX_LEVELS)
-        table, counts = pyramid_level_tables((h, w), resize_h, uniforms)
-        worst = int((table[:, 1:, 0].astype(np.int64) * table[:, 1:, 1]).sum(axis=1).max())
-        n_max = int(counts.max())
-        # depth: keep only the `depth`+1 coarsest levels (reference noise.py:198-200) -- per sample the count can
-        # differ, so the skip is applied through the weights only when every sample agrees; otherwise per level count
-        weights = np.zeros(PYRAMID_MAX_LEVELS, dtype=np.float64)
-        for l in range(n_max):
-            weights[l] = props.strength**l
-        if props.depth < n_max - 1:
-            if len(set(counts.tolist())) != 1:
-                raise SkrampleHipError("Pyramid depth truncation with per-sample level counts that differ is not supported in one launch")
-            for l in range(max(0, (n_max - 1) - props.depth)):
-                weights[l] = 0.0
         dev = seeds.device
+        key = ("ws", batch, lead, h, w)
+        if key not in state:
+            state.clear()
+            state[key] = (
+                torch.empty(batch * lead * h * w, dtype=torch.float32, device=dev),
+                torch.empty(batch * lead * 2, dtype=torch.float64, device=dev),
+                torch.empty(batch * (PYRAMID_MAX_LEVELS * 2 + 1), dtype=torch.int32, device=dev),
+            )
+        scratch, partials, levels = state[key]
         out = torch.empty((batch, *unit_shape), dtype=dtype, device=dev)
-        scratch = torch.empty(batch * lead * h * w, dtype=torch.float32, device=dev)
-        partials = torch.empty(batch * lead * 2, dtype=torch.float64, device=dev)
-        table_d = torch.from_numpy(table).to(dev)
-        counts_d = torch.from_numpy(counts).to(dev)
         lib, hstream = _launch_ctx(seeds)
-        # base normal: this draw's own stream; levels: stream_levels (+1+l)
-        if stream_levels != stream:
-            raise SkrampleHipError("static pyramids are not implemented on this engine yet")
         _hip.check(
             lib.skr_noise_pyramid(
-                out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), partials.data_ptr(), seeds.data_ptr(), stream, batch, lead, h, w,
-                table_d.data_ptr(), counts_d.data_ptr(), (ctypes.c_double * PYRAMID_MAX_LEVELS)(*weights.tolist()), int(worst), 1, 1, hstream,
+                out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), partials.data_ptr(), levels.data_ptr(), seeds.data_ptr(), stream,
+                batch, lead, h, w, 1 if resize_h else 0, float(props.strength), int(min(props.depth, 1 << 20)), 1, hstream,
             ),
             "skr_noise_pyramid",
         )
+        state["levels"] = levels  # device table of the last draw: [batch][8][2] sizes, then [batch] counts
         return out
 
 

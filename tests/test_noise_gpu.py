@@ -129,11 +129,15 @@ def test_pyramid(unit, kw, dev):
     props = PN.PyramidProps(**kw)
     g = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=props, dtype=torch.float32)
     for n in range(2):
-        try:
-            got = g.generate(None).cpu()
-        except _hip.SkrampleHipError as exc:  # depth with differing per-sample level counts
-            assert "depth" in str(exc) and "depth" in kw
-            return
+        got = g.generate(None).cpu()
+        # the level geometry drawn on the device equals the host/oracle rule
+        lead, h, w, resize_h = PN.Pyramid._geometry(unit, props)
+        table, counts = PN.pyramid_level_tables((h, w), resize_h, uniform01(np.array(seeds, dtype=np.uint64), n * 256 + 255, PN.PYRAMID_MAX_LEVELS))
+        dev_levels = g._state["levels"].cpu().numpy()
+        dev_counts = dev_levels[len(seeds) * 16 :]
+        assert np.array_equal(dev_counts, counts)
+        for b in range(len(seeds)):
+            assert np.array_equal(dev_levels[b * 16 : b * 16 + counts[b] * 2].reshape(-1, 2), table[b, : counts[b]])
         ref = torch.stack([pyramid_reference(unit, s, n * 256, **kw) for s in seeds])
         assert rel(got, ref) < 2e-5, (unit, kw, n, rel(got, ref))
         assert (got.reshape(3, -1).std(dim=1) - 1).abs().max() < 1e-4

@@ -486,3 +486,34 @@ def test_runge_kutta_wrapper_equals_functional(wrapper, dev):
             assert res.dtype == torch.float64
             x = res[0, 0].item()
         assert abs(want - x) < 1e-8 * max(1, abs(want)), (model.__name__, transform, order, eta)
+
+
+def test_rk_stage_programs_replay_bitwise(dev):
+    "the Runge-Kutta wrappers replay cached stage launches on later passes: identical results"
+    from skrample_amd.pytorch import noise as PN
+
+    shape, steps = (2, 4, 32, 32), 4
+    g = torch.Generator().manual_seed(12)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    pool = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps * 6)]
+    wrappers = [
+        PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=6, stochasticity=1),
+        PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=4, stochasticity=0.5, model=PM.VelocityModel()),
+        PD.RKUltraWrapperScheduler(PS.Linear(), sampler_order=2, model=PM.FlowModel()),
+        PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=5, derivative_transform=None),
+        PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=3, stochasticity=1, noise_type=PN.Pyramid, noise_props=PN.PyramidProps()),
+        PD.DynasauRKWrapperScheduler(PS.Scaled(), sampler_order=3, stochasticity=1),
+    ]
+    for w in wrappers:
+        passes = []
+        for rep in range(3):
+            w.set_timesteps(steps)
+            x, traj = x0, []
+            for i, t in enumerate(w.timesteps):
+                x, pred = w.step(pool[i], t, x, generator=[5, 6], return_dict=False)
+                traj.append((x, torch.as_tensor(pred.materialize() if isinstance(pred, lazy.LazyTensor) else pred)))
+            passes.append(traj)
+        cached = [k for k, v in w._rk_programs.items() if v]
+        assert len(cached) >= len(passes[0]) - w.order, (type(w).__name__, w.sampler_order, len(cached), len(passes[0]))
+        for a, b, c in zip(*passes):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0]) and torch.equal(a[1], b[1]) and torch.equal(a[1], c[1]), (type(w).__name__, w.sampler_order)
