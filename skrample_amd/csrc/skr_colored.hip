@@ -15,6 +15,7 @@
 // Reductions are per block into fixed slots and summed in a fixed order (bit-reproducible, no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
@@ -42,26 +43,56 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 
 __device__ __forceinline__ unsigned brev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
 
-// In-place radix-2 DIT over L lines of N points held in `buf` (line-major, stride N+1), input already in
-// bit-reversed order.  `tw` holds exp(-2 pi i k / N), k < N/2; INVERSE conjugates it.
+// In-place DIT over L lines of N points held in `buf` (line-major, stride N+1), input already in bit-reversed
+// order.  `tw` holds exp(-2 pi i k / N), k < N/2; INVERSE conjugates it.  Two radix-2 stages are fused per LDS
+// round trip (each work item carries 4 points through stages s and s+1 in registers), with one plain radix-2
+// stage left over when log2 N is odd: half the LDS traffic and half the barriers of a stage-by-stage FFT.
+template <bool INVERSE>
+__device__ __forceinline__ float2 twid(const float2* tw, int idx) {
+  float2 w = tw[idx];
+  if (INVERSE) w.y = -w.y;
+  return w;
+}
+
 template <bool INVERSE>
 __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, int logN, int L) {
   const int half_n = N >> 1, ld = N + 1;
-  const int total = L * half_n;
-  for (int s = 0; s < logN; ++s) {
-    const int half = 1 << s;
-    const int tw_step = half_n >> s;
+  int s = 0;
+  if (logN & 1) {  // leftover radix-2 stage first (half = 1, twiddle = 1)
     __syncthreads();
+    const int total = L * half_n;
     for (int t = threadIdx.x; t < total; t += FFT_THREADS) {
-      const int line = t / half_n, k = t - line * half_n;
-      const int pos = k & (half - 1);
-      const int i0 = ((k >> s) << (s + 1)) + pos;
-      float2 w = tw[pos * tw_step];
-      if (INVERSE) w.y = -w.y;
-      float2* p = buf + line * ld;
-      const float2 a = p[i0], b = cmul(p[i0 + half], w);
-      p[i0] = make_float2(a.x + b.x, a.y + b.y);
-      p[i0 + half] = make_float2(a.x - b.x, a.y - b.y);
+      const int line = t >> (logN - 1), k = t & (half_n - 1);
+      float2* p = buf + line * ld + 2 * k;
+      const float2 a = p[0], b = p[1];
+      p[0] = make_float2(a.x + b.x, a.y + b.y);
+      p[1] = make_float2(a.x - b.x, a.y - b.y);
+    }
+    s = 1;
+  }
+  const int quarter = N >> 2;
+  for (; s < logN; s += 2) {
+    const int h = 1 << s;
+    const int step1 = half_n >> s, step2 = half_n >> (s + 1);
+    __syncthreads();
+    const int total = L * quarter;
+    for (int t = threadIdx.x; t < total; t += FFT_THREADS) {
+      const int line = t >> (logN - 2), k = t & (quarter - 1);
+      const int pos = k & (h - 1);
+      float2* p = buf + line * ld + ((k >> s) << (s + 2)) + pos;
+      float2 e0 = p[0], e1 = p[h], e2 = p[2 * h], e3 = p[3 * h];
+      // stage s: (e0,e1) and (e2,e3), same twiddle
+      const float2 w1 = twid<INVERSE>(tw, pos * step1);
+      const float2 b1 = cmul(e1, w1), b3 = cmul(e3, w1);
+      const float2 f0 = make_float2(e0.x + b1.x, e0.y + b1.y), f1 = make_float2(e0.x - b1.x, e0.y - b1.y);
+      const float2 f2 = make_float2(e2.x + b3.x, e2.y + b3.y), f3 = make_float2(e2.x - b3.x, e2.y - b3.y);
+      // stage s+1: (f0,f2) at position pos, (f1,f3) at position pos + h
+      const float2 w2 = twid<INVERSE>(tw, pos * step2), w3 = twid<INVERSE>(tw, (pos + h) * step2);
+      const float2 c2 = cmul(f2, w2), c3 = cmul(f3, w3);
+      p[0] = make_float2(f0.x + c2.x, f0.y + c2.y);
+      p[2 * h] = make_float2(f0.x - c2.x, f0.y - c2.y);
+      p[h] = make_float2(f1.x + c3.x, f1.y + c3.y);
+      p[3 * h] = make_float2(f1.x - c3.x, f1.y - c3.y);
     }
   }
   __syncthreads();
@@ -108,7 +139,7 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
     // draw the white noise straight into LDS (bit-reversed), 4 normals per Philox call
     const uint64_t seed = a.seeds[smp];
     for (int q = threadIdx.x; q < lines * (N / 4); q += FFT_THREADS) {
-      const int line = q / (N / 4), n4 = (q - line * (N / 4)) * 4;
+      const int line = q >> (logN - 2), n4 = (q & (N / 4 - 1)) * 4;
       const int64_t e = (line0 + line) * N + n4;  // element index inside the sample
       float z[4];
       normal4(seed, a.stream, (uint64_t)e >> 2, z);
@@ -120,16 +151,23 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
       }
     }
     fft_tile<false>(buf, tw, N, logN, lines);
+    // the tile's half spectra are contiguous in memory: [lines][d3h]; walk it with one running (line, k) pair
     float2* dst = a.spec + (smp * n_lines + line0) * a.d3h;
-    for (int q = threadIdx.x; q < lines * a.d3h; q += FFT_THREADS) {
-      const int line = q / a.d3h, k = q - line * a.d3h;
-      dst[(int64_t)line * a.d3h + k] = buf[line * ld + k];
+    {
+      const int total = lines * a.d3h;
+      int line = threadIdx.x / a.d3h, k = threadIdx.x - line * a.d3h;
+      const int dl = FFT_THREADS / a.d3h, dk = FFT_THREADS - dl * a.d3h;
+      for (int q = threadIdx.x; q < total; q += FFT_THREADS) {
+        dst[q] = buf[line * ld + k];
+        line += dl; k += dk;
+        if (k >= a.d3h) { k -= a.d3h; ++line; }
+      }
     }
     block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + blockIdx.x) * 2);
   } else {
     const float2* src = a.spec + (smp * n_lines + line0) * a.d3h;
     for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
-      const int line = q / N, k = q - line * N;
+      const int line = q >> logN, k = q & (N - 1);
       float2 v;
       if (k < a.d3h) v = src[(int64_t)line * a.d3h + k];
       else { v = src[(int64_t)line * a.d3h + (N - k)]; v.y = -v.y; }  // Hermitian half
@@ -139,7 +177,7 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
     const float scale = 1.0f / ((float)a.d1 * (float)a.d2 * (float)a.d3);
     float* dst = a.real_out + (smp * n_lines + line0) * N;
     for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
-      const int line = q / N, n = q - line * N;
+      const int line = q >> logN, n = q & (N - 1);
       const float v = buf[line * ld + n].x * scale;
       dst[(int64_t)line * N + n] = v;
       s1 += (double)v;
@@ -153,7 +191,8 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
 //   element n of line q (within a sample):  (q / inner) * outer + (q % inner) + n * stride
 // MODE 0 forward, 1 inverse, 2 forward + radial weights + inverse (outermost axis)
 template <int MODE>
-__global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const ColoredArgs a, int N, int logN, int L, int64_t n_lines, int64_t inner, int64_t outer, int64_t stride, int axis /*1 or 2*/) {
+__global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const ColoredArgs a, int N, int logN, int logL, int64_t n_lines, int64_t inner, int64_t outer, int64_t stride, int axis /*1 or 2*/) {
+  const int L = 1 << logL;
   extern __shared__ float2 smem[];
   const int ld = N + 1;
   float2* tw = smem;
@@ -163,17 +202,20 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const Colore
   const int lines = (int)((n_lines - line0) < L ? (n_lines - line0) : L);
   float2* base = a.spec + smp * (int64_t)a.d1 * a.d2 * a.d3h;
   make_twiddles(tw, N);
-  // coalesced along the line index j (adjacent lines are adjacent in memory)
-  for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
-    const int n = q / lines, j = q - n * lines;
-    const int64_t ql = line0 + j;
-    buf[j * ld + brev(n, logN)] = base[(ql / inner) * outer + (ql % inner) + (int64_t)n * stride];
+  // coalesced along the line index j (adjacent lines are adjacent in memory).  Per-thread line offsets are
+  // loop invariant when FFT_THREADS is a multiple of L (L is a power of two <= 64).
+  const int jt = threadIdx.x & (L - 1), nt0 = threadIdx.x >> logL, dn = FFT_THREADS >> logL;
+  const int64_t qt = line0 + jt;
+  const int64_t off_t = (qt / inner) * outer + (qt % inner);
+  const bool live = jt < lines;
+  if (live) {
+    for (int n = nt0; n < N; n += dn) buf[jt * ld + brev(n, logN)] = base[off_t + (int64_t)n * stride];
   }
   fft_tile<MODE == 1>(buf, tw, N, logN, lines);
   if (MODE == 2) {
     // natural-order spectrum along this axis: weight, then bit-reverse in place for the inverse transform
     for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
-      const int j = q / N, k = q - j * N;
+      const int j = q >> logN, k = q & (N - 1);
       const int64_t ql = line0 + j;
       // frequency coordinates of this line's other axes
       int k2, k3;
@@ -194,16 +236,14 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const Colore
     __syncthreads();
     // in-place bit reversal (swap pairs once)
     for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
-      const int j = q / N, k = q - j * N;
+      const int j = q >> logN, k = q & (N - 1);
       const int r = (int)brev(k, logN);
       if (k < r) { float2 t = buf[j * ld + k]; buf[j * ld + k] = buf[j * ld + r]; buf[j * ld + r] = t; }
     }
     fft_tile<true>(buf, tw, N, logN, lines);
   }
-  for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
-    const int n = q / lines, j = q - n * lines;
-    const int64_t ql = line0 + j;
-    base[(ql / inner) * outer + (ql % inner) + (int64_t)n * stride] = buf[j * ld + n];
+  if (live) {
+    for (int n = nt0; n < N; n += dn) base[off_t + (int64_t)n * stride] = buf[jt * ld + n];
   }
 }
 
@@ -231,6 +271,17 @@ __global__ __launch_bounds__(256) void colored_finish(T* out, const ColoredArgs 
 }
 
 }  // namespace skr
+
+// points per block tile; default 4096 (32 KiB of LDS).  SKR_FFT_TILE overrides it for tuning runs.
+static int fft_tile_points() {
+  static int cached = 0;
+  if (!cached) {
+    const char* e = getenv("SKR_FFT_TILE");
+    int v = e ? atoi(e) : 0;
+    cached = (v >= 256 && v <= skr::FFT_MAX_TILE && !(v & (v - 1))) ? v : skr::FFT_MAX_TILE;
+  }
+  return cached;
+}
 
 static int ilog2_exact(int64_t v) {
   if (v < 2 || (v & (v - 1))) return -1;
@@ -267,7 +318,8 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
 
   // pass A: last axis forward
   const int64_t lines_last = (int64_t)d1 * d2;
-  int La = FFT_MAX_TILE / d3; if (La > lines_last) La = (int)lines_last; if (La < 1) La = 1;
+  const int tile = fft_tile_points();
+  int La = tile / d3; if (La > lines_last) La = (int)lines_last; if (La < 1) La = 1;
   const int64_t blocks_a = (lines_last + La - 1) / La;
   if (blocks_a > partial_slots) return SKR_ERR_SHAPE;
   a.n_slots = (int32_t)blocks_a;
@@ -276,14 +328,15 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   SKR_CHECK_LAUNCH();
 
   auto strided = [&](int mode, int N, int logN, int64_t n_lines, int64_t inner, int64_t outer, int64_t stride, int axis) -> int {
-    int L = FFT_MAX_TILE / N; if (L > n_lines) L = (int)n_lines; if (L < 1) L = 1;
-    if (L > 64) L = 64;  // keep the coalesced run per row modest so more blocks are in flight
+    int logL = 0;
+    while ((2 << logL) * N <= tile && (2 << logL) <= 64) ++logL;  // L = 2^logL lines per tile, <= 64 (512 B runs)
+    const int L = 1 << logL;
     const int64_t blocks = (n_lines + L - 1) / L;
     const size_t lds = sizeof(float2) * ((size_t)N / 2 + (size_t)L * (N + 1));
     dim3 grid((unsigned)blocks, (unsigned)batch);
-    if (mode == 0) hipLaunchKernelGGL(colored_strided_axis<0>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, L, n_lines, inner, outer, stride, axis);
-    else if (mode == 1) hipLaunchKernelGGL(colored_strided_axis<1>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, L, n_lines, inner, outer, stride, axis);
-    else hipLaunchKernelGGL(colored_strided_axis<2>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, L, n_lines, inner, outer, stride, axis);
+    if (mode == 0) hipLaunchKernelGGL(colored_strided_axis<0>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, logL, n_lines, inner, outer, stride, axis);
+    else if (mode == 1) hipLaunchKernelGGL(colored_strided_axis<1>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, logL, n_lines, inner, outer, stride, axis);
+    else hipLaunchKernelGGL(colored_strided_axis<2>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, logL, n_lines, inner, outer, stride, axis);
     return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
   };
   const int64_t d3h = a.d3h;

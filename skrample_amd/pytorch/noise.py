@@ -323,7 +323,7 @@ class Colored(TensorNoiseCommon):
         dev = seeds.device
         key = ("ws", batch, d1, d2, d3)
         if key not in state:
-            slots = -(-(d1 * d2) // max(1, 4096 // d3))
+            slots = -(-(d1 * d2) // max(1, 256 // d3))  # enough for the smallest tile the library may pick
             state.clear()
             state[key] = (
                 torch.empty(batch * d1 * d2 * (d3 // 2 + 1), dtype=torch.complex64, device=dev),
