@@ -376,6 +376,10 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
     allow_dynamic: bool = True
     invert_prediction: bool = False
     fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
+    alias_history: bool = True
+    """(not in the reference) keep history entries as aliases of the caller's `sample` / `model_output` tensors.
+    Set False when the caller overwrites those buffers in place between steps (e.g. a CUDA/HIP-graphed network
+    with static output memory): the wrapper then snapshots both tensors, at 4 B/element of extra traffic."""
 
     def __post_init__(self) -> None:
         super().__post_init__()
@@ -485,6 +489,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         idx = self._lookup(table, timestep, self._index + self._calls)
         self._calls += 1
         step = Step.from_int(idx, len(table))
+        if not self.alias_history and self.sampler.require_previous > 0:
+            sample, model_output = sample.clone(), model_output.clone()
 
         prediction = LazyTensor(-Lin.leaf(model_output), model_output.dtype) if self.invert_prediction else model_output
         noise = None
@@ -548,6 +554,8 @@ class RKWrapperCore(SkrampleWrapperCore):
     allow_dynamic: bool = True
     invert_prediction: bool = False
     fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
+    alias_history: bool = True
+    "(not in the reference) see SkrampleWrapperScheduler.alias_history; False snapshots `sample` / `model_output` per stage"
 
     def __post_init__(self) -> None:
         super().__post_init__()
@@ -659,6 +667,8 @@ class RKWrapperCore(SkrampleWrapperCore):
         expected = self.all_points[self._index].timestep
         if value is not None:
             assert value == expected, f"Expected timestep {expected} for step {self._index}, got {timestep=}!"
+        if not self.alias_history and self.order > 1:
+            sample, model_output = sample.clone(), model_output.clone()
 
         # stage programs: the same lower-once / replay-by-binding scheme as SkrampleWrapperScheduler.step
         owner = (self.schedule, self._steps, self.sampler_order, self.stochasticity, self.model, self.derivative_transform, self.compute_scale, self.invert_prediction)

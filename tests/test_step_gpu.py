@@ -517,3 +517,23 @@ def test_rk_stage_programs_replay_bitwise(dev):
         assert len(cached) >= len(passes[0]) - w.order, (type(w).__name__, w.sampler_order, len(cached), len(passes[0]))
         for a, b, c in zip(*passes):
             assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0]) and torch.equal(a[1], b[1]) and torch.equal(a[1], c[1]), (type(w).__name__, w.sampler_order)
+
+
+def test_alias_history_off_survives_buffer_reuse(dev):
+    "with alias_history=False the caller may overwrite sample / model_output in place between steps"
+    shape, steps = (2, 4, 16, 16), 6
+    g = torch.Generator().manual_seed(13)
+    x0 = torch.randn(shape, generator=g).to(dev)
+    outs = [torch.randn(shape, generator=g).to(dev) for _ in range(steps)]
+    for mk in (lambda **k: PD.SkrampleWrapperScheduler(PT.DPM(order=3), PS.Scaled(), **k), lambda **k: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=4, **k)):
+        ref_w, w = mk(), mk(alias_history=False)
+        ref_w.set_timesteps(steps)
+        w.set_timesteps(steps)
+        x_ref = x0.clone()
+        static_x, static_out = x0.clone(), torch.empty_like(x0)  # one pair of buffers reused for every call
+        for i, t in enumerate(w.timesteps):
+            x_ref = ref_w.step(outs[i % steps].clone(), t, x_ref, return_dict=False)[0]
+            static_out.copy_(outs[i % steps])
+            res = w.step(static_out, t, static_x, return_dict=False)[0]
+            static_x.copy_(res)
+            assert torch.equal(res, x_ref), i
