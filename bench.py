@@ -288,7 +288,7 @@ def main() -> None:
                 "traffic": load_traffic(),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_us_per_launch": kernel_ms * 1e3,
-                "kernel": "skr::step_kernel<bf16,bf16,bf16,bf16,float,ST0,!HAS1,NOISE,!CONV>",
+                "kernel": "skr::step_kernel_k<bf16_t, K=4, NOISE=true, UV=1>",
             },
             "wrapper_steps_per_s": wrapper_rate,
         }

@@ -14,11 +14,11 @@ import statistics
 import sys
 
 round_tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-needle = sys.argv[2] if len(sys.argv) > 2 else "true, false, true, false"  # ST0, !HAS1, NOISE, !CONV
+needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k<skr::bf16_t, 4, true, 1>"  # headline: K=4 bf16 + Philox
 
 
 def counter(path: str, name: str) -> list[float]:
-    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "step_kernel" in r["Kernel_Name"] and needle in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if needle in r["Kernel_Name"] and r["Counter_Name"] == name]
 
 
 rows = list(csv.DictReader(open("gpurun_out/prof_trace/r01_kernel_stats.csv")))
@@ -33,7 +33,7 @@ write = counter("gpurun_out/prof_write/r01_counter_collection.csv", "WRITE_SIZE"
 # steady-state launches only (the first, order-1 step of every schedule reads no history)
 fetch = [v for v in fetch if v > 0.75 * max(fetch)]
 out = {
-    "kernel": "skr::step_kernel<bf16,bf16,bf16,bf16,float,ST0,!HAS1,NOISE,!CONV> (DPM-2 SDE, B=256x4x128x128)",
+    "kernel": "skr::step_kernel_k<bf16_t, K=4, NOISE=true, UV=1> (DPM-2 SDE, B=256x4x128x128)",
     "fetch_size_kib_mean": statistics.mean(fetch),
     "write_size_kib_mean": statistics.mean(write),
     "launches": [len(fetch), len(write)],
