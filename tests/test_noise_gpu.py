@@ -227,3 +227,35 @@ def test_colored_with_unipc_wrapper(dev):
         ref = o.step(out, t, x, noise=noise)[0]
         assert rel(got, ref) < 1e-5, i
         x = ref
+
+
+@pytest.mark.parametrize(
+    ("kind", "props", "unit", "batch"),
+    [
+        (PN.Random, None, (4, 128, 128), 64),
+        (PN.Offset, PN.OffsetProps(), (4, 128, 128), 64),
+        (PN.Pyramid, PN.PyramidProps(), (4, 256, 256), 64),  # cfg5 per-GPU shard
+        (PN.Colored, PN.ColoredProps(), (16, 128, 128), 32),  # cfg3 unit shape
+    ],
+)
+def test_generators_full_size_properties(kind, props, unit, batch, dev):
+    """BASELINE-size units: batch shards reproduce the full batch bit for bit (what makes 8-GPU sharding exact),
+    repeated construction is deterministic, successive draws differ, moments are sane."""
+    seeds = [1000 + i for i in range(batch)]
+    step = Step(0.45, 0.5)
+
+    def draws(sd, n=2):
+        g = PN.BatchTensorNoise.from_batch_inputs(kind, unit, sd, props=props, dtype=torch.bfloat16)
+        return [g.generate(step) for _ in range(n)]
+
+    full = draws(seeds)
+    again = draws(seeds)
+    lo, hi = draws(seeds[: batch // 2]), draws(seeds[batch // 2 :])
+    for f, a, l, h in zip(full, again, lo, hi):
+        assert torch.equal(f, a)
+        assert torch.equal(f[: batch // 2], l) and torch.equal(f[batch // 2 :], h)
+    assert not torch.equal(full[0], full[1])
+    x = full[0].float().reshape(batch, -1)
+    assert torch.isfinite(x).all()
+    assert (x.std(dim=1) - 1).abs().max() < (0.02 if kind is not PN.Offset else 0.05)
+    assert x.mean(dim=1).abs().max() < (0.05 if kind is not PN.Offset else 0.15)  # Offset: mean of 4 channel offsets ~ N(0, 0.02)
