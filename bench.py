@@ -182,13 +182,24 @@ def main() -> None:
     numel = batch * C * H * W
     plans = capture_plans(dev, batch, first_sample=rank * batch)
 
-    # rotating buffer sets: (x, out, x_prev, out_prev, y) each 2 B/elem -> 168 MB per set at B=256
+    # rotating buffer sets: (x, out, x_prev, out_prev, y) each 2 B/elem -> 168 MB per set at B=256.
+    # In a sampling loop `x`, `x_prev` and `y` are tensors the engine itself allocated (step results), so they
+    # come from its output allocator (lazy.empty_output: 4 KiB-staggered placement); `out` / `out_prev` stand
+    # for the network's tensors and come straight from torch's allocator.
+    from skrample_amd.sampling.lazy import empty_output
+
     nsets = max(args.sets, 4)
     g = torch.Generator(device=dev).manual_seed(99 + rank)
     sets = []
     for _ in range(nsets):
-        bufs = {r: torch.randn(numel, device=dev, generator=g).to(torch.bfloat16) for r in ("x", "out", "x_prev", "out_prev")}
-        bufs["y"] = torch.empty(numel, device=dev, dtype=torch.bfloat16)
+        bufs = {}
+        for r in ("x", "out", "x_prev", "out_prev", "y"):
+            if r in ("out", "out_prev"):
+                bufs[r] = torch.randn(numel, device=dev, generator=g).to(torch.bfloat16)
+            else:
+                bufs[r] = empty_output((numel,), torch.bfloat16, dev)
+                if r != "y":
+                    bufs[r].copy_(torch.randn(numel, device=dev, generator=g))
         sets.append(bufs)
 
     stream = torch.cuda.current_stream(dev).cuda_stream

@@ -813,8 +813,8 @@ class RKWrapperCore(SkrampleWrapperCore):
         elif prog["noise"] == "tensor" and not isinstance(noise, Tensor):
             return None
         dev = sample.device
-        out0 = torch.empty(prog["shape"], dtype=prog["out_dtypes"][0], device=dev)
-        out1 = torch.empty(prog["shape"], dtype=prog["out_dtypes"][1], device=dev) if prog["out_dtypes"][1] is not None else None
+        out0 = lazy.empty_output(prog["shape"], prog["out_dtypes"][0], dev)
+        out1 = lazy.empty_output(prog["shape"], prog["out_dtypes"][1], dev) if prog["out_dtypes"][1] is not None else None
         arr = prog["ptrs"]
         for i, t in enumerate(ops):
             arr[i] = t.data_ptr()

@@ -252,6 +252,31 @@ def _default_dtype(form: Lin) -> torch.dtype:
     return torch.float32
 
 
+# ---- HBM-aware output placement ---------------------------------------------------------------------------
+# A step reads 4-5 equally sized tensors at the same offsets.  torch's caching allocator hands out large blocks
+# at 2 MiB multiples, so all streams then start on the same HBM channel/bank phase and collide; shifting the
+# tensors this engine allocates (every step result, i.e. the next step's `sample` and history `sample`) by odd
+# multiples of 4 KiB takes ~3.5 % off the fused DPM-2 step (tools/tune/tune_step.hip, "mask=21" runs).
+_STAGGER_SLOTS = 8
+_STAGGER_BYTES = 8192
+_stagger_next = 0
+
+
+def empty_output(shape, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    "uninitialised result tensor whose start is shifted by 4 KiB + k*8 KiB (k cycles) inside its allocation"
+    global _stagger_next
+    numel = math.prod(shape)
+    item = torch.empty((), dtype=dtype).element_size()
+    if numel * item < (1 << 20):  # small tensors live in L2 / MALL anyway
+        return torch.empty(shape, dtype=dtype, device=device)
+    k = _stagger_next
+    _stagger_next = (k + 1) % _STAGGER_SLOTS
+    shift = (4096 + k * _STAGGER_BYTES) // item
+    pad = (4096 + _STAGGER_SLOTS * _STAGGER_BYTES) // item
+    flat = torch.empty(numel + pad, dtype=dtype, device=device)
+    return flat[shift : shift + numel].view(shape)
+
+
 def _prepare_tensor(t: torch.Tensor) -> torch.Tensor:
     if not t.is_contiguous():
         t = t.contiguous()
@@ -394,8 +419,8 @@ def evaluate(forms: Sequence[Lin], dtypes: Sequence[torch.dtype | None], acc_f64
             plan.zeta0, plan.stream0 = fused0[1], fused0[0].stream
         if fused1 is not None:
             plan.zeta1, plan.stream1 = fused1[1], fused1[0].stream
-    out0 = torch.empty(shape, dtype=out_dtypes[0], device=device)
-    out1 = torch.empty(shape, dtype=out_dtypes[1], device=device) if f1 is not None else None
+    out0 = empty_output(shape, out_dtypes[0], device)
+    out1 = empty_output(shape, out_dtypes[1], device) if f1 is not None else None
     _hip.launch_step(plan, [prepared[i] for i in order], out0, out1, seeds, numel, device)
     return [out0] if out1 is None else [out0, out1]
 

@@ -18,7 +18,7 @@ from typing import Any, Sequence
 import torch
 
 from .. import _hip
-from .lazy import LazyTensor, Lin, PhiloxNoise
+from .lazy import LazyTensor, Lin, PhiloxNoise, empty_output
 from .structured import SKSamples
 
 Role = tuple  # ("x",) ("o",) ("n",) ("px", k) ("pi", k) ("po", k) ("pn", k)   k = negative index into the history
@@ -150,8 +150,8 @@ class StepProgram:
             if seeds_ptr is not None and ptr != seeds_ptr:
                 return None
             seeds_ptr = ptr
-        out0 = torch.empty(self.shape, dtype=self.out_dtypes[0], device=device)
-        out1 = torch.empty(self.shape, dtype=self.out_dtypes[1], device=device) if self.out_dtypes[1] is not None else None
+        out0 = empty_output(self.shape, self.out_dtypes[0], device)
+        out1 = empty_output(self.shape, self.out_dtypes[1], device) if self.out_dtypes[1] is not None else None
         n = len(ops)
         if self.ptr_array is None:
             self.ptr_array = (ctypes.c_void_p * max(n, 1))()

@@ -202,6 +202,8 @@ void timeit(const char* name, F launch, double bytes, int iters = 200) {
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 256;
   const int64_t stagger = argc > 2 ? atoll(argv[2]) : 0;
+  const int64_t pitch_mib = argc > 3 ? atoll(argv[3]) : 36;
+  const int mask = argc > 4 ? atoi(argv[4]) : 31;
   const int64_t sample = 4 * 128 * 128;
   const int64_t n = (int64_t)B * sample;
   const int NS = 4;
@@ -211,11 +213,11 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(seeds, hs.data(), B * 8, hipMemcpyHostToDevice));
   std::vector<uint16_t> host(n);
   for (int64_t i = 0; i < n; ++i) host[i] = 0x3f80 + (rand() & 0x7f);
-  char* slab; const int64_t pitch = n * 2 + (4 << 20); CK(hipMalloc((void**)&slab, pitch * 5 * NS + (64 << 20)));
-  printf("stagger=%lld bytes\n", (long long)stagger);
+  char* slab; const int64_t pitch = pitch_mib << 20; CK(hipMalloc((void**)&slab, pitch * 5 * NS + (64 << 20)));
+  printf("stagger=%lld bytes pitch=%lld MiB mask=%d\n", (long long)stagger, (long long)pitch_mib, mask);
   for (int s = 0; s < NS; ++s) {
-    for (int j = 0; j < 4; ++j) { void* p = slab + pitch * (s * 5 + j) + stagger * j; CK(hipMemcpy(p, host.data(), n * 2, hipMemcpyHostToDevice)); sets[s].in[j] = (const u32x4_t*)p; }
-    void* o = slab + pitch * (s * 5 + 4) + stagger * 4; sets[s].out = (u32x4_t*)o;
+    for (int j = 0; j < 4; ++j) { void* p = slab + pitch * (s * 5 + j) + (((mask >> j) & 1) ? stagger * (j + 1) : 0); CK(hipMemcpy(p, host.data(), n * 2, hipMemcpyHostToDevice)); sets[s].in[j] = (const u32x4_t*)p; }
+    void* o = slab + pitch * (s * 5 + 4) + (((mask >> 4) & 1) ? stagger * 5 : 0); sets[s].out = (u32x4_t*)o;
     sets[s].seeds = seeds; sets[s].c[0] = 1.01f; sets[s].c[1] = -0.53f; sets[s].c[2] = 0.12f; sets[s].c[3] = 0.43f;
     sets[s].zeta = 0.3f; sets[s].stream = 1; sets[s].nvec = n / 8; sets[s].vps = sample / 8;
   }
