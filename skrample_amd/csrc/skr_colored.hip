@@ -247,6 +247,75 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const Colore
   }
 }
 
+// ---- pass C for short outer axes (d1 <= 16, i.e. the channel axis of every latent): one LINE PER LANE --------
+// The whole column lives in registers: 2..16-point forward DFT, radial weights, inverse DFT, with no LDS and
+// no barrier.  Adjacent lanes own adjacent columns, so every load/store instruction is fully coalesced.
+template <bool INV> __device__ __forceinline__ float2 mul_i(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <bool INV> __device__ __forceinline__ void dft4(float2& v0, float2& v1, float2& v2, float2& v3) {
+  const float2 a = cadd(v0, v2), b = csub(v0, v2), c = cadd(v1, v3), d = mul_i<INV>(csub(v1, v3));
+  v0 = cadd(a, c); v2 = csub(a, c); v1 = cadd(b, d); v3 = csub(b, d);
+}
+template <bool INV> __device__ __forceinline__ float2 rot8(float2 a) {  // a * exp(-+ i pi/4)
+  constexpr float r = 0.70710678118654752440f;
+  return INV ? make_float2(r * (a.x - a.y), r * (a.x + a.y)) : make_float2(r * (a.x + a.y), r * (a.y - a.x));
+}
+template <bool INV> __device__ __forceinline__ void dft8(float2 v[8]) {
+  float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  dft4<INV>(e0, e1, e2, e3);
+  dft4<INV>(o0, o1, o2, o3);
+  o1 = rot8<INV>(o1); o2 = mul_i<INV>(o2); o3 = mul_i<INV>(rot8<INV>(o3));
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0); v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2); v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+template <bool INV> __device__ __forceinline__ void dft16(float2 v[16]) {
+  float2 e[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+  dft8<INV>(e);
+  dft8<INV>(o);
+  constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+  const float sg = INV ? 1.f : -1.f;
+  const float2 w[8] = {{1.f, 0.f}, {c1, sg * s1}, {h, sg * h}, {s1, sg * c1}, {0.f, sg}, {-s1, sg * c1}, {-h, sg * h}, {-c1, sg * s1}};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const float2 t = cmul(o[k], w[k]); v[k] = cadd(e[k], t); v[k + 8] = csub(e[k], t); }
+}
+template <int N, bool INV> __device__ __forceinline__ void dft_n(float2 v[N]) {
+  if constexpr (N == 16) dft16<INV>(v);
+  else if constexpr (N == 8) dft8<INV>(v);
+  else if constexpr (N == 4) dft4<INV>(v[0], v[1], v[2], v[3]);
+  else { const float2 t = v[0]; v[0] = cadd(t, v[1]); v[1] = csub(t, v[1]); }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs a) {
+  const int64_t cols = (int64_t)a.d2 * a.d3h;  // columns per sample; element n of column q sits at q + n*cols
+  const int64_t smp = blockIdx.y;
+  float2* base = a.spec + smp * (int64_t)N * cols;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < cols; q += (int64_t)gridDim.x * 256) {
+    float2 v[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] = base[q + (int64_t)n * cols];
+    dft_n<N, false>(v);
+    const int k2 = (int)(q / a.d3h), k3 = (int)(q - (int64_t)k2 * a.d3h);
+    const float f2 = axis_freq(k2, a.d2), f3 = (float)k3 / (float)a.d3;
+    const float rest = f2 * f2 + f3 * f3;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float f1 = axis_freq(k, N);
+      float radius = sqrtf(f1 * f1 + rest) * a.inv_rmax;
+      radius = radius < a.eps_clip ? a.eps_clip : radius;
+      const float wgt = powf(radius, a.exponent_half_neg);
+      v[k] = make_float2(v[k].x * wgt, v[k].y * wgt);
+    }
+    dft_n<N, true>(v);
+#pragma unroll
+    for (int n = 0; n < N; ++n) base[q + (int64_t)n * cols] = v[n];
+  }
+}
+
 // ---- pass F: rescale per sample ---------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colored_finish(T* out, const ColoredArgs a, int64_t unit, int has_energy, double energy) {
@@ -345,7 +414,18 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     // axis 2 (length d2, stride d3h): lines = (i1, k3)
     if ((rc = strided(0, d2, l2, (int64_t)d1 * d3h, d3h, (int64_t)d2 * d3h, d3h, 2)) != SKR_OK) return rc;
     // axis 1 (length d1, stride d2*d3h): lines = (k2, k3), fused forward + weights + inverse
-    if ((rc = strided(2, d1, l1, (int64_t)d2 * d3h, (int64_t)d2 * d3h, 0, (int64_t)d2 * d3h, 1)) != SKR_OK) return rc;
+    if (d1 <= 16) {
+      const int64_t cols = (int64_t)d2 * d3h;
+      int64_t bx = (cols + 255) / 256; if (bx > 4096) bx = 4096;
+      dim3 grid((unsigned)bx, (unsigned)batch);
+      switch (d1) {
+        case 2: hipLaunchKernelGGL(colored_outer_axis_regs<2>, grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(colored_outer_axis_regs<4>, grid, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(colored_outer_axis_regs<8>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(colored_outer_axis_regs<16>, grid, dim3(256), 0, s, a); break;
+      }
+      SKR_CHECK_LAUNCH();
+    } else if ((rc = strided(2, d1, l1, (int64_t)d2 * d3h, (int64_t)d2 * d3h, 0, (int64_t)d2 * d3h, 1)) != SKR_OK) return rc;
     if ((rc = strided(1, d2, l2, (int64_t)d1 * d3h, d3h, (int64_t)d2 * d3h, d3h, 2)) != SKR_OK) return rc;
   } else {
     if ((rc = strided(2, d2, l2, d3h, d3h, 0, d3h, 2)) != SKR_OK) return rc;
