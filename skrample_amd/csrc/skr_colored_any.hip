@@ -1,0 +1,200 @@
+// Colored noise for per-sample shapes that are NOT powers of two (e.g. 96x96 or 152x104 latents): the same
+// pipeline as skr_colored.hip -- Philox white noise, rfftn, radial power-law weights, irfftn, per-sample
+// rescale -- with the transforms delegated to hipFFT (a plain library FFT, loaded lazily with dlopen so the
+// engine has no link-time dependency on it).  Generation, weighting, statistics and rescaling stay hand-written.
+// Plans are cached per (rank, dims, batch); creating one allocates hipFFT's work area (first call per shape only).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "../../include/skrample_hip.h"
+#include "skr_philox.h"
+
+namespace {
+
+typedef void* hipfftHandle_t;  // hipfftHandle is an opaque pointer
+typedef int (*plan_many_fn)(hipfftHandle_t*, int, int*, int*, int, int, int*, int, int, int /*type*/, int);
+typedef int (*exec_r2c_fn)(hipfftHandle_t, float*, void*);
+typedef int (*exec_c2r_fn)(hipfftHandle_t, void*, float*);
+typedef int (*set_stream_fn)(hipfftHandle_t, hipStream_t);
+constexpr int HIPFFT_R2C = 0x2a, HIPFFT_C2R = 0x2c;
+
+struct FftApi {
+  plan_many_fn plan_many = nullptr;
+  exec_r2c_fn r2c = nullptr;
+  exec_c2r_fn c2r = nullptr;
+  set_stream_fn set_stream = nullptr;
+  bool ok = false;
+};
+
+FftApi& api() {
+  static FftApi a;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = dlopen("libhipfft.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/libhipfft.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    a.plan_many = (plan_many_fn)dlsym(h, "hipfftPlanMany");
+    a.r2c = (exec_r2c_fn)dlsym(h, "hipfftExecR2C");
+    a.c2r = (exec_c2r_fn)dlsym(h, "hipfftExecC2R");
+    a.set_stream = (set_stream_fn)dlsym(h, "hipfftSetStream");
+    a.ok = a.plan_many && a.r2c && a.c2r && a.set_stream;
+  });
+  return a;
+}
+
+struct Plans { hipfftHandle_t fwd, inv; };
+std::mutex g_mutex;
+std::map<std::tuple<int, int, int, int, int64_t>, Plans> g_plans;
+
+constexpr int SLOTS = 256;  // partial-sum slots per sample (one per block of the stats kernels)
+
+struct AnyArgs {
+  float* real;          // [batch][unit]
+  float2* spec;         // [batch][d1][d2][d3h]
+  double* partials;     // [2][batch][SLOTS][2]
+  const uint64_t* seeds;
+  uint64_t stream;
+  int64_t batch, unit;
+  int32_t d1, d2, d3, d3h;
+  float exponent_half_neg, eps_clip, inv_rmax;
+};
+
+__device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
+  __shared__ double red[2][4];
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) { slot[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]; slot[1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]; }
+}
+
+// white noise (one lane per Philox block of a sample) + per-block sums; grid = (SLOTS, batch)
+__global__ __launch_bounds__(256) void any_white(const AnyArgs a) {
+  const int64_t smp = blockIdx.y;
+  const uint64_t seed = a.seeds[smp];
+  const int64_t blocks = (a.unit + 3) / 4;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < blocks; b += (int64_t)SLOTS * 256) {
+    float z[4];
+    skr::normal4(seed, a.stream, (uint64_t)b, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t e = b * 4 + j;
+      if (e < a.unit) { a.real[smp * a.unit + e] = z[j]; s1 += (double)z[j]; s2 += (double)z[j] * (double)z[j]; }
+    }
+  }
+  block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * SLOTS + blockIdx.x) * 2);
+}
+
+__device__ __forceinline__ float axis_freq(int k, int d) { const int m = k < d - k ? k : d - k; return (float)m / (float)d; }
+
+__global__ __launch_bounds__(256) void any_weights(const AnyArgs a) {
+  const int64_t per = (int64_t)a.d1 * a.d2 * a.d3h, total = per * a.batch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i % per;
+    const int k3 = (int)(r % a.d3h); r /= a.d3h;
+    const int k2 = (int)(r % a.d2);
+    const int k1 = (int)(r / a.d2);
+    const float f1 = a.d1 > 1 ? axis_freq(k1, a.d1) : 0.f, f2 = a.d2 > 1 ? axis_freq(k2, a.d2) : 0.f, f3 = (float)k3 / (float)a.d3;
+    float radius = sqrtf(f1 * f1 + f2 * f2 + f3 * f3) * a.inv_rmax;
+    radius = radius < a.eps_clip ? a.eps_clip : radius;
+    const float w = powf(radius, a.exponent_half_neg);
+    float2 v = a.spec[i];
+    a.spec[i] = make_float2(v.x * w, v.y * w);
+  }
+}
+
+__global__ __launch_bounds__(256) void any_stats(const AnyArgs a) {
+  const int64_t smp = blockIdx.y;
+  const float scale = 1.0f / (float)a.unit;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)SLOTS * 256) {
+    const float v = a.real[smp * a.unit + e] * scale;
+    s1 += (double)v; s2 += (double)v * (double)v;
+  }
+  block_sums(s1, s2, a.partials + ((1 * a.batch + smp) * SLOTS + blockIdx.x) * 2);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void any_finish(T* out, const AnyArgs a, int has_energy, double energy) {
+  const int64_t smp = blockIdx.y;
+  double w1 = 0, w2 = 0, c1 = 0, c2 = 0;
+  for (int s = 0; s < SLOTS; ++s) {
+    const double* pw = a.partials + ((0 * a.batch + smp) * SLOTS + s) * 2;
+    const double* pc = a.partials + ((1 * a.batch + smp) * SLOTS + s) * 2;
+    w1 += pw[0]; w2 += pw[1]; c1 += pc[0]; c2 += pc[1];
+  }
+  const double n = (double)a.unit;
+  const double wstd = sqrt((w2 - w1 * w1 / n) / (n - 1.0)), cstd = sqrt((c2 - c1 * c1 / n) / (n - 1.0));
+  float factor = 1.0f / (float)a.unit;
+  if ((float)cstd > 1e-8f) factor *= has_energy ? (float)energy / (float)cstd : (float)wstd / (float)cstd;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)gridDim.x * 256) out[smp * a.unit + e] = (T)(a.real[smp * a.unit + e] * factor);
+}
+
+}  // namespace
+
+extern "C" int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
+                                     const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
+                                     double exponent, int32_t has_energy, double energy, void* stream) {
+  if (batch < 0 || rank < 1 || rank > 3 || !dims) return SKR_ERR_SHAPE;
+  for (int i = 0; i < rank; ++i) if (dims[i] < 2) return SKR_ERR_SHAPE;
+  if (batch == 0) return SKR_OK;
+  if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || !seeds_dev) return SKR_ERR_NULL;
+  if (batch > 65535) return SKR_ERR_UNSUPPORTED;
+  FftApi& f = api();
+  if (!f.ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
+  int n[3] = {1, 1, 1};
+  for (int i = 0; i < rank; ++i) n[3 - rank + i] = dims[i];
+  AnyArgs a;
+  a.real = scratch_f32; a.spec = reinterpret_cast<float2*>(spec_c64); a.partials = partials_f64; a.seeds = seeds_dev; a.stream = stream_id;
+  a.batch = batch; a.d1 = n[0]; a.d2 = n[1]; a.d3 = n[2]; a.d3h = n[2] / 2 + 1; a.unit = (int64_t)n[0] * n[1] * n[2];
+  a.exponent_half_neg = (float)(-exponent / 2.0);
+  double n_eff = 0;
+  for (int i = 0; i < rank; ++i) n_eff += dims[i];
+  n_eff /= rank;
+  a.eps_clip = (float)(0.5 / (n_eff > 4.0 ? n_eff : 4.0));
+  float r2 = 0.f;
+  for (int i = 0; i < rank; ++i) { const float m = (float)(dims[i] / 2) / (float)dims[i]; r2 += m * m; }
+  a.inv_rmax = r2 > 0.f ? 1.0f / sqrtf(r2) : 1.0f;
+
+  Plans plans;
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto key = std::make_tuple(rank, n[0], n[1], n[2], batch);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+      int nn[3];
+      for (int i = 0; i < rank; ++i) nn[i] = dims[i];
+      Plans p;
+      if (f.plan_many(&p.fwd, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, (int)batch) != 0) return SKR_ERR_UNSUPPORTED;
+      if (f.plan_many(&p.inv, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, (int)batch) != 0) return SKR_ERR_UNSUPPORTED;
+      it = g_plans.emplace(key, p).first;
+    }
+    plans = it->second;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  f.set_stream(plans.fwd, s);
+  f.set_stream(plans.inv, s);
+
+  hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+  if (f.r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
+  int64_t wb = ((int64_t)a.d1 * a.d2 * a.d3h * batch + 255) / 256; if (wb > 256 * 32) wb = 256 * 32;
+  hipLaunchKernelGGL(any_weights, dim3((unsigned)wb), dim3(256), 0, s, a);
+  if (f.c2r(plans.inv, a.spec, a.real) != 0) return SKR_ERR_LAUNCH;
+  hipLaunchKernelGGL(any_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+  int64_t fb = (a.unit + 255) / 256; if (fb > 64) fb = 64;
+  dim3 grid((unsigned)fb, (unsigned)batch);
+  switch (out_dtype) {
+    case SKR_BF16: hipLaunchKernelGGL(any_finish<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, a, has_energy, energy); break;
+    case SKR_F16: hipLaunchKernelGGL(any_finish<_Float16>, grid, dim3(256), 0, s, (_Float16*)out, a, has_energy, energy); break;
+    case SKR_F32: hipLaunchKernelGGL(any_finish<float>, grid, dim3(256), 0, s, (float*)out, a, has_energy, energy); break;
+    case SKR_F64: hipLaunchKernelGGL(any_finish<double>, grid, dim3(256), 0, s, (double*)out, a, has_energy, energy); break;
+    default: return SKR_ERR_DTYPE;
+  }
+  return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}

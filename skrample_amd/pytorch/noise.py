@@ -292,20 +292,21 @@ class Pyramid(TensorNoiseCommon):
 class Colored(TensorNoiseCommon):
     """Power-law coloured noise: white Philox noise shaped in the Fourier domain by f^(-exponent/2), the
     exponent moving from `color_start` to `color_end` over the schedule; per-sample std preserved (or set to
-    `energy`).  Transform axes must be powers of two (2-D or 3-D per sample after dropping size-1 dims)."""
+    `energy`).  Power-of-two shapes (every BASELINE config) run on the hand-written LDS FFT kernels; any other
+    shape takes the same pipeline with the transforms done by hipFFT."""
 
     @classmethod
     def from_inputs(cls, shape, seed, props=ColoredProps(), dtype=torch.float32):
         return cls(tuple(shape), seed, dtype, props)
 
     @staticmethod
-    def _axes(unit_shape) -> tuple[int, int, int]:
+    def _axes(unit_shape) -> tuple[list[int], bool]:
+        "(transform dims after dropping size-1 axes, whether the hand-written power-of-two path applies)"
         dims = [d for d in unit_shape if d != 1]
-        if len(dims) == 2:
-            dims = [1, *dims]
-        if len(dims) != 3 or any(d & (d - 1) for d in dims) or dims[2] < 4 or dims[1] < 2:
-            raise SkrampleHipError(f"Colored noise on this engine needs a 2-D/3-D per-sample shape with power-of-two sizes, got {tuple(unit_shape)}")
-        return dims[0], dims[1], dims[2]
+        if not 1 <= len(dims) <= 3:
+            raise SkrampleHipError(f"Colored noise needs 1 to 3 transform axes per sample, got shape {tuple(unit_shape)}")
+        pow2 = len(dims) >= 2 and all(d & (d - 1) == 0 for d in dims) and dims[-1] >= 4 and max(dims) <= 4096
+        return dims, pow2
 
     @classmethod
     def _batch_lazy(cls, unit_shape, seeds, stream, step, props, dtype, state):
@@ -315,32 +316,43 @@ class Colored(TensorNoiseCommon):
 
     @classmethod
     def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        import ctypes
+
         exponent = colored_exponent(step, props)
         batch = seeds.shape[0]
         if exponent == 0.0 and props.energy is None:
             return PhiloxNoise(seeds, stream, (batch, *unit_shape), seeds.device).realize(dtype)
-        d1, d2, d3 = cls._axes(unit_shape)
+        dims, pow2 = cls._axes(unit_shape)
         dev = seeds.device
-        key = ("ws", batch, d1, d2, d3)
+        unit = math.prod(dims)
+        half = unit // dims[-1] * (dims[-1] // 2 + 1)
+        key = ("ws", batch, tuple(dims))
         if key not in state:
-            slots = -(-(d1 * d2) // max(1, 256 // d3))  # enough for the smallest tile the library may pick
+            slots = max(256, -(-(unit // dims[-1]) // max(1, 256 // dims[-1])))
             state.clear()
             state[key] = (
-                torch.empty(batch * d1 * d2 * (d3 // 2 + 1), dtype=torch.complex64, device=dev),
-                torch.empty(batch * d1 * d2 * d3, dtype=torch.float32, device=dev),
+                torch.empty(batch * half, dtype=torch.complex64, device=dev),
+                torch.empty(batch * unit, dtype=torch.float32, device=dev),
                 torch.empty(4 * batch * slots, dtype=torch.float64, device=dev),
                 slots,
             )
         spec, scratch, partials, slots = state[key]
         out = torch.empty((batch, *unit_shape), dtype=dtype, device=dev)
         lib, hstream = _launch_ctx(seeds)
-        _hip.check(
-            lib.skr_noise_colored(
+        has_energy, energy = (0, 0.0) if props.energy is None else (1, float(props.energy))
+        if pow2:
+            d1, d2, d3 = ([1] + dims)[-3:]
+            status = lib.skr_noise_colored(
                 out.data_ptr(), _hip.DTYPE_CODE[dtype], spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), slots, seeds.data_ptr(), stream,
-                batch, d1, d2, d3, float(exponent), 0 if props.energy is None else 1, 0.0 if props.energy is None else float(props.energy), hstream,
-            ),
-            "skr_noise_colored",
-        )
+                batch, d1, d2, d3, float(exponent), has_energy, energy, hstream,
+            )
+            _hip.check(status, "skr_noise_colored")
+        else:
+            status = lib.skr_noise_colored_any(
+                out.data_ptr(), _hip.DTYPE_CODE[dtype], spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), seeds.data_ptr(), stream,
+                batch, len(dims), (ctypes.c_int32 * len(dims))(*dims), float(exponent), has_energy, energy, hstream,
+            )
+            _hip.check(status, "skr_noise_colored_any")
         return out
 
 
