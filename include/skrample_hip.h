@@ -110,14 +110,16 @@ int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* seeds_dev, ui
 /* Pyramid.generate (noise.py:146-207) over the last two dims (resize_h = 1) or the last dim (resize_h = 0,
  * h must be 1) of a [batch][lead][h][w] tensor:
  *   out = (N(base) + sum_{l >= skip} strength^l * upsample_bilinear(N(level l)))  /  per-sample unbiased std
- * The per-sample level geometry is drawn on the device (uniforms = stream_base+255); level l >= 1 normals
- * (stream_base+1+l, shape [lead][h_l][w_l]) are generated into LDS and sampled there; level 0 is full resolution;
+ * The base normal is stream_base+0; the pyramid component uses stream_levels (= stream_base for a fresh pyramid
+ * per draw, the first draw's id for PyramidProps.static): geometry uniforms = stream_levels+255, level l normals
+ * (stream_levels+1+l, shape [lead][h_l][w_l]) are generated into LDS and sampled there; level 0 is full resolution;
  * skip = max(0, n_levels-1-depth).  Workspaces: scratch_f32 [batch*lead*h*w], partials_f64 [batch*lead*2],
  * level_ws int32 [batch*17] (receives the level table, readable for tests).  Limits: w % 4 == 0 and
  * about h*w <= 380*380 (the level stage must fit 152 KiB of LDS). */
 int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64, int32_t* level_ws,
-                      const uint64_t* seeds_dev, uint64_t stream_base, int64_t batch, int64_t lead, int64_t h,
-                      int64_t w, int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream);
+                      const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
+                      int64_t lead, int64_t h, int64_t w, int32_t resize_h, double strength, int32_t depth,
+                      int32_t with_base, void* stream);
 
 /* Colored.generate / colorize_noise (noise.py:337-425): white Philox noise shaped in the Fourier domain by
  * clamp(radial_frequency, eps)^(-exponent/2) and rescaled per sample to the white noise's std (or `energy`).

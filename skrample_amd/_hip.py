@@ -96,7 +96,7 @@ def load() -> ctypes.CDLL:
         lib.skr_noise_random.restype = ctypes.c_int
         lib.skr_noise_offset.argtypes = [vp, i32, vp, u64, u64, i64, ctypes.POINTER(i64), i32, ctypes.c_uint32, ctypes.c_double, vp]
         lib.skr_noise_offset.restype = ctypes.c_int
-        lib.skr_noise_pyramid.argtypes = [vp, i32, vp, vp, vp, vp, u64, i64, i64, i64, i64, i32, ctypes.c_double, i32, i32, vp]
+        lib.skr_noise_pyramid.argtypes = [vp, i32, vp, vp, vp, vp, u64, u64, i64, i64, i64, i64, i32, ctypes.c_double, i32, i32, vp]
         lib.skr_noise_pyramid.restype = ctypes.c_int
         lib.skr_noise_colored.argtypes = [vp, i32, vp, vp, vp, i64, vp, u64, i64, i32, i32, i32, ctypes.c_double, i32, ctypes.c_double, vp]
         lib.skr_noise_colored.restype = ctypes.c_int

@@ -74,7 +74,8 @@ struct PyramidArgs {
   const uint64_t* seeds;
   int32_t* level_hw;       // [batch][PYR_MAX_LEVELS][2] (h_l, w_l); level 0 is (h, w)
   int32_t* n_levels;       // [batch]
-  uint64_t stream_base;
+  uint64_t stream_base;    // base normal: stream_base + 0
+  uint64_t stream_levels;  // level l normal: stream_levels + 1 + l, geometry uniforms: stream_levels + 255
   int64_t batch;
   int32_t lead, h, w;
   int32_t resize_h, depth, with_base;
@@ -90,7 +91,7 @@ __global__ void pyramid_geometry(const PyramidArgs a) {
   const uint64_t seed = a.seeds[smp];
   uint32_t words[PYR_MAX_LEVELS];
   for (int blk = 0; blk < PYR_MAX_LEVELS / 4; ++blk) {
-    u32x4 c{(uint32_t)blk, 0u, (uint32_t)(a.stream_base + 255), (uint32_t)((a.stream_base + 255) >> 32)};
+    u32x4 c{(uint32_t)blk, 0u, (uint32_t)(a.stream_levels + 255), (uint32_t)((a.stream_levels + 255) >> 32)};
     c = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     words[blk * 4] = c.x; words[blk * 4 + 1] = c.y; words[blk * 4 + 2] = c.z; words[blk * 4 + 3] = c.w;
   }
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
       const int64_t blk = e >> 2;
       const int lane0 = (int)(e & 3);
       float z[8];
-      normal4(seed, a.stream_base + 1 + l, (uint64_t)blk, z);
-      if (lane0) normal4(seed, a.stream_base + 1 + l, (uint64_t)blk + 1, z + 4);
+      normal4(seed, a.stream_levels + 1 + l, (uint64_t)blk, z);
+      if (lane0) normal4(seed, a.stream_levels + 1 + l, (uint64_t)blk + 1, z + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (i4 + j < n) g[i4 + j] = z[lane0 + j];
     }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
     if (a.with_base) normal4(seed, a.stream_base, (uint64_t)e0 >> 2, v);
     if (w0 != 0.f) {
       float z[4];
-      normal4(seed, a.stream_base + 1, (uint64_t)e0 >> 2, z);
+      normal4(seed, a.stream_levels + 1, (uint64_t)e0 >> 2, z);
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = fmaf(z[j], w0, v[j]);
     }
@@ -259,7 +260,7 @@ extern "C" int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* se
 }
 
 extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64, int32_t* level_ws /* [batch*17] */,
-                                 const uint64_t* seeds_dev, uint64_t stream_base, int64_t batch, int64_t lead, int64_t h, int64_t w,
+                                 const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch, int64_t lead, int64_t h, int64_t w,
                                  int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream) {
   if (batch < 0 || lead < 1 || h < 1 || w < 1 || depth < 0) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
@@ -274,7 +275,7 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   skr::PyramidArgs a;
   a.scratch = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
   a.level_hw = level_ws; a.n_levels = level_ws + batch * skr::PYR_MAX_LEVELS * 2;
-  a.stream_base = stream_base; a.batch = batch; a.lead = (int32_t)lead; a.h = (int32_t)h; a.w = (int32_t)w;
+  a.stream_base = stream_base; a.stream_levels = stream_levels; a.batch = batch; a.lead = (int32_t)lead; a.h = (int32_t)h; a.w = (int32_t)w;
   a.resize_h = resize_h; a.depth = depth; a.with_base = with_base; a.strength = (float)strength;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(skr::pyramid_geometry, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, a);

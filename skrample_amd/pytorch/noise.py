@@ -261,14 +261,15 @@ class Pyramid(TensorNoiseCommon):
 
     @classmethod
     def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
-        if props.static:
-            raise SkrampleHipError("static pyramids are not implemented on this engine yet")
+        # static: the pyramid component is frozen at the first draw (same streams every time), only the base changes
+        stream_levels = state.setdefault("static_stream", stream) if props.static else stream
         lead, h, w, resize_h = cls._geometry(unit_shape, props)
         batch = seeds.shape[0]
         dev = seeds.device
         key = ("ws", batch, lead, h, w)
         if key not in state:
-            state.clear()
+            for k in [k for k in state if k != "static_stream"]:
+                del state[k]
             state[key] = (
                 torch.empty(batch * lead * h * w, dtype=torch.float32, device=dev),
                 torch.empty(batch * lead * 2, dtype=torch.float64, device=dev),
@@ -280,7 +281,7 @@ class Pyramid(TensorNoiseCommon):
         _hip.check(
             lib.skr_noise_pyramid(
                 out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), partials.data_ptr(), levels.data_ptr(), seeds.data_ptr(), stream,
-                batch, lead, h, w, 1 if resize_h else 0, float(props.strength), int(min(props.depth, 1 << 20)), 1, hstream,
+                stream_levels, batch, lead, h, w, 1 if resize_h else 0, float(props.strength), int(min(props.depth, 1 << 20)), 1, hstream,
             ),
             "skr_noise_pyramid",
         )

@@ -143,6 +143,27 @@ def test_pyramid(unit, kw, dev):
         assert (got.reshape(3, -1).std(dim=1) - 1).abs().max() < 1e-4
 
 
+def test_pyramid_static(dev):
+    "PyramidProps.static: the pyramid component of the first draw is reused, only the base normal is fresh"
+    unit, seeds = (4, 32, 32), [51, 52]
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=PN.PyramidProps(static=True), dtype=torch.float32)
+    for n in range(3):
+        got = g.generate(None).cpu()
+        refs = []
+        for s in seeds:
+            uniforms = iter(uniform01(np.array([s], dtype=np.uint64), 255, 8)[0].tolist())
+            level = {"l": 0}
+
+            def lv(shape, s=s, level=level):
+                v = spec_normal(s, 1 + level["l"], shape)
+                level["l"] += 1
+                return v
+
+            pyr = ON.pyramid_component(unit, lv, lambda: next(uniforms))
+            refs.append(ON.pyramid_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), None, static_pyramid=pyr))
+        assert rel(got, torch.stack(refs)) < 2e-5, n
+
+
 def test_pyramid_through_wrapper(dev):
     "cfg5-style use: RKUltra + Pyramid noise through the scheduler wrapper (noise realised as a tensor term)"
     import skrample_amd.diffusers as PD
