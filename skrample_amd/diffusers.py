@@ -469,6 +469,15 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         if device is not None:
             self._device = torch.device(device)
 
+    def reset_run(self) -> None:
+        """(not in the reference) rewind to the first step of the current schedule WITHOUT touching device state:
+        history is dropped and the noise generator's draw counter restarts, but its device seed vector and the
+        lowered step programs stay.  Used by skrample_amd.graphs to re-run a loop inside a HIP-graph capture."""
+        self._calls = 0
+        self._previous, self._raw_outputs, self._raw_samples = [], [], []
+        if self._noise_generator is not None:
+            self._noise_generator._draws = 0
+
     def _timestep_table(self) -> list[float]:
         key = (self.schedule, self._steps)
         if getattr(self, "_timestep_list", None) is None or self._timestep_key != key:
@@ -633,6 +642,13 @@ class RKWrapperCore(SkrampleWrapperCore):
         self._noise_generator = None
         if device is not None:
             self._device = torch.device(device)
+
+    def reset_run(self) -> None:
+        "(not in the reference) see SkrampleWrapperScheduler.reset_run"
+        self._index = 0
+        self._derivatives, self._sample = [], None
+        if self._noise_generator is not None:
+            self._noise_generator._draws = 0
 
     def scale_noise(self, sample: Tensor, timestep: Tensor, noise: Tensor) -> Tensor:
         idx = self._lookup(self.schedule_np[:, 0].tolist(), timestep, 0)

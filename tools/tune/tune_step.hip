@@ -6,6 +6,8 @@
 #include <vector>
 #include <algorithm>
 #include "../../skrample_amd/csrc/skr_philox.h"
+#include "../../include/skrample_hip.h"
+#include <dlfcn.h>
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -222,6 +224,26 @@ int main(int argc, char** argv) {
     sets[s].zeta = 0.3f; sets[s].stream = 1; sets[s].nvec = n / 8; sets[s].vps = sample / 8;
   }
   printf("B=%d n=%lld\n", B, (long long)n);
+  auto lib_block = [&]()   {
+    // the shipped library kernel on the very same buffers
+    void* h = dlopen("skrample_amd/csrc/libskrample_hip.so", RTLD_NOW);
+    if (h) {
+      typedef int (*launch_fn)(const skr_step_plan*, const void* const*, void*, void*, const uint64_t*, int64_t, void*);
+      launch_fn launch = (launch_fn)dlsym(h, "skr_step_launch");
+      skr_step_plan p = {};
+      p.n_terms = 4; p.n_group_a = 4; p.dtype_a = SKR_BF16; p.dtype_b = SKR_BF16; p.out0_dtype = SKR_BF16; p.out1_dtype = SKR_NONE;
+      p.coef0[0] = 1.01; p.coef0[1] = -0.53; p.coef0[2] = 0.12; p.coef0[3] = 0.43;
+      p.sample_numel = sample;
+      for (int noise = 0; noise < 2; ++noise) {
+        p.noise_mode = noise; p.zeta0 = noise ? 0.3 : 0.0; p.stream0 = 1;
+        auto go = [&](int i) { const void* ins[4] = {sets[i % NS].in[0], sets[i % NS].in[1], sets[i % NS].in[2], sets[i % NS].in[3]}; launch(&p, ins, sets[i % NS].out, nullptr, seeds, n, nullptr); };
+        timeit(noise ? "LIB skr_step_launch K=4 philox" : "LIB skr_step_launch K=4 no noise", go, (double)n * 10);
+      }
+    } else printf("(library not found: %s)\n", dlerror());
+  };
+  lib_block();
+  run2<4, 1, 256, true>("k2 uv1 blk256 nf  bx32 (early)", sets, B, 32);
+  lib_block();
   {
     double rb = (double)n * 2 * 4, wb = (double)n * 2;
     timeit("read-only 4 streams uv1 grid2048", [&](int i) { hipLaunchKernelGGL((k_read<4, 1>), dim3(2048), dim3(256), 0, 0, sets[i % NS]); }, rb);
@@ -269,6 +291,7 @@ int main(int argc, char** argv) {
   run2<4, 1, 1024, true>("k2 uv1 blk1024 nf bx8", sets, B, 8);
   run2<4, 1, 128, true>("k2 uv1 blk128 nf  bx64", sets, B, 64);
   run2<4, 1, 64, true>("k2 uv1 blk64 nf  bx128", sets, B, 128);
+  lib_block();
   printf("-- VALU only (no memory)\n");
   run<4, true, true, 1, true, true, false>("philox+boxmuller only uv1 cap2048", sets, 2048);
   run<4, true, true, 1, true, true, false>("philox+boxmuller only uv1 nocap", sets, 0);
