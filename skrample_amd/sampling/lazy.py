@@ -301,8 +301,6 @@ def evaluate(forms: Sequence[Lin], dtypes: Sequence[torch.dtype | None], acc_f64
     else:
         f0 = forms[0].expanded()
     f1 = forms[1].expanded(keep=forms[0]) if len(forms) == 2 else None
-    if conv is not None:
-        f0_terms_hint = (id(conv.sample), id(conv.output))
     shape, device = f0.shape, f0.device
     numel = math.prod(shape)
     out_dtypes = [d if d is not None else (f.dtype if isinstance(f, RoundedConversion) else _default_dtype(f)) for d, f in zip(dtypes, forms)]

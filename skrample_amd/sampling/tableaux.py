@@ -267,22 +267,19 @@ def _butcher6() -> Tableau:
     )
 
 
-def _surd21(text: str) -> float:
-    "'p/q' or 'p/q+r/s' meaning p/q + (r/s)*sqrt(21), evaluated in that order"
-    rational, _, surd = text.partition("+") if "+" in text[1:] or text.count("-") > 1 else (text, "", "")
-    if not surd and ("+" in text[1:] or "-" in text[1:]):
-        idx = max(text.rfind("+"), text.rfind("-"))
-        rational, surd = text[:idx], text[idx:]
-    value = _frac(rational)
-    if surd:
-        sign = -1.0 if surd.startswith("-") else 1.0
-        value = value + sign * (_frac(surd.lstrip("+-")) * _S21) if sign > 0 else value - _frac(surd.lstrip("+-")) * _S21
-    return value
-
-
 def _frac(text: str) -> float:
     num, _, den = text.partition("/")
     return int(num) / int(den) if den else float(int(num))
+
+
+def _surd21(text: str) -> float:
+    "'p/q' or 'p/q+r/s' / 'p/q-r/s' meaning p/q +- (r/s)*sqrt(21)"
+    cut = max(text.rfind("+"), text.rfind("-"))
+    if cut <= 0:  # no surd part (a leading '-' is the sign of the rational)
+        return _frac(text)
+    rational, surd = text[:cut], text[cut + 1 :]
+    term = _frac(surd) * _S21
+    return _frac(rational) + term if text[cut] == "+" else _frac(rational) - term
 
 
 def _cv8() -> Tableau:

@@ -326,3 +326,51 @@ def test_lazy_algebra_is_symbolic():
         lazy.lift(np.ones(3))
     with pytest.raises(lazy.SkrampleHipError):
         lazy.lift(torch.ones(3))  # CPU tensor: refused, there is no CPU tensor path
+
+
+# ---- schedule behaviour the reference pins in tests/self_scheduling.py:49-151 -----------------------------------
+ALL_BASES = [PS.Linear, PS.Scaled, lambda **k: PS.Scaled(beta_scale=1, **k)]
+ALL_MODIFIERS = [None, PS.NoSub, PS.NoMod, PS.Beta, PS.FlowShift, PS.Karras, PS.Exponential, PS.Probit, PS.Hyper, PS.Sinner]
+
+
+@pytest.mark.parametrize(("base", "modifier"), itertools.product(ALL_BASES, ALL_MODIFIERS))
+def test_schedule_properties(base, modifier):
+    sched = modifier(base()) if modifier else base()
+    t100 = [0, 1, *np.random.default_rng(1).random(98)]
+    batch = sched.points_np(t100)
+    single = np.array([sched.point(t) for t in t100], dtype=np.float64)
+    assert np.array_equal(batch, single)  # continuously variable: batch == point by point, exactly
+    assert sched.point(0) == (0, 0, 1)  # zero point
+    if modifier:
+        np.testing.assert_allclose(sched.point(1), base().point(1), rtol=0, atol=1e-15)  # modifiers keep the t=1 point
+    for steps in (1, 2, 3, 999, 1000, 1001):  # timestep inversion with negative base_timesteps
+        fwd = modifier(base(base_timesteps=steps)) if modifier else base(base_timesteps=steps)
+        bwd = modifier(base(base_timesteps=-steps)) if modifier else base(base_timesteps=-steps)
+        pts = np.linspace(0, 1, steps)
+        a, b = fwd.points_np(pts).copy(), bwd.points_np(pts).copy()
+        b[:, 0] = steps - b[:, 0]
+        np.testing.assert_allclose(b, a, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("base", ALL_BASES)
+def test_sigmas_to_points(base):
+    sched = base()
+    pts = sched.points_np(np.linspace(1, 0, 33))
+    inv = sched._sigmas_to_points(pts[:, 1], pts[:, 2])
+    for _ in range(99):
+        inv = sched._sigmas_to_points(inv[:, 1], inv[:, 2])
+    dev = np.abs(pts - inv)
+    assert (dev <= 0.001 * np.abs(pts) + 1e-12).all()  # within 0.1 %, as the reference asks
+
+
+@pytest.mark.parametrize(("modifier", "timesteps", "steps"), itertools.product([None, PS.Karras, PS.FlowShift, PS.Hyper], [1, 999, 1000, 1001, -1001, -1], [1, 999, 1002]))
+def test_terminal_timesteps(modifier, timesteps, steps):
+    "every wrapper exposes steps * order timesteps (reference test_terminal_timesteps)"
+    sched = modifier(PS.Linear(base_timesteps=abs(timesteps))) if modifier else PS.Linear(base_timesteps=abs(timesteps))
+    for w in (
+        PD.SkrampleWrapperScheduler(PT.Euler(), sched, model=PM.FlowModel()),
+        PD.RKUltraWrapperScheduler(sched, sampler_order=1, model=PM.FlowModel()),
+        PD.DynasauRKWrapperScheduler(sched, sampler_order=1, model=PM.FlowModel()),
+    ):
+        w.set_timesteps(steps)
+        assert len(w.timesteps) == steps * w.order
