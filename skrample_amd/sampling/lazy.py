@@ -262,19 +262,29 @@ _STAGGER_BYTES = 8192
 _stagger_next = 0
 
 
+_ITEMSIZE = {torch.bfloat16: 2, torch.float16: 2, torch.float32: 4, torch.float64: 8}
+_strides_cache: dict = {}
+
+
 def empty_output(shape, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
     "uninitialised result tensor whose start is shifted by 4 KiB + k*8 KiB (k cycles) inside its allocation"
     global _stagger_next
+    shape = tuple(shape)
     numel = math.prod(shape)
-    item = torch.empty((), dtype=dtype).element_size()
-    if numel * item < (1 << 20):  # small tensors live in L2 / MALL anyway
+    item = _ITEMSIZE.get(dtype, 4)
+    if numel * item < (16 << 20):  # small tensors are launch/host-bound and live in L2 / MALL anyway
         return torch.empty(shape, dtype=dtype, device=device)
     k = _stagger_next
     _stagger_next = (k + 1) % _STAGGER_SLOTS
-    shift = (4096 + k * _STAGGER_BYTES) // item
-    pad = (4096 + _STAGGER_SLOTS * _STAGGER_BYTES) // item
-    flat = torch.empty(numel + pad, dtype=dtype, device=device)
-    return flat[shift : shift + numel].view(shape)
+    strides = _strides_cache.get(shape)
+    if strides is None:
+        acc, rev = 1, []
+        for d in reversed(shape):
+            rev.append(acc)
+            acc *= d
+        strides = _strides_cache[shape] = tuple(reversed(rev))
+    flat = torch.empty(numel + (4096 + _STAGGER_SLOTS * _STAGGER_BYTES) // item, dtype=dtype, device=device)
+    return flat.as_strided(shape, strides, (4096 + k * _STAGGER_BYTES) // item)
 
 
 def _prepare_tensor(t: torch.Tensor) -> torch.Tensor:
