@@ -123,6 +123,10 @@ __device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
 }
 
 // ---- pass A / E: last axis (contiguous lines of d3 reals <-> d3h complex) -------------------------------------
+// Two real lines share one complex transform ("two for one"): z = x_a + i x_b, Z = FFT(z), and
+//   X_a[k] = (Z[k] + conj Z[N-k]) / 2,   X_b[k] = (Z[k] - conj Z[N-k]) / (2i);
+// backwards, Z[k] = X_a[k] + i X_b[k] for k <= N/2 and conj X_a[N-k] + i conj X_b[N-k] above, x_a = Re z, x_b = Im z.
+// L is the number of REAL lines per tile (even); the LDS tile holds L/2 complex lines.
 template <bool FORWARD>
 __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredArgs a, int logN, int L) {
   extern __shared__ float2 smem[];
@@ -132,56 +136,63 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
   const int64_t smp = blockIdx.y;
   const int64_t n_lines = (int64_t)a.d1 * a.d2;
   const int64_t line0 = (int64_t)blockIdx.x * L;
-  const int lines = (int)((n_lines - line0) < L ? (n_lines - line0) : L);
+  const int lines = (int)((n_lines - line0) < L ? (n_lines - line0) : L);  // even: n_lines and L are even
+  const int pairs = lines >> 1;
   make_twiddles(tw, N);
   double s1 = 0.0, s2 = 0.0;
   if (FORWARD) {
-    // draw the white noise straight into LDS (bit-reversed), 4 normals per Philox call
+    // draw the white noise straight into LDS (bit-reversed), 4 normals per Philox call and line
     const uint64_t seed = a.seeds[smp];
-    for (int q = threadIdx.x; q < lines * (N / 4); q += FFT_THREADS) {
-      const int line = q >> (logN - 2), n4 = (q & (N / 4 - 1)) * 4;
-      const int64_t e = (line0 + line) * N + n4;  // element index inside the sample
-      float z[4];
-      normal4(seed, a.stream, (uint64_t)e >> 2, z);
+    for (int q = threadIdx.x; q < pairs * (N / 4); q += FFT_THREADS) {
+      const int pr = q >> (logN - 2), n4 = (q & (N / 4 - 1)) * 4;
+      const int64_t ea = (line0 + 2 * pr) * N + n4;  // element index inside the sample (line 2pr), line 2pr+1 is N further
+      float za[4], zb[4];
+      normal4(seed, a.stream, (uint64_t)ea >> 2, za);
+      normal4(seed, a.stream, (uint64_t)(ea + N) >> 2, zb);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        buf[line * ld + brev(n4 + j, logN)] = make_float2(z[j], 0.f);
-        s1 += (double)z[j];
-        s2 += (double)z[j] * (double)z[j];
+        buf[pr * ld + brev(n4 + j, logN)] = make_float2(za[j], zb[j]);
+        s1 += (double)za[j] + (double)zb[j];
+        s2 += (double)za[j] * (double)za[j] + (double)zb[j] * (double)zb[j];
       }
     }
-    fft_tile<false>(buf, tw, N, logN, lines);
-    // the tile's half spectra are contiguous in memory: [lines][d3h]; walk it with one running (line, k) pair
+    fft_tile<false>(buf, tw, N, logN, pairs);
+    // untangle and store the two half spectra of every pair; [lines][d3h] is contiguous in memory
     float2* dst = a.spec + (smp * n_lines + line0) * a.d3h;
     {
-      const int total = lines * a.d3h;
-      int line = threadIdx.x / a.d3h, k = threadIdx.x - line * a.d3h;
+      const int total = pairs * a.d3h;
+      int pr = threadIdx.x / a.d3h, k = threadIdx.x - pr * a.d3h;
       const int dl = FFT_THREADS / a.d3h, dk = FFT_THREADS - dl * a.d3h;
       for (int q = threadIdx.x; q < total; q += FFT_THREADS) {
-        dst[q] = buf[line * ld + k];
-        line += dl; k += dk;
-        if (k >= a.d3h) { k -= a.d3h; ++line; }
+        const float2 zk = buf[pr * ld + k], zn = buf[pr * ld + ((N - k) & (N - 1))];
+        dst[(int64_t)(2 * pr) * a.d3h + k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        dst[(int64_t)(2 * pr + 1) * a.d3h + k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        pr += dl; k += dk;
+        if (k >= a.d3h) { k -= a.d3h; ++pr; }
       }
     }
     block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + blockIdx.x) * 2);
   } else {
     const float2* src = a.spec + (smp * n_lines + line0) * a.d3h;
-    for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
-      const int line = q >> logN, k = q & (N - 1);
-      float2 v;
-      if (k < a.d3h) v = src[(int64_t)line * a.d3h + k];
-      else { v = src[(int64_t)line * a.d3h + (N - k)]; v.y = -v.y; }  // Hermitian half
-      buf[line * ld + brev(k, logN)] = v;
+    for (int q = threadIdx.x; q < pairs * N; q += FFT_THREADS) {
+      const int pr = q >> logN, k = q & (N - 1);
+      const int m = k < a.d3h ? k : N - k;
+      float2 xa = src[(int64_t)(2 * pr) * a.d3h + m], xb = src[(int64_t)(2 * pr + 1) * a.d3h + m];
+      if (m == 0 || 2 * m == N) { xa.y = 0.f; xb.y = 0.f; }  // irfft ignores the imaginary part of DC / Nyquist
+      if (k >= a.d3h) { xa.y = -xa.y; xb.y = -xb.y; }         // Hermitian half
+      buf[pr * ld + brev(k, logN)] = make_float2(xa.x - xb.y, xa.y + xb.x);
     }
-    fft_tile<true>(buf, tw, N, logN, lines);
+    fft_tile<true>(buf, tw, N, logN, pairs);
     const float scale = 1.0f / ((float)a.d1 * (float)a.d2 * (float)a.d3);
     float* dst = a.real_out + (smp * n_lines + line0) * N;
-    for (int q = threadIdx.x; q < lines * N; q += FFT_THREADS) {
-      const int line = q >> logN, n = q & (N - 1);
-      const float v = buf[line * ld + n].x * scale;
-      dst[(int64_t)line * N + n] = v;
-      s1 += (double)v;
-      s2 += (double)v * (double)v;
+    for (int q = threadIdx.x; q < pairs * N; q += FFT_THREADS) {
+      const int pr = q >> logN, n = q & (N - 1);
+      const float2 z = buf[pr * ld + n];
+      const float va = z.x * scale, vb = z.y * scale;
+      dst[(int64_t)(2 * pr) * N + n] = va;
+      dst[(int64_t)(2 * pr + 1) * N + n] = vb;
+      s1 += (double)va + (double)vb;
+      s2 += (double)va * (double)va + (double)vb * (double)vb;
     }
     block_sums(s1, s2, a.partials + ((1 * a.batch + smp) * a.n_slots + blockIdx.x) * 2);
   }
@@ -388,11 +399,11 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   // pass A: last axis forward
   const int64_t lines_last = (int64_t)d1 * d2;
   const int tile = fft_tile_points();
-  int La = tile / d3; if (La > lines_last) La = (int)lines_last; if (La < 1) La = 1;
+  int La = 2 * (tile / d3); if (La > lines_last) La = (int)lines_last; if (La < 2) La = 2;  // real lines per tile (pairs share a transform)
   const int64_t blocks_a = (lines_last + La - 1) / La;
   if (blocks_a > partial_slots) return SKR_ERR_SHAPE;
   a.n_slots = (int32_t)blocks_a;
-  const size_t lds_a = sizeof(float2) * ((size_t)d3 / 2 + (size_t)La * (d3 + 1));
+  const size_t lds_a = sizeof(float2) * ((size_t)d3 / 2 + (size_t)(La / 2) * (d3 + 1));
   hipLaunchKernelGGL(colored_last_axis<true>, dim3((unsigned)blocks_a, (unsigned)batch), dim3(FFT_THREADS), lds_a, s, a, l3, La);
   SKR_CHECK_LAUNCH();
 

@@ -329,7 +329,7 @@ class Colored(TensorNoiseCommon):
         half = unit // dims[-1] * (dims[-1] // 2 + 1)
         key = ("ws", batch, tuple(dims))
         if key not in state:
-            slots = max(256, -(-(unit // dims[-1]) // max(1, 256 // dims[-1])))
+            slots = max(256, -(-(unit // dims[-1]) // max(2, 2 * (256 // dims[-1]))))
             state.clear()
             state[key] = (
                 torch.empty(batch * half, dtype=torch.complex64, device=dev),
