@@ -562,3 +562,72 @@ def test_whole_loop_graph_capture(dev):
     x1 = torch.randn(shape, generator=g).bfloat16().to(dev)
     assert torch.equal(loop(x1), eager(x1, seeds))  # new latents, same graph
     assert torch.equal(loop(x1, seeds=[9, 8, 7, 6]), eager(x1, [9, 8, 7, 6]))  # new seeds are read from device memory
+
+
+@pytest.mark.parametrize("name", ["Stepanov10", "Feagin14"])
+def test_many_stage_runge_kutta(name, dev):
+    """15- and 35-stage tableaux through the RK wrapper: launches with up to 37 operands vs the oracle.
+    These tableaux have large coefficients of alternating sign, so an fp32 evaluation (the reference's as much as
+    ours) carries cancellation noise above 1e-5; the arithmetic is therefore checked strictly in float64
+    (<= 1e-10) and in float32 against the float64 truth with the reference's own fp32 error as the yardstick."""
+    from skrample_amd.sampling import tableaux as PTab
+
+    tab = getattr(PTab.RKZ, name).tableau()
+    stages = len(tab.stages)
+    otab = (tuple((s.c, tuple(s.a)) for s in tab.stages), tuple(tab.weights))  # coefficients are pinned by tests/golden/tables.json
+    g = torch.Generator().manual_seed(15)
+    shape = (2, 4, 16, 16)
+    noises = [torch.randn(shape, generator=g, dtype=torch.float64) for _ in range(2)]
+    x0 = torch.randn(shape, generator=g, dtype=torch.float64)
+    outs = [torch.randn(shape, generator=g, dtype=torch.float64) * 0.1 for _ in range(2 * stages)]
+
+    def run(dtype):
+        w = PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=stages, stochasticity=0.5, providers={stages: getattr(PTab.RKZ, name)}, compute_scale=dtype)
+        o = OW.RKDriver(otab, OS.scaled(), "eps", "data", 0.5, compute=dtype)
+        w.set_timesteps(2)
+        o.set_timesteps(2)
+        assert w.order == stages and torch.equal(w.timesteps, o.timesteps)
+        w._noise_generator = Injected([n.to(dtype) for n in noises], dev)
+        pending = [n.to(dtype) for n in noises]
+        x, got_all, ref_all = x0.to(dtype), [], []
+        for i, t in enumerate(w.timesteps):
+            out = outs[i].to(dtype) + x * 0.5
+            got_all.append(w.step(out.to(dev), t, x.to(dev), return_dict=False)[0].cpu())
+            ref_all.append(o.step(out, t, x, noise_fn=lambda st: pending.pop(0)))
+            x = ref_all[-1]
+        return got_all, ref_all
+
+    got64, ref64 = run(torch.float64)
+    for i, (a, b) in enumerate(zip(got64, ref64)):
+        assert rel_err(a, b) <= 1e-10, (name, i, rel_err(a, b))
+    got32, ref32 = run(torch.float32)
+    for i, (a, b, truth) in enumerate(zip(got32, ref32, ref64)):
+        ours, theirs = rel_err(a, truth), rel_err(b, truth)
+        assert ours <= max(REL_TOL_F32, 2 * theirs), (name, i, ours, theirs)
+
+
+def test_img2img_entry_points(dev):
+    "scale_noise / add_noise / set_begin_index: the img2img path (reference diffusers.py:375-381,540-543)"
+    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2), PS.Scaled())
+    w.set_timesteps(10)
+    g = torch.Generator().manual_seed(16)
+    clean, noise = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g)
+    t = w.timesteps[4]
+    p = w.schedule.schedule(10)[4]
+    noisy = w.scale_noise(clean.to(dev), t, noise.to(dev))
+    assert_close(noisy, clean * p.alpha + noise * p.sigma, torch.float32, "scale_noise")
+    assert_close(w.add_noise(clean.to(dev), noise.to(dev), w.timesteps[4:5]), clean * p.alpha + noise * p.sigma, torch.float32, "add_noise")
+    assert w.add_noise(clean.to(dev), noise.to(dev), w.timesteps[:0]).cpu().equal(clean)
+    # start in the middle of the schedule with device-resident timesteps (no host sync): begin index drives the order
+    w.set_timesteps(10, device=dev)
+    w.set_begin_index(4)
+    o = OW.StepDriver(OA.make("dpm", 2), OS.scaled(), "eps")
+    o.set_timesteps(10)
+    x = noisy.cpu()
+    for i in range(4, 10):
+        out = torch.randn(2, 4, 16, 16, generator=g)
+        got = w.step(out.to(dev), w.timesteps[i], x.to(dev), return_dict=False)[0]
+        ref = o.step(out, o.timesteps[i], x)[0]
+        assert_close(got, ref, torch.float32, f"begin_index step {i}")
+        x = ref
+    assert w.config["begin_index"] == 4
