@@ -119,9 +119,11 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
   l1 = src - (float)i0;
 }
 
-__global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
+constexpr int PYR_THREADS = 512;  // 8 waves per block: two 70 KiB blocks per CU keep 16 waves in flight
+
+__global__ __launch_bounds__(PYR_THREADS) void pyramid_pass1(const PyramidArgs a) {
   extern __shared__ float lds[];  // levels >= 1, back to back
-  __shared__ double red[2][4];
+  __shared__ double red[2][PYR_THREADS / 64];
   __shared__ int s_lh[PYR_MAX_LEVELS], s_lw[PYR_MAX_LEVELS], s_off[PYR_MAX_LEVELS];
   __shared__ float s_wgt[PYR_MAX_LEVELS], s_sy[PYR_MAX_LEVELS], s_sx[PYR_MAX_LEVELS];
   const int slice = blockIdx.x;  // smp * lead + c
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
     if (s_wgt[l] == 0.f) continue;
     const int n = s_lh[l] * s_lw[l];
     float* g = lds + s_off[l];
-    for (int i4 = threadIdx.x * 4; i4 < n; i4 += 1024) {  // level tensor is [lead][lh][lw]; 4 normals per Philox call
+    for (int i4 = threadIdx.x * 4; i4 < n; i4 += PYR_THREADS * 4) {  // level tensor is [lead][lh][lw]; 4 normals per Philox call
       const int64_t e = (int64_t)c * n + i4;
       const int64_t blk = e >> 2;
       const int lane0 = (int)(e & 3);
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
   const int n4 = a.h * w4;
   const float w0 = s_wgt[0];
   double s1 = 0.0, s2 = 0.0;
-  for (int q = threadIdx.x; q < n4; q += 256) {
+  for (int q = threadIdx.x; q < n4; q += PYR_THREADS) {
     const int y = q / w4, x0 = (q - y * w4) * 4;
     const int64_t e0 = ((int64_t)c * a.h + y) * a.w + x0;  // element index inside the sample
     float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -207,8 +209,10 @@ __global__ __launch_bounds__(256) void pyramid_pass1(const PyramidArgs a) {
   if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    a.partials[(int64_t)slice * 2 + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-    a.partials[(int64_t)slice * 2 + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    double t1 = 0.0, t2 = 0.0;
+    for (int wv = 0; wv < PYR_THREADS / 64; ++wv) { t1 += red[0][wv]; t2 += red[1][wv]; }
+    a.partials[(int64_t)slice * 2 + 0] = t1;
+    a.partials[(int64_t)slice * 2 + 1] = t2;
   }
 }
 
@@ -284,7 +288,7 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   if (lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(skr::pyramid_pass1, dim3((unsigned)(batch * lead)), dim3(256), lds_bytes, s, a);
+  hipLaunchKernelGGL(skr::pyramid_pass1, dim3((unsigned)(batch * lead)), dim3(skr::PYR_THREADS), lds_bytes, s, a);
   if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
   const int64_t unit = lead * h * w;
   int64_t bx = (unit / 4 + 255) / 256;
