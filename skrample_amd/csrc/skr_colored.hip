@@ -358,7 +358,7 @@ static int fft_tile_points() {
   if (!cached) {
     const char* e = getenv("SKR_FFT_TILE");
     int v = e ? atoi(e) : 0;
-    cached = (v >= 256 && v <= skr::FFT_MAX_TILE && !(v & (v - 1))) ? v : skr::FFT_MAX_TILE;
+    cached = (v >= 256 && v <= 16384 && !(v & (v - 1))) ? v : skr::FFT_MAX_TILE;
   }
   return cached;
 }
@@ -371,6 +371,8 @@ static int ilog2_exact(int64_t v) {
 }
 
 #define SKR_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH; } while (0)
+// kernels that need more than the default 48 KiB of dynamic LDS must opt in
+#define SKR_ALLOW_LDS(kernel, bytes) do { if ((bytes) > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) return SKR_ERR_UNSUPPORTED; } while (0)
 
 extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64, int64_t partial_slots,
                                  const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t d1, int32_t d2, int32_t d3,
@@ -404,6 +406,9 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   if (blocks_a > partial_slots) return SKR_ERR_SHAPE;
   a.n_slots = (int32_t)blocks_a;
   const size_t lds_a = sizeof(float2) * ((size_t)d3 / 2 + (size_t)(La / 2) * (d3 + 1));
+  if (lds_a > 150 * 1024) return SKR_ERR_UNSUPPORTED;
+  SKR_ALLOW_LDS(colored_last_axis<true>, lds_a);
+  SKR_ALLOW_LDS(colored_last_axis<false>, lds_a);
   hipLaunchKernelGGL(colored_last_axis<true>, dim3((unsigned)blocks_a, (unsigned)batch), dim3(FFT_THREADS), lds_a, s, a, l3, La);
   SKR_CHECK_LAUNCH();
 
@@ -414,6 +419,10 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     const int64_t blocks = (n_lines + L - 1) / L;
     const size_t lds = sizeof(float2) * ((size_t)N / 2 + (size_t)L * (N + 1));
     dim3 grid((unsigned)blocks, (unsigned)batch);
+    if (lds > 150 * 1024) return SKR_ERR_UNSUPPORTED;
+    SKR_ALLOW_LDS(colored_strided_axis<0>, lds);
+    SKR_ALLOW_LDS(colored_strided_axis<1>, lds);
+    SKR_ALLOW_LDS(colored_strided_axis<2>, lds);
     if (mode == 0) hipLaunchKernelGGL(colored_strided_axis<0>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, logL, n_lines, inner, outer, stride, axis);
     else if (mode == 1) hipLaunchKernelGGL(colored_strided_axis<1>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, logL, n_lines, inner, outer, stride, axis);
     else hipLaunchKernelGGL(colored_strided_axis<2>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, logL, n_lines, inner, outer, stride, axis);

@@ -138,6 +138,66 @@ __global__ __launch_bounds__(BLK) void k2(const Args a) {
   }
 }
 
+// software-pipelined per-sample grid: the loads of trip i+1 are in flight while trip i does Philox + FMAs
+template <int K, int BLK>
+__global__ __launch_bounds__(BLK) void k3(const Args a) {
+  const int64_t smp = blockIdx.y;
+  const int64_t vlo = smp * a.vps, vhi = vlo + a.vps;
+  const uint64_t seed = a.seeds[smp];
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  int64_t v = vlo + (int64_t)blockIdx.x * BLK + threadIdx.x;
+  u32x4_t nxt[K];
+  if (v < vhi) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) nxt[j] = __builtin_nontemporal_load(a.in[j] + v);
+  }
+  while (v < vhi) {
+    u32x4_t raw[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) raw[j] = nxt[j];
+    const int64_t vn = v + stride;
+    if (vn < vhi) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) nxt[j] = __builtin_nontemporal_load(a.in[j] + vn);
+    }
+    float z[8];
+    const uint64_t blk = (uint64_t)(v - vlo) * 2;
+    skr::normal4(seed, a.stream, blk, z);
+    skr::normal4(seed, a.stream, blk + 1, z + 4);
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[2 * i] = __builtin_fmaf(a.c[j], __uint_as_float(raw[j][i] << 16), s[2 * i]);
+        s[2 * i + 1] = __builtin_fmaf(a.c[j], __uint_as_float(raw[j][i] & 0xFFFF0000u), s[2 * i + 1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.zeta, z[i], s[i]);
+    u32x4_t q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = pack_bf16(s[2 * i], s[2 * i + 1]);
+    __builtin_nontemporal_store(q, a.out + v);
+    v = vn;
+  }
+}
+
+template <int K, int BLK>
+void run3(const char* name, std::vector<Args>& sets, int B, int bx, int iters = 200) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  dim3 grid(bx, B);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k3<K, BLK>), grid, dim3(BLK), 0, 0, sets[i % sets.size()]);
+  CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k3<K, BLK>), grid, dim3(BLK), 0, 0, sets[i % sets.size()]);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / iters;
+  double bytes = (double)sets[0].nvec * 16 * (K + 1);
+  printf("%-46s grid=%dx%d  %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, bx, B, us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
+}
+
 template <int K, int UV, int BLK, bool NF>
 void run2(const char* name, std::vector<Args>& sets, int B, int bx, int iters = 200) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -276,6 +336,13 @@ int main(int argc, char** argv) {
   run<4, true, true, 2, true, true, true>("noise first nt/nt uv2 cap2048", sets, 2048);
   run<4, true, true, 2, true, true, true>("noise first nt/nt uv2 nocap", sets, 0);
   run<4, false, false, 1, true, true, true>("noise first plain uv1 nocap", sets, 0);
+  printf("-- pipelined per-sample grid with noise\n");
+  run3<4, 256>("k3 pipelined blk256 bx32 (1 trip)", sets, B, 32);
+  run3<4, 256>("k3 pipelined blk256 bx16 (2 trips)", sets, B, 16);
+  run3<4, 256>("k3 pipelined blk256 bx8  (4 trips)", sets, B, 8);
+  run3<4, 256>("k3 pipelined blk256 bx4  (8 trips)", sets, B, 4);
+  run3<4, 512>("k3 pipelined blk512 bx4  (4 trips)", sets, B, 4);
+  run3<4, 128>("k3 pipelined blk128 bx16 (4 trips)", sets, B, 16);
   printf("-- per-sample grid with noise\n");
   run2<4, 1, 256, true>("k2 uv1 blk256 nf  bx32", sets, B, 32);
   run2<4, 1, 256, false>("k2 uv1 blk256 nl  bx32", sets, B, 32);
