@@ -1,50 +1,64 @@
-"""Configuration mix-ins shared by the samplers (reference `skrample/sampling/traits.py:9-61`):
-they define the public, frozen-dataclass config surface (order, stochasticity, derivative space)."""
+"""Configuration mix-ins that make up a sampler's public, frozen-dataclass config surface.
+
+These are the knobs of reference `skrample/sampling/traits.py:9-61` under the same names, so that
+`DPM(order=2, stochasticity=1, derivative_transform=...)` constructs identically:
+
+  order                 (HigherOrder)          requested solver order; the order actually used ramps up over
+                                               the first steps and back down at the end of the schedule
+  stochasticity         (Stochastic)           eta: 0 = deterministic ODE step, 1 = full SDE step
+  derivative_transform  (DerivativeTransform)  prediction space the multistep / Runge-Kutta arithmetic runs in
+                                               (default x-hat-0; None = the model's own space)
+
+They carry no tensor code: on this engine a sampler turns these numbers into kernel coefficients.
+"""
 
 from __future__ import annotations
 
-import abc
-import dataclasses
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
 
-from .. import common
-from . import models
+from ..common import Point
+from .models import DataModel, DiffusionModel
 
-
-@dataclasses.dataclass(frozen=True)
-class SamplingCommon:
-    def add_noise(self, sample, noise, point: common.Point):
-        return point.add_noise(sample, noise)
-
-    def remove_noise(self, sample, noise, point: common.Point):
-        return point.remove_noise(sample, noise)
+_X_HAT_SPACE = DataModel()  # shared default instance: conversions short-circuit on identity (models.ModelConvert)
 
 
-@dataclasses.dataclass(frozen=True)
-class HigherOrder(abc.ABC):
+@dataclass(frozen=True)
+class Stochastic:
+    stochasticity: float = 0
+
+
+@dataclass(frozen=True)
+class DerivativeTransform:
+    derivative_transform: DiffusionModel | None = _X_HAT_SPACE
+
+
+@dataclass(frozen=True)
+class HigherOrder(ABC):
     order: int = 2
-    "requested solver order; the order actually used ramps up at the start and down at the end"
+
+    @staticmethod
+    @abstractmethod
+    def max_order() -> int:
+        "largest order the solver implements"
 
     @staticmethod
     def min_order() -> int:
+        "smallest order the solver will use"
         return 1
 
-    @staticmethod
-    @abc.abstractmethod
-    def max_order() -> int: ...
 
-
-@dataclasses.dataclass(frozen=True)
-class Stochastic:
-    stochasticity: float = 0
-    "eta: 0 = deterministic ODE, 1 = full SDE"
-
-
-@dataclasses.dataclass(frozen=True)
-class DerivativeTransform:
-    derivative_transform: models.DiffusionModel | None = models.DataModel()  # noqa: RUF009 - immutable
-    "space in which the multistep / Runge-Kutta arithmetic happens (None = the model's own space)"
-
-
-@dataclasses.dataclass(frozen=True)
+@dataclass(frozen=True)
 class UnifiedModelling(DerivativeTransform, Stochastic, HigherOrder):
-    "order + stochasticity + derivative space, in one MRO-stable bundle"
+    "order + stochasticity + derivative space in one MRO-stable bundle (field order: order, stochasticity, derivative_transform)"
+
+
+@dataclass(frozen=True)
+class SamplingCommon:
+    "noising helpers every sampler exposes; both are plain forwards to `Point`"
+
+    def remove_noise(self, sample, noise, point: Point):
+        return point.remove_noise(sample, noise)
+
+    def add_noise(self, sample, noise, point: Point):
+        return point.add_noise(sample, noise)
