@@ -139,6 +139,12 @@ int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c64, float* s
                           const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank,
                           const int32_t* dims, double exponent, int32_t has_energy, double energy, void* stream);
 
+/* mean(|a - b|^power), power 1 or 2 (FunctionalAdaptive.mae / .mse, skrample/sampling/functional.py:197-214);
+ * a may be NULL (= zeros).  Deterministic two-stage reduction in double; the result lands in out_dev[0]
+ * (the adaptive sampler reads it back: step-size control is a host decision).  partials_dev: 1024 doubles. */
+int skr_error_mean(const void* a_or_null, const void* b, int32_t dtype, int64_t numel, int32_t power,
+                   double* out_dev, double* partials_dev, void* stream);
+
 /* raw generator outputs, for parity tests of the RNG itself */
 int skr_philox_u32(uint32_t* out /* [n_blocks*4] device */, uint64_t seed, uint64_t stream_id,
                    uint64_t first_block, int64_t n_blocks, void* stream);

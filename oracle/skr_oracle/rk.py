@@ -240,3 +240,86 @@ class InsideOutRK:
             res = self._stage(cast(sample), synth, space, pts[i0], pts[i1], pts[self.index + 1], noise_fn)
             self.index += 1
         return res
+
+
+# ---- adaptive Runge-Kutta (functional.py:197-214, 352-472) ----------------------------------------------------
+# embedded pairs: (nodes, weights, error_weights)   providers.py:391-398, 418-427, 449-460
+EMB_HEUN = (((0, ()), (1, (1,))), (1 / 2, 1 / 2), (1, 0))
+EMB_BOGACKI_SHAMPINE = (
+    ((0, ()), (1 / 2, (1 / 2,)), (3 / 4, (0, 3 / 4)), (1, (2 / 9, 1 / 3, 4 / 9))),
+    (2 / 9, 1 / 3, 4 / 9, 0),
+    (7 / 24, 1 / 4, 1 / 3, 1 / 8),
+)
+EMB_FEHLBERG = (
+    (
+        (0, ()),
+        (1 / 4, (1 / 4,)),
+        (3 / 8, (3 / 32, 9 / 32)),
+        (12 / 13, (1932 / 2197, -7200 / 2197, 7296 / 2197)),
+        (1, (439 / 216, -8, 3680 / 513, -845 / 4104)),
+        (1 / 2, (-8 / 27, 2, -3544 / 2565, 1859 / 4104, -11 / 40)),
+    ),
+    (16 / 135, 0, 6656 / 12825, 28561 / 56430, -9 / 50, 2 / 55),
+    (25 / 216, 0, 1408 / 2565, 2197 / 4104, -1 / 5, 0),
+)
+DEFAULT_EMBEDDED = {2: EMB_HEUN, 4: EMB_BOGACKI_SHAMPINE, 6: EMB_FEHLBERG}  # functional.py:46-50
+
+
+def _mean(v) -> float:
+    "common.py:193-198"
+    return v if isinstance(v, (float, int)) else v.mean().item()
+
+
+def mse(a, b) -> float:
+    "functional.py:206-209"
+    return _mean(abs(a - b) ** 2)
+
+
+def mae(a, b) -> float:
+    "functional.py:201-204"
+    return _mean(abs(a - b))
+
+
+def step_tableau_embedded(emb, x, model, pred, sched: Sched, step, deriv=None):
+    "functional.py:55-105 with both weight rows: returns (high, low)"
+    nodes, w_hi, w_lo = emb
+    hi = step_tableau((nodes, w_hi), x, model, pred, sched, step, deriv)
+    lo = step_tableau((nodes, w_lo), x, model, pred, sched, step, deriv)
+    return hi, lo
+
+
+def rkmoire_loop(x, model, pred, sched: Sched, steps: int, include=slice(None), callback=None, order: int = 2, deriv="data", evaluator=mse,
+                 threshold: float = 1e-4, initial: float = 1 / 50, maximum: float = 1 / 4, adaption: float = 0.3, discard: float = float("inf"),
+                 rescale_init: bool = True, rescale_max: bool = False, providers=None):
+    "functional.py:396-472: error-controlled step size over an embedded pair"
+    providers = DEFAULT_EMBEDDED if providers is None else providers
+    if order >= min(providers) and (m := max(o for o in providers if o <= order)):
+        emb = providers[m]
+    else:
+        emb = EMB_HEUN
+    if rescale_init:
+        initial *= len(emb[0]) / 2
+    if rescale_max:
+        maximum *= len(emb[0]) / 2
+    step_size = max(round(steps * initial), 1)
+    eps = 1e-16
+    indices = list(range(steps))[include]
+    step = indices[0]
+    while step <= indices[-1]:
+        step_next = min(step + step_size, indices[-1] + 1)
+        if step_next < steps:
+            hi, lo = step_tableau_embedded(emb, x, model, pred, sched, (step / steps, step_next / steps), deriv)
+            s0, s1, s2 = sched.ipoints_np([step / steps, step_next / steps, (step_next + step_size) / steps])[:, 1].tolist()
+            slope = abs(s0 - s1) / abs(s1 - s2)
+            error = evaluator(lo, hi) / max(evaluator(0, hi), eps)
+            adjustment = (threshold / max(error, eps)) ** adaption / slope
+            step_size = max(round(min(step_size * adjustment, steps * maximum)), 1)
+            if step_next - step > step_size and 1 / max(adjustment, eps) > discard:
+                continue
+        else:
+            hi = step_tableau((emb[0], emb[1]), x, model, pred, sched, (step / steps, 1), deriv)
+        x = hi
+        if callback:
+            callback(x, step_next - 1, sched.ipoints(stp_from_int(step, steps)))
+        step = step_next
+    return x

@@ -29,6 +29,7 @@ EXPORTS = (
     "skr_noise_pyramid",
     "skr_noise_colored",
     "skr_noise_colored_any",
+    "skr_error_mean",
     "skr_philox_u32",
     "skr_abi_version",
     "skr_strerror",
@@ -102,6 +103,8 @@ def load() -> ctypes.CDLL:
         lib.skr_noise_colored.restype = ctypes.c_int
         lib.skr_noise_colored_any.argtypes = [vp, i32, vp, vp, vp, vp, u64, i64, i32, ctypes.POINTER(i32), ctypes.c_double, i32, ctypes.c_double, vp]
         lib.skr_noise_colored_any.restype = ctypes.c_int
+        lib.skr_error_mean.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp]
+        lib.skr_error_mean.restype = ctypes.c_int
         lib.skr_philox_u32.argtypes = [vp, u64, u64, u64, i64, vp]
         lib.skr_philox_u32.restype = ctypes.c_int
         lib.skr_abi_version.restype = ctypes.c_int

@@ -2,8 +2,8 @@
 
 Public surface follows reference `skrample/sampling/functional.py`: step_tableau (:55-105),
 FunctionalSampler.sample_model / generate_model (:108-149), RKUltra (:217-268), DynasauRK (:271-349)
-and the provider maps (:18-52).  The adaptive RKMoire (:352-472) is out of scope (needs a global
-error reduction and a host round-trip per step).
+RKMoire (:352-472, adaptive: one fused launch for the embedded pair, one reduction launch + read-back per error
+norm) and the provider maps (:18-52).
 
 One Runge-Kutta step with s stages costs exactly s fused launches: every stage input
 X_j = Gamma*x0 + Delta * (sum_i a_ji d_i)/sum_i a_ji and the final combination are single lazy
@@ -97,9 +97,11 @@ def step_tableau(
         else:
             out = model(stage_in, *point)
             derivs.append(convert.form_to(stage_in, out, point) if convert else lift(out))
-    return tuple(
-        _materialise(space.update_form(base, common.sumprod(derivs, row), delta, noise, stochasticity), sample) for row in weight_rows
-    )
+    forms = [space.update_form(base, common.sumprod(derivs, row), delta, noise, stochasticity) for row in weight_rows]
+    if len(forms) == 2 and all(isinstance(f, Lin) for f in forms):  # embedded pair: both solutions from ONE launch
+        dtype = sample.dtype if hasattr(sample, "dtype") else None
+        return tuple(lazy.evaluate(forms, [dtype, dtype]))
+    return tuple(_materialise(f, sample) for f in forms)
 
 
 @dataclasses.dataclass(frozen=True)
@@ -143,6 +145,29 @@ class FunctionalSinglestep(FunctionalSampler):
             if callback:
                 callback(sample, n, schedule.istep(step))
         return sample
+
+
+def _error_mean(a, b, power: int) -> float:
+    "mean(|a - b|^power): python numbers on the host, device tensors through skr_error_mean"
+    if isinstance(b, (int, float)) and isinstance(a, (int, float)):
+        return abs(a - b) ** power
+    return lazy.error_mean(a, b, power)
+
+
+@dataclasses.dataclass(frozen=True)
+class FunctionalAdaptive(FunctionalSampler):
+    "samplers that choose their own step size from an error estimate"
+
+    @staticmethod
+    def mae(a, b) -> float:
+        return _error_mean(a, b, 1)
+
+    @staticmethod
+    def mse(a, b) -> float:
+        return _error_mean(a, b, 2)
+
+    evaluator: Callable[[Any, Any], float] = mse
+    threshold: float = 1e-2
 
 
 @dataclasses.dataclass(frozen=True)
@@ -212,3 +237,70 @@ class DynasauRK(FunctionalUnified, FunctionalSinglestep):
 
     def step(self, sample, model, model_transform, schedule, step, rng=None):
         return step_tableau(self.tableau(step), sample, model, model_transform, schedule, step, self.derivative_transform, rng(step) if rng else None, self.stochasticity)[0]
+
+
+@dataclasses.dataclass(frozen=True)
+class RKMoire(traits.DerivativeTransform, FunctionalAdaptive, FunctionalHigher):
+    """Adaptive Runge-Kutta over an embedded pair: every step yields a high- and a low-order solution (one fused
+    launch for both), their relative error (one reduction launch each, read back) sets the next step size."""
+
+    providers: Mapping[int, Any] = MappingProxyType(DEFAULT_EMBEDDED_PROVIDERS)
+    threshold: float = 1e-4
+    initial: float = 1 / 50
+    "first step, as a fraction of the schedule"
+    maximum: float = 1 / 4
+    "largest step, as a fraction of the schedule"
+    adaption: float = 0.3
+    "exponent of the step-size controller"
+    discard: float = float("inf")
+    "redo a step whose size has to shrink by more than this factor"
+    rescale_init: bool = True
+    rescale_max: bool = False
+
+    @staticmethod
+    def min_order() -> int:
+        return 2
+
+    @staticmethod
+    def max_order() -> int:
+        return 99
+
+    def adjust_steps(self, steps: int) -> int:
+        return steps
+
+    def tableau(self, order: int | None = None) -> tableaux.EmbeddedTableau:
+        order = self.order if order is None else order
+        usable = [k for k in self.providers if k <= order]
+        if order >= min(self.providers) and usable and max(usable):
+            return self.providers[max(usable)].tableau()
+        return tableaux.RKE2.Heun.tableau()
+
+    def sample_model(self, sample, model, model_transform, schedule, steps, include=slice(None), rng=None, callback=None):
+        pair = self.tableau()
+        first, largest = self.initial, self.maximum
+        if self.rescale_init:
+            first *= len(pair.stages) / 2  # relative to Heun's two evaluations
+        if self.rescale_max:
+            largest *= len(pair.stages) / 2
+        stride = max(round(steps * first), 1)
+        tiny = 1e-16
+        wanted = list(range(steps))[include]
+        at = wanted[0]
+        while at <= wanted[-1]:
+            upto = min(at + stride, wanted[-1] + 1)
+            if upto < steps:
+                high, low = step_tableau(pair, sample, model, model_transform, schedule, Step(at / steps, upto / steps), self.derivative_transform)
+                s0, s1, s2 = schedule.ipoints_np([at / steps, upto / steps, (upto + stride) / steps])[:, 1].tolist()
+                slope = abs(s0 - s1) / abs(s1 - s2)  # how much the next sigma step grows by itself
+                error = self.evaluator(low, high) / max(self.evaluator(0, high), tiny)
+                adjustment = (self.threshold / max(error, tiny)) ** self.adaption / slope
+                stride = max(round(min(stride * adjustment, steps * largest)), 1)
+                if upto - at > stride and 1 / max(adjustment, tiny) > self.discard:
+                    continue  # too optimistic: retry from the same point with the smaller stride
+            else:  # last stretch: the error estimate would not be used
+                high = step_tableau(pair.unembed(), sample, model, model_transform, schedule, Step(at / steps, 1), self.derivative_transform)[0]
+            sample = high
+            if callback:
+                callback(sample, upto - 1, schedule.istep(Step.from_int(at, steps)))
+            at = upto
+        return sample

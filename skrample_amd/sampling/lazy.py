@@ -440,6 +440,29 @@ def cast(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return evaluate([Lin.leaf(t)], [dtype])[0]
 
 
+_norm_ws: dict = {}
+
+
+def error_mean(a, b: torch.Tensor, power: int) -> float:
+    "mean(|a - b|^power) over a device tensor pair (a may be the number 0); one reduction launch + read-back"
+    _check_tensor(b)
+    if isinstance(a, torch.Tensor):
+        _check_tensor(a)
+        if a.dtype != b.dtype or a.shape != b.shape:
+            raise SkrampleHipError("error norm operands must share dtype and shape")
+        a = _prepare_tensor(a)
+    elif a != 0:
+        raise SkrampleHipError("error norm against a non-zero scalar is not supported")
+    b = _prepare_tensor(b)
+    ws = _norm_ws.get(b.device)
+    if ws is None:
+        ws = _norm_ws[b.device] = torch.empty(1025, dtype=torch.float64, device=b.device)
+    lib = _hip.load()
+    status = lib.skr_error_mean(a.data_ptr() if isinstance(a, torch.Tensor) else None, b.data_ptr(), _hip.DTYPE_CODE[b.dtype], b.numel(), power, ws.data_ptr(), ws.data_ptr() + 8, _hip.current_stream_ptr(b.device))
+    _hip.check(status, "skr_error_mean")
+    return ws[0].item()
+
+
 def settle(value, like=None, dtype: torch.dtype | None = None):
     "number -> number; form -> tensor (one launch)"
     if isinstance(value, Lin):

@@ -374,3 +374,15 @@ def test_terminal_timesteps(modifier, timesteps, steps):
     ):
         w.set_timesteps(steps)
         assert len(w.timesteps) == steps * w.order
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 99])
+def test_rkmoire_equals_oracle_on_scalars(order):
+    "adaptive RK (reference functional.py:352-472): same accepted steps and result as the oracle"
+    f = lambda x, t, s, a: x + math.sin(x) * s  # noqa: E731
+    for (so, sp), (po, pp), steps in itertools.product([SCHEDULES["linear"], SCHEDULES["scaled"]], [MODELS["data"], MODELS["flow"], MODELS["v"]], (10, 37)):
+        for kw in ({}, dict(threshold=1e-2, adaption=0.5, discard=1.5), dict(rescale_max=True, maximum=0.5)):
+            seen_o, seen_p = [], []
+            a = OK.rkmoire_loop(1.3, f, po, so(), steps, order=order, callback=lambda x, i, d: seen_o.append(i), **kw)
+            b = PF.RKMoire(order=order, **kw).sample_model(1.3, f, pp, sp(), steps, callback=lambda x, i, d: seen_p.append(i))
+            assert seen_o == seen_p and abs(a - b) < 1e-9 * max(1, abs(a)), (order, steps, kw)

@@ -631,3 +631,25 @@ def test_img2img_entry_points(dev):
         assert_close(got, ref, torch.float32, f"begin_index step {i}")
         x = ref
     assert w.config["begin_index"] == 4
+
+
+def test_rkmoire_on_device(dev):
+    "adaptive RK on device tensors: embedded pair from one launch, error norms by the reduction kernel, vs the oracle"
+    from skrample_amd.sampling import functional as PF
+
+    g = torch.Generator().manual_seed(17)
+    wmat = torch.randn(16, 16, generator=g, dtype=torch.float64) * 0.05
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, REL_TOL_F32)):
+        x0 = torch.randn(2, 4, 16, 16, generator=g, dtype=torch.float64).to(dtype)
+        wc, wd = wmat.to(dtype), wmat.to(dtype).to(dev)
+        for order, (sp, so), (pp, po) in ((2, SCHEDULES["scaled"], (PM.VelocityModel(), "v")), (4, SCHEDULES["linear"], (PM.FlowModel(), "flow")), (6, SCHEDULES["scaled"], (PM.DataModel(), "data"))):
+            seen_o, seen_p = [], []
+            ref = OK.rkmoire_loop(x0, lambda x, t, s, a: x @ wc + x * s, po, sp(), 24, order=order, callback=lambda x, i, d: seen_o.append(i))
+            got = PF.RKMoire(order=order).sample_model(x0.to(dev), lambda x, t, s, a: x @ wd + x * s, pp, so(), 24, callback=lambda x, i, d: seen_p.append(i))
+            assert seen_o == seen_p, (dtype, order, seen_o, seen_p)
+            assert got.dtype == dtype and rel_err(got, ref) <= tol, (dtype, order, rel_err(got, ref))
+    # the norms themselves
+    a, b = torch.randn(3, 1000, generator=g), torch.randn(3, 1000, generator=g)
+    assert abs(PF.FunctionalAdaptive.mse(a.to(dev), b.to(dev)) - ((a.double() - b.double()) ** 2).mean().item()) < 1e-12
+    assert abs(PF.FunctionalAdaptive.mae(a.to(dev), b.to(dev)) - (a.double() - b.double()).abs().mean().item()) < 1e-12
+    assert abs(PF.FunctionalAdaptive.mse(0, b.bfloat16().to(dev)) - (b.bfloat16().double() ** 2).mean().item()) < 1e-12
