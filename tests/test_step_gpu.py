@@ -653,3 +653,33 @@ def test_rkmoire_on_device(dev):
     assert abs(PF.FunctionalAdaptive.mse(a.to(dev), b.to(dev)) - ((a.double() - b.double()) ** 2).mean().item()) < 1e-12
     assert abs(PF.FunctionalAdaptive.mae(a.to(dev), b.to(dev)) - (a.double() - b.double()).abs().mean().item()) < 1e-12
     assert abs(PF.FunctionalAdaptive.mse(0, b.bfloat16().to(dev)) - (b.bfloat16().double() ** 2).mean().item()) < 1e-12
+
+
+def test_noise_seeding_rules(dev):
+    "reference get_step_noise (diffusers.py:312-346): per-item generators, a single generator for batch 1, else seeds from the data"
+    from skrample_amd.pytorch import noise as PN
+
+    def run(shape, generator, x0):
+        w = PD.SkrampleWrapperScheduler(PT.Euler(stochasticity=1), PS.Scaled())
+        w.set_timesteps(4)
+        x = x0
+        for t in w.timesteps:
+            x = w.step(torch.zeros_like(x0), t, x, generator=generator, return_dict=False)[0]
+        return x, w
+
+    g = torch.Generator().manual_seed(18)
+    x3 = torch.randn(3, 4, 16, 16, generator=g).to(dev)
+    a, w = run(x3.shape, None, x3)  # fallback: one seed per item from its middle element
+    b, _ = run(x3.shape, None, x3)
+    assert torch.equal(a, b) and len(w._noise_generator.generators) == 3
+    c, _ = run(x3.shape, torch.Generator().manual_seed(1), x3)  # a lone generator for a batch of 3 is ignored, as in the reference
+    assert torch.equal(a, c)
+    d, _ = run(x3.shape, [torch.Generator().manual_seed(s) for s in (1, 2, 3)], x3)
+    e, _ = run(x3.shape, [1, 2, 3], x3)  # ints are accepted as seeds
+    assert torch.equal(d, e) and not torch.equal(a, d)
+    assert not torch.equal(d[0], d[1])  # different seeds, different noise
+    x1 = x3[:1].contiguous()
+    f, w1 = run(x1.shape, torch.Generator().manual_seed(1), x1)
+    assert torch.equal(f, d[:1]) and len(w1._noise_generator.generators) == 1  # same seed, same item => same result
+    with pytest.raises(_hip.SkrampleHipError):
+        PN.Brownian.from_inputs((4, 8, 8), 1)
