@@ -5,6 +5,7 @@
 
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
+#include "skr_pack.h"
 
 extern "C" int skr_abi_version(void) { return SKR_ABI_VERSION; }
 
@@ -42,20 +43,50 @@ __global__ __launch_bounds__(256) void random_kernel(T* out, const uint64_t* see
   }
 }
 
+// Aligned fast path (sample_numel % 8 == 0 and a 16-byte aligned base): blockIdx.y = sample, every thread draws two
+// Philox blocks and writes its 8 values with one packed non-temporal store.  Same (seed, stream, block) -> value
+// mapping as the kernel above, so both produce identical bits.
+template <typename T>
+__global__ __launch_bounds__(256) void random_kernel_v8(T* out, const uint64_t* seeds, uint64_t stream_id, int64_t sample_numel) {
+  const int64_t smp = blockIdx.y, vps = sample_numel >> 3;
+  const uint64_t seed = seeds[smp];
+  T* dst = out + smp * sample_numel;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < vps; v += (int64_t)gridDim.x * 256) {
+    float z[8];
+    skr::normal4(seed, stream_id, (uint64_t)(2 * v), z);
+    skr::normal4(seed, stream_id, (uint64_t)(2 * v + 1), z + 4);
+    skr::store8_from_f32<T>(dst, v, z);
+  }
+}
+
+template <typename T>
+static void launch_random(void* out, const uint64_t* seeds, uint64_t stream_id, int64_t batch, int64_t sample_numel, hipStream_t s) {
+  const bool fast = sample_numel % 8 == 0 && batch <= 65535 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (fast) {
+    const int64_t vps = sample_numel / 8;
+    int64_t bx = (vps + 255) / 256;
+    const int64_t cap = (256 * 16 + batch - 1) / batch;  // ~16 blocks per CU over the whole grid
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(random_kernel_v8<T>, dim3((unsigned)bx, (unsigned)batch), dim3(256), 0, s, (T*)out, seeds, stream_id, sample_numel);
+    return;
+  }
+  const int64_t bps = (sample_numel + 3) / 4, total = bps * batch;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(random_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, (T*)out, seeds, stream_id, sample_numel, bps, total);
+}
+
 extern "C" int skr_noise_random(void* out, int32_t out_dtype, const uint64_t* seeds_dev, uint64_t stream_id,
                                 int64_t batch, int64_t sample_numel, void* stream) {
   if (batch < 0 || sample_numel < 0) return SKR_ERR_SHAPE;
   if (batch == 0 || sample_numel == 0) return SKR_OK;
   if (!out || !seeds_dev) return SKR_ERR_NULL;
-  const int64_t bps = (sample_numel + 3) / 4, total = bps * batch;
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (out_dtype) {
-    case SKR_BF16: hipLaunchKernelGGL(random_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (__bf16*)out, seeds_dev, stream_id, sample_numel, bps, total); break;
-    case SKR_F16: hipLaunchKernelGGL(random_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (_Float16*)out, seeds_dev, stream_id, sample_numel, bps, total); break;
-    case SKR_F32: hipLaunchKernelGGL(random_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)out, seeds_dev, stream_id, sample_numel, bps, total); break;
-    case SKR_F64: hipLaunchKernelGGL(random_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (double*)out, seeds_dev, stream_id, sample_numel, bps, total); break;
+    case SKR_BF16: launch_random<__bf16>(out, seeds_dev, stream_id, batch, sample_numel, s); break;
+    case SKR_F16: launch_random<_Float16>(out, seeds_dev, stream_id, batch, sample_numel, s); break;
+    case SKR_F32: launch_random<float>(out, seeds_dev, stream_id, batch, sample_numel, s); break;
+    case SKR_F64: launch_random<double>(out, seeds_dev, stream_id, batch, sample_numel, s); break;
     default: return SKR_ERR_DTYPE;
   }
   return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;

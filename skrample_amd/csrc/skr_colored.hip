@@ -61,7 +61,7 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
   if (logN & 1) {  // leftover radix-2 stage first (half = 1, twiddle = 1)
     __syncthreads();
     const int total = L * half_n;
-    for (int t = threadIdx.x; t < total; t += FFT_THREADS) {
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
       const int line = t >> (logN - 1), k = t & (half_n - 1);
       float2* p = buf + line * ld + 2 * k;
       const float2 a = p[0], b = p[1];
@@ -76,7 +76,7 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
     const int step1 = half_n >> s, step2 = half_n >> (s + 1);
     __syncthreads();
     const int total = L * quarter;
-    for (int t = threadIdx.x; t < total; t += FFT_THREADS) {
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
       const int line = t >> (logN - 2), k = t & (quarter - 1);
       const int pos = k & (h - 1);
       float2* p = buf + line * ld + ((k >> s) << (s + 2)) + pos;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
 }
 
 __device__ __forceinline__ void make_twiddles(float2* tw, int N) {
-  for (int k = threadIdx.x; k < N / 2; k += FFT_THREADS) {
+  for (int k = threadIdx.x; k < N / 2; k += blockDim.x) {
     float s, c;
     sincospif(-2.0f * (float)k / (float)N, &s, &c);
     tw[k] = make_float2(c, s);
@@ -110,14 +110,14 @@ __device__ __forceinline__ float axis_freq(int k, int d) { const int m = k < d -
 
 // block-wide sum of two doubles into partial slot (fixed order)
 __device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
-  __shared__ double red[2][FFT_THREADS / 64];
+  __shared__ double red[2][16];  // up to 1024 threads
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double a = 0.0, b = 0.0;
-    for (int w = 0; w < FFT_THREADS / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[0][w]; b += red[1][w]; }
     slot[0] = a; slot[1] = b;
   }
 }
@@ -196,6 +196,111 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
     }
     block_sums(s1, s2, a.partials + ((1 * a.batch + smp) * a.n_slots + blockIdx.x) * 2);
   }
+}
+
+// ---- fused passes over the two inner axes: one (sample, i1) plane of d2 x d3 per block, entirely in LDS ---------
+// MODE 0: white noise -> rows (two-for-one) -> columns -> half spectrum to HBM          (replaces passes A + B)
+// MODE 1: half spectrum -> columns^-1 -> rows^-1 -> real plane + statistics            (replaces passes D + E)
+// MODE 2: both, with the radial weights applied in LDS in between (2-D units: the spectrum never leaves the CU)
+// LDS: T1 = (d2/2) x (d3+1) complex (row pairs), T2 = d3h x (d2+1) complex (columns), plus both twiddle tables;
+// the host only selects these kernels when that fits (128 x 128 planes: 134 KiB).
+constexpr int PLANE_THREADS = 1024;
+
+template <int MODE>
+__global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs a, int logH, int logW) {
+  extern __shared__ float2 smem[];
+  const int H = a.d2, W = a.d3, WH = a.d3h, ldw = W + 1, ldh = H + 1, pairs = H >> 1;
+  float2* tw_w = smem;
+  float2* tw_h = tw_w + W / 2;
+  float2* t1 = tw_h + H / 2;
+  float2* t2 = t1 + pairs * ldw;
+  const int64_t smp = blockIdx.y;
+  const int i1 = blockIdx.x;
+  const int nthr = blockDim.x;
+  make_twiddles(tw_w, W);
+  make_twiddles(tw_h, H);
+  float2* plane = a.spec + ((smp * a.d1 + i1) * (int64_t)H) * WH;
+  double s1 = 0.0, s2 = 0.0;
+
+  if (MODE != 1) {
+    const uint64_t seed = a.seeds[smp];
+    for (int q = threadIdx.x; q < pairs * (W / 4); q += nthr) {
+      const int pr = q >> (logW - 2), n4 = (q & (W / 4 - 1)) * 4;
+      const int64_t ea = ((int64_t)i1 * H + 2 * pr) * W + n4;
+      float za[4], zb[4];
+      normal4(seed, a.stream, (uint64_t)ea >> 2, za);
+      normal4(seed, a.stream, (uint64_t)(ea + W) >> 2, zb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t1[pr * ldw + brev(n4 + j, logW)] = make_float2(za[j], zb[j]);
+        s1 += (double)za[j] + (double)zb[j];
+        s2 += (double)za[j] * (double)za[j] + (double)zb[j] * (double)zb[j];
+      }
+    }
+    fft_tile<false>(t1, tw_w, W, logW, pairs);
+    // untangle the row pairs straight into the column tile (bit-reversed along H for the column transform)
+    for (int q = threadIdx.x; q < pairs * WH; q += nthr) {
+      const int pr = q / WH, k = q - pr * WH;
+      const float2 zk = t1[pr * ldw + k], zn = t1[pr * ldw + ((W - k) & (W - 1))];
+      t2[k * ldh + brev(2 * pr, logH)] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+      t2[k * ldh + brev(2 * pr + 1, logH)] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    }
+    fft_tile<false>(t2, tw_h, H, logH, WH);
+    block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
+    if (MODE == 0) {
+      for (int q = threadIdx.x; q < H * WH; q += nthr) {
+        const int row = q / WH, k = q - row * WH;
+        plane[q] = t2[k * ldh + row];
+      }
+      return;
+    }
+    // MODE 2: weights in place, then bit-reverse the columns for the inverse transform
+    for (int q = threadIdx.x; q < H * WH; q += nthr) {
+      const int k = q >> logH, row = q & (H - 1);
+      const float f2 = axis_freq(row, H), f3 = (float)k / (float)W;
+      float radius = sqrtf(f2 * f2 + f3 * f3) * a.inv_rmax;
+      radius = radius < a.eps_clip ? a.eps_clip : radius;
+      const float wgt = powf(radius, a.exponent_half_neg);
+      float2 v = t2[k * ldh + row];
+      t2[k * ldh + row] = make_float2(v.x * wgt, v.y * wgt);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < H * WH; q += nthr) {
+      const int k = q >> logH, row = q & (H - 1);
+      const int r = (int)brev(row, logH);
+      if (row < r) { float2 t = t2[k * ldh + row]; t2[k * ldh + row] = t2[k * ldh + r]; t2[k * ldh + r] = t; }
+    }
+  } else {
+    for (int q = threadIdx.x; q < H * WH; q += nthr) {
+      const int row = q / WH, k = q - row * WH;
+      t2[k * ldh + brev(row, logH)] = plane[q];
+    }
+  }
+
+  fft_tile<true>(t2, tw_h, H, logH, WH);
+  // pack row pairs (Hermitian expansion along W), bit-reversed along W
+  for (int q = threadIdx.x; q < pairs * W; q += nthr) {
+    const int pr = q >> logW, k = q & (W - 1);
+    const int m = k < WH ? k : W - k;
+    float2 xa = t2[m * ldh + 2 * pr], xb = t2[m * ldh + 2 * pr + 1];
+    if (m == 0 || 2 * m == W) { xa.y = 0.f; xb.y = 0.f; }
+    if (k >= WH) { xa.y = -xa.y; xb.y = -xb.y; }
+    t1[pr * ldw + brev(k, logW)] = make_float2(xa.x - xb.y, xa.y + xb.x);
+  }
+  fft_tile<true>(t1, tw_w, W, logW, pairs);
+  const float scale = 1.0f / ((float)a.d1 * (float)H * (float)W);
+  float* dst = a.real_out + ((smp * a.d1 + i1) * (int64_t)H) * W;
+  s1 = 0.0; s2 = 0.0;
+  for (int q = threadIdx.x; q < pairs * W; q += nthr) {
+    const int pr = q >> logW, n = q & (W - 1);
+    const float2 z = t1[pr * ldw + n];
+    const float va = z.x * scale, vb = z.y * scale;
+    dst[(int64_t)(2 * pr) * W + n] = va;
+    dst[(int64_t)(2 * pr + 1) * W + n] = vb;
+    s1 += (double)va + (double)vb;
+    s2 += (double)va * (double)va + (double)vb * (double)vb;
+  }
+  block_sums(s1, s2, a.partials + ((1 * a.batch + smp) * a.n_slots + i1) * 2);
 }
 
 // ---- pass B / C / D: a strided axis of length N; lines start at consecutive complex positions --------------------
@@ -398,6 +503,56 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   a.inv_rmax = rmax > 0.f ? 1.0f / rmax : 1.0f;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
+  const int64_t d3h = a.d3h;
+  // fused plane kernels when one d2 x d3 plane (+ its half spectrum) fits the CU's LDS
+  const size_t lds_plane = sizeof(float2) * ((size_t)d3 / 2 + d2 / 2 + (size_t)(d2 / 2) * (d3 + 1) + (size_t)d3h * (d2 + 1));
+  const bool fused = lds_plane <= 150 * 1024 && getenv("SKR_FFT_NO_FUSE") == nullptr;
+  auto outer_axis = [&]() -> int {
+    // axis 1 (length d1, stride d2*d3h): forward, radial weights, inverse in one pass
+    if (d1 <= 16) {
+      const int64_t cols = (int64_t)d2 * d3h;
+      int64_t bx = (cols + 255) / 256; if (bx > 4096) bx = 4096;
+      dim3 grid((unsigned)bx, (unsigned)batch);
+      switch (d1) {
+        case 2: hipLaunchKernelGGL(colored_outer_axis_regs<2>, grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(colored_outer_axis_regs<4>, grid, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(colored_outer_axis_regs<8>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(colored_outer_axis_regs<16>, grid, dim3(256), 0, s, a); break;
+      }
+      return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+    }
+    return -1;  // caller uses the LDS tile kernel
+  };
+
+  if (fused) {
+    if (d1 > partial_slots) return SKR_ERR_SHAPE;
+    a.n_slots = d1;
+    dim3 grid((unsigned)d1, (unsigned)batch);
+    if (nd == 2) {
+      SKR_ALLOW_LDS(colored_plane<2>, lds_plane);
+      hipLaunchKernelGGL(colored_plane<2>, grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3);
+      SKR_CHECK_LAUNCH();
+    } else {
+      SKR_ALLOW_LDS(colored_plane<0>, lds_plane);
+      SKR_ALLOW_LDS(colored_plane<1>, lds_plane);
+      hipLaunchKernelGGL(colored_plane<0>, grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3);
+      SKR_CHECK_LAUNCH();
+      int rc = outer_axis();
+      if (rc == -1) {
+        int logL = 0;
+        const int tile = fft_tile_points();
+        while ((2 << logL) * d1 <= tile && (2 << logL) <= 64) ++logL;
+        const int64_t n_lines = (int64_t)d2 * d3h, blocks = (n_lines + (1 << logL) - 1) >> logL;
+        const size_t lds = sizeof(float2) * ((size_t)d1 / 2 + ((size_t)1 << logL) * (d1 + 1));
+        SKR_ALLOW_LDS(colored_strided_axis<2>, lds);
+        hipLaunchKernelGGL(colored_strided_axis<2>, dim3((unsigned)blocks, (unsigned)batch), dim3(FFT_THREADS), lds, s, a, d1, l1, logL, n_lines, n_lines, (int64_t)0, n_lines, 1);
+        rc = hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+      }
+      if (rc != SKR_OK) return rc;
+      hipLaunchKernelGGL(colored_plane<1>, grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3);
+      SKR_CHECK_LAUNCH();
+    }
+  } else {
   // pass A: last axis forward
   const int64_t lines_last = (int64_t)d1 * d2;
   const int tile = fft_tile_points();
@@ -428,24 +583,13 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     else hipLaunchKernelGGL(colored_strided_axis<2>, grid, dim3(FFT_THREADS), lds, s, a, N, logN, logL, n_lines, inner, outer, stride, axis);
     return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
   };
-  const int64_t d3h = a.d3h;
   int rc;
   if (nd == 3) {
     // axis 2 (length d2, stride d3h): lines = (i1, k3)
     if ((rc = strided(0, d2, l2, (int64_t)d1 * d3h, d3h, (int64_t)d2 * d3h, d3h, 2)) != SKR_OK) return rc;
-    // axis 1 (length d1, stride d2*d3h): lines = (k2, k3), fused forward + weights + inverse
-    if (d1 <= 16) {
-      const int64_t cols = (int64_t)d2 * d3h;
-      int64_t bx = (cols + 255) / 256; if (bx > 4096) bx = 4096;
-      dim3 grid((unsigned)bx, (unsigned)batch);
-      switch (d1) {
-        case 2: hipLaunchKernelGGL(colored_outer_axis_regs<2>, grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(colored_outer_axis_regs<4>, grid, dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL(colored_outer_axis_regs<8>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(colored_outer_axis_regs<16>, grid, dim3(256), 0, s, a); break;
-      }
-      SKR_CHECK_LAUNCH();
-    } else if ((rc = strided(2, d1, l1, (int64_t)d2 * d3h, (int64_t)d2 * d3h, 0, (int64_t)d2 * d3h, 1)) != SKR_OK) return rc;
+    rc = outer_axis();
+    if (rc == -1) rc = strided(2, d1, l1, (int64_t)d2 * d3h, (int64_t)d2 * d3h, 0, (int64_t)d2 * d3h, 1);
+    if (rc != SKR_OK) return rc;
     if ((rc = strided(1, d2, l2, (int64_t)d1 * d3h, d3h, (int64_t)d2 * d3h, d3h, 2)) != SKR_OK) return rc;
   } else {
     if ((rc = strided(2, d2, l2, d3h, d3h, 0, d3h, 2)) != SKR_OK) return rc;
@@ -454,6 +598,7 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   // pass E: last axis inverse -> real scratch
   hipLaunchKernelGGL(colored_last_axis<false>, dim3((unsigned)blocks_a, (unsigned)batch), dim3(FFT_THREADS), lds_a, s, a, l3, La);
   SKR_CHECK_LAUNCH();
+  }
 
   // pass F
   const int64_t unit = (int64_t)d1 * d2 * d3;

@@ -6,6 +6,7 @@
 
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
+#include "skr_pack.h"
 
 namespace skr {
 
@@ -28,6 +29,14 @@ struct OffsetArgs {
   uint32_t mask;
   float gain;  // strength^2
 };
+
+// torch evaluates `noise + offset * strength**2` as a rounded multiply, then a rounded add: no FMA contraction here
+// (hip's __fadd_rn is a plain `+` and would still be contracted with a neighbouring multiply)
+__device__ __forceinline__ float add_offset(float z, float off, float gain) {
+#pragma clang fp contract(off)
+  const float scaled = off * gain;
+  return z + scaled;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void offset_kernel(const OffsetArgs a) {
@@ -53,9 +62,64 @@ __global__ __launch_bounds__(256) void offset_kernel(const OffsetArgs a) {
       const int64_t i0 = rem;
       const int64_t ridx = ((((a.mask & 1) ? i0 : 0) * r1 + ((a.mask & 2) ? i1 : 0)) * r2 + ((a.mask & 4) ? i2 : 0)) * r3 + ((a.mask & 8) ? i3 : 0);
       if (ridx != last_ridx) { off = normal1(seed, a.stream_offset, (uint64_t)ridx); last_ridx = ridx; }
-      put<T>((T*)a.out, smp * unit + e, z[j] + off * a.gain);
+      put<T>((T*)a.out, smp * unit + e, add_offset(z[j], off, a.gain));
     }
   }
+}
+
+// Aligned fast path: d3 % 8 == 0, unit < 2^31, 16-byte aligned base.  blockIdx.y = sample; a thread owns 8
+// consecutive elements of one innermost row, so the index decomposition is done once (32-bit) and the offset
+// normal is drawn once per thread unless the innermost axis itself is kept, in which case the 8 reduced indices
+// are consecutive and cost two Philox blocks.  Same per-element arithmetic as the kernel above.
+template <typename T>
+__global__ __launch_bounds__(256) void offset_kernel_v8(const OffsetArgs a) {
+  const uint32_t d1 = (uint32_t)a.d1, d2 = (uint32_t)a.d2, d3 = (uint32_t)a.d3;
+  const uint32_t unit = (uint32_t)(a.d0 * a.d1 * a.d2 * a.d3), vps = unit >> 3;
+  const uint32_t r1 = (a.mask & 2) ? d1 : 1, r2 = (a.mask & 4) ? d2 : 1, r3 = (a.mask & 8) ? d3 : 1;
+  const int64_t smp = blockIdx.y;
+  const uint64_t seed = a.seeds[smp];
+  T* dst = (T*)a.out + smp * (int64_t)unit;
+  for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < vps; v += gridDim.x * 256) {
+    float z[8];
+    normal4(seed, a.stream_base, (uint64_t)(2 * v), z);
+    normal4(seed, a.stream_base, (uint64_t)(2 * v) + 1, z + 4);
+    uint32_t rem = v * 8;
+    const uint32_t i3 = rem % d3; rem /= d3;
+    const uint32_t i2 = rem % d2; rem /= d2;
+    const uint32_t i1 = rem % d1;
+    const uint32_t i0 = rem / d1;
+    const uint64_t ridx = (uint64_t)((((a.mask & 1) ? i0 : 0) * r1 + ((a.mask & 2) ? i1 : 0)) * r2 + ((a.mask & 4) ? i2 : 0)) * r3 + ((a.mask & 8) ? i3 : 0);
+    if (a.mask & 8) {
+      // i3 % 8 == 0 and r3 = d3 % 8 == 0 => ridx % 8 == 0: two whole Philox blocks
+      float o[8];
+      normal4(seed, a.stream_offset, ridx >> 2, o);
+      normal4(seed, a.stream_offset, (ridx >> 2) + 1, o + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = add_offset(z[j], o[j], a.gain);
+    } else {
+      const float off = normal1(seed, a.stream_offset, ridx);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = add_offset(z[j], off, a.gain);
+    }
+    store8_from_f32<T>(dst, (int64_t)v, z);
+  }
+}
+
+template <typename T>
+static void launch_offset(const OffsetArgs& a, hipStream_t s) {
+  const int64_t unit = a.d0 * a.d1 * a.d2 * a.d3;
+  const bool fast = a.d3 % 8 == 0 && unit < (1ll << 31) && a.batch <= 65535 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+  if (fast) {
+    int64_t bx = (unit / 8 + 255) / 256;
+    const int64_t cap = (256 * 16 + a.batch - 1) / a.batch;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(offset_kernel_v8<T>, dim3((unsigned)bx, (unsigned)a.batch), dim3(256), 0, s, a);
+    return;
+  }
+  const int64_t total = ((unit + 3) / 4) * a.batch;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(offset_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
 // ---- Pyramid ---------------------------------------------------------------------------------------------
@@ -249,15 +313,12 @@ extern "C" int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* se
   a.out = out; a.seeds = seeds_dev; a.stream_base = stream_base; a.stream_offset = stream_offset; a.batch = batch;
   a.mask = (keep_mask & ((1u << ndim) - 1u)) << (4 - ndim);
   a.gain = (float)(strength * strength);
-  const int64_t total = ((unit + 3) / 4) * batch;
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (out_dtype) {
-    case SKR_BF16: hipLaunchKernelGGL(skr::offset_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case SKR_F16: hipLaunchKernelGGL(skr::offset_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case SKR_F32: hipLaunchKernelGGL(skr::offset_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case SKR_F64: hipLaunchKernelGGL(skr::offset_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case SKR_BF16: skr::launch_offset<__bf16>(a, s); break;
+    case SKR_F16: skr::launch_offset<_Float16>(a, s); break;
+    case SKR_F32: skr::launch_offset<float>(a, s); break;
+    case SKR_F64: skr::launch_offset<double>(a, s); break;
     default: return SKR_ERR_DTYPE;
   }
   return status_of_launch();

@@ -64,7 +64,7 @@ def test_random_generator(dev):
     assert abs(big.mean().item()) < 5e-3 and abs(big.std().item() - 1) < 5e-3 and abs((big**4).mean().item() - 3) < 0.05
 
 
-@pytest.mark.parametrize(("unit", "props"), [((4, 16, 16), PN.OffsetProps()), ((4, 33, 20), PN.OffsetProps(dims=(0, 2), strength=0.5)), ((16, 8, 8), PN.OffsetProps(dims=(1,), strength=1.5)), ((3, 5), PN.OffsetProps(dims=(-1,))), ((2, 3, 8, 8), PN.OffsetProps(dims=(0, 1)))])
+@pytest.mark.parametrize(("unit", "props"), [((4, 16, 16), PN.OffsetProps()), ((4, 33, 20), PN.OffsetProps(dims=(0, 2), strength=0.5)), ((16, 8, 8), PN.OffsetProps(dims=(1,), strength=1.5)), ((3, 5), PN.OffsetProps(dims=(-1,))), ((2, 3, 8, 8), PN.OffsetProps(dims=(0, 1))), ((4, 8, 16), PN.OffsetProps(dims=(-1,))), ((4, 8, 16), PN.OffsetProps(dims=(0, 2), strength=0.7))])
 def test_offset(unit, props, dev):
     seeds = [11, 12]
     g = PN.BatchTensorNoise.from_batch_inputs(PN.Offset, unit, seeds, props=props, dtype=torch.float32)
@@ -77,6 +77,31 @@ def test_offset(unit, props, dev):
             draws = [spec_normal(s, n * 256 + 1, ON.offset_shape(unit, dims)), spec_normal(s, n * 256, unit)]
             refs.append(ON.offset_noise(unit, ON.Replay(draws).randn, dims, props.strength))
         assert rel(got, torch.stack(refs)) < TOL, (unit, props, n)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, torch.float64])
+def test_vector_and_generic_kernels_agree_bitwise(dtype, dev):
+    "the packed 8-wide kernels (aligned base) and the generic ones (base off by one element) must write the same bits"
+    import ctypes
+
+    lib, unit, batch = _hip.load(), (4, 8, 16), 3
+    numel = 4 * 8 * 16
+    seeds = torch.tensor([21, 22, 23], dtype=torch.int64, device=dev)
+    hs = _hip.current_stream_ptr(seeds.device)
+    code = _hip.DTYPE_CODE[dtype]
+    for mask in (None, 1, 4, 5):
+        buf = torch.zeros(2, batch * numel + 8, dtype=dtype, device=dev)
+        for row, shift in ((0, 0), (1, 1)):
+            ptr = buf[row, shift:].data_ptr()
+            if mask is None:
+                _hip.check(lib.skr_noise_random(ptr, code, seeds.data_ptr(), 512, batch, numel, hs), "skr_noise_random")
+            else:
+                shape = (ctypes.c_int64 * 3)(*unit)
+                _hip.check(lib.skr_noise_offset(ptr, code, seeds.data_ptr(), 512, 513, batch, shape, 3, mask, 0.6, hs), "skr_noise_offset")
+        torch.cuda.synchronize()
+        fast, generic = buf[0, : batch * numel], buf[1, 1 : batch * numel + 1]
+        assert torch.equal(fast, generic), (dtype, mask)
+        assert fast.float().std().item() > 0.5 and (buf[0, batch * numel :] == 0).all() and (buf[1, 0] == 0).all()
 
 
 def test_offset_static_and_dtypes(dev):
