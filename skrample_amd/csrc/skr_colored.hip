@@ -57,12 +57,20 @@ __device__ __forceinline__ float2 twid(const float2* tw, int idx) {
 template <bool INVERSE>
 __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, int logN, int L) {
   const int half_n = N >> 1, ld = N + 1;
+  // Work-item -> (line, k) mapping.  Early stages (butterfly span h < 32) touch points 4h apart, which lands
+  // consecutive k on the same LDS banks; there consecutive lanes take consecutive LINES instead (line stride
+  // N+1 complex is odd, so 32 lanes cover all 64 banks and share one twiddle).  t / L by multiply-high
+  // (exact for t, L < 2^16).
+  const bool by_line = L >= 32;
+  const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
   int s = 0;
   if (logN & 1) {  // leftover radix-2 stage first (half = 1, twiddle = 1)
     __syncthreads();
     const int total = L * half_n;
     for (int t = threadIdx.x; t < total; t += blockDim.x) {
-      const int line = t >> (logN - 1), k = t & (half_n - 1);
+      int line, k;
+      if (by_line) { k = (int)__umulhi((uint32_t)t, magic); line = t - k * L; }
+      else { line = t >> (logN - 1); k = t & (half_n - 1); }
       float2* p = buf + line * ld + 2 * k;
       const float2 a = p[0], b = p[1];
       p[0] = make_float2(a.x + b.x, a.y + b.y);
@@ -76,8 +84,11 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
     const int step1 = half_n >> s, step2 = half_n >> (s + 1);
     __syncthreads();
     const int total = L * quarter;
+    const bool line_major = by_line && h < 32;
     for (int t = threadIdx.x; t < total; t += blockDim.x) {
-      const int line = t >> (logN - 2), k = t & (quarter - 1);
+      int line, k;
+      if (line_major) { k = (int)__umulhi((uint32_t)t, magic); line = t - k * L; }
+      else { line = t >> (logN - 2); k = t & (quarter - 1); }
       const int pos = k & (h - 1);
       float2* p = buf + line * ld + ((k >> s) << (s + 2)) + pos;
       float2 e0 = p[0], e1 = p[h], e2 = p[2 * h], e3 = p[3 * h];
@@ -202,9 +213,11 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
 // MODE 0: white noise -> rows (two-for-one) -> columns -> half spectrum to HBM          (replaces passes A + B)
 // MODE 1: half spectrum -> columns^-1 -> rows^-1 -> real plane + statistics            (replaces passes D + E)
 // MODE 2: both, with the radial weights applied in LDS in between (2-D units: the spectrum never leaves the CU)
-// LDS: T1 = (d2/2) x (d3+1) complex (row pairs), T2 = d3h x (d2+1) complex (columns), plus both twiddle tables;
-// the host only selects these kernels when that fits (128 x 128 planes: 134 KiB).
-constexpr int PLANE_THREADS = 1024;
+// The row tile ((d2/2) x (d3+1) complex, row pairs) and the column tile (d3h x (d2+1) complex) share ONE LDS
+// region: the transposing steps between them stage every item in registers across a barrier.  A 128 x 128 plane
+// then needs 67 KiB, so two blocks fit a CU and one block's HBM phase overlaps the other's butterflies.
+constexpr int PLANE_THREADS = 512;
+constexpr int PLANE_ITEMS = 18;  // staged items per thread: the host keeps (d2/2)*max(d3h, d3) <= PLANE_THREADS * PLANE_ITEMS
 
 template <int MODE>
 __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs a, int logH, int logW) {
@@ -212,11 +225,11 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
   const int H = a.d2, W = a.d3, WH = a.d3h, ldw = W + 1, ldh = H + 1, pairs = H >> 1;
   float2* tw_w = smem;
   float2* tw_h = tw_w + W / 2;
-  float2* t1 = tw_h + H / 2;
-  float2* t2 = t1 + pairs * ldw;
+  float2* t1 = tw_h + H / 2;  // row-pair tile
+  float2* t2 = t1;            // column tile (aliases t1)
   const int64_t smp = blockIdx.y;
   const int i1 = blockIdx.x;
-  const int nthr = blockDim.x;
+  const uint32_t magic_wh = (uint32_t)((0x100000000ull + (uint32_t)WH - 1) / (uint32_t)WH);  // q / WH == umulhi(q, magic) for q < 2^16
   make_twiddles(tw_w, W);
   make_twiddles(tw_h, H);
   float2* plane = a.spec + ((smp * a.d1 + i1) * (int64_t)H) * WH;
@@ -224,81 +237,115 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
 
   if (MODE != 1) {
     const uint64_t seed = a.seeds[smp];
-    for (int q = threadIdx.x; q < pairs * (W / 4); q += nthr) {
+    for (int q = threadIdx.x; q < pairs * (W / 4); q += PLANE_THREADS) {
       const int pr = q >> (logW - 2), n4 = (q & (W / 4 - 1)) * 4;
       const int64_t ea = ((int64_t)i1 * H + 2 * pr) * W + n4;
       float za[4], zb[4];
       normal4(seed, a.stream, (uint64_t)ea >> 2, za);
       normal4(seed, a.stream, (uint64_t)(ea + W) >> 2, zb);
+      float p1 = 0.f, p2 = 0.f;  // 8 values in fp32, then one widening add: the per-block totals stay double
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         t1[pr * ldw + brev(n4 + j, logW)] = make_float2(za[j], zb[j]);
-        s1 += (double)za[j] + (double)zb[j];
-        s2 += (double)za[j] * (double)za[j] + (double)zb[j] * (double)zb[j];
+        p1 += za[j] + zb[j];
+        p2 = __builtin_fmaf(za[j], za[j], __builtin_fmaf(zb[j], zb[j], p2));
       }
+      s1 += (double)p1; s2 += (double)p2;
     }
     fft_tile<false>(t1, tw_w, W, logW, pairs);
-    // untangle the row pairs straight into the column tile (bit-reversed along H for the column transform)
-    for (int q = threadIdx.x; q < pairs * WH; q += nthr) {
-      const int pr = q / WH, k = q - pr * WH;
-      const float2 zk = t1[pr * ldw + k], zn = t1[pr * ldw + ((W - k) & (W - 1))];
-      t2[k * ldh + brev(2 * pr, logH)] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-      t2[k * ldh + brev(2 * pr + 1, logH)] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    {
+      // untangle the row pairs into the column tile (bit-reversed along H for the column transform)
+      float2 ra[PLANE_ITEMS], rb[PLANE_ITEMS];
+      const int total = pairs * WH;
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = threadIdx.x + i * PLANE_THREADS;
+        if (q < total) {
+          const int pr = (int)__umulhi((uint32_t)q, magic_wh), k = q - pr * WH;
+          const float2 zk = t1[pr * ldw + k], zn = t1[pr * ldw + ((W - k) & (W - 1))];
+          ra[i] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+          rb[i] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = threadIdx.x + i * PLANE_THREADS;
+        if (q < total) {
+          const int pr = (int)__umulhi((uint32_t)q, magic_wh), k = q - pr * WH;
+          t2[k * ldh + brev(2 * pr, logH)] = ra[i];
+          t2[k * ldh + brev(2 * pr + 1, logH)] = rb[i];
+        }
+      }
     }
     fft_tile<false>(t2, tw_h, H, logH, WH);
     block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
     if (MODE == 0) {
-      for (int q = threadIdx.x; q < H * WH; q += nthr) {
-        const int row = q / WH, k = q - row * WH;
+      for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
+        const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
         plane[q] = t2[k * ldh + row];
       }
       return;
     }
     // MODE 2: weights in place, then bit-reverse the columns for the inverse transform
-    for (int q = threadIdx.x; q < H * WH; q += nthr) {
+    for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
       const int k = q >> logH, row = q & (H - 1);
-      const float f2 = axis_freq(row, H), f3 = (float)k / (float)W;
-      float radius = sqrtf(f2 * f2 + f3 * f3) * a.inv_rmax;
+      const float f1 = 0.f, f2 = axis_freq(row, H), f3 = (float)k / (float)W;
+      float radius = sqrtf(f1 * f1 + f2 * f2 + f3 * f3) * a.inv_rmax;
       radius = radius < a.eps_clip ? a.eps_clip : radius;
       const float wgt = powf(radius, a.exponent_half_neg);
       float2 v = t2[k * ldh + row];
       t2[k * ldh + row] = make_float2(v.x * wgt, v.y * wgt);
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < H * WH; q += nthr) {
+    for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
       const int k = q >> logH, row = q & (H - 1);
       const int r = (int)brev(row, logH);
       if (row < r) { float2 t = t2[k * ldh + row]; t2[k * ldh + row] = t2[k * ldh + r]; t2[k * ldh + r] = t; }
     }
   } else {
-    for (int q = threadIdx.x; q < H * WH; q += nthr) {
-      const int row = q / WH, k = q - row * WH;
+    for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
+      const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
       t2[k * ldh + brev(row, logH)] = plane[q];
     }
   }
 
   fft_tile<true>(t2, tw_h, H, logH, WH);
-  // pack row pairs (Hermitian expansion along W), bit-reversed along W
-  for (int q = threadIdx.x; q < pairs * W; q += nthr) {
-    const int pr = q >> logW, k = q & (W - 1);
-    const int m = k < WH ? k : W - k;
-    float2 xa = t2[m * ldh + 2 * pr], xb = t2[m * ldh + 2 * pr + 1];
-    if (m == 0 || 2 * m == W) { xa.y = 0.f; xb.y = 0.f; }
-    if (k >= WH) { xa.y = -xa.y; xb.y = -xb.y; }
-    t1[pr * ldw + brev(k, logW)] = make_float2(xa.x - xb.y, xa.y + xb.x);
+  {
+    // pack row pairs (Hermitian expansion along W), bit-reversed along W
+    float2 rz[PLANE_ITEMS];
+    const int total = pairs * W;
+#pragma unroll
+    for (int i = 0; i < PLANE_ITEMS; ++i) {
+      const int q = threadIdx.x + i * PLANE_THREADS;
+      if (q < total) {
+        const int pr = q >> logW, k = q & (W - 1);
+        const int m = k < WH ? k : W - k;
+        float2 xa = t2[m * ldh + 2 * pr], xb = t2[m * ldh + 2 * pr + 1];
+        if (m == 0 || 2 * m == W) { xa.y = 0.f; xb.y = 0.f; }
+        if (k >= WH) { xa.y = -xa.y; xb.y = -xb.y; }
+        rz[i] = make_float2(xa.x - xb.y, xa.y + xb.x);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PLANE_ITEMS; ++i) {
+      const int q = threadIdx.x + i * PLANE_THREADS;
+      if (q < total) t1[(q >> logW) * ldw + brev(q & (W - 1), logW)] = rz[i];
+    }
   }
   fft_tile<true>(t1, tw_w, W, logW, pairs);
   const float scale = 1.0f / ((float)a.d1 * (float)H * (float)W);
   float* dst = a.real_out + ((smp * a.d1 + i1) * (int64_t)H) * W;
   s1 = 0.0; s2 = 0.0;
-  for (int q = threadIdx.x; q < pairs * W; q += nthr) {
+  for (int q = threadIdx.x; q < pairs * W; q += PLANE_THREADS) {
     const int pr = q >> logW, n = q & (W - 1);
     const float2 z = t1[pr * ldw + n];
     const float va = z.x * scale, vb = z.y * scale;
     dst[(int64_t)(2 * pr) * W + n] = va;
     dst[(int64_t)(2 * pr + 1) * W + n] = vb;
-    s1 += (double)va + (double)vb;
-    s2 += (double)va * (double)va + (double)vb * (double)vb;
+    s1 += (double)(va + vb);
+    s2 += (double)__builtin_fmaf(va, va, vb * vb);
   }
   block_sums(s1, s2, a.partials + ((1 * a.batch + smp) * a.n_slots + i1) * 2);
 }
@@ -505,8 +552,10 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
 
   const int64_t d3h = a.d3h;
   // fused plane kernels when one d2 x d3 plane (+ its half spectrum) fits the CU's LDS
-  const size_t lds_plane = sizeof(float2) * ((size_t)d3 / 2 + d2 / 2 + (size_t)(d2 / 2) * (d3 + 1) + (size_t)d3h * (d2 + 1));
-  const bool fused = lds_plane <= 150 * 1024 && getenv("SKR_FFT_NO_FUSE") == nullptr;
+  const size_t tile_points = (size_t)(d2 / 2) * (d3 + 1) > (size_t)d3h * (d2 + 1) ? (size_t)(d2 / 2) * (d3 + 1) : (size_t)d3h * (d2 + 1);
+  const size_t lds_plane = sizeof(float2) * ((size_t)d3 / 2 + d2 / 2 + tile_points);
+  const bool fused = lds_plane <= 150 * 1024 && (int64_t)(d2 / 2) * d3 <= PLANE_THREADS * PLANE_ITEMS && (int64_t)(d2 / 2) * d3h <= PLANE_THREADS * PLANE_ITEMS &&
+                     getenv("SKR_FFT_NO_FUSE") == nullptr;
   auto outer_axis = [&]() -> int {
     // axis 1 (length d1, stride d2*d3h): forward, radial weights, inverse in one pass
     if (d1 <= 16) {
