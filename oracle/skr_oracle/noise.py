@@ -1,6 +1,10 @@
 """Noise generators (torch CPU restatement) and the counter-based RNG specification used by the
-HIP kernels.  Follows reference skrample/pytorch/noise.py (all but Brownian, whose arithmetic lives
-in the un-vendored torchsde).
+HIP kernels.  Follows reference skrample/pytorch/noise.py.  Brownian is the exception: its arithmetic
+lives in the un-vendored dependency torchsde (>=0.2.6, pyproject.toml:22; call site noise.py:222-242), so
+`brownian_noise` below restates the published construction (Brownian-bridge bisection of [0,1]; Li et al. 2020
+"Scalable gradients for SDEs" virtual Brownian tree / Kidger et al. 2021 Brownian Interval) on the Philox
+streams and is PARITY UNPINNED against torchsde's own random values -- only the law (variance, independence,
+additivity over adjacent steps) and the reference's call-site arithmetic (normalise, clamp, / sqrt(dt)) are pinned.
 
 Every generator takes its random draws through small callables (`randn(shape)`, `rand1()`), so the
 deterministic part (offset broadcast, pyramid up-sampling + blend, spectral colouring, per-sample
@@ -268,3 +272,39 @@ def philox_normal(seed: int, stream: int, n: int, offset: int = 0) -> np.ndarray
     flat = box_muller(philox4x32(ctr, key)).reshape(-1)
     start = offset - (offset // 4) * 4
     return flat[start : start + n]
+
+
+# ---- Brownian (reference noise.py:210-242; tree from torchsde, see the module header) -------------------
+BROWNIAN_STREAMS = 1 << 63
+
+
+def brownian_depth(max_steps: int = 10_000) -> int:
+    return math.ceil(math.log2(max_steps * 10)) + 2
+
+
+def brownian_value(seed: int, n: int, t: float, depth: int) -> np.ndarray:
+    """W(t) for n elements of one sample (float64), by explicit bisection: W(0) = 0, W(1) = Z_0 and for the dyadic
+    interval with heap index h (root 1, children 2h, 2h+1): W(mid) = (W(a)+W(b))/2 + sqrt(b-a)/2 * Z_h, with
+    Z_h = philox_normal(seed, 2^63 | h); linear inside a leaf after `depth` levels."""
+    lo, hi, node = 0.0, 1.0, 1
+    w_lo = np.zeros(n)
+    w_hi = philox_normal(seed, BROWNIAN_STREAMS | 0, n).astype(np.float64)
+    for _ in range(depth):
+        if t == lo or t == hi:
+            break
+        mid = 0.5 * (lo + hi)
+        w_mid = 0.5 * (w_lo + w_hi) + 0.5 * math.sqrt(hi - lo) * philox_normal(seed, BROWNIAN_STREAMS | node, n).astype(np.float64)
+        if t < mid:
+            hi, w_hi, node = mid, w_mid, 2 * node
+        else:
+            lo, w_lo, node = mid, w_mid, 2 * node + 1
+    f = (t - lo) / (hi - lo)
+    return (1 - f) * w_lo + f * w_hi
+
+
+def brownian_noise(seed: int, shape, step, max_steps: int = 10_000) -> torch.Tensor:
+    "Brownian.generate (noise.py:238-242): step.normal().clamp(), then tree(t0, t1) / sqrt(distance); fp64 result"
+    t0, t1 = stp_clamp(stp_normal(step))
+    n, depth = math.prod(shape), brownian_depth(max_steps)
+    inc = brownian_value(seed, n, t1, depth) - brownian_value(seed, n, t0, depth)
+    return torch.from_numpy(inc / math.sqrt(t1 - t0)).reshape(tuple(shape))

@@ -92,6 +92,91 @@ extern "C" int skr_noise_random(void* out, int32_t out_dtype, const uint64_t* se
   return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
 }
 
+// ---- weighted sum of Philox normal streams (Brownian increments) -----------------------------------------
+struct WeightedArgs {
+  uint64_t stream_ids[SKR_MAX_WEIGHTED_STREAMS];
+  float weights[SKR_MAX_WEIGHTED_STREAMS];
+  int32_t n;
+};
+
+// ALIGNED: sample_numel % 8 == 0 and a 16-byte aligned base -> blockIdx.y = sample, 8 elements per thread, packed
+// store.  Otherwise one Philox block (4 elements) per thread with bounds checks.  Stream ids and weights are
+// wave-uniform (scalar loads from the kernel arguments); fp32 FMA accumulation in stream order.
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(256) void weighted_kernel(T* out, const uint64_t* seeds, const WeightedArgs a, int64_t sample_numel, int64_t blocks_per_sample, int64_t total_blocks) {
+  if constexpr (ALIGNED) {
+    const int64_t smp = blockIdx.y, vps = sample_numel >> 3;
+    const uint64_t seed = seeds[smp];
+    T* dst = out + smp * sample_numel;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < vps; v += (int64_t)gridDim.x * 256) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < a.n; ++k) {
+        float z[8];
+        skr::normal4(seed, a.stream_ids[k], (uint64_t)(2 * v), z);
+        skr::normal4(seed, a.stream_ids[k], (uint64_t)(2 * v + 1), z + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(a.weights[k], z[j], acc[j]);
+      }
+      skr::store8_from_f32<T>(dst, v, acc);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_blocks; i += (int64_t)gridDim.x * 256) {
+      const int64_t smp = i / blocks_per_sample, blk = i - smp * blocks_per_sample;
+      const uint64_t seed = seeds[smp];
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < a.n; ++k) {
+        float z[4];
+        skr::normal4(seed, a.stream_ids[k], (uint64_t)blk, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(a.weights[k], z[j], acc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (blk * 4 + j < sample_numel) out[smp * sample_numel + blk * 4 + j] = (T)acc[j];
+      }
+    }
+  }
+}
+
+template <typename T>
+static void launch_weighted(void* out, const uint64_t* seeds, const WeightedArgs& a, int64_t batch, int64_t sample_numel, hipStream_t s) {
+  const bool fast = sample_numel % 8 == 0 && batch <= 65535 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  const int64_t bps = (sample_numel + 3) / 4, total = bps * batch;
+  if (fast) {
+    int64_t bx = (sample_numel / 8 + 255) / 256;
+    const int64_t cap = (256 * 16 + batch - 1) / batch;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL((weighted_kernel<T, true>), dim3((unsigned)bx, (unsigned)batch), dim3(256), 0, s, (T*)out, seeds, a, sample_numel, bps, total);
+    return;
+  }
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL((weighted_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)out, seeds, a, sample_numel, bps, total);
+}
+
+extern "C" int skr_noise_weighted(void* out, int32_t out_dtype, const uint64_t* seeds_dev, const uint64_t* stream_ids, const double* weights,
+                                  int32_t n_streams, int64_t batch, int64_t sample_numel, void* stream) {
+  if (batch < 0 || sample_numel < 0 || n_streams < 0) return SKR_ERR_SHAPE;
+  if (n_streams > SKR_MAX_WEIGHTED_STREAMS) return SKR_ERR_UNSUPPORTED;
+  if (batch == 0 || sample_numel == 0) return SKR_OK;
+  if (!out || !seeds_dev || (n_streams > 0 && (!stream_ids || !weights))) return SKR_ERR_NULL;
+  WeightedArgs a;
+  for (int k = 0; k < SKR_MAX_WEIGHTED_STREAMS; ++k) {
+    a.stream_ids[k] = k < n_streams ? stream_ids[k] : 0;
+    a.weights[k] = k < n_streams ? (float)weights[k] : 0.f;
+  }
+  a.n = n_streams;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (out_dtype) {
+    case SKR_BF16: launch_weighted<__bf16>(out, seeds_dev, a, batch, sample_numel, s); break;
+    case SKR_F16: launch_weighted<_Float16>(out, seeds_dev, a, batch, sample_numel, s); break;
+    case SKR_F32: launch_weighted<float>(out, seeds_dev, a, batch, sample_numel, s); break;
+    case SKR_F64: launch_weighted<double>(out, seeds_dev, a, batch, sample_numel, s); break;
+    default: return SKR_ERR_DTYPE;
+  }
+  return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}
+
 __global__ void philox_dump_kernel(uint32_t* out, uint64_t seed, uint64_t stream_id, uint64_t first, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

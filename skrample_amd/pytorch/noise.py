@@ -16,7 +16,8 @@ Pyramid :116-207, Colored :255-435, BatchTensorNoise :438-466).  What differs:
   the deterministic stages (offset broadcast, pyramid up-sampling, spectral colouring, per-sample
   normalisation) are parity-tested on injected draws (tests/test_noise_gpu.py).
 
-`Brownian` (torchsde-backed in the reference) is out of scope for this engine.
+`Brownian` (torchsde.BrownianInterval in the reference, :210-242) is a stateless virtual Brownian tree here:
+W(t) is a fixed linear function of Philox-keyed node normals, walked on the host in fp64 and summed in one launch.
 """
 
 from __future__ import annotations
@@ -24,6 +25,7 @@ from __future__ import annotations
 import math
 from abc import ABC, abstractmethod
 from dataclasses import dataclass, field
+from functools import lru_cache
 from typing import Any, Sequence
 
 import torch
@@ -357,18 +359,75 @@ class Colored(TensorNoiseCommon):
         return out
 
 
+BROWNIAN_STREAMS = 1 << 63  # Philox stream namespace of the tree nodes (disjoint from the per-draw streams n*256+k)
+
+
+def brownian_depth(max_steps: int) -> int:
+    "dyadic levels below [0,1]: leaves are 4x finer than the reference's tolerance 1/(10*max_steps) (noise.py:230)"
+    return math.ceil(math.log2(max_steps * 10)) + 2
+
+
+def brownian_path(t: float, depth: int) -> dict[int, float]:
+    """W(t), t in [0,1], as weights over independent standard normals.  Node 0 is W(1); node h >= 1 is the
+    Brownian-bridge normal of the dyadic interval with heap index h (root [0,1] = 1, children 2h / 2h+1):
+    W(mid) = (W(a) + W(b))/2 + sqrt(b-a)/2 * Z_h.  Below `depth` levels the path is linear inside the leaf.
+    All arithmetic is on dyadic rationals, exact in fp64 except the final interpolation."""
+    lo, hi, node = 0.0, 1.0, 1
+    w_lo: dict[int, float] = {}
+    w_hi: dict[int, float] = {0: 1.0}
+    for _ in range(depth):
+        if t == lo or t == hi:
+            break
+        mid = 0.5 * (lo + hi)
+        w_mid = {k: 0.5 * (w_lo.get(k, 0.0) + w_hi.get(k, 0.0)) for k in {*w_lo, *w_hi}}
+        w_mid[node] = 0.5 * math.sqrt(hi - lo)
+        if t < mid:
+            hi, w_hi, node = mid, w_mid, 2 * node
+        else:
+            lo, w_lo, node = mid, w_mid, 2 * node + 1
+    f = (t - lo) / (hi - lo)
+    return {k: (1 - f) * w_lo.get(k, 0.0) + f * w_hi.get(k, 0.0) for k in {*w_lo, *w_hi}}
+
+
+@lru_cache(maxsize=4096)
+def brownian_increment(time_from: float, time_to: float, depth: int) -> tuple[tuple[int, ...], tuple[float, ...]]:
+    "(node ids, weights) of (W(time_to) - W(time_from)) / sqrt(time_to - time_from); unit variance up to the leaf interpolation"
+    a, b = brownian_path(time_from, depth), brownian_path(time_to, depth)
+    scale = 1.0 / math.sqrt(time_to - time_from)
+    nodes = sorted({*a, *b})
+    weights = [(b.get(k, 0.0) - a.get(k, 0.0)) * scale for k in nodes]
+    keep = [(k, w) for k, w in zip(nodes, weights) if w != 0.0]
+    return tuple(k for k, _ in keep), tuple(w for _, w in keep)
+
+
 @dataclass
 class Brownian(TensorNoiseCommon):
-    def _setup(self) -> None:
-        raise SkrampleHipError("Brownian noise (torchsde BrownianInterval in the reference) is outside this engine's scope")
+    """Noise that is a deterministic function of the Step: increments of one fixed Brownian path per seed, so
+    overlapping / adjacent steps are consistent (reference noise.py:210-242, there via torchsde.BrownianInterval).
+    Here the path is a virtual dyadic tree keyed by Philox -- every query is one launch, no tree state."""
 
     @classmethod
     def from_inputs(cls, shape, seed, props=BrownianProps(), dtype=torch.float32):
         return cls(tuple(shape), seed, dtype, props)
 
     @classmethod
-    def _batch(cls, *a, **k):
-        raise SkrampleHipError("Brownian noise is outside this engine's scope")
+    def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
+        import ctypes
+
+        if not step:
+            return Random._batch(unit_shape, seeds, stream, step, props, dtype, state)
+        step = step.normal().clamp()
+        depth = brownian_depth(props.max_steps)
+        nodes, weights = brownian_increment(float(step.time_from), float(step.time_to), depth)
+        if len(nodes) > 64:
+            raise SkrampleHipError(f"Brownian max_steps={props.max_steps} needs {len(nodes)} tree nodes per query (limit 64)")
+        out = torch.empty((seeds.shape[0], *unit_shape), dtype=dtype, device=seeds.device)
+        lib, hstream = _launch_ctx(seeds)
+        ids = (ctypes.c_uint64 * len(nodes))(*[BROWNIAN_STREAMS | n for n in nodes])
+        wts = (ctypes.c_double * len(nodes))(*weights)
+        numel = math.prod(unit_shape)
+        _hip.check(lib.skr_noise_weighted(out.data_ptr(), _hip.DTYPE_CODE[dtype], seeds.data_ptr(), ids, wts, len(nodes), seeds.shape[0], numel, hstream), "skr_noise_weighted")
+        return out
 
 
 @dataclass

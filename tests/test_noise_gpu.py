@@ -6,6 +6,8 @@ test_noise_fixtures); here the same stages consume the normals/uniforms that the
 result.  Draw n of a generator owns Philox streams n*256 + k: k=0 base normal, k=1.. auxiliary normals,
 k=255 uniforms."""
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -77,6 +79,51 @@ def test_offset(unit, props, dev):
             draws = [spec_normal(s, n * 256 + 1, ON.offset_shape(unit, dims)), spec_normal(s, n * 256, unit)]
             refs.append(ON.offset_noise(unit, ON.Replay(draws).randn, dims, props.strength))
         assert rel(got, torch.stack(refs)) < TOL, (unit, props, n)
+
+
+@pytest.mark.parametrize("unit", [(4, 16, 16), (3, 5, 7)])
+def test_brownian(unit, dev):
+    "increments of one fixed Brownian path per seed: oracle parity, additivity over adjacent steps, determinism"
+    seeds = [31, 32]
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, props=PN.BrownianProps(), dtype=torch.float32)
+    steps = [Step(0.35, 0.4), Step(0.4, 0.45), Step(0.35, 0.45), Step(0.0, 0.05), Step(0.95, 1.0), Step(0.5, 0.75)]
+    got = {s: g.generate(s).cpu().double() for s in steps}
+    for s, v in got.items():
+        ref = torch.stack([ON.brownian_noise(seed, unit, s) for seed in seeds])
+        assert rel(v, ref) < TOL, s
+    a, b, ab = got[steps[0]], got[steps[1]], got[steps[2]]
+    assert rel((a + b) * math.sqrt(0.05), ab * math.sqrt(0.1)) < 1e-5  # W(.35,.4) + W(.4,.45) = W(.35,.45)
+    assert torch.equal(g.generate(Step(0.4, 0.35)).cpu().double(), a)  # direction-normalised, stateless
+    assert torch.equal(g.generate(Step(1.0, 1.05)).cpu().double(), got[steps[4]])  # clamped into [0,1]
+    assert not torch.equal(a[0], a[1])
+    white = g.generate(None)  # no step: plain white noise, a fresh draw each call
+    assert white.shape == (2, *unit) and not torch.equal(white, g.generate(None))
+    h = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, props=PN.BrownianProps(), dtype=torch.bfloat16).generate(steps[0])
+    assert h.dtype == torch.bfloat16 and (h.cpu().double() - a).abs().max() <= 2.0**-6
+
+
+def test_brownian_statistics_and_wrapper(dev):
+    from skrample_amd import scheduling
+    from skrample_amd.diffusers import SkrampleWrapperScheduler
+    from skrample_amd.sampling import structured
+
+    unit, seeds = (4, 64, 64), list(range(8))
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, dtype=torch.float32)
+    incs = [g.generate(Step.from_int(k, 20)).double() for k in range(20)]
+    for v in incs[:4]:
+        assert abs(v.mean().item()) < 8e-3 and abs(v.std().item() - 1) < 8e-3 and abs((v**4).mean().item() - 3) < 0.08
+    for u, v in ((incs[0], incs[1]), (incs[3], incs[9]), (incs[18], incs[19])):
+        assert abs((u * v).mean().item()) < 8e-3  # disjoint increments are independent
+    total = sum(incs) * math.sqrt(1 / 20)  # = W(1), a unit normal
+    assert abs(total.std().item() - 1) < 8e-3
+    assert rel(total.float(), g.generate(Step(0.0, 1.0)).double().float()) < 1e-4
+
+    w = SkrampleWrapperScheduler(structured.DPM(order=2, stochasticity=1.0), scheduling.Karras(scheduling.Scaled()), noise_type=PN.Brownian)
+    w.set_timesteps(6)
+    x = torch.randn(2, *unit, device=dev, dtype=torch.bfloat16)
+    for t in w.timesteps:
+        x = w.step(torch.randn_like(x), t, x, generator=[torch.Generator().manual_seed(3), torch.Generator().manual_seed(4)], return_dict=False)[0]
+    assert torch.isfinite(x.float()).all()
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, torch.float64])

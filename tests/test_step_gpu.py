@@ -681,5 +681,3 @@ def test_noise_seeding_rules(dev):
     x1 = x3[:1].contiguous()
     f, w1 = run(x1.shape, torch.Generator().manual_seed(1), x1)
     assert torch.equal(f, d[:1]) and len(w1._noise_generator.generators) == 1  # same seed, same item => same result
-    with pytest.raises(_hip.SkrampleHipError):
-        PN.Brownian.from_inputs((4, 8, 8), 1)

@@ -17,3 +17,4 @@ for B, unit in [(256,(16,128,128)), (64,(4,128,128)), (64,(4,256,256)), (256,(4,
     timeit(f"Offset   B={B} {unit}", PN.BatchTensorNoise.from_batch_inputs(PN.Offset, unit, seeds, props=PN.OffsetProps(), dtype=torch.bfloat16), None)
     timeit(f"Pyramid  B={B} {unit}", PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=PN.PyramidProps(), dtype=torch.bfloat16), None)
     timeit(f"Colored  B={B} {unit}", PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.bfloat16), Step(0.45,0.5))
+    timeit(f"Brownian B={B} {unit}", PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, props=PN.BrownianProps(), dtype=torch.bfloat16), Step(0.45,0.5))

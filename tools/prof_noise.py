@@ -7,6 +7,9 @@ B, unit = 256, (16,128,128)
 seeds = list(range(B))
 g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.bfloat16)
 p = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, (4,256,256), list(range(64)), props=PN.PyramidProps(), dtype=torch.bfloat16)
+o = PN.BatchTensorNoise.from_batch_inputs(PN.Offset, unit, seeds, props=PN.OffsetProps(), dtype=torch.bfloat16)
+r = PN.BatchTensorNoise.from_batch_inputs(PN.Random, unit, seeds, dtype=torch.bfloat16)
+br = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, dtype=torch.bfloat16)
 for _ in range(10):
-    g.generate(Step(0.45,0.5)); p.generate(None)
+    g.generate(Step(0.45,0.5)); p.generate(None); o.generate(None); r.generate(None); br.generate(Step(0.45,0.5))
 torch.cuda.synchronize()
