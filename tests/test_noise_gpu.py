@@ -352,3 +352,45 @@ def test_generators_full_size_properties(kind, props, unit, batch, dev):
     assert torch.isfinite(x).all()
     assert (x.std(dim=1) - 1).abs().max() < (0.02 if kind is not PN.Offset else 0.05)
     assert x.mean(dim=1).abs().max() < (0.05 if kind is not PN.Offset else 0.15)  # Offset: mean of 4 channel offsets ~ N(0, 0.02)
+
+
+@pytest.mark.parametrize(("steps", "begin", "schedule_name"), [(10, 5, "sinner"), (11, 6, "scaled")])
+def test_diffusers_brownian(steps, begin, schedule_name, dev):
+    "mirror of the reference's tests/self_sampling.py:503-537 (Euler-Maruyama, fp64 compute, begin index, one generator)"
+    import skrample_amd.diffusers as PD
+    import skrample_amd.scheduling as PS
+    from skrample_amd.sampling import models as PM
+    from skrample_amd.sampling import structured as PT
+
+    schedule = PS.Sinner(PS.Linear()) if schedule_name == "sinner" else PS.Scaled()
+    wrapper = PD.SkrampleWrapperScheduler(sampler=PT.Euler(stochasticity=1), schedule=schedule, model=PM.DataModel(), compute_scale=torch.float64, noise_type=PN.Brownian)
+    generator = torch.Generator().manual_seed(42)
+    wrapper.set_timesteps(steps)
+    begin *= wrapper.order
+    wrapper.set_begin_index(begin)
+    outs = []
+    for t in wrapper.timesteps[begin:]:
+        outs.append(wrapper.step(torch.randn([1, 16, 128], dtype=torch.float64, device=dev), t, torch.randn([1, 16, 128], dtype=torch.float64, device=dev), return_dict=False, generator=generator)[0])
+    assert all(torch.isfinite(o).all() and o.dtype == torch.float64 for o in outs)
+    assert wrapper._noise_generator is not None and len(wrapper._noise_generator.generators) == 1
+    assert isinstance(wrapper._noise_generator.generators[0], PN.Brownian)
+
+
+@pytest.mark.parametrize(("steps", "begin", "order", "schedule_name"), [(10, 5, 1, "sinner"), (11, 6, 2, "scaled"), (10, 6, 5, "scaled"), (11, 5, 6, "sinner"), (10, 5, 12, "scaled")])
+def test_rku_brownian(steps, begin, order, schedule_name, dev):
+    "mirror of the reference's tests/self_sampling.py:582-623 (RKUltra wrapper with Brownian noise)"
+    import skrample_amd.diffusers as PD
+    import skrample_amd.scheduling as PS
+    from skrample_amd.sampling import models as PM
+
+    schedule = PS.Sinner(PS.Linear()) if schedule_name == "sinner" else PS.Scaled()
+    wrapper = PD.RKUltraWrapperScheduler(schedule=schedule, sampler_order=order, stochasticity=1, model=PM.DataModel(), compute_scale=torch.float64, noise_type=PN.Brownian)
+    generator = torch.Generator().manual_seed(42)
+    wrapper.set_timesteps(steps)
+    begin *= wrapper.order
+    wrapper.set_begin_index(begin)
+    for t in wrapper.timesteps[begin:]:
+        out = wrapper.step(torch.randn([1, 16, 128], dtype=torch.float64, device=dev), t, torch.randn([1, 16, 128], dtype=torch.float64, device=dev), return_dict=False, generator=generator)[0]
+        assert torch.isfinite(out).all()
+    assert wrapper._noise_generator is not None and len(wrapper._noise_generator.generators) == 1
+    assert isinstance(wrapper._noise_generator.generators[0], PN.Brownian)
