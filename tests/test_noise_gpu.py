@@ -249,7 +249,7 @@ def test_pyramid_through_wrapper(dev):
     assert torch.isfinite(x.float()).all() and x.dtype == torch.bfloat16
 
 
-@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104)])
+@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64)])
 def test_colored(unit, dev):
     seeds = [31, 32]
     cases = [

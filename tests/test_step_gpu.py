@@ -564,6 +564,34 @@ def test_whole_loop_graph_capture(dev):
     assert torch.equal(loop(x1, seeds=[9, 8, 7, 6]), eager(x1, [9, 8, 7, 6]))  # new seeds are read from device memory
 
 
+@pytest.mark.parametrize(("wrapper_type", "kw"), [(PD.RKUltraWrapperScheduler, {"sampler_order": 6, "stochasticity": 1.0}), (PD.DynasauRKWrapperScheduler, {"sampler_order": 3})])
+def test_whole_loop_graph_capture_runge_kutta(wrapper_type, kw, dev):
+    "the RK wrappers' stage loop (6 network calls per step for Cash-Karp) is capturable too and replays bit-identically"
+    from skrample_amd.graphs import capture_sampling_loop
+
+    shape, steps, seeds = (3, 4, 16, 32), 4, [3, 4, 5]
+    g = torch.Generator().manual_seed(15)
+    weight = (torch.randn(32, 32, generator=g) * 0.05).to(dev).bfloat16()
+    net = lambda x, t: (x @ weight) + x * (t / 1000)  # noqa: E731
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+
+    def eager(x, sd):
+        w = wrapper_type(PS.Scaled(), **kw)
+        w.set_timesteps(steps)
+        for t in w.timesteps.tolist():
+            x = w.step(net(x, t), t, x, generator=sd, return_dict=False)[0]
+        return x
+
+    w = wrapper_type(PS.Scaled(), **kw)
+    loop = capture_sampling_loop(w, net, x0, steps, seeds=seeds)
+    assert len(w.timesteps) >= steps * 2
+    assert torch.equal(loop(x0), eager(x0, seeds))
+    x1 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    assert torch.equal(loop(x1), eager(x1, seeds))
+    if kw.get("stochasticity"):
+        assert torch.equal(loop(x1, seeds=[9, 8, 7]), eager(x1, [9, 8, 7]))
+
+
 @pytest.mark.parametrize("name", ["Stepanov10", "Feagin14"])
 def test_many_stage_runge_kutta(name, dev):
     """15- and 35-stage tableaux through the RK wrapper: launches with up to 37 operands vs the oracle.
