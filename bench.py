@@ -261,6 +261,23 @@ def main() -> None:
             torch.cuda.synchronize(dev)
             wrapper_rate = SCHEDULE_STEPS / (time.perf_counter() - tw)
 
+    # streaming reference point of this box: runtime device-to-device copy of 512 MiB (read + write
+    # counted), far larger than the 256 MiB Infinity Cache -- context for the roofline fraction, not a target
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbs = 10 * 2 * src.numel() / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
+
     if rank == 0:
         steps_per_s = world * args.steps / wall
         algo_bytes = numel * ALGO_BYTES_PER_ELEM
@@ -300,6 +317,7 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_us_per_launch": kernel_ms * 1e3,
                 "kernel": "skr::step_kernel_k<bf16_t, K=4, NOISE=true, UV=1>",
+                "measured_d2d_memcpy": copy_gbs,  # hipMemcpy D2D of 512 MiB on this box, read+write GB/s
             },
             "wrapper_steps_per_s": wrapper_rate,
         }
