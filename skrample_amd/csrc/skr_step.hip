@@ -10,6 +10,7 @@
 // by us).  The reference equivalent is ~16 separate aten passes + 17 copies per step
 // (SURVEY.md section 8a, rows S2-S12).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/skrample_hip.h"
@@ -225,11 +226,25 @@ template <typename T> __device__ __forceinline__ float rnd(float v) {
 }
 __device__ __forceinline__ double rnd_d(double v) { return v; }
 
-__device__ __forceinline__ float mul_(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float sub_(float a, float b) { return __fsub_rn(a, b); }
+// individually rounded ops: hip's __fmul_rn / __fsub_rn are plain operators that the compiler may still contract
+// into an FMA with a neighbour, so contraction is switched off inside these helpers
+__device__ __forceinline__ float mul_(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float sub_(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
 __device__ __forceinline__ float div_(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ double mul_(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ double sub_(double a, double b) { return __dsub_rn(a, b); }
+__device__ __forceinline__ double mul_(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double sub_(double a, double b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
 __device__ __forceinline__ double div_(double a, double b) { return __ddiv_rn(a, b); }
 
 template <typename T, typename M>
@@ -453,6 +468,65 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k(const FastArgs a) {
   }
 }
 
+// ---- compile-time-K Runge-Kutta stage: rounded pair conversion + chained second output ------------------
+// out0 = convert_rounded(in[0], in[1])            (the stage's derivative, stored in T)
+// out1 = chain*out0 + sum_k c1[k]*in[k]           (next stage input / step result, stored in T)
+// Same arithmetic, in the same order, as step_kernel<..., CONV> -- but every operand is loaded exactly once
+// (the generic kernel fetches the converted pair a second time), all K loads are issued back to back and the
+// term list is a template constant.
+struct RkArgs {
+  const void* in[8];
+  float c1[8];
+  void* out0;
+  void* out1;
+  float chain;
+  float ck[4];
+  int32_t conv_to, conv_from;
+  int64_t numel;
+};
+
+template <typename T, int K, int UV>
+__global__ __launch_bounds__(BLOCK) void step_kernel_rk(const RkArgs a) {
+  const int64_t vhi = a.numel / VEC;
+  const int64_t stride = (int64_t)gridDim.x * (BLOCK * UV);
+  const float k[4] = {a.ck[0], a.ck[1], a.ck[2], a.ck[3]};
+  for (int64_t v0 = (int64_t)blockIdx.x * (BLOCK * UV) + threadIdx.x; v0 < vhi; v0 += stride) {
+    Raw<T> raw[UV][K];
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      if (v0 + u * BLOCK < vhi) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) raw[u][j] = load_raw<T>(a.in[j], v0 + u * BLOCK);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int64_t v = v0 + u * BLOCK;
+      if (v >= vhi) continue;
+      float sv[VEC], ov[VEC], d[VEC], s1[VEC];
+      widen<T, float>(raw[u][0], sv);
+      widen<T, float>(raw[u][1], ov);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        d[i] = convert_rounded<T, float>(sv[i], ov[i], a.conv_to, a.conv_from, k);
+        s1[i] = fma_(a.c1[1], ov[i], fma_(a.c1[0], sv[i], 0.f));
+      }
+#pragma unroll
+      for (int j = 2; j < K; ++j) {
+        float w[VEC];
+        widen<T, float>(raw[u][j], w);
+        const float c = a.c1[j];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s1[i] = fma_(c, w[i], s1[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s1[i] = fma_(a.chain, d[i], s1[i]);
+      store8<T, float>(a.out1, v, s1);
+      store8<T, float>(a.out0, v, d);
+    }
+  }
+}
+
 struct Geometry { dim3 grid; int mode; };
 
 template <int UV, bool NOISE>
@@ -509,6 +583,29 @@ static int launch_k(StepArgs<float>& args, hipStream_t stream, bool& taken) {
   }
 }
 
+template <typename T, int UV>
+static int launch_rk_uv(const StepArgs<float>& args, hipStream_t stream) {
+  Geometry g = geometry<UV, false>(args.numel, args.sample_numel);
+  RkArgs ra;
+  for (int k = 0; k < 8; ++k) { ra.in[k] = k < args.n_terms ? args.in[k] : nullptr; ra.c1[k] = k < args.n_terms ? args.c1[k] : 0.f; }
+  ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
+  for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
+  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel;
+#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_rk<T, N, UV>), g.grid, dim3(BLOCK), 0, stream, ra); break
+  switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
+#undef SKR_K
+  return finish_launch();
+}
+
+template <typename T>
+static int launch_rk(const StepArgs<float>& args, hipStream_t stream) {
+  static const int forced = [] { const char* e = getenv("SKR_RK_UV"); return e ? atoi(e) : 0; }();
+  const int uv = forced ? forced : 1;  // measured on the cfg5 shard: 1, 2 and 4 vectors per lane are within 2 %
+  if (uv == 4) return launch_rk_uv<T, 4>(args, stream);
+  if (uv == 2) return launch_rk_uv<T, 2>(args, stream);
+  return launch_rk_uv<T, 1>(args, stream);
+}
+
 template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bool ST0, bool HAS1, bool NOISE, bool CONV>
 static int launch(StepArgs<Acc>& args, hipStream_t stream) {
   // fast path: uniform 16/32-bit dtype, single output of the same dtype, fp32 accumulate
@@ -518,6 +615,10 @@ static int launch(StepArgs<Acc>& args, hipStream_t stream) {
       const int rc = launch_k<TA, NOISE>(args, stream, taken);
       if (taken) return rc;
     }
+  }
+  // Runge-Kutta stage fast path: uniform dtype in and out, conversion + chained result, no in-kernel noise
+  if constexpr (std::is_same<Acc, float>::value && std::is_same<TA, TB>::value && std::is_same<TO0, TA>::value && std::is_same<TO1, TA>::value && ST0 && HAS1 && CONV && !NOISE) {
+    if (args.n_terms >= 2 && args.n_terms <= 8 && args.numel % VEC == 0) return launch_rk<TA>(args, stream);
   }
   constexpr int UV = uv_for(NOISE, HAS1);
   Geometry g = geometry<UV, NOISE>(args.numel, args.sample_numel);

@@ -274,6 +274,34 @@ def test_c_abi_direct(dev):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize(("kinds", "n_terms"), [((1, 0), 2), ((1, 1), 4), ((2, 2), 7), ((3, 3), 8), ((0, 1), 5)])
+def test_runge_kutta_stage_kernels_agree_bitwise(dtype, kinds, n_terms, dev):
+    """the compile-time-K stage kernel (numel % 8 == 0) and the general kernel (ragged numel, same leading data)
+    must produce the same derivative and the same next stage input, bit for bit"""
+    n = 8 * 1024
+    g = torch.Generator().manual_seed(n_terms)
+    ins_long = [torch.randn(n + 3, generator=g).to(dtype).to(dev) for _ in range(n_terms)]
+    ins_short = [t[:n].clone() for t in ins_long]
+    plan = _hip.StepPlanC()
+    code = _hip.DTYPE_CODE[dtype]
+    plan.n_terms, plan.n_group_a, plan.dtype_a, plan.dtype_b = n_terms, n_terms, code, code
+    plan.out0_dtype, plan.out1_dtype, plan.chain = code, code, 0.3125
+    plan.convert_to, plan.convert_from = kinds
+    for i, v in enumerate((0.7, 0.9, 0.4, 1.3)):
+        plan.convert_k[i] = v
+    for k in range(n_terms):
+        plan.coef0[k], plan.coef1[k] = 0.0, (-1) ** k * (0.2 + 0.1 * k)
+    outs = []
+    for ins, m in ((ins_short, n), (ins_long, n + 3)):
+        o0, o1 = torch.full((m,), 7.0, device=dev, dtype=dtype), torch.full((m,), 7.0, device=dev, dtype=dtype)
+        _hip.launch_step(plan, ins, o0, o1, None, m, dev)
+        outs.append((o0, o1))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0][:n]) and torch.equal(outs[0][1], outs[1][1][:n])
+    assert torch.isfinite(outs[0][0].float()).all() and outs[0][0].float().abs().max() > 0.1
+
+
 def test_wrapper_contract(dev):
     "return types, dtype/device of results, ValueError on unknown timestep, history trimming, no sync for device timesteps"
     w = PD.SkrampleWrapperScheduler(PT.DPM(order=3), PS.Scaled())
