@@ -151,6 +151,52 @@ def test_samplers_vs_oracle(sampler, dev):
             x = ref
 
 
+FLOW_SCHEDULES = ("linear", "flowshift_linear", "sinner_linear", "probit_linear")
+VP_SCHEDULES = ("scaled", "karras_scaled", "hyper_scaled", "exponential_scaled", "scaled_neg_b1", "zsnr", "beta_zsnr_flowshift")
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_sweep_vs_oracle(seed, dev):
+    """seeded random draw over (sampler x schedule x predictor x tensor dtype x ragged shape x run length): the wrapper on
+    the device against the oracle's StepDriver, teacher-forced, injected noise"""
+    import random
+
+    rng = random.Random(1000 + seed)
+    sampler = rng.choice(sorted(SAMPLERS))
+    mk_o, mk_p = SAMPLERS[sampler]
+    if rng.random() < 0.4:
+        sname, mname = rng.choice(FLOW_SCHEDULES), rng.choice(("flow", "data", "v"))
+    else:
+        sname = rng.choice(VP_SCHEDULES)
+        mname = rng.choice(("v", "data") if sname in ("zsnr", "beta_zsnr_flowshift") else ("eps", "v", "data"))
+    dtype = rng.choice((torch.float32, torch.float32, torch.bfloat16, torch.float16))
+    shape = (rng.randint(1, 3), rng.randint(1, 5), rng.choice((8, 13, 16, 31)), rng.choice((8, 10, 24, 17)))
+    steps = rng.randint(2, 12)
+    g = torch.Generator().manual_seed(seed)
+    w = PD.SkrampleWrapperScheduler(mk_p(), SCHEDULES[sname][1](), MODELS[mname][1])
+    o = OW.StepDriver(mk_o(), oracle_schedule(sname, steps), MODELS[mname][0])
+    w.set_timesteps(steps)
+    o.set_timesteps(steps)
+    np.testing.assert_allclose(w.timesteps.numpy(), o.timesteps.numpy(), rtol=0, atol=1e-9)
+    noises = [torch.randn(shape, generator=g) for _ in range(steps)]
+    w._noise_generator = Injected(noises, dev)
+    x = torch.randn(shape, generator=g).to(dtype)
+    what = f"{sampler}/{sname}/{mname}/{dtype}/{shape}/{steps}"
+    for i, t in enumerate(w.timesteps):
+        out = torch.randn(shape, generator=g).to(dtype)
+        try:
+            ref = o.step(out, t, x, noise=noises[i])[0]
+        except ZeroDivisionError:  # degenerate schedule (e.g. all points equal): the reference's arithmetic raises, so must ours
+            with pytest.raises(ZeroDivisionError):
+                w.step(out.to(dev), t, x.to(dev), return_dict=False)
+            return
+        got = w.step(out.to(dev), t, x.to(dev), return_dict=False)[0]
+        if not torch.isfinite(ref.float()).all():  # a degenerate pairing (e.g. division by alpha = 0): nothing to compare
+            return
+        assert_close(got, ref, dtype, f"{what} step {i}")
+        x = ref
+
+
 def test_inner_boundary_sample_packed(dev):
     "StructuredSampler.sample on HIP tensors: aliases in the record, fresh result tensor, inputs untouched"
     sched, model = PS.Karras(PS.Scaled()), PM.NoiseModel()
