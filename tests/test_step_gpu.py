@@ -53,7 +53,7 @@ def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
     return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
-def assert_close(got, ref, dtype, what=""):
+def assert_close(got, ref, dtype, what="", flips=0.05):
     assert got.dtype == dtype and tuple(got.shape) == tuple(ref.shape), (what, got.dtype, got.shape)
     g, r = got.detach().cpu(), ref.detach().cpu()
     assert torch.isfinite(g.float()).all(), what
@@ -66,7 +66,7 @@ def assert_close(got, ref, dtype, what=""):
         ulp = ulp + REL_TOL_F32 * r.float().abs().max()
         bad = (g.float() - r.float()).abs() > ulp
         assert not bad.any(), (what, int(bad.sum()), (g.float() - r.float()).abs().max().item())
-        assert (g != r).float().mean().item() < 0.05, (what, "too many last-place flips", (g != r).float().mean().item())
+        assert (g != r).float().mean().item() < flips, (what, "too many last-place flips", (g != r).float().mean().item())
 
 
 # ---- reference fixtures through the scheduler wrapper ---------------------------------------------------
@@ -706,6 +706,44 @@ def test_many_stage_runge_kutta(name, dev):
     for i, (a, b, truth) in enumerate(zip(got32, ref32, ref64)):
         ours, theirs = rel_err(a, truth), rel_err(b, truth)
         assert ours <= max(REL_TOL_F32, 2 * theirs), (name, i, ours, theirs)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_sweep_runge_kutta_vs_oracle(seed, dev):
+    "seeded random draw over (RK order x schedule x predictor x eta x dtype x ragged shape) through RKUltraWrapperScheduler"
+    import random
+
+    rng = random.Random(500 + seed)
+    order = rng.randint(1, 6)
+    if rng.random() < 0.4:
+        sname, mname = rng.choice(("linear", "flowshift_linear", "sinner_linear")), rng.choice(("flow", "data", "v"))
+    else:
+        sname, mname = rng.choice(("scaled", "hyper_scaled", "scaled_neg_b1")), rng.choice(("eps", "v", "data"))
+    eta = rng.choice((0.0, 0.0, 0.5, 1.0))
+    dtype = rng.choice((torch.float32, torch.float32, torch.bfloat16, torch.float16))
+    shape = (rng.randint(1, 3), rng.randint(1, 4), rng.choice((8, 13, 16)), rng.choice((8, 10, 17)))
+    steps = rng.randint(2, 5)
+    g = torch.Generator().manual_seed(seed)
+    w = PD.RKUltraWrapperScheduler(SCHEDULES[sname][1](), sampler_order=order, stochasticity=eta, model=MODELS[mname][1])
+    o = OW.RKDriver(OK.pick_tableau(order), SCHEDULES[sname][0](), MODELS[mname][0], "data", eta)
+    w.set_timesteps(steps)
+    o.set_timesteps(steps)
+    np.testing.assert_allclose(w.timesteps.numpy(), o.timesteps.numpy(), rtol=0, atol=1e-9)
+    noises = [torch.randn(shape, generator=g) for _ in range(steps)]
+    w._noise_generator = Injected(noises, dev)
+    pending = list(noises)
+    x = torch.randn(shape, generator=g).to(dtype)
+    what = f"rk{order}/{sname}/{mname}/eta{eta}/{dtype}/{shape}/{steps}"
+    for i, t in enumerate(w.timesteps):
+        out = (torch.randn(shape, generator=g) * 0.2 + x.float() * 0.5).to(dtype)
+        ref = o.step(out, t, x, noise_fn=lambda st: pending.pop(0))
+        got = w.step(out.to(dev), t, x.to(dev), return_dict=False)[0]
+        if not torch.isfinite(ref.float()).all():
+            return
+        # (a 6-stage combination sums up to 9 terms in a different order than the reference: a few more last-place
+        #  flips than a multistep update, every one still within one unit in the last place)
+        assert_close(got, ref, dtype, f"{what} call {i}", flips=0.10)
+        x = ref
 
 
 def test_img2img_entry_points(dev):
