@@ -638,6 +638,32 @@ def test_whole_loop_graph_capture(dev):
     assert torch.equal(loop(x1, seeds=[9, 8, 7, 6]), eager(x1, [9, 8, 7, 6]))  # new seeds are read from device memory
 
 
+@pytest.mark.parametrize("noise", ["Offset", "Pyramid", "Colored", "Brownian"])
+def test_whole_loop_graph_capture_structured_noise(noise, dev):
+    "every generator is a fixed chain of launches on the caller's stream (no host read-back), so loops that use them capture too"
+    from skrample_amd.graphs import capture_sampling_loop
+    from skrample_amd.pytorch import noise as PN
+
+    kind = getattr(PN, noise)
+    shape, steps, seeds = (3, 4, 32, 32), 5, [3, 4, 5]
+    g = torch.Generator().manual_seed(16)
+    net = lambda x, t: x * (0.5 + t / 2000)  # noqa: E731
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=kind)  # noqa: E731
+
+    def eager(x, sd):
+        w = mk()
+        w.set_timesteps(steps)
+        for t in w.timesteps.tolist():
+            x = w.step(net(x, t), t, x, generator=sd, return_dict=False)[0]
+        return x
+
+    loop = capture_sampling_loop(mk(), net, x0, steps, seeds=seeds)
+    assert torch.equal(loop(x0), eager(x0, seeds))
+    assert torch.equal(loop(x0, seeds=[7, 8, 9]), eager(x0, [7, 8, 9]))
+    assert not torch.equal(loop(x0, seeds=[7, 8, 9]), loop(x0, seeds=seeds))
+
+
 @pytest.mark.parametrize(("wrapper_type", "kw"), [(PD.RKUltraWrapperScheduler, {"sampler_order": 6, "stochasticity": 1.0}), (PD.DynasauRKWrapperScheduler, {"sampler_order": 3})])
 def test_whole_loop_graph_capture_runge_kutta(wrapper_type, kw, dev):
     "the RK wrappers' stage loop (6 network calls per step for Cash-Karp) is capturable too and replays bit-identically"
