@@ -458,6 +458,79 @@ def test_full_size_properties(dev):
     assert torch.equal(y2, y1 * 4)
 
 
+FULL_SIZE = {
+    # name: (wrapper factory, oracle factory, shape per GPU, calls)
+    "cfg3_unipc3_sde_flow": (
+        lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel()),
+        lambda n: OW.StepDriver(OA.make("unipc", 3, eta=1), OS.linear(), "flow"),
+        (256, 16, 128, 128),
+        5,
+    ),
+    "cfg4_adams4_v_zsnr": (
+        lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=4), PS.ZSNR(), PM.VelocityModel()),
+        lambda n: OW.StepDriver(OA.make("adams", 4), OS.zsnr(), "v"),
+        (256, 4, 128, 128),
+        6,
+    ),
+    "cfg5_rkultra6_sde": (
+        lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=6, stochasticity=1),
+        lambda n: OW.RKDriver(OK.pick_tableau(6), OS.scaled(), "eps", "data", 1.0),
+        (64, 4, 256, 256),
+        12,
+    ),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE))
+def test_full_size_baseline_configs(name, dev):
+    """BASELINE configs 3-5 at their full per-GPU size: determinism, bitwise shard invariance (two half batches
+    reproduce the whole), and the oracle on a few samples of the full-size run (teacher-forced)."""
+    mk_w, mk_o, shape, calls = FULL_SIZE[name]
+    B, steps = shape[0], 20
+    gd = torch.Generator(device=dev).manual_seed(4321)
+    x = torch.randn(shape, device=dev, generator=gd).bfloat16()
+    outs = [torch.randn(shape, device=dev, generator=gd).bfloat16() for _ in range(3)]
+    seeds = [42 + i for i in range(B)]
+
+    def run(lo, hi):
+        w = mk_w()
+        w.set_timesteps(steps)
+        cur, ins, res = x[lo:hi], [], []
+        for i in range(calls):
+            o_ = (outs[i % 3][lo:hi] * 0.25 + cur * 0.5).bfloat16()  # a "network" that depends on the trajectory
+            ins.append((cur, o_))
+            cur = w.step(o_, w.timesteps[i], cur, generator=seeds[lo:hi], return_dict=False)[0]
+            res.append(cur)
+        return ins, res, w
+
+    ins, full, w = run(0, B)
+    _, again, _ = run(0, B)
+    _, lo_half, _ = run(0, B // 2)
+    _, hi_half, _ = run(B // 2, B)
+    for f, a, l, h in zip(full, again, lo_half, hi_half):
+        assert torch.equal(f, a) and torch.equal(f[: B // 2], l) and torch.equal(f[B // 2 :], h)
+        assert torch.isfinite(f.float()).all()
+
+    idx = [0, B // 2, B - 1]
+    o = mk_o(steps)
+    o.set_timesteps(steps)
+    np.testing.assert_allclose(w.timesteps.numpy()[:calls], o.timesteps.numpy()[:calls], rtol=0, atol=1e-9)
+    n = int(np.prod(shape[1:]))
+    draws = iter(range(10**6))
+
+    def philox_noise(_step=None):
+        d = next(draws)
+        return torch.from_numpy(np.stack([ON.philox_normal(seeds[j], d * 256, n) for j in idx])).reshape(len(idx), *shape[1:])
+
+    for i in range(calls):
+        xin, oin = ins[i][0][idx].cpu(), ins[i][1][idx].cpu()
+        if isinstance(o, OW.RKDriver):
+            ref = o.step(oin, o.timesteps[i], xin, noise_fn=philox_noise)
+        else:
+            ref = o.step(oin, o.timesteps[i], xin, noise=philox_noise() if OA.require_noise(o.cfg) else None)[0]
+        assert_close(full[i][idx], ref, torch.bfloat16, f"{name} call {i}", flips=0.10)
+
+
 def test_step_programs_replay_bitwise(dev):
     "second pass through a wrapper replays cached step programs: results identical to the first (algebra) pass"
     from skrample_amd.pytorch import noise as PN
