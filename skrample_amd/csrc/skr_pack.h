@@ -12,6 +12,23 @@ typedef double pk_f64x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
 
+// 16-byte streaming store for 16-bit outputs (one full 1 KiB run per wave instruction; wider outputs take two
+// or four instructions that each cover half / a quarter of every line, and measured slower with write-through, so
+// they stay non-temporal).  Output tensors are written once and never re-read by the launch; on gfx950 a
+// write-through store (`sc0 sc1`) drains to HBM as it is issued and measured 4-5 % faster for the whole
+// 4-read/1-write step kernel than a non-temporal (`nt`) or plain (write-back) store, which leave the lines to be
+// evicted from L2 in bursts (tools/tune/tune_policy.hip: 27.4 vs 28.8 us at 256x4x128x128 bf16).  The compiler has
+// no spelling for that policy on a plain vector store, hence the inline assembly.  Two things the compiler would
+// otherwise do for us: (1) gfx940+ needs 2 wait states between a >8-byte VMEM store and a VALU write to its data
+// VGPRs (LLVM's "12-dword store" hazard; the hazard recogniser cannot see into inline asm) -- the `s_nop 1` travels
+// with the store; (2) vmcnt bookkeeping -- an outstanding store the compiler does not know about only makes its
+// waits for later loads more conservative, never less (loads return in order).
+template <typename V>
+__device__ __forceinline__ void store16_stream(V* p, V v) {
+  static_assert(sizeof(V) == 16, "one dwordx4");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 template <typename T>
 __device__ __forceinline__ uint32_t pack_pair(float a, float b) {
   if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) {
@@ -31,11 +48,11 @@ __device__ __forceinline__ void store8_from_f32(T* base, int64_t vec, const floa
     pk_u32x4 q;
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = pack_pair<T>(v[2 * i], v[2 * i + 1]);
-    __builtin_nontemporal_store(q, reinterpret_cast<pk_u32x4*>(base) + vec);
+    store16_stream(reinterpret_cast<pk_u32x4*>(base) + vec, q);
   } else if constexpr (sizeof(T) == 4) {
     pk_f32x4* p = reinterpret_cast<pk_f32x4*>(base) + vec * 2;
     pk_f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-    __builtin_nontemporal_store(a, p);
+    __builtin_nontemporal_store(a, p);  // 32 B per lane = two half-covered lines per instruction: leave the merge to L2
     __builtin_nontemporal_store(b, p + 1);
   } else {
     pk_f64x2* p = reinterpret_cast<pk_f64x2*>(base) + vec * 4;

@@ -15,6 +15,7 @@
 
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
+#include "skr_pack.h"
 
 namespace skr {
 
@@ -147,12 +148,12 @@ __device__ __forceinline__ void store8(void* base, int64_t vec, const Acc v[VEC]
       if constexpr (std::is_same<T, bf16_t>::value) q[i] = pack_bf16((float)v[2 * i], (float)v[2 * i + 1]);
       else q[i] = pack_f16((float)v[2 * i], (float)v[2 * i + 1]);
     }
-    __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t*>(base) + vec);
+    store16_stream(reinterpret_cast<u32x4_t*>(base) + vec, q);
   } else if constexpr (sizeof(T) == 4) {
     f32x4_t* p = reinterpret_cast<f32x4_t*>(base) + vec * 2;
     f32x4_t a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     f32x4_t b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
-    __builtin_nontemporal_store(a, p);
+    __builtin_nontemporal_store(a, p);  // 32 B per lane = two half-covered lines per instruction: leave the merge to L2
     __builtin_nontemporal_store(b, p + 1);
   } else {
     f64x2_t* p = reinterpret_cast<f64x2_t*>(base) + vec * 4;
