@@ -41,6 +41,62 @@ template <int ST> __device__ __forceinline__ void stg(u32x4_t* p, u32x4_t v) {
   if constexpr (ST == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(p), "v"(v) : "memory");
 }
 
+// UV vectors per lane (BLK apart), one trip, per-sample grid
+template <int LD, int ST, int UV, int BLK>
+__global__ __launch_bounds__(BLK) void kuv(const Args a) {
+  const int64_t smp = blockIdx.y;
+  const int64_t vlo = smp * a.vps, vhi = vlo + a.vps;
+  const uint64_t seed = a.seeds[smp];
+  const int64_t v0 = vlo + (int64_t)blockIdx.x * BLK * UV + threadIdx.x;
+  u32x4_t r[UV][4];
+#pragma unroll
+  for (int u = 0; u < UV; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[u][j] = ldg<LD>(a.in[j] + v0 + u * BLK);
+  float z[UV][8];
+#pragma unroll
+  for (int u = 0; u < UV; ++u) {
+    const uint64_t blk = (uint64_t)(v0 + u * BLK - vlo) * 2;
+    skr::normal4(seed, a.stream, blk, z[u]);
+    skr::normal4(seed, a.stream, blk + 1, z[u] + 4);
+  }
+#pragma unroll
+  for (int u = 0; u < UV; ++u) {
+    if (u == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[u][0]), "+v"(r[u][1]), "+v"(r[u][2]), "+v"(r[u][3]) : "n"((UV - 1) * 4));
+    else if (u == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[u][0]), "+v"(r[u][1]), "+v"(r[u][2]), "+v"(r[u][3]) : "n"((UV - 2) * 4 > 0 ? (UV - 2) * 4 : 0));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[u][0]), "+v"(r[u][1]), "+v"(r[u][2]), "+v"(r[u][3]));
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[2 * i] = __builtin_fmaf(a.c[j], __uint_as_float(r[u][j][i] << 16), s[2 * i]);
+        s[2 * i + 1] = __builtin_fmaf(a.c[j], __uint_as_float(r[u][j][i] & 0xFFFF0000u), s[2 * i + 1]);
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.zeta, z[u][i], s[i]);
+    u32x4_t q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = pack_bf16(s[2 * i], s[2 * i + 1]);
+    stg<ST>(a.out + v0 + u * BLK, q);
+  }
+}
+
+template <int LD, int ST, int UV, int BLK>
+void runuv(const char* name, std::vector<Args>& sets, int B, int iters = 300) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  dim3 grid((unsigned)(sets[0].vps / (BLK * UV)), B);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((kuv<LD, ST, UV, BLK>), grid, dim3(BLK), 0, 0, sets[i % sets.size()]);
+  CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((kuv<LD, ST, UV, BLK>), grid, dim3(BLK), 0, 0, sets[i % sets.size()]);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / iters;
+  double bytes = (double)sets[0].nvec * 16 * 5;
+  printf("%-34s grid=%ux%d %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, grid.x, B, us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
+}
+
 template <int LD, int ST, bool NOISE>
 __global__ __launch_bounds__(256) void k(const Args a) {
   const int64_t smp = blockIdx.y;
@@ -107,21 +163,17 @@ int main() {
     sets[s].zeta = 0.3f; sets[s].stream = 1; sets[s].nvec = n / 8; sets[s].vps = sample / 8;
   }
   for (int rep = 0; rep < 2; ++rep) {
-    printf("-- with noise (rep %d)\n", rep);
-    run<1, 1, true>("ld nt         st nt", sets, B);
-    run<1, 2, true>("ld nt         st sc1", sets, B);
-    run<1, 3, true>("ld nt         st sc0 sc1", sets, B);
-    run<1, 6, true>("ld nt         st sc0", sets, B);
-    run<1, 7, true>("ld nt         st sc0 nt", sets, B);
-    run<4, 2, true>("ld sc1 nt     st sc1", sets, B);
-    run<5, 3, true>("ld sc0sc1nt   st sc0 sc1", sets, B);
-    run<0, 2, true>("ld plain      st sc1", sets, B);
-    printf("-- without noise\n");
-    run<1, 1, false>("ld nt         st nt", sets, B);
-    run<1, 2, false>("ld nt         st sc1", sets, B);
-    run<1, 3, false>("ld nt         st sc0 sc1", sets, B);
-    run<1, 6, false>("ld nt         st sc0", sets, B);
-    run<0, 2, false>("ld plain      st sc1", sets, B);
+    printf("-- with noise, st sc0 sc1 (rep %d)\n", rep);
+    run<1, 3, true>("base uv1 blk256", sets, B);
+    runuv<1, 3, 1, 256>("uv1 blk256", sets, B);
+    runuv<1, 3, 2, 256>("uv2 blk256", sets, B);
+    runuv<1, 3, 4, 256>("uv4 blk256", sets, B);
+    runuv<1, 3, 1, 512>("uv1 blk512", sets, B);
+    runuv<1, 3, 2, 512>("uv2 blk512", sets, B);
+    runuv<1, 3, 1, 1024>("uv1 blk1024", sets, B);
+    runuv<1, 3, 1, 128>("uv1 blk128", sets, B);
+    runuv<1, 3, 2, 128>("uv2 blk128", sets, B);
+    runuv<1, 3, 1, 64>("uv1 blk64", sets, B);
   }
   return 0;
 }
