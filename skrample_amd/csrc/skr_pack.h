@@ -29,6 +29,12 @@ __device__ __forceinline__ void store16_stream(V* p, V v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
+template <typename V>
+__device__ __forceinline__ void store8_stream(V* p, V v) {  // 8-byte form (no wide-store hazard below 12 bytes)
+  static_assert(sizeof(V) == 8, "one dwordx2");
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 template <typename T>
 __device__ __forceinline__ uint32_t pack_pair(float a, float b) {
   if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) {
@@ -52,8 +58,8 @@ __device__ __forceinline__ void store8_from_f32(T* base, int64_t vec, const floa
   } else if constexpr (sizeof(T) == 4) {
     pk_f32x4* p = reinterpret_cast<pk_f32x4*>(base) + vec * 2;
     pk_f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-    __builtin_nontemporal_store(a, p);  // 32 B per lane = two half-covered lines per instruction: leave the merge to L2
-    __builtin_nontemporal_store(b, p + 1);
+    p[0] = a;  // 32 B per lane = two half-covered lines per instruction: plain write-back stores, L2 merges the halves
+    p[1] = b;
   } else {
     pk_f64x2* p = reinterpret_cast<pk_f64x2*>(base) + vec * 4;
 #pragma unroll

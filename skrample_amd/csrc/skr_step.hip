@@ -66,19 +66,48 @@ template <> struct Raw<f16_t> { u32x4_t q; };
 template <> struct Raw<float> { f32x4_t q[2]; };
 template <> struct Raw<double> { f64x2_t q[4]; };
 
-template <typename T>
+// Which 8 elements lane-slot `v` owns, as two groups of 4 consecutive elements (group index = element / 4):
+//   TILE = false  the 8 consecutive elements 8v .. 8v+7            -> groups 2v, 2v+1
+//   TILE = true   within the wave's 512-element tile, elements 4l..4l+3 and 256+4l..256+4l+3 (l = lane)
+//                 -> groups 128*(v>>6) + l and that + 64
+// With 8 consecutive elements a 16-bit operand is one 16-byte access per lane (a full KiB per wave instruction), but a
+// 32-bit operand is two 16-byte accesses to the lane's own 32 bytes: each wave instruction then covers only HALF of
+// every line it touches, which costs ~20 % on loads and far more on write-through stores.  The tile layout makes
+// every wave instruction cover whole lines for 16- and 32-bit operands alike (16-bit: two 8-byte accesses, 512 B
+// each; 32-bit: two 16-byte accesses, 1 KiB each).  Used whenever a 32-bit tensor takes part and the launch is made of
+// whole tiles (tools/tune/tune_policy.hip: 2 bf16 + 3 fp32 in, fp32 + bf16 out: 66.9 -> 54.7 us).
+template <bool TILE> __device__ __forceinline__ int64_t group0(int64_t v) {
+  if constexpr (TILE) return ((v >> 6) << 7) + (v & 63);
+  else return 2 * v;
+}
+template <bool TILE> __device__ __forceinline__ int64_t group1(int64_t v) {
+  if constexpr (TILE) return ((v >> 6) << 7) + (v & 63) + 64;
+  else return 2 * v + 1;
+}
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+template <typename T, bool TILE = false>
 __device__ __forceinline__ Raw<T> load_raw(const void* base, int64_t vec) {
   Raw<T> r;
   if constexpr (sizeof(T) == 2) {
-    r.q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(base) + vec);
+    if constexpr (TILE) {
+      const u32x2_t* p = reinterpret_cast<const u32x2_t*>(base);
+      const u32x2_t lo = __builtin_nontemporal_load(p + group0<true>(vec)), hi = __builtin_nontemporal_load(p + group1<true>(vec));
+      r.q = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+    } else {
+      r.q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(base) + vec);
+    }
   } else if constexpr (sizeof(T) == 4) {
-    const f32x4_t* p = reinterpret_cast<const f32x4_t*>(base) + vec * 2;
-    r.q[0] = __builtin_nontemporal_load(p);
-    r.q[1] = __builtin_nontemporal_load(p + 1);
+    const f32x4_t* p = reinterpret_cast<const f32x4_t*>(base);
+    r.q[0] = __builtin_nontemporal_load(p + group0<TILE>(vec));
+    r.q[1] = __builtin_nontemporal_load(p + group1<TILE>(vec));
   } else {
-    const f64x2_t* p = reinterpret_cast<const f64x2_t*>(base) + vec * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r.q[i] = __builtin_nontemporal_load(p + i);
+    const f64x2_t* p = reinterpret_cast<const f64x2_t*>(base);
+    const int64_t g0 = group0<TILE>(vec) * 2, g1 = group1<TILE>(vec) * 2;
+    r.q[0] = __builtin_nontemporal_load(p + g0);
+    r.q[1] = __builtin_nontemporal_load(p + g0 + 1);
+    r.q[2] = __builtin_nontemporal_load(p + g1);
+    r.q[3] = __builtin_nontemporal_load(p + g1 + 1);
   }
   return r;
 }
@@ -139,7 +168,7 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
   return lo | (hi << 16);
 }
 
-template <typename T, typename Acc>
+template <typename T, typename Acc, bool TILE = false>
 __device__ __forceinline__ void store8(void* base, int64_t vec, const Acc v[VEC]) {
   if constexpr (sizeof(T) == 2) {
     u32x4_t q;
@@ -148,19 +177,31 @@ __device__ __forceinline__ void store8(void* base, int64_t vec, const Acc v[VEC]
       if constexpr (std::is_same<T, bf16_t>::value) q[i] = pack_bf16((float)v[2 * i], (float)v[2 * i + 1]);
       else q[i] = pack_f16((float)v[2 * i], (float)v[2 * i + 1]);
     }
-    store16_stream(reinterpret_cast<u32x4_t*>(base) + vec, q);
+    if constexpr (TILE) {
+      u32x2_t* p = reinterpret_cast<u32x2_t*>(base);
+      store8_stream(p + group0<true>(vec), u32x2_t{q[0], q[1]});
+      store8_stream(p + group1<true>(vec), u32x2_t{q[2], q[3]});
+    } else {
+      store16_stream(reinterpret_cast<u32x4_t*>(base) + vec, q);
+    }
   } else if constexpr (sizeof(T) == 4) {
-    f32x4_t* p = reinterpret_cast<f32x4_t*>(base) + vec * 2;
+    f32x4_t* p = reinterpret_cast<f32x4_t*>(base);
     f32x4_t a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     f32x4_t b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
-    __builtin_nontemporal_store(a, p);  // 32 B per lane = two half-covered lines per instruction: leave the merge to L2
-    __builtin_nontemporal_store(b, p + 1);
+    if constexpr (TILE) {  // whole lines per wave instruction: write through
+      store16_stream(p + group0<true>(vec), a);
+      store16_stream(p + group1<true>(vec), b);
+    } else {  // 32 B per lane = two half-covered lines per instruction: plain write-back stores, so L2 merges the halves
+      p[2 * vec] = a;  // (measured: plain 33.5 us, non-temporal 41.0 us, write-through 47.2 us for 4 bf16 in -> fp32 out)
+      p[2 * vec + 1] = b;
+    }
   } else {
-    f64x2_t* p = reinterpret_cast<f64x2_t*>(base) + vec * 4;
+    f64x2_t* p = reinterpret_cast<f64x2_t*>(base);
+    const int64_t g[2] = {group0<TILE>(vec) * 2, group1<TILE>(vec) * 2};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f64x2_t a = {(double)v[2 * i], (double)v[2 * i + 1]};
-      __builtin_nontemporal_store(a, p + i);
+      __builtin_nontemporal_store(a, p + g[i >> 1] + (i & 1));
     }
   }
 }
@@ -173,7 +214,7 @@ __device__ __forceinline__ void store_scalar(void* base, int64_t i, Acc v) {
 }
 
 // ---- accumulate one dtype group: N terms x UV vectors of independent 16-byte loads, then FMAs --------
-template <typename T, typename Acc, bool HAS1, int N, int UV>
+template <typename T, typename Acc, bool HAS1, int N, int UV, bool TILE>
 __device__ __forceinline__ void acc_batch(const StepArgs<Acc>& a, int k, int64_t v0, int64_t vhi, Acc s0[UV][VEC], Acc s1[UV][VEC]) {
   Raw<T> raw[UV][N];
 #pragma unroll
@@ -181,7 +222,7 @@ __device__ __forceinline__ void acc_batch(const StepArgs<Acc>& a, int k, int64_t
     const int64_t v = v0 + u * BLOCK;
     if (v < vhi) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) raw[u][j] = load_raw<T>(a.in[k + j], v);
+      for (int j = 0; j < N; ++j) raw[u][j] = load_raw<T, TILE>(a.in[k + j], v);
     }
   }
 #pragma unroll
@@ -203,11 +244,11 @@ __device__ __forceinline__ void acc_batch(const StepArgs<Acc>& a, int k, int64_t
   }
 }
 
-template <typename T, typename Acc, bool HAS1, int UV>
+template <typename T, typename Acc, bool HAS1, int UV, bool TILE>
 __device__ __forceinline__ void acc_group(const StepArgs<Acc>& a, int k, int kend, int64_t v0, int64_t vhi, Acc s0[UV][VEC], Acc s1[UV][VEC]) {
-  for (; k + 4 <= kend; k += 4) acc_batch<T, Acc, HAS1, 4, UV>(a, k, v0, vhi, s0, s1);
-  if (k + 2 <= kend) { acc_batch<T, Acc, HAS1, 2, UV>(a, k, v0, vhi, s0, s1); k += 2; }
-  if (k < kend) acc_batch<T, Acc, HAS1, 1, UV>(a, k, v0, vhi, s0, s1);
+  for (; k + 4 <= kend; k += 4) acc_batch<T, Acc, HAS1, 4, UV, TILE>(a, k, v0, vhi, s0, s1);
+  if (k + 2 <= kend) { acc_batch<T, Acc, HAS1, 2, UV, TILE>(a, k, v0, vhi, s0, s1); k += 2; }
+  if (k < kend) acc_batch<T, Acc, HAS1, 1, UV, TILE>(a, k, v0, vhi, s0, s1);
 }
 
 // ---- rounded pair conversion (Runge-Kutta wrapper) ---------------------------------------------------
@@ -284,7 +325,7 @@ __device__ __forceinline__ void locate(const StepArgs<Acc>& a, int64_t e0, int64
   else if (r >= a.sample_numel) { ++smp; r -= a.sample_numel; }
 }
 
-template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bool ST0, bool HAS1, bool NOISE, bool CONV>
+template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bool ST0, bool HAS1, bool NOISE, bool CONV, bool TILE>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
   constexpr int UV = uv_for(NOISE, HAS1);
   // Geometry.  mode 1 (per-sample grid): blockIdx.y/z pick the sample, so the seed is one scalar
@@ -329,16 +370,18 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
         const int64_t v = v0 + u * BLOCK;
         if (v >= vhi) continue;
         const uint64_t seed = a.grid_mode == 1 ? seed_u : seed_l[u];
-        const uint64_t blk = a.grid_mode == 1 ? (uint64_t)(v - vlo) * 2 : (uint64_t)r_l[u] >> 2;
-        if (a.zeta0 != (Acc)0) { normal4(seed, a.stream0, blk, z0[u]); normal4(seed, a.stream0, blk + 1, z0[u] + 4); }
+        // Philox blocks of this slot's two 4-element groups (TILE launches always use the per-sample grid)
+        const uint64_t blk = a.grid_mode == 1 ? (uint64_t)group0<TILE>(v - vlo) : (uint64_t)r_l[u] >> 2;
+        const uint64_t blk_hi = a.grid_mode == 1 ? (uint64_t)group1<TILE>(v - vlo) : blk + 1;
+        if (a.zeta0 != (Acc)0) { normal4(seed, a.stream0, blk, z0[u]); normal4(seed, a.stream0, blk_hi, z0[u] + 4); }
         if constexpr (HAS1) {
-          if (a.zeta1 != (Acc)0) { normal4(seed, a.stream1, blk, z1[u]); normal4(seed, a.stream1, blk + 1, z1[u] + 4); }
+          if (a.zeta1 != (Acc)0) { normal4(seed, a.stream1, blk, z1[u]); normal4(seed, a.stream1, blk_hi, z1[u] + 4); }
         }
       }
     }
 
-    acc_group<TA, Acc, HAS1, UV>(a, 0, a.n_a, v0, vhi, s0, s1);
-    if constexpr (!std::is_same<TA, TB>::value) acc_group<TB, Acc, HAS1, UV>(a, a.n_a, a.n_terms, v0, vhi, s0, s1);
+    acc_group<TA, Acc, HAS1, UV, TILE>(a, 0, a.n_a, v0, vhi, s0, s1);
+    if constexpr (!std::is_same<TA, TB>::value) acc_group<TB, Acc, HAS1, UV, TILE>(a, a.n_a, a.n_terms, v0, vhi, s0, s1);
     if constexpr (CONV) {
       // out0 = rounded conversion of (in[0], in[1]); the host zeroes coef0 so s0 is still 0 here
       using M = typename OpMath<TA>::type;
@@ -348,8 +391,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
         const int64_t v = v0 + u * BLOCK;
         if (v >= vhi) continue;
         M sv[VEC], ov[VEC];
-        widen<TA, M>(load_raw<TA>(a.in[0], v), sv);
-        widen<TA, M>(load_raw<TA>(a.in[1], v), ov);
+        widen<TA, M>(load_raw<TA, TILE>(a.in[0], v), sv);
+        widen<TA, M>(load_raw<TA, TILE>(a.in[1], v), ov);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s0[u][i] = (Acc)convert_rounded<TA, M>(sv[i], ov[i], a.conv_to, a.conv_from, k);
       }
@@ -364,9 +407,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s1[u][i] = fma_(a.chain, s0[u][i], s1[u][i]);
         if constexpr (NOISE) { if (a.zeta1 != (Acc)0) fma_noise8<Acc>(a.zeta1, z1[u], s1[u]); }
-        store8<TO1, Acc>(a.out1, v, s1[u]);
+        store8<TO1, Acc, TILE>(a.out1, v, s1[u]);
       }
-      if constexpr (ST0) store8<TO0, Acc>(a.out0, v, s0[u]);
+      if constexpr (ST0) store8<TO0, Acc, TILE>(a.out0, v, s0[u]);
     }
   }
 
@@ -419,7 +462,7 @@ struct FastArgs {  // compact kernarg (2-3 cache lines instead of the general 1.
   int64_t numel, vps;
 };
 
-template <typename T, int K, bool NOISE, int UV>
+template <typename T, int K, bool NOISE, int UV, bool TILE>
 __global__ __launch_bounds__(BLOCK) void step_kernel_k(const FastArgs a) {
   int64_t vlo = 0, vhi = a.numel / VEC;
   uint64_t seed_u = 0;
@@ -436,16 +479,15 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k(const FastArgs a) {
     for (int u = 0; u < UV; ++u) {
       if (v0 + u * BLOCK < vhi) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) raw[u][j] = load_raw<T>(a.in[j], v0 + u * BLOCK);
+        for (int j = 0; j < K; ++j) raw[u][j] = load_raw<T, TILE>(a.in[j], v0 + u * BLOCK);
       }
     }
     float z[UV][VEC];
     if constexpr (NOISE) {
 #pragma unroll
       for (int u = 0; u < UV; ++u) {
-        const uint64_t blk = (uint64_t)(v0 + u * BLOCK - vlo) * 2;
-        normal4(seed_u, a.stream0, blk, z[u]);
-        normal4(seed_u, a.stream0, blk + 1, z[u] + 4);
+        normal4(seed_u, a.stream0, (uint64_t)group0<TILE>(v0 + u * BLOCK - vlo), z[u]);
+        normal4(seed_u, a.stream0, (uint64_t)group1<TILE>(v0 + u * BLOCK - vlo), z[u] + 4);
       }
     }
 #pragma unroll
@@ -464,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k(const FastArgs a) {
         for (int i = 0; i < VEC; ++i) s[i] = fma_(c, w[i], s[i]);
       }
       if constexpr (NOISE) fma_noise8<float>(a.zeta0, z[u], s);
-      store8<T, float>(a.out0, v, s);
+      store8<T, float, TILE>(a.out0, v, s);
     }
   }
 }
@@ -486,7 +528,7 @@ struct RkArgs {
   int64_t numel;
 };
 
-template <typename T, int K, int UV>
+template <typename T, int K, int UV, bool TILE>
 __global__ __launch_bounds__(BLOCK) void step_kernel_rk(const RkArgs a) {
   const int64_t vhi = a.numel / VEC;
   const int64_t stride = (int64_t)gridDim.x * (BLOCK * UV);
@@ -497,7 +539,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_rk(const RkArgs a) {
     for (int u = 0; u < UV; ++u) {
       if (v0 + u * BLOCK < vhi) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) raw[u][j] = load_raw<T>(a.in[j], v0 + u * BLOCK);
+        for (int j = 0; j < K; ++j) raw[u][j] = load_raw<T, TILE>(a.in[j], v0 + u * BLOCK);
       }
     }
 #pragma unroll
@@ -522,8 +564,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_rk(const RkArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) s1[i] = fma_(a.chain, d[i], s1[i]);
-      store8<T, float>(a.out1, v, s1);
-      store8<T, float>(a.out0, v, d);
+      store8<T, float, TILE>(a.out1, v, s1);
+      store8<T, float, TILE>(a.out0, v, d);
     }
   }
 }
@@ -550,6 +592,12 @@ static Geometry geometry(int64_t numel, int64_t sample_numel) {
   return {dim3((unsigned)blocks, 1, 1), 0};
 }
 
+// whole 512-element tiles everywhere (and, with in-kernel noise, samples made of whole tiles on the per-sample grid)
+static bool tile_ok(int64_t numel, int64_t sample_numel, bool noise, int grid_mode) {
+  static const bool tile_off = getenv("SKR_NO_TILE") != nullptr;  // tuning switch
+  return !tile_off && numel % 512 == 0 && (!noise || (grid_mode == 1 && sample_numel % 512 == 0));
+}
+
 static int finish_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_last_hip_error = (int)e; return SKR_ERR_LAUNCH; }
@@ -565,8 +613,14 @@ static int launch_k_uv(StepArgs<float>& args, hipStream_t stream, bool& taken) {
   fa.out0 = args.out0; fa.seeds = args.seeds; fa.zeta0 = args.zeta0; fa.stream0 = args.stream0;
   fa.numel = args.numel; fa.vps = args.sample_numel / VEC;
   taken = true;
-#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_k<T, N, NOISE, UV>), g.grid, dim3(BLOCK), 0, stream, fa); break
-  switch (args.n_terms) { SKR_K(1); SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
+#define SKR_K(N, TILE) case N: hipLaunchKernelGGL((step_kernel_k<T, N, NOISE, UV, TILE>), g.grid, dim3(BLOCK), 0, stream, fa); break
+  if constexpr (sizeof(T) == 4) {  // 32-bit tensors: whole-line tile layout when the launch is made of whole tiles
+    if (tile_ok(args.numel, args.sample_numel, NOISE, g.mode)) {
+      switch (args.n_terms) { SKR_K(1, true); SKR_K(2, true); SKR_K(3, true); SKR_K(4, true); SKR_K(5, true); SKR_K(6, true); SKR_K(7, true); SKR_K(8, true); }
+      return finish_launch();
+    }
+  }
+  switch (args.n_terms) { SKR_K(1, false); SKR_K(2, false); SKR_K(3, false); SKR_K(4, false); SKR_K(5, false); SKR_K(6, false); SKR_K(7, false); SKR_K(8, false); }
 #undef SKR_K
   return finish_launch();
 }
@@ -592,8 +646,14 @@ static int launch_rk_uv(const StepArgs<float>& args, hipStream_t stream) {
   ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
   for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
   ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel;
-#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_rk<T, N, UV>), g.grid, dim3(BLOCK), 0, stream, ra); break
-  switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
+#define SKR_K(N, TILE) case N: hipLaunchKernelGGL((step_kernel_rk<T, N, UV, TILE>), g.grid, dim3(BLOCK), 0, stream, ra); break
+  if constexpr (sizeof(T) == 4) {
+    if (tile_ok(args.numel, args.sample_numel, false, g.mode)) {
+      switch (args.n_terms) { SKR_K(2, true); SKR_K(3, true); SKR_K(4, true); SKR_K(5, true); SKR_K(6, true); SKR_K(7, true); SKR_K(8, true); }
+      return finish_launch();
+    }
+  }
+  switch (args.n_terms) { SKR_K(2, false); SKR_K(3, false); SKR_K(4, false); SKR_K(5, false); SKR_K(6, false); SKR_K(7, false); SKR_K(8, false); }
 #undef SKR_K
   return finish_launch();
 }
@@ -626,7 +686,15 @@ static int launch(StepArgs<Acc>& args, hipStream_t stream) {
   args.grid_mode = g.mode;
   args.aligned = (args.sample_numel % VEC) == 0;
   args.vps = args.sample_numel / VEC;
-  hipLaunchKernelGGL((step_kernel<TA, TB, TO0, TO1, Acc, ST0, HAS1, NOISE, CONV>), g.grid, dim3(BLOCK), 0, stream, args);
+  constexpr bool HAS32 = std::is_same<Acc, float>::value && (std::is_same<TA, float>::value || std::is_same<TB, float>::value ||
+                                                               (ST0 && std::is_same<TO0, float>::value) || (HAS1 && std::is_same<TO1, float>::value));
+  if constexpr (HAS32) {  // a 32-bit tensor takes part: whole-line tile layout when the launch is made of whole tiles
+    if (tile_ok(args.numel, args.sample_numel, NOISE, g.mode)) {
+      hipLaunchKernelGGL((step_kernel<TA, TB, TO0, TO1, Acc, ST0, HAS1, NOISE, CONV, true>), g.grid, dim3(BLOCK), 0, stream, args);
+      return finish_launch();
+    }
+  }
+  hipLaunchKernelGGL((step_kernel<TA, TB, TO0, TO1, Acc, ST0, HAS1, NOISE, CONV, false>), g.grid, dim3(BLOCK), 0, stream, args);
   return finish_launch();
 }
 

@@ -221,8 +221,10 @@ def test_inner_boundary_sample_packed(dev):
     assert_close(sched.ipoint(0.3).add_noise(xd, od), x * p.alpha + out * p.sigma, torch.float32, "add_noise")
 
 
-def test_in_kernel_philox_matches_oracle_spec(dev):
-    "DPM-2 SDE with Random noise drawn inside the step kernel == oracle fed the spec'd Philox normals"
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_in_kernel_philox_matches_oracle_spec(dtype, dev):
+    """DPM-2 SDE with Random noise drawn inside the step kernel == oracle fed the spec'd Philox normals
+    (bf16: 8 consecutive elements per lane; fp32: the whole-line tile layout -- the element -> Philox block map must hold in both)"""
     steps, shape, seeds = 7, (3, 4, 32, 32), [11, 2**40 + 5, 2**63 + 9]
     w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))
     o = OW.StepDriver(OA.make("dpm", 2, eta=1), OS.karras(OS.scaled(), steps=steps), "eps")
@@ -230,14 +232,14 @@ def test_in_kernel_philox_matches_oracle_spec(dev):
     o.set_timesteps(steps)
     g = torch.Generator().manual_seed(5)
     gens = [torch.Generator().manual_seed(s) for s in seeds]
-    x = torch.randn(shape, generator=g).bfloat16()
+    x = torch.randn(shape, generator=g).to(dtype)
     n = shape[1] * shape[2] * shape[3]
     for i, t in enumerate(w.timesteps):
-        out = torch.randn(shape, generator=g).bfloat16()
+        out = torch.randn(shape, generator=g).to(dtype)
         got = w.step(out.to(dev), t, x.to(dev), generator=gens, return_dict=False)[0]
         noise = torch.from_numpy(np.stack([ON.philox_normal(s, i * 256, n) for s in seeds])).reshape(shape)
         ref = o.step(out, t, x, noise=noise)[0]
-        assert_close(got, ref, torch.bfloat16, f"philox step {i}")
+        assert_close(got, ref, dtype, f"philox step {i}")
         x = ref
 
 
@@ -346,6 +348,38 @@ def test_runge_kutta_stage_kernels_agree_bitwise(dtype, kinds, n_terms, dev):
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0][:n]) and torch.equal(outs[0][1], outs[1][1][:n])
     assert torch.isfinite(outs[0][0].float()).all() and outs[0][0].float().abs().max() > 0.1
+
+
+@pytest.mark.parametrize(("dtypes", "n_terms", "two_outputs"), [((torch.float32, torch.float32), 1, False), ((torch.float32, torch.float32), 4, False), ((torch.float32, torch.float32), 8, False),
+                                                                  ((torch.float32, torch.float32), 11, True), ((torch.bfloat16, torch.float32), 6, True), ((torch.float16, torch.float32), 9, True), ((torch.bfloat16, torch.float32), 3, False)])
+def test_tile_layout_agrees_bitwise(dtypes, n_terms, two_outputs, dev):
+    """launches made of whole 512-element tiles use the whole-line tile layout when a 32-bit tensor takes part; a ragged
+    launch over the same leading data uses 8 consecutive elements per lane -- same bits required"""
+    ta, tb = dtypes
+    n = 512 * 37
+    g = torch.Generator().manual_seed(n_terms)
+    n_a = n_terms if ta == tb else max(1, n_terms // 2)
+    long_ins = [torch.randn(n + 5, generator=g).to(ta if k < n_a else tb).to(dev) for k in range(n_terms)]
+    plan = _hip.StepPlanC()
+    plan.n_terms, plan.n_group_a, plan.dtype_a, plan.dtype_b = n_terms, n_a, _hip.DTYPE_CODE[ta], _hip.DTYPE_CODE[tb]
+    plan.out0_dtype = _hip.F32
+    plan.out1_dtype = _hip.DTYPE_CODE[ta] if two_outputs else -1
+    plan.chain = -0.375
+    for k in range(n_terms):
+        plan.coef0[k], plan.coef1[k] = (-1) ** k * (0.3 + 0.05 * k), 0.1 * (k + 1)
+    res = []
+    for m in (n, n + 5):
+        ins = [t[:m].clone() for t in long_ins]
+        o0 = torch.full((m,), 3.0, device=dev)
+        o1 = torch.full((m,), 3.0, device=dev, dtype=ta) if two_outputs else None
+        _hip.launch_step(plan, ins, o0, o1, None, m, dev)
+        res.append((o0, o1))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0], res[1][0][:n])
+    if two_outputs:
+        assert torch.equal(res[0][1], res[1][1][:n])
+    ref = sum(plan.coef0[k] * long_ins[k][:n].double() for k in range(n_terms))
+    assert rel_err(res[0][0], ref) < 1e-5
 
 
 def test_wrapper_contract(dev):

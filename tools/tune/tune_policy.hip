@@ -97,6 +97,125 @@ void runuv(const char* name, std::vector<Args>& sets, int B, int iters = 300) {
   printf("%-34s grid=%ux%d %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, grid.x, B, us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
 }
 
+// fp32 output (32 B per lane): SPLIT = each lane writes its own 32 contiguous bytes with two instructions (each
+// instruction covers half of every line); FULL = instruction 0 writes the wave's first KiB, instruction 1 the second
+// (what a lane exchange before the store would produce).  Timing only: values land in permuted places under FULL.
+template <int ST, bool FULL>
+__global__ __launch_bounds__(256) void kf32(const Args a, u32x4_t* out32) {
+  const int64_t v = (int64_t)blockIdx.y * a.vps + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  u32x4_t r0 = ldg<1>(a.in[0] + v), r1 = ldg<1>(a.in[1] + v), r2 = ldg<1>(a.in[2] + v), r3 = ldg<1>(a.in[3] + v);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+  u32x4_t raw[4] = {r0, r1, r2, r3};
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[2 * i] = __builtin_fmaf(a.c[j], __uint_as_float(raw[j][i] << 16), s[2 * i]);
+      s[2 * i + 1] = __builtin_fmaf(a.c[j], __uint_as_float(raw[j][i] & 0xFFFF0000u), s[2 * i + 1]);
+    }
+  u32x4_t q0 = {__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3])};
+  u32x4_t q1 = {__float_as_uint(s[4]), __float_as_uint(s[5]), __float_as_uint(s[6]), __float_as_uint(s[7])};
+  if constexpr (FULL) {
+    const int64_t wave_base = (v & ~(int64_t)63) * 2;  // in 16-byte units
+    const int lane = threadIdx.x & 63;
+    stg<ST>(out32 + wave_base + lane, q0);
+    stg<ST>(out32 + wave_base + 64 + lane, q1);
+  } else {
+    stg<ST>(out32 + 2 * v, q0);
+    stg<ST>(out32 + 2 * v + 1, q1);
+  }
+}
+
+template <int ST, bool FULL>
+void runf32(const char* name, std::vector<Args>& sets, std::vector<u32x4_t*>& outs, int B, int iters = 300) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  dim3 grid(32, B);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((kf32<ST, FULL>), grid, dim3(256), 0, 0, sets[i % sets.size()], outs[i % outs.size()]);
+  CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((kf32<ST, FULL>), grid, dim3(256), 0, 0, sets[i % sets.size()], outs[i % outs.size()]);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / iters;
+  double bytes = (double)sets[0].nvec * 16 * 6;
+  printf("%-34s %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
+}
+
+// UniPC-like mix: 2 bf16 inputs + 3 fp32 inputs -> fp32 out0 + bf16 out1 (26 B/element).
+// L44 = false: lane owns 8 consecutive elements (bf16: one 16-B access; fp32: two 16-B accesses to its own 32 B).
+// L44 = true : lane owns elements {4l..4l+3} and {256+4l..} of its wave's 512-element tile (bf16: two 8-B accesses,
+//              fp32: two 16-B accesses) -- every wave instruction covers whole lines.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <bool L44, int ST32>
+__global__ __launch_bounds__(256) void kmix(const Args a, const u32x4_t* f0, const u32x4_t* f1, const u32x4_t* f2, u32x4_t* out32) {
+  const int64_t v = (int64_t)blockIdx.y * a.vps + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = v >> 6;  // 512 elements
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+  u32x4_t h[2];   // bf16 operands, 8 elements each
+  u32x4_t w[3][2];  // fp32 operands
+  const u32x4_t* fp[3] = {f0, f1, f2};
+  if constexpr (L44) {
+    const u32x2_t* b0 = (const u32x2_t*)a.in[0]; const u32x2_t* b1 = (const u32x2_t*)a.in[1];
+    const int64_t g0 = tile * 128 + lane, g1 = g0 + 64;  // in 4-element groups
+    u32x2_t x0 = __builtin_nontemporal_load(b0 + g0), x1 = __builtin_nontemporal_load(b0 + g1);
+    u32x2_t y0 = __builtin_nontemporal_load(b1 + g0), y1 = __builtin_nontemporal_load(b1 + g1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { w[j][0] = __builtin_nontemporal_load(fp[j] + g0); w[j][1] = __builtin_nontemporal_load(fp[j] + g1); }
+    h[0] = u32x4_t{x0[0], x0[1], x1[0], x1[1]}; h[1] = u32x4_t{y0[0], y0[1], y1[0], y1[1]};
+  } else {
+    h[0] = __builtin_nontemporal_load(a.in[0] + v); h[1] = __builtin_nontemporal_load(a.in[1] + v);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { w[j][0] = __builtin_nontemporal_load(fp[j] + 2 * v); w[j][1] = __builtin_nontemporal_load(fp[j] + 2 * v + 1); }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[2 * i] = __builtin_fmaf(a.c[j], __uint_as_float(h[j][i] << 16), s[2 * i]);
+      s[2 * i + 1] = __builtin_fmaf(a.c[j], __uint_as_float(h[j][i] & 0xFFFF0000u), s[2 * i + 1]);
+    }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i] = __builtin_fmaf(a.c[j], __uint_as_float(w[j][0][i]), s[i]); s[4 + i] = __builtin_fmaf(a.c[j], __uint_as_float(w[j][1][i]), s[4 + i]); }
+  u32x4_t q0 = {__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3])};
+  u32x4_t q1 = {__float_as_uint(s[4]), __float_as_uint(s[5]), __float_as_uint(s[6]), __float_as_uint(s[7])};
+  u32x4_t qb;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qb[i] = pack_bf16(s[2 * i] * 0.5f, s[2 * i + 1] * 0.5f);
+  if constexpr (L44) {
+    const int64_t g0 = tile * 128 + lane, g1 = g0 + 64;
+    stg<ST32>(out32 + g0, q0);
+    stg<ST32>(out32 + g1, q1);
+    u32x2_t* ob = (u32x2_t*)a.out;
+    u32x2_t lo = {qb[0], qb[1]}, hi = {qb[2], qb[3]};
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(ob + g0), "v"(lo) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(ob + g1), "v"(hi) : "memory");
+  } else {
+    stg<ST32>(out32 + 2 * v, q0);
+    stg<ST32>(out32 + 2 * v + 1, q1);
+    stg<3>(a.out + v, qb);
+  }
+}
+
+template <bool L44, int ST32>
+void runmix(const char* name, std::vector<Args>& sets, std::vector<u32x4_t*>& f32s, int B, int iters = 300) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  dim3 grid(32, B);
+  auto go = [&](int i) { const int k = i % 2; hipLaunchKernelGGL((kmix<L44, ST32>), grid, dim3(256), 0, 0, sets[i % sets.size()], f32s[4 * k], f32s[4 * k + 1], f32s[4 * k + 2], f32s[4 * k + 3]); };
+  for (int i = 0; i < 10; ++i) go(i);
+  CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) go(i);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / iters;
+  double bytes = (double)sets[0].nvec * 8 * 22;  // 2*2 + 3*4 + 4 + 2 = 22 B/element
+  printf("%-40s %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
+}
+
 template <int LD, int ST, bool NOISE>
 __global__ __launch_bounds__(256) void k(const Args a) {
   const int64_t smp = blockIdx.y;
@@ -162,18 +281,15 @@ int main() {
     sets[s].seeds = seeds; sets[s].c[0] = 1.01f; sets[s].c[1] = -0.53f; sets[s].c[2] = 0.12f; sets[s].c[3] = 0.43f;
     sets[s].zeta = 0.3f; sets[s].stream = 1; sets[s].nvec = n / 8; sets[s].vps = sample / 8;
   }
+  std::vector<u32x4_t*> f32s(8);
+  for (auto& o : f32s) { CK(hipMalloc((void**)&o, n * 4 + (1 << 20))); CK(hipMemset(o, 0, n * 4)); }
   for (int rep = 0; rep < 2; ++rep) {
-    printf("-- with noise, st sc0 sc1 (rep %d)\n", rep);
-    run<1, 3, true>("base uv1 blk256", sets, B);
-    runuv<1, 3, 1, 256>("uv1 blk256", sets, B);
-    runuv<1, 3, 2, 256>("uv2 blk256", sets, B);
-    runuv<1, 3, 4, 256>("uv4 blk256", sets, B);
-    runuv<1, 3, 1, 512>("uv1 blk512", sets, B);
-    runuv<1, 3, 2, 512>("uv2 blk512", sets, B);
-    runuv<1, 3, 1, 1024>("uv1 blk1024", sets, B);
-    runuv<1, 3, 1, 128>("uv1 blk128", sets, B);
-    runuv<1, 3, 2, 128>("uv2 blk128", sets, B);
-    runuv<1, 3, 1, 64>("uv1 blk64", sets, B);
+    printf("-- 2 bf16 + 3 fp32 reads, fp32 + bf16 writes (rep %d)\n", rep);
+    runmix<false, 1>("8-consecutive, fp32 st nt (current)", sets, f32s, B);
+    runmix<false, 0>("8-consecutive, fp32 st plain", sets, f32s, B);
+    runmix<true, 1>("4+4 tile,      fp32 st nt", sets, f32s, B);
+    runmix<true, 3>("4+4 tile,      fp32 st sc0 sc1", sets, f32s, B);
+    runmix<true, 0>("4+4 tile,      fp32 st plain", sets, f32s, B);
   }
   return 0;
 }
