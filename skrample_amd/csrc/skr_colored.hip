@@ -19,6 +19,7 @@
 
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
+#include "skr_pack.h"
 
 namespace skr {
 
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void colored_finish(T* out, const ColoredArgs 
   T* dst = out + smp * unit;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < unit; i += (int64_t)gridDim.x * 1024) {
     const float4 v = *reinterpret_cast<const float4*>(src + i);
-    dst[i] = (T)(v.x * factor); dst[i + 1] = (T)(v.y * factor); dst[i + 2] = (T)(v.z * factor); dst[i + 3] = (T)(v.w * factor);
+    store4_from_f32<T>(dst + i, v.x * factor, v.y * factor, v.z * factor, v.w * factor);
   }
 }
 

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void normalise_pass2(T* out, const float* scra
   T* dst = out + smp * unit;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < unit; i += (int64_t)gridDim.x * 1024) {
     const float4 v = *reinterpret_cast<const float4*>(src + i);
-    dst[i] = (T)(v.x * inv); dst[i + 1] = (T)(v.y * inv); dst[i + 2] = (T)(v.z * inv); dst[i + 3] = (T)(v.w * inv);
+    store4_from_f32<T>(dst + i, v.x * inv, v.y * inv, v.z * inv, v.w * inv);
   }
 }
 

@@ -70,4 +70,17 @@ __device__ __forceinline__ void store8_from_f32(T* base, int64_t vec, const floa
   }
 }
 
+// 4 consecutive values at `dst` (8-byte aligned for 16-bit T, 16-byte for float): one streaming store
+template <typename T>
+__device__ __forceinline__ void store4_from_f32(T* dst, float a, float b, float c, float d) {
+  if constexpr (sizeof(T) == 2) {
+    typedef uint32_t pk_u32x2 __attribute__((ext_vector_type(2)));
+    store8_stream(reinterpret_cast<pk_u32x2*>(dst), pk_u32x2{pack_pair<T>(a, b), pack_pair<T>(c, d)});
+  } else if constexpr (sizeof(T) == 4) {
+    store16_stream(reinterpret_cast<pk_f32x4*>(dst), pk_f32x4{a, b, c, d});
+  } else {
+    dst[0] = (T)a; dst[1] = (T)b; dst[2] = (T)c; dst[3] = (T)d;
+  }
+}
+
 }  // namespace skr
