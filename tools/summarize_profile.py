@@ -14,7 +14,7 @@ import statistics
 import sys
 
 round_tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k<skr::bf16_t, 4, true, 1>"  # headline: K=4 bf16 + Philox
+needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k<skr::bf16_t, 4, true, 1, false>"  # headline: K=4 bf16 + Philox
 
 
 def counter(path: str, name: str) -> list[float]:
