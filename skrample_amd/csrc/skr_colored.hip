@@ -305,9 +305,26 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       if (row < r) { float2 t = t2[k * ldh + row]; t2[k * ldh + row] = t2[k * ldh + r]; t2[k * ldh + r] = t; }
     }
   } else {
-    for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
-      const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
-      t2[k * ldh + brev(row, logH)] = plane[q];
+    // all of the plane's loads are issued before the first LDS write (a rolled loop would pay one HBM latency per trip)
+    const int total = H * WH;  // <= 2 * PLANE_THREADS * PLANE_ITEMS (host check)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float2 rz[PLANE_ITEMS];
+      const int base = half * PLANE_THREADS * PLANE_ITEMS;
+      if (base >= total) break;
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = base + threadIdx.x + i * PLANE_THREADS;
+        if (q < total) rz[i] = plane[q];
+      }
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = base + threadIdx.x + i * PLANE_THREADS;
+        if (q < total) {
+          const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
+          t2[k * ldh + brev(row, logH)] = rz[i];
+        }
+      }
     }
   }
 
