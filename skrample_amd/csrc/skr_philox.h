@@ -28,17 +28,21 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
   return c;
 }
 
-// u = x * 2^-32 + 2^-33  in (0, 1]   (two roundings, exactly as the oracle's float32 numpy code)
+// u = x * 2^-32 + 2^-33  in (0, 1]: the product is exact, the sum rounds once (fused or not), and the largest
+// input gives exactly 1.0f (2^32 * 2^-32 + 2^-33 rounds to 1), so no clamp is needed; the smallest gives 2^-33.
 __device__ __forceinline__ float u01(uint32_t x) {
-  float u = __fadd_rn(__fmul_rn((float)x, 2.3283064365386963e-10f), 1.1641532182693481e-10f);
-  return fminf(u, 1.0f);
+  return __builtin_fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
 // (r cos 2*pi*u1, r sin 2*pi*u1), r = sqrt(-2 ln u0).
-// v_sin_f32 / v_cos_f32 take their argument in revolutions, so the 2*pi never materialises.
+// Raw hardware transcendentals: v_log_f32 is log2 (so -2 ln u0 = log2(u0) * (-2 ln 2), one multiply), v_sqrt_f32,
+// v_sin_f32 / v_cos_f32 take their argument in revolutions (the 2*pi never materialises).  Their operands are never
+// denormal here (u0 >= 2^-33, and -2 ln u0 is 0 or >= 1.1e-7), so the library's denormal pre-scaling and the
+// Newton fix-up of the correctly rounded sqrt -- together ~100 of the ~270 instructions of two blocks -- are not
+// needed; each is accurate to 1 ulp, well inside the 2e-6 the oracle comparison allows for the hardware sin/cos.
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
   const float u0 = u01(a), u1 = u01(b);
-  const float r = __builtin_sqrtf(-2.0f * __logf(u0));
+  const float r = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u0) * -1.3862943611198906f);
   z0 = r * __builtin_amdgcn_cosf(u1);
   z1 = r * __builtin_amdgcn_sinf(u1);
 }
