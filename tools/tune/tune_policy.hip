@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <dlfcn.h>
+#include "../../include/skrample_hip.h"
 #include "../../skrample_amd/csrc/skr_philox.h"
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -281,15 +283,31 @@ int main() {
     sets[s].seeds = seeds; sets[s].c[0] = 1.01f; sets[s].c[1] = -0.53f; sets[s].c[2] = 0.12f; sets[s].c[3] = 0.43f;
     sets[s].zeta = 0.3f; sets[s].stream = 1; sets[s].nvec = n / 8; sets[s].vps = sample / 8;
   }
-  std::vector<u32x4_t*> f32s(8);
-  for (auto& o : f32s) { CK(hipMalloc((void**)&o, n * 4 + (1 << 20))); CK(hipMemset(o, 0, n * 4)); }
-  for (int rep = 0; rep < 2; ++rep) {
-    printf("-- 2 bf16 + 3 fp32 reads, fp32 + bf16 writes (rep %d)\n", rep);
-    runmix<false, 1>("8-consecutive, fp32 st nt (current)", sets, f32s, B);
-    runmix<false, 0>("8-consecutive, fp32 st plain", sets, f32s, B);
-    runmix<true, 1>("4+4 tile,      fp32 st nt", sets, f32s, B);
-    runmix<true, 3>("4+4 tile,      fp32 st sc0 sc1", sets, f32s, B);
-    runmix<true, 0>("4+4 tile,      fp32 st plain", sets, f32s, B);
+  void* h = dlopen("skrample_amd/csrc/libskrample_hip.so", RTLD_NOW);
+  typedef int (*launch_fn)(const skr_step_plan*, const void* const*, void*, void*, const uint64_t*, int64_t, void*);
+  launch_fn launch = h ? (launch_fn)dlsym(h, "skr_step_launch") : nullptr;
+  skr_step_plan p = {};
+  p.n_terms = 4; p.n_group_a = 4; p.dtype_a = SKR_BF16; p.dtype_b = SKR_BF16; p.out0_dtype = SKR_BF16; p.out1_dtype = SKR_NONE;
+  p.coef0[0] = 1.01; p.coef0[1] = -0.53; p.coef0[2] = 0.12; p.coef0[3] = 0.43; p.sample_numel = sample;
+  p.noise_mode = 1; p.zeta0 = 0.3; p.stream0 = 1;
+  auto lib = [&](const char* name) {
+    if (!launch) { printf("(library not found)\n"); return; }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto go = [&](int i) { const Args& a = sets[i % sets.size()]; const void* ins[4] = {a.in[0], a.in[1], a.in[2], a.in[3]}; launch(&p, ins, a.out, nullptr, seeds, n, nullptr); };
+    for (int i = 0; i < 10; ++i) go(i);
+    CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+    for (int i = 0; i < 300; ++i) go(i);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / 300;
+    printf("%-34s               %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, us, (double)n * 10 / us / 1e6, (double)n * 10 / us / 1e6 / 8.0);
+  };
+  for (int rep = 0; rep < 3; ++rep) {
+    printf("-- with noise, st sc0 sc1 (rep %d)\n", rep);
+    runuv<1, 3, 1, 256>("uv1 blk256", sets, B);
+    lib("LIB skr_step_launch philox");
+    runuv<1, 3, 1, 1024>("uv1 blk1024", sets, B);
+    run<1, 3, true>("k (early exit) uv1 blk256", sets, B);
+    lib("LIB skr_step_launch philox");
   }
   return 0;
 }
