@@ -39,7 +39,7 @@ __device__ __forceinline__ u32x4_t ld(const u32x4_t* p) {
 }
 template <bool NT>
 __device__ __forceinline__ void st(u32x4_t* p, u32x4_t v) {
-  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");  // "nt" slot now = write-through
   else *p = v;
 }
 
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(BLK) void k2(const Args a) {
       u32x4_t q;
 #pragma unroll
       for (int i = 0; i < 4; ++i) q[i] = pack_bf16(s[2 * i], s[2 * i + 1]);
-      __builtin_nontemporal_store(q, a.out + v0 + u * BLK);
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(a.out + v0 + u * BLK), "v"(q) : "memory");
     }
   }
 }
