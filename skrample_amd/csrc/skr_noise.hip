@@ -185,7 +185,9 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
 
 constexpr int PYR_THREADS = 512;  // 8 waves per block: two 70 KiB blocks per CU keep 16 waves in flight
 
-__global__ __launch_bounds__(PYR_THREADS) void pyramid_pass1(const PyramidArgs a) {
+// STRIP: the block width divides PYR_THREADS, so a thread keeps its 4 columns for every row (see below)
+template <bool STRIP>
+__global__ __launch_bounds__(PYR_THREADS, STRIP ? 2 : 4) void pyramid_pass1(const PyramidArgs a) {
   extern __shared__ float lds[];  // levels >= 1, back to back
   __shared__ double red[2][PYR_THREADS / 64];
   __shared__ int s_lh[PYR_MAX_LEVELS], s_lw[PYR_MAX_LEVELS], s_off[PYR_MAX_LEVELS];
@@ -231,8 +233,10 @@ __global__ __launch_bounds__(PYR_THREADS) void pyramid_pass1(const PyramidArgs a
   const int n4 = a.h * w4;
   const float w0 = s_wgt[0];
   double s1 = 0.0, s2 = 0.0;
-  for (int q = threadIdx.x; q < n4; q += PYR_THREADS) {
-    const int y = q / w4, x0 = (q - y * w4) * 4;
+  float* const dst = a.scratch + (int64_t)slice * a.h * a.w;
+
+  // one group of 4 pixels at row y, columns x0..x0+3.  X(l, j, xa, xb, lx) yields the horizontal source taps.
+  auto pixel_group = [&](int y, int x0, int q, auto&& taps) {
     const int64_t e0 = ((int64_t)c * a.h + y) * a.w + x0;  // element index inside the sample
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.with_base) normal4(seed, a.stream_base, (uint64_t)e0 >> 2, v);
@@ -242,7 +246,9 @@ __global__ __launch_bounds__(PYR_THREADS) void pyramid_pass1(const PyramidArgs a
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = fmaf(z[j], w0, v[j]);
     }
-    for (int l = 1; l < nl; ++l) {
+#pragma unroll
+    for (int l = 1; l < PYR_MAX_LEVELS; ++l) {
+      if (l >= nl) break;
       const float wl = s_wgt[l];
       if (wl == 0.f) continue;
       const int lh = s_lh[l], lw = s_lw[l];
@@ -252,20 +258,50 @@ __global__ __launch_bounds__(PYR_THREADS) void pyramid_pass1(const PyramidArgs a
       src_index(y, s_sy[l], lh, y0, y1, ly);
       const float* r0 = g + y0 * lw;
       const float* r1 = g + y1 * lw;
-      const float sx = s_sx[l];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int xa, xb;
         float lx;
-        src_index(x0 + j, sx, lw, xa, xb, lx);
+        taps(l, j, xa, xb, lx);
         const float top = (1.f - lx) * r0[xa] + lx * r0[xb];
         const float bot = (1.f - lx) * r1[xa] + lx * r1[xb];
         v[j] += wl * ((1.f - ly) * top + ly * bot);
       }
     }
+    const float p1 = (v[0] + v[1]) + (v[2] + v[3]);  // 4 values in fp32, then one widening add: the per-slice totals stay double
+    const float p2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+    s1 += (double)p1; s2 += (double)p2;
+    *reinterpret_cast<float4*>(dst + (int64_t)q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  };
+
+  if constexpr (STRIP) {
+    // column strips: a thread keeps its 4 columns for every row it visits, so the horizontal taps of the first
+    // PYR_CACHED levels are computed once (packed xa | xb << 16 and the blend weight) instead of once per pixel and row
+    constexpr int PYR_CACHED = 5;  // levels 1..4 in registers (deeper levels are rare and tiny: computed in place)
+    const int xg = threadIdx.x % w4, x0 = xg * 4, ystep = PYR_THREADS / w4;
+    int tap_idx[PYR_CACHED][4];
+    float tap_lx[PYR_CACHED][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { s1 += (double)v[j]; s2 += (double)v[j] * (double)v[j]; }
-    *reinterpret_cast<float4*>(a.scratch + (int64_t)slice * a.h * a.w + (int64_t)q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int l = 1; l < PYR_CACHED; ++l) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int xa = 0, xb = 0;
+        float lx = 0.f;
+        if (l < nl) src_index(x0 + j, s_sx[l], s_lw[l], xa, xb, lx);
+        tap_idx[l][j] = xa | (xb << 16);
+        tap_lx[l][j] = lx;
+      }
+    }
+    for (int y = threadIdx.x / w4; y < a.h; y += ystep)
+      pixel_group(y, x0, y * w4 + xg, [&](int l, int j, int& xa, int& xb, float& lx) {
+        if (l < PYR_CACHED) { xa = tap_idx[l][j] & 0xFFFF; xb = tap_idx[l][j] >> 16; lx = tap_lx[l][j]; }
+        else src_index(x0 + j, s_sx[l], s_lw[l], xa, xb, lx);
+      });
+  } else {
+    for (int q = threadIdx.x; q < n4; q += PYR_THREADS) {
+      const int y = q / w4, x0 = (q - y * w4) * 4;
+      pixel_group(y, x0, q, [&](int l, int j, int& xa, int& xb, float& lx) { src_index(x0 + j, s_sx[l], s_lw[l], xa, xb, lx); });
+    }
   }
   // block reduction in a fixed order
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
@@ -347,9 +383,13 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
   const size_t lds_bytes = sizeof(float) * (size_t)bound;
   if (lds_bytes > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(skr::pyramid_pass1, dim3((unsigned)(batch * lead)), dim3(skr::PYR_THREADS), lds_bytes, s, a);
+  const int64_t w4 = w / 4;
+  // strips pay off when a thread visits enough rows to amortise its tap table
+  if (skr::PYR_THREADS % w4 == 0 && h / (skr::PYR_THREADS / w4) >= 12) hipLaunchKernelGGL(skr::pyramid_pass1<true>, dim3((unsigned)(batch * lead)), dim3(skr::PYR_THREADS), lds_bytes, s, a);
+  else hipLaunchKernelGGL(skr::pyramid_pass1<false>, dim3((unsigned)(batch * lead)), dim3(skr::PYR_THREADS), lds_bytes, s, a);
   if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
   const int64_t unit = lead * h * w;
   int64_t bx = (unit / 4 + 255) / 256;
