@@ -120,6 +120,15 @@ __device__ __forceinline__ void make_twiddles(float2* tw, int N) {
 
 __device__ __forceinline__ float axis_freq(int k, int d) { const int m = k < d - k ? k : d - k; return (float)m / (float)d; }
 
+// clamp(radius, eps)^(-exponent/2) on the raw transcendental units: radius >= eps > 0 is never denormal, so
+// exp2(e * log2(r)) needs neither libm's powf special cases (~40 instructions) nor sqrt's correctly-rounded fix-up;
+// relative error ~1e-6 for the exponents in use (|e| <= 2), inside the generator's 1e-5 parity bar.
+__device__ __forceinline__ float radial_weight(float sum_sq, float inv_rmax, float eps_clip, float exponent_half_neg) {
+  float radius = __builtin_amdgcn_sqrtf(sum_sq) * inv_rmax;
+  radius = radius < eps_clip ? eps_clip : radius;
+  return __builtin_amdgcn_exp2f(exponent_half_neg * __builtin_amdgcn_logf(radius));
+}
+
 // block-wide sum of two doubles into partial slot (fixed order)
 __device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
   __shared__ double red[2][16];  // up to 1024 threads
@@ -292,9 +301,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
     for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
       const int k = q >> logH, row = q & (H - 1);
       const float f1 = 0.f, f2 = axis_freq(row, H), f3 = (float)k / (float)W;
-      float radius = sqrtf(f1 * f1 + f2 * f2 + f3 * f3) * a.inv_rmax;
-      radius = radius < a.eps_clip ? a.eps_clip : radius;
-      const float wgt = powf(radius, a.exponent_half_neg);
+      const float wgt = radial_weight(f1 * f1 + f2 * f2 + f3 * f3, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
       float2 v = t2[k * ldh + row];
       t2[k * ldh + row] = make_float2(v.x * wgt, v.y * wgt);
     }
@@ -408,9 +415,7 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const Colore
         k3 = (int)ql; f1 = 0.f; f2 = axis_freq(k, a.d2);
       }
       f3 = (float)k3 / (float)a.d3;
-      float radius = sqrtf(f1 * f1 + f2 * f2 + f3 * f3) * a.inv_rmax;
-      radius = radius < a.eps_clip ? a.eps_clip : radius;
-      const float wgt = powf(radius, a.exponent_half_neg);
+      const float wgt = radial_weight(f1 * f1 + f2 * f2 + f3 * f3, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
       float2 v = buf[j * ld + k];
       buf[j * ld + k] = make_float2(v.x * wgt, v.y * wgt);
     }
@@ -486,9 +491,7 @@ __global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const float f1 = axis_freq(k, N);
-      float radius = sqrtf(f1 * f1 + rest) * a.inv_rmax;
-      radius = radius < a.eps_clip ? a.eps_clip : radius;
-      const float wgt = powf(radius, a.exponent_half_neg);
+      const float wgt = radial_weight(f1 * f1 + rest, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
       v[k] = make_float2(v[k].x * wgt, v[k].y * wgt);
     }
     dft_n<N, true>(v);
