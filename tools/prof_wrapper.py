@@ -1,3 +1,4 @@
+"""Host cost of one eager scheduler step (cfg2 shape, GPU time is ~7 us so the loop is host-bound)."""
 import sys, time, cProfile, pstats
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -5,16 +6,17 @@ import skrample_amd.diffusers as PD, skrample_amd.scheduling as PS
 from skrample_amd.sampling import structured as PT
 dev = torch.device('cuda:0')
 w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))
-B=256
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 x = torch.randn(B,4,128,128, device=dev).bfloat16(); out = torch.randn_like(x)
 seeds = list(range(B))
 def loop(n=3):
     for _ in range(n):
         w.set_timesteps(20)
-        for t in w.timesteps:
+        ts = w.timesteps.tolist()
+        for t in ts:
             w.step(out, t, x, generator=seeds, return_dict=False)
     torch.cuda.synchronize()
 loop(2)
-t=time.perf_counter(); loop(5); dt=time.perf_counter()-t; print("us/step", dt/100*1e6)
-pr = cProfile.Profile(); pr.enable(); loop(5); pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+t=time.perf_counter(); loop(20); dt=time.perf_counter()-t; print("us/step", dt/400*1e6)
+pr = cProfile.Profile(); pr.enable(); loop(20); pr.disable()
+pstats.Stats(pr).sort_stats('tottime').print_stats(22)
