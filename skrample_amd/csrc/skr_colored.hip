@@ -344,7 +344,9 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
     for (int i = 0; i < PLANE_ITEMS; ++i) {
       const int q = threadIdx.x + i * PLANE_THREADS;
       if (q < total) {
-        const int pr = q >> logW, k = q & (W - 1);
+        // consecutive lanes take consecutive row PAIRS of one frequency: the bit-reversed write below then walks
+        // lines (odd stride, conflict-free) instead of scattering 16 lanes over two banks of one line
+        const int pr = q & (pairs - 1), k = q >> (logH - 1);
         const int m = k < WH ? k : W - k;
         float2 xa = t2[m * ldh + 2 * pr], xb = t2[m * ldh + 2 * pr + 1];
         if (m == 0 || 2 * m == W) { xa.y = 0.f; xb.y = 0.f; }
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
 #pragma unroll
     for (int i = 0; i < PLANE_ITEMS; ++i) {
       const int q = threadIdx.x + i * PLANE_THREADS;
-      if (q < total) t1[(q >> logW) * ldw + brev(q & (W - 1), logW)] = rz[i];
+      if (q < total) t1[(q & (pairs - 1)) * ldw + brev(q >> (logH - 1), logW)] = rz[i];
     }
   }
   fft_tile<true>(t1, tw_w, W, logW, pairs);
