@@ -221,11 +221,14 @@ def test_inner_boundary_sample_packed(dev):
     assert_close(sched.ipoint(0.3).add_noise(xd, od), x * p.alpha + out * p.sigma, torch.float32, "add_noise")
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 32, 32), (2, 3, 16, 16), (2, 6, 16, 16), (3, 1, 8, 8)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_in_kernel_philox_matches_oracle_spec(dtype, dev):
+def test_in_kernel_philox_matches_oracle_spec(dtype, shape, dev):
     """DPM-2 SDE with Random noise drawn inside the step kernel == oracle fed the spec'd Philox normals
     (bf16: 8 consecutive elements per lane; fp32: the whole-line tile layout -- the element -> Philox block map must hold in both)"""
-    steps, shape, seeds = 7, (3, 4, 32, 32), [11, 2**40 + 5, 2**63 + 9]
+    # per-sample sizes 4096 (whole tiles), 768 (launch is whole tiles, samples are not: 8-consecutive layout),
+    # 1536 (three tiles per sample: partial block on the per-sample grid), 64 (flat grid)
+    steps, seeds = 7, [11, 2**40 + 5, 2**63 + 9][: shape[0]]
     w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))
     o = OW.StepDriver(OA.make("dpm", 2, eta=1), OS.karras(OS.scaled(), steps=steps), "eps")
     w.set_timesteps(steps)
