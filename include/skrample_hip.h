@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 3
+#define SKR_ABI_VERSION 4
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 enum skr_status {
@@ -101,13 +101,18 @@ int skr_noise_random(void* out, int32_t out_dtype, const uint64_t* seeds_dev, ui
                      int64_t batch, int64_t sample_numel, void* stream);
 
 /* Brownian.generate (noise.py:210-242; the tree itself is torchsde.BrownianInterval, an un-vendored dependency):
- * out = sum_{k < n_streams} weights[k] * N(stream_ids[k]).  The Brownian path W(t) on [0,1] is a fixed linear
- * function of per-node normals (terminal value + one Brownian-bridge midpoint normal per dyadic interval), so an
- * increment (W(t1) - W(t0)) / sqrt(t1 - t0) is a weighted sum of at most 2*depth+1 node normals; the host walks the
- * tree in fp64 and passes node stream ids + weights (host pointers, copied into the launch).  n_streams <= 64. */
+ *   out = scale * (S_to - S_from),   S_x = sum_{k < n_streams} weights_x[k] * N(stream_ids[k])
+ * The Brownian path W(t) on [0,1] is a fixed linear function of per-node normals (terminal value + one
+ * Brownian-bridge midpoint normal per dyadic interval), so W(t) is a weighted sum of at most depth+1 node normals; the
+ * host walks the tree in fp64 and passes the node stream ids (ascending) with each endpoint's weights (host pointers,
+ * copied into the launch; a node off one endpoint's path has weight 0 there).  n_streams <= 64.
+ * cache_f32 (optional, [batch*sample_numel] fp32, updated in place) receives S_to; with from_cache != 0 it is read as
+ * S_from first (weights_from may then be null) -- the sequential-steps case, where each query starts where the last
+ * one ended, costs one path instead of two.  Cache hits and misses produce identical bits. */
 #define SKR_MAX_WEIGHTED_STREAMS 64
-int skr_noise_weighted(void* out, int32_t out_dtype, const uint64_t* seeds_dev, const uint64_t* stream_ids,
-                       const double* weights, int32_t n_streams, int64_t batch, int64_t sample_numel, void* stream);
+int skr_noise_brownian(void* out, int32_t out_dtype, const uint64_t* seeds_dev, const uint64_t* stream_ids,
+                       const double* weights_to, const double* weights_from, int32_t n_streams, double scale,
+                       float* cache_f32, int32_t from_cache, int64_t batch, int64_t sample_numel, void* stream);
 
 /* Offset.generate (noise.py:84-113): out = N(stream_base) + strength^2 * N(stream_offset)[broadcast].
  * `unit_shape[ndim]` (ndim <= 4) is the per-sample shape; bit k of keep_mask set = dimension k of the unit

@@ -13,7 +13,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
 DTYPE_CODE = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32, torch.float64: F64}
@@ -26,7 +26,7 @@ EXPORTS = (
     "skr_step_launch",
     "skr_noise_random",
     "skr_noise_offset",
-    "skr_noise_weighted",
+    "skr_noise_brownian",
     "skr_noise_pyramid",
     "skr_noise_colored",
     "skr_noise_colored_any",
@@ -98,8 +98,8 @@ def load() -> ctypes.CDLL:
         lib.skr_noise_random.restype = ctypes.c_int
         lib.skr_noise_offset.argtypes = [vp, i32, vp, u64, u64, i64, ctypes.POINTER(i64), i32, ctypes.c_uint32, ctypes.c_double, vp]
         lib.skr_noise_offset.restype = ctypes.c_int
-        lib.skr_noise_weighted.argtypes = [vp, i32, vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), i32, i64, i64, vp]
-        lib.skr_noise_weighted.restype = ctypes.c_int
+        lib.skr_noise_brownian.argtypes = [vp, i32, vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), i32, ctypes.c_double, vp, i32, i64, i64, vp]
+        lib.skr_noise_brownian.restype = ctypes.c_int
         lib.skr_noise_pyramid.argtypes = [vp, i32, vp, vp, vp, vp, u64, u64, i64, i64, i64, i64, i32, ctypes.c_double, i32, i32, vp]
         lib.skr_noise_pyramid.restype = ctypes.c_int
         lib.skr_noise_colored.argtypes = [vp, i32, vp, vp, vp, i64, vp, u64, i64, i32, i32, i32, ctypes.c_double, i32, ctypes.c_double, vp]

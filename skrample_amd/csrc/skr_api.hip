@@ -92,86 +92,124 @@ extern "C" int skr_noise_random(void* out, int32_t out_dtype, const uint64_t* se
   return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
 }
 
-// ---- weighted sum of Philox normal streams (Brownian increments) -----------------------------------------
-struct WeightedArgs {
+// ---- Brownian increments: difference of two weighted sums of Philox normal streams ---------------------------
+// out = scale * (S_to - S_from),  S_x = sum_k w_x[k] * N(stream_ids[k])   (fp32 FMA chain in node order)
+// S_from is either computed in the same pass or, when the previous query ended where this one starts, read from the
+// per-generator cache of S_to (fp32, updated in place).  A zero weight leaves an FMA chain untouched, so S(t) has the
+// same bits whether it was accumulated alongside another path or on its own: cache hits and misses agree bit for bit.
+struct BrownianArgs {
   uint64_t stream_ids[SKR_MAX_WEIGHTED_STREAMS];
-  float weights[SKR_MAX_WEIGHTED_STREAMS];
+  float w_to[SKR_MAX_WEIGHTED_STREAMS];
+  float w_from[SKR_MAX_WEIGHTED_STREAMS];
+  float* cache;  // [batch * sample_numel] fp32 or null
+  float scale;
   int32_t n;
+  int32_t from_cache;  // S_from = cache (else accumulate w_from)
 };
 
-// ALIGNED: sample_numel % 8 == 0 and a 16-byte aligned base -> blockIdx.y = sample, 8 elements per thread, packed
+// ALIGNED: sample_numel % 8 == 0 and 16-byte aligned bases -> blockIdx.y = sample, 8 elements per thread, packed
 // store.  Otherwise one Philox block (4 elements) per thread with bounds checks.  Stream ids and weights are
-// wave-uniform (scalar loads from the kernel arguments); fp32 FMA accumulation in stream order.
-template <typename T, bool ALIGNED>
-__global__ __launch_bounds__(256) void weighted_kernel(T* out, const uint64_t* seeds, const WeightedArgs a, int64_t sample_numel, int64_t blocks_per_sample, int64_t total_blocks) {
+// wave-uniform (scalar loads from the kernel arguments).
+template <typename T, bool ALIGNED, bool FROM_CACHE>
+__global__ __launch_bounds__(256) void brownian_kernel(T* out, const uint64_t* seeds, const BrownianArgs a, int64_t sample_numel, int64_t blocks_per_sample, int64_t total_blocks) {
+  constexpr int W = ALIGNED ? 8 : 4;
+  auto body = [&](uint64_t seed, uint64_t blk0, int64_t e0, int64_t limit) {
+    float to[W], from[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { to[j] = 0.f; from[j] = 0.f; }
+    for (int k = 0; k < a.n; ++k) {
+      float z[W];
+      skr::normal4(seed, a.stream_ids[k], blk0, z);
+      if constexpr (ALIGNED) skr::normal4(seed, a.stream_ids[k], blk0 + 1, z + 4);
+      const float wt = a.w_to[k];
+#pragma unroll
+      for (int j = 0; j < W; ++j) to[j] = __builtin_fmaf(wt, z[j], to[j]);
+      if constexpr (!FROM_CACHE) {
+        const float wf = a.w_from[k];
+#pragma unroll
+        for (int j = 0; j < W; ++j) from[j] = __builtin_fmaf(wf, z[j], from[j]);
+      }
+    }
+    if constexpr (ALIGNED) {  // 32 contiguous bytes per lane: explicit 16-byte accesses
+      float4* c4 = reinterpret_cast<float4*>(a.cache + e0);
+      if constexpr (FROM_CACHE) {
+        const float4 lo = c4[0], hi = c4[1];
+        from[0] = lo.x; from[1] = lo.y; from[2] = lo.z; from[3] = lo.w; from[4] = hi.x; from[5] = hi.y; from[6] = hi.z; from[7] = hi.w;
+      }
+      if (a.cache) { c4[0] = make_float4(to[0], to[1], to[2], to[3]); c4[1] = make_float4(to[4], to[5], to[6], to[7]); }
+    } else {
+      if constexpr (FROM_CACHE) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) if (j < limit) from[j] = a.cache[e0 + j];
+      }
+      if (a.cache) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) if (j < limit) a.cache[e0 + j] = to[j];
+      }
+    }
+    float r[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) r[j] = a.scale * (to[j] - from[j]);
+    if constexpr (ALIGNED) {
+      skr::store8_from_f32<T>(out, e0 >> 3, r);
+    } else {
+#pragma unroll
+      for (int j = 0; j < W; ++j) if (j < limit) out[e0 + j] = (T)r[j];
+    }
+  };
   if constexpr (ALIGNED) {
     const int64_t smp = blockIdx.y, vps = sample_numel >> 3;
     const uint64_t seed = seeds[smp];
-    T* dst = out + smp * sample_numel;
-    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < vps; v += (int64_t)gridDim.x * 256) {
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int k = 0; k < a.n; ++k) {
-        float z[8];
-        skr::normal4(seed, a.stream_ids[k], (uint64_t)(2 * v), z);
-        skr::normal4(seed, a.stream_ids[k], (uint64_t)(2 * v + 1), z + 4);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(a.weights[k], z[j], acc[j]);
-      }
-      skr::store8_from_f32<T>(dst, v, acc);
-    }
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < vps; v += (int64_t)gridDim.x * 256) body(seed, (uint64_t)(2 * v), smp * sample_numel + 8 * v, 8);
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_blocks; i += (int64_t)gridDim.x * 256) {
       const int64_t smp = i / blocks_per_sample, blk = i - smp * blocks_per_sample;
-      const uint64_t seed = seeds[smp];
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int k = 0; k < a.n; ++k) {
-        float z[4];
-        skr::normal4(seed, a.stream_ids[k], (uint64_t)blk, z);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(a.weights[k], z[j], acc[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (blk * 4 + j < sample_numel) out[smp * sample_numel + blk * 4 + j] = (T)acc[j];
-      }
+      const int64_t left = sample_numel - blk * 4;
+      body(seeds[smp], (uint64_t)blk, smp * sample_numel + blk * 4, left < 4 ? left : 4);
     }
   }
 }
 
 template <typename T>
-static void launch_weighted(void* out, const uint64_t* seeds, const WeightedArgs& a, int64_t batch, int64_t sample_numel, hipStream_t s) {
-  const bool fast = sample_numel % 8 == 0 && batch <= 65535 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+static void launch_brownian(void* out, const uint64_t* seeds, const BrownianArgs& a, int64_t batch, int64_t sample_numel, hipStream_t s) {
+  const bool fast = sample_numel % 8 == 0 && batch <= 65535 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.cache) & 15) == 0;
   const int64_t bps = (sample_numel + 3) / 4, total = bps * batch;
   if (fast) {
     int64_t bx = (sample_numel / 8 + 255) / 256;
     const int64_t cap = (256 * 16 + batch - 1) / batch;
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL((weighted_kernel<T, true>), dim3((unsigned)bx, (unsigned)batch), dim3(256), 0, s, (T*)out, seeds, a, sample_numel, bps, total);
+    dim3 grid((unsigned)bx, (unsigned)batch);
+    if (a.from_cache) hipLaunchKernelGGL((brownian_kernel<T, true, true>), grid, dim3(256), 0, s, (T*)out, seeds, a, sample_numel, bps, total);
+    else hipLaunchKernelGGL((brownian_kernel<T, true, false>), grid, dim3(256), 0, s, (T*)out, seeds, a, sample_numel, bps, total);
     return;
   }
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL((weighted_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)out, seeds, a, sample_numel, bps, total);
+  if (a.from_cache) hipLaunchKernelGGL((brownian_kernel<T, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)out, seeds, a, sample_numel, bps, total);
+  else hipLaunchKernelGGL((brownian_kernel<T, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)out, seeds, a, sample_numel, bps, total);
 }
 
-extern "C" int skr_noise_weighted(void* out, int32_t out_dtype, const uint64_t* seeds_dev, const uint64_t* stream_ids, const double* weights,
-                                  int32_t n_streams, int64_t batch, int64_t sample_numel, void* stream) {
+extern "C" int skr_noise_brownian(void* out, int32_t out_dtype, const uint64_t* seeds_dev, const uint64_t* stream_ids, const double* weights_to,
+                                  const double* weights_from, int32_t n_streams, double scale, float* cache_f32, int32_t from_cache,
+                                  int64_t batch, int64_t sample_numel, void* stream) {
   if (batch < 0 || sample_numel < 0 || n_streams < 0) return SKR_ERR_SHAPE;
   if (n_streams > SKR_MAX_WEIGHTED_STREAMS) return SKR_ERR_UNSUPPORTED;
   if (batch == 0 || sample_numel == 0) return SKR_OK;
-  if (!out || !seeds_dev || (n_streams > 0 && (!stream_ids || !weights))) return SKR_ERR_NULL;
-  WeightedArgs a;
+  if (!out || !seeds_dev || (n_streams > 0 && (!stream_ids || !weights_to))) return SKR_ERR_NULL;
+  if (from_cache ? !cache_f32 : (n_streams > 0 && !weights_from)) return SKR_ERR_NULL;
+  BrownianArgs a;
   for (int k = 0; k < SKR_MAX_WEIGHTED_STREAMS; ++k) {
     a.stream_ids[k] = k < n_streams ? stream_ids[k] : 0;
-    a.weights[k] = k < n_streams ? (float)weights[k] : 0.f;
+    a.w_to[k] = k < n_streams ? (float)weights_to[k] : 0.f;
+    a.w_from[k] = (k < n_streams && weights_from) ? (float)weights_from[k] : 0.f;
   }
-  a.n = n_streams;
+  a.cache = cache_f32; a.scale = (float)scale; a.n = n_streams; a.from_cache = from_cache ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (out_dtype) {
-    case SKR_BF16: launch_weighted<__bf16>(out, seeds_dev, a, batch, sample_numel, s); break;
-    case SKR_F16: launch_weighted<_Float16>(out, seeds_dev, a, batch, sample_numel, s); break;
-    case SKR_F32: launch_weighted<float>(out, seeds_dev, a, batch, sample_numel, s); break;
-    case SKR_F64: launch_weighted<double>(out, seeds_dev, a, batch, sample_numel, s); break;
+    case SKR_BF16: launch_brownian<__bf16>(out, seeds_dev, a, batch, sample_numel, s); break;
+    case SKR_F16: launch_brownian<_Float16>(out, seeds_dev, a, batch, sample_numel, s); break;
+    case SKR_F32: launch_brownian<float>(out, seeds_dev, a, batch, sample_numel, s); break;
+    case SKR_F64: launch_brownian<double>(out, seeds_dev, a, batch, sample_numel, s); break;
     default: return SKR_ERR_DTYPE;
   }
   return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;

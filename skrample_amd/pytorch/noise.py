@@ -400,11 +400,23 @@ def brownian_increment(time_from: float, time_to: float, depth: int) -> tuple[tu
     return tuple(k for k, _ in keep), tuple(w for _, w in keep)
 
 
+@lru_cache(maxsize=4096)
+def brownian_endpoints(time_from: float | None, time_to: float, depth: int) -> tuple[tuple[int, ...], tuple[float, ...], tuple[float, ...]]:
+    """(ascending node ids, weights of W(time_to), weights of W(time_from)) over the union of both paths; with
+    time_from = None only W(time_to)'s own nodes (the caller has W(time_from) cached)"""
+    b = brownian_path(time_to, depth)
+    a = brownian_path(time_from, depth) if time_from is not None else {}
+    nodes = tuple(sorted({*a, *b}))
+    return nodes, tuple(b.get(k, 0.0) for k in nodes), tuple(a.get(k, 0.0) for k in nodes)
+
+
 @dataclass
 class Brownian(TensorNoiseCommon):
     """Noise that is a deterministic function of the Step: increments of one fixed Brownian path per seed, so
     overlapping / adjacent steps are consistent (reference noise.py:210-242, there via torchsde.BrownianInterval).
-    Here the path is a virtual dyadic tree keyed by Philox -- every query is one launch, no tree state."""
+    Here the path is a virtual dyadic tree keyed by Philox -- every query is one launch and needs no tree state.
+    The only state is an optimisation: W(time_to) of the last query is kept (fp32), so a query that starts where
+    the previous one ended -- every step of a sampling loop -- evaluates one path instead of two, with identical bits."""
 
     @classmethod
     def from_inputs(cls, shape, seed, props=BrownianProps(), dtype=torch.float32):
@@ -418,15 +430,25 @@ class Brownian(TensorNoiseCommon):
             return Random._batch(unit_shape, seeds, stream, step, props, dtype, state)
         step = step.normal().clamp()
         depth = brownian_depth(props.max_steps)
-        nodes, weights = brownian_increment(float(step.time_from), float(step.time_to), depth)
+        t0, t1 = float(step.time_from), float(step.time_to)
+        shape = (seeds.shape[0], *unit_shape)
+        cache = state.get("brownian_cache")
+        if cache is None or tuple(cache.shape) != shape or cache.device != seeds.device:
+            cache = state["brownian_cache"] = torch.empty(shape, dtype=torch.float32, device=seeds.device)
+            state["brownian_cache_time"] = None
+        hit = state.get("brownian_cache_time") == t0
+        nodes, w_to, w_from = brownian_endpoints(None if hit else t0, t1, depth)
         if len(nodes) > 64:
             raise SkrampleHipError(f"Brownian max_steps={props.max_steps} needs {len(nodes)} tree nodes per query (limit 64)")
-        out = torch.empty((seeds.shape[0], *unit_shape), dtype=dtype, device=seeds.device)
+        out = torch.empty(shape, dtype=dtype, device=seeds.device)
         lib, hstream = _launch_ctx(seeds)
         ids = (ctypes.c_uint64 * len(nodes))(*[BROWNIAN_STREAMS | n for n in nodes])
-        wts = (ctypes.c_double * len(nodes))(*weights)
-        numel = math.prod(unit_shape)
-        _hip.check(lib.skr_noise_weighted(out.data_ptr(), _hip.DTYPE_CODE[dtype], seeds.data_ptr(), ids, wts, len(nodes), seeds.shape[0], numel, hstream), "skr_noise_weighted")
+        wt = (ctypes.c_double * len(nodes))(*w_to)
+        wf = (ctypes.c_double * len(nodes))(*w_from)
+        status = lib.skr_noise_brownian(out.data_ptr(), _hip.DTYPE_CODE[dtype], seeds.data_ptr(), ids, wt, wf, len(nodes), 1.0 / math.sqrt(t1 - t0),
+                                        cache.data_ptr(), 1 if hit else 0, seeds.shape[0], math.prod(unit_shape), hstream)
+        _hip.check(status, "skr_noise_brownian")
+        state["brownian_cache_time"] = t1
         return out
 
 

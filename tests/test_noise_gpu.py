@@ -100,6 +100,16 @@ def test_brownian(unit, dev):
     assert white.shape == (2, *unit) and not torch.equal(white, g.generate(None))
     h = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, props=PN.BrownianProps(), dtype=torch.bfloat16).generate(steps[0])
     assert h.dtype == torch.bfloat16 and (h.cpu().double() - a).abs().max() <= 2.0**-6
+    # the W(time_to) cache: a query that starts where the previous one ended evaluates one path instead of two and
+    # must produce the same bits as a fresh generator that evaluates both
+    for dtype in (torch.float32, torch.bfloat16):
+        seq = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, dtype=dtype)
+        chain = [seq.generate(Step.from_int(k, 20)) for k in range(5, 9)]  # 3 cache hits
+        assert seq._state["brownian_cache_time"] == 9 / 20
+        for k, v in zip(range(5, 9), chain):
+            fresh = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, dtype=dtype).generate(Step.from_int(k, 20))
+            assert torch.equal(v, fresh), (dtype, k)
+        assert torch.equal(seq.generate(Step.from_int(2, 20)), PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, dtype=dtype).generate(Step.from_int(2, 20)))  # miss after hits
 
 
 def test_brownian_statistics_and_wrapper(dev):
