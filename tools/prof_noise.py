@@ -11,5 +11,5 @@ o = PN.BatchTensorNoise.from_batch_inputs(PN.Offset, unit, seeds, props=PN.Offse
 r = PN.BatchTensorNoise.from_batch_inputs(PN.Random, unit, seeds, dtype=torch.bfloat16)
 br = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, dtype=torch.bfloat16)
 for _ in range(10):
-    g.generate(Step(0.45,0.5)); p.generate(None); o.generate(None); r.generate(None); br.generate(Step(0.45,0.5))
+    g.generate(Step(0.45,0.5)); p.generate(None); o.generate(None); r.generate(None); br.generate(Step(0.35,0.4))
 torch.cuda.synchronize()
