@@ -23,8 +23,9 @@ constexpr int VEC = 8;       // elements per lane per trip
 constexpr int BLOCK = 256;   // 4 waves
 // vectors per lane per trip (spaced BLOCK apart so every wave access stays 1 KiB contiguous).  Measured on
 // MI355X (tools/tune/tune_step.hip, B=256 DPM-2): without Philox more bytes in flight per lane win
-// (UV 1/2/4 -> 29.3/28.2/27.4 us); with Philox one vector per lane and one trip per lane is best
-// (UV 1/2/4 -> 28.3/29.7/30.9 us): the VALU work then overlaps other waves' loads instead of its own.
+// (UV 1/2/4 -> 29.3/28.2/27.4 us with non-temporal stores; 26.9/26.4/26.7 with the write-through stores used now);
+// with Philox one vector per lane and one trip per lane is best (UV 1/2/4 -> 26.4/27.1/28.0 us): the VALU work then
+// overlaps other waves' loads instead of its own.
 constexpr int uv_for(bool noise, bool has1) { return noise ? 1 : (has1 ? 2 : 4); }
 constexpr int MAXK = SKR_MAX_TERMS;
 
