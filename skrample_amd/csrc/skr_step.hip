@@ -264,8 +264,13 @@ template <> struct OpMath<double> { using type = double; };
 
 template <typename T> __device__ __forceinline__ float rnd(float v) {
   if constexpr (std::is_same<T, bf16_t>::value) return __uint_as_float(pack_bf16(v, 0.f) << 16);
-  else if constexpr (std::is_same<T, f16_t>::value) return (float)(_Float16)v;
-  else return v;
+  else if constexpr (std::is_same<T, f16_t>::value) {
+    // The reference rounds twice (fp32 op result, then to half).  Left alone, the compiler folds `half(k * float(h))`
+    // into v_fma_mixlo_f16, which rounds the exact product ONCE and differs from torch on fp32 ties (seen as 1-ulp
+    // derivative mismatches in ~4 % of elements).  The empty asm pins the fp32 result in a VGPR first.
+    asm("" : "+v"(v));
+    return (float)(_Float16)v;
+  } else return v;
 }
 __device__ __forceinline__ double rnd_d(double v) { return v; }
 

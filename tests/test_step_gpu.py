@@ -385,6 +385,34 @@ def test_tile_layout_agrees_bitwise(dtypes, n_terms, two_outputs, dev):
     assert rel_err(res[0][0], ref) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("kinds", [(1, 0), (2, 0), (3, 0), (0, 1), (1, 1), (2, 2), (3, 3), (1, 2)])
+def test_rounded_conversion_equals_torch_op_by_op(dtype, kinds, dev):
+    """the RK wrapper's derivative (out0 of a CONV launch) must carry exactly the roundings torch applies when the
+    reference evaluates to_x / from_x one tensor op at a time in the input dtype (fp32 op result, then the tensor
+    dtype: in fp16 a fused multiply-convert would round once and miss the reference on fp32 ties)"""
+    n = 8 * 4096
+    g = torch.Generator().manual_seed(hash(kinds) % 1000)
+    s_, o_ = (torch.randn(n, generator=g) * 1.5).to(dtype), torch.randn(n, generator=g).to(dtype)
+    k = (0.9, 0.09999999999999998, 0.7310585786300049, 0.35)
+    to_kind, from_kind = kinds
+    x = {0: lambda: o_, 1: lambda: (s_ - k[0] * o_) / k[1], 2: lambda: k[1] * s_ - k[0] * o_, 3: lambda: o_ * k[0]}[to_kind]()
+    ref = {0: lambda: x, 1: lambda: (s_ - k[2] * x) / k[3], 2: lambda: (k[2] * s_ - x) / k[3], 3: lambda: x / k[2]}[from_kind]()
+    assert ref.dtype == dtype
+    plan = _hip.StepPlanC()
+    code = _hip.DTYPE_CODE[dtype]
+    plan.n_terms, plan.n_group_a, plan.dtype_a, plan.dtype_b = 2, 2, code, code
+    plan.out0_dtype, plan.out1_dtype, plan.chain = code, code, 1.0
+    plan.convert_to, plan.convert_from = kinds
+    for i, v in enumerate(k):
+        plan.convert_k[i] = v
+    for m in (n, n - 3):  # compile-time-K stage kernel, general kernel
+        o0, o1 = torch.empty(m, device=dev, dtype=dtype), torch.empty(m, device=dev, dtype=dtype)
+        _hip.launch_step(plan, [s_[:m].clone().to(dev), o_[:m].clone().to(dev)], o0, o1, None, m, dev)
+        torch.cuda.synchronize()
+        assert torch.equal(o0.cpu(), ref[:m]), (dtype, kinds, m, int((o0.cpu() != ref[:m]).sum()))
+
+
 def test_wrapper_contract(dev):
     "return types, dtype/device of results, ValueError on unknown timestep, history trimming, no sync for device timesteps"
     w = PD.SkrampleWrapperScheduler(PT.DPM(order=3), PS.Scaled())
