@@ -8,9 +8,50 @@ import test_step_gpu as T
 dev = torch.device("cuda:0")
 from skrample_amd import _hip; _hip.load()
 bad = 0
+import random
+import numpy as np
+from test_step_gpu import PD, OW, OA, ON, SAMPLERS, SCHEDULES, MODELS, oracle_schedule, assert_close, FLOW_SCHEDULES, VP_SCHEDULES
+
+
+def sweep_in_kernel_philox(seed, dev):
+    "like test_random_sweep_vs_oracle, but the noise is drawn by the engine (in-kernel Philox or skr_noise_random) from per-sample seeds"
+    rng = random.Random(9000 + seed)
+    sampler = rng.choice(sorted(SAMPLERS))
+    mk_o, mk_p = SAMPLERS[sampler]
+    if not OA.require_noise(mk_o()):
+        return
+    if rng.random() < 0.4:
+        sname, mname = rng.choice(FLOW_SCHEDULES), rng.choice(("flow", "data", "v"))
+    else:
+        sname = rng.choice(VP_SCHEDULES[:5])
+        mname = rng.choice(("eps", "v", "data"))
+    dtype = rng.choice((torch.float32, torch.bfloat16, torch.float16))
+    shape = (rng.randint(1, 3), rng.randint(1, 5), rng.choice((8, 13, 16, 32)), rng.choice((8, 10, 16, 17, 64)))
+    steps = rng.randint(2, 9)
+    seeds = [rng.randrange(2**64) for _ in range(shape[0])]
+    g = torch.Generator().manual_seed(seed)
+    w = PD.SkrampleWrapperScheduler(mk_p(), SCHEDULES[sname][1](), MODELS[mname][1])
+    o = OW.StepDriver(mk_o(), oracle_schedule(sname, steps), MODELS[mname][0])
+    w.set_timesteps(steps); o.set_timesteps(steps)
+    n = int(np.prod(shape[1:]))
+    x = torch.randn(shape, generator=g).to(dtype)
+    for i, t in enumerate(w.timesteps):
+        out = torch.randn(shape, generator=g).to(dtype)
+        noise = torch.from_numpy(np.stack([ON.philox_normal(s, i * 256, n) for s in seeds])).reshape(shape)
+        try:
+            ref = o.step(out, t, x, noise=noise)[0]
+        except ZeroDivisionError:
+            return
+        got = w.step(out.to(dev), t, x.to(dev), generator=seeds, return_dict=False)[0]
+        if not torch.isfinite(ref.float()).all():
+            return
+        assert_close(got, ref, dtype, f"{sampler}/{sname}/{mname}/{dtype}/{shape}/{steps} step {i}", flips=0.10)
+        x = ref
+
+
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (48, 700)
 for seed in range(lo, hi):
-    for fn in (T.test_random_sweep_vs_oracle, T.test_random_sweep_runge_kutta_vs_oracle):
+    for fn in (T.test_random_sweep_vs_oracle, T.test_random_sweep_runge_kutta_vs_oracle, sweep_in_kernel_philox):
         try:
             fn.__wrapped__(seed, dev) if hasattr(fn, "__wrapped__") else fn(seed, dev)
         except Exception as e:
