@@ -41,6 +41,7 @@ __device__ __forceinline__ uint32_t pack_pair(float a, float b) {
     pk_f32x2 f = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, pk_bf16x2));  // v_cvt_pk_bf16_f32
   } else {
+    asm("" : "+v"(a), "+v"(b));  // convert the rounded fp32 value (no fused multiply-convert)
     const uint32_t lo = __builtin_bit_cast(uint16_t, (_Float16)a);
     const uint32_t hi = __builtin_bit_cast(uint16_t, (_Float16)b);
     return lo | (hi << 16);

@@ -164,6 +164,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   return __builtin_bit_cast(uint32_t, h);
 }
 __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  // round the fp32 accumulator, as the reference does (compute in fp32, then .to(half)): without the pin the compiler
+  // may fuse the last FMA with the conversion (v_fma_mixlo_f16), which rounds the exact sum once
+  asm("" : "+v"(a), "+v"(b));
   const uint32_t lo = __builtin_bit_cast(uint16_t, (_Float16)a);
   const uint32_t hi = __builtin_bit_cast(uint16_t, (_Float16)b);
   return lo | (hi << 16);
