@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 4
+#define SKR_ABI_VERSION 5
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 enum skr_status {
@@ -129,11 +129,21 @@ int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* seeds_dev, ui
  * (stream_levels+1+l, shape [lead][h_l][w_l]) are generated into LDS and sampled there; level 0 is full resolution;
  * skip = max(0, n_levels-1-depth).  Workspaces: scratch_f32 [batch*lead*h*w], partials_f64 [batch*lead*2],
  * level_ws int32 [batch*17] (receives the level table, readable for tests).  Limits: w % 4 == 0 and
- * about h*w <= 380*380 (the level stage must fit 152 KiB of LDS). */
+ * about h*w <= 380*380 (the level stage must fit 152 KiB of LDS); returns SKR_ERR_UNSUPPORTED beyond them --
+ * skr_noise_pyramid_any below covers every shape. */
 int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64, int32_t* level_ws,
                       const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
                       int64_t lead, int64_t h, int64_t w, int32_t resize_h, double strength, int32_t depth,
                       int32_t with_base, void* stream);
+
+/* Same generator for any plane size and width (no `w % 4`, no LDS limit): the level normals are generated into
+ * levels_f32 ([batch * lead*h*w] fp32) and sampled from global memory.  partials_f64 = [batch * n_slots * 2],
+ * n_slots (1..65535) = workgroups per sample of the main pass.  Same values as skr_noise_pyramid where both apply
+ * (up to the summation order of the per-sample statistics). */
+int skr_noise_pyramid_any(void* out, int32_t out_dtype, float* scratch_f32, float* levels_f32, double* partials_f64,
+                          int32_t n_slots, int32_t* level_ws, const uint64_t* seeds_dev, uint64_t stream_base,
+                          uint64_t stream_levels, int64_t batch, int64_t lead, int64_t h, int64_t w, int32_t resize_h,
+                          double strength, int32_t depth, int32_t with_base, void* stream);
 
 /* Colored.generate / colorize_noise (noise.py:337-425): white Philox noise shaped in the Fourier domain by
  * clamp(radial_frequency, eps)^(-exponent/2) and rescaled per sample to the white noise's std (or `energy`).

@@ -13,7 +13,8 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 4
+ABI_VERSION = 5
+SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
 DTYPE_CODE = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32, torch.float64: F64}
@@ -28,6 +29,7 @@ EXPORTS = (
     "skr_noise_offset",
     "skr_noise_brownian",
     "skr_noise_pyramid",
+    "skr_noise_pyramid_any",
     "skr_noise_colored",
     "skr_noise_colored_any",
     "skr_error_mean",
@@ -102,6 +104,8 @@ def load() -> ctypes.CDLL:
         lib.skr_noise_brownian.restype = ctypes.c_int
         lib.skr_noise_pyramid.argtypes = [vp, i32, vp, vp, vp, vp, u64, u64, i64, i64, i64, i64, i32, ctypes.c_double, i32, i32, vp]
         lib.skr_noise_pyramid.restype = ctypes.c_int
+        lib.skr_noise_pyramid_any.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, u64, u64, i64, i64, i64, i64, i32, ctypes.c_double, i32, i32, vp]
+        lib.skr_noise_pyramid_any.restype = ctypes.c_int
         lib.skr_noise_colored.argtypes = [vp, i32, vp, vp, vp, i64, vp, u64, i64, i32, i32, i32, ctypes.c_double, i32, ctypes.c_double, vp]
         lib.skr_noise_colored.restype = ctypes.c_int
         lib.skr_noise_colored_any.argtypes = [vp, i32, vp, vp, vp, vp, u64, i64, i32, ctypes.POINTER(i32), ctypes.c_double, i32, ctypes.c_double, vp]

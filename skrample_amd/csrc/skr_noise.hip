@@ -326,9 +326,125 @@ __global__ __launch_bounds__(256) void normalise_pass2(T* out, const float* scra
   const float inv = (float)(1.0 / sqrt(var));
   const float* src = scratch + smp * unit;
   T* dst = out + smp * unit;
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < unit; i += (int64_t)gridDim.x * 1024) {
-    const float4 v = *reinterpret_cast<const float4*>(src + i);
-    store4_from_f32<T>(dst + i, v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+  if ((unit & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < unit; i += (int64_t)gridDim.x * 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      store4_from_f32<T>(dst + i, v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    }
+  } else {  // ragged units (any-shape path)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < unit; i += (int64_t)gridDim.x * 256) put<T>(dst, i, src[i] * inv);
+  }
+}
+
+// ---- any-shape fallback: levels in global memory ----------------------------------------------------------------
+// For planes whose coarse levels do not fit LDS (about h*w > 380^2) or whose width is not a multiple of 4.  Same
+// arithmetic per pixel as pyramid_pass1; the level normals are generated once into `levels` ([batch][cap] fp32,
+// cap = lead*h*w >= the sum of all level sizes) and sampled from there (L2-resident for the coarse levels).
+struct PyramidAnyArgs {
+  PyramidArgs p;
+  float* levels;
+  int64_t cap;
+  int32_t n_slots;
+};
+
+__device__ __forceinline__ void pyramid_tables(const PyramidArgs& a, int smp, int nl, int* s_lh, int* s_lw, int64_t* s_off, float* s_wgt, float* s_sy, float* s_sx) {
+  const int32_t* hw = a.level_hw + (int64_t)smp * PYR_MAX_LEVELS * 2;
+  const int skip = (nl - 1) - a.depth > 0 ? (nl - 1) - a.depth : 0;
+  int64_t off = 0;
+  float wgt = 1.f;
+  for (int l = 0; l < nl; ++l) {
+    s_lh[l] = hw[2 * l]; s_lw[l] = hw[2 * l + 1];
+    s_off[l] = off;
+    s_wgt[l] = l >= skip ? wgt : 0.f;
+    s_sy[l] = (float)s_lh[l] / (float)a.h;
+    s_sx[l] = (float)s_lw[l] / (float)a.w;
+    if (l >= 1) off += (int64_t)a.lead * s_lh[l] * s_lw[l];
+    wgt *= a.strength;
+  }
+}
+
+__global__ __launch_bounds__(256) void pyramid_levels_any(const PyramidAnyArgs q) {
+  const PyramidArgs& a = q.p;
+  __shared__ int s_lh[PYR_MAX_LEVELS], s_lw[PYR_MAX_LEVELS];
+  __shared__ int64_t s_off[PYR_MAX_LEVELS];
+  __shared__ float s_wgt[PYR_MAX_LEVELS], s_sy[PYR_MAX_LEVELS], s_sx[PYR_MAX_LEVELS];
+  const int smp = blockIdx.y;
+  const int nl = a.n_levels[smp];
+  if (threadIdx.x == 0) pyramid_tables(a, smp, nl, s_lh, s_lw, s_off, s_wgt, s_sy, s_sx);
+  __syncthreads();
+  const uint64_t seed = a.seeds[smp];
+  float* dst = q.levels + (int64_t)smp * q.cap;
+  for (int l = 1; l < nl; ++l) {
+    if (s_wgt[l] == 0.f) continue;
+    const int64_t n = (int64_t)a.lead * s_lh[l] * s_lw[l];  // level tensor [lead][lh][lw], element e = Philox block e/4 lane e%4
+    for (int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x; blk * 4 < n; blk += (int64_t)gridDim.x * 256) {
+      float z[4];
+      normal4(seed, a.stream_levels + 1 + l, (uint64_t)blk, z);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (blk * 4 + j < n) dst[s_off[l] + blk * 4 + j] = z[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pyramid_pass1_any(const PyramidAnyArgs q) {
+  const PyramidArgs& a = q.p;
+  __shared__ double red[2][4];
+  __shared__ int s_lh[PYR_MAX_LEVELS], s_lw[PYR_MAX_LEVELS];
+  __shared__ int64_t s_off[PYR_MAX_LEVELS];
+  __shared__ float s_wgt[PYR_MAX_LEVELS], s_sy[PYR_MAX_LEVELS], s_sx[PYR_MAX_LEVELS];
+  const int smp = blockIdx.y;
+  const int nl = a.n_levels[smp];
+  if (threadIdx.x == 0) pyramid_tables(a, smp, nl, s_lh, s_lw, s_off, s_wgt, s_sy, s_sx);
+  __syncthreads();
+  const uint64_t seed = a.seeds[smp];
+  const int64_t plane = (int64_t)a.h * a.w, unit = (int64_t)a.lead * plane;
+  const float* lv = q.levels + (int64_t)smp * q.cap;
+  float* dst = a.scratch + (int64_t)smp * unit;
+  const float w0 = s_wgt[0];
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g * 4 < unit; g += (int64_t)gridDim.x * 256) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.with_base) normal4(seed, a.stream_base, (uint64_t)g, v);
+    if (w0 != 0.f) {
+      float z[4];
+      normal4(seed, a.stream_levels + 1, (uint64_t)g, z);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaf(z[j], w0, v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t e = g * 4 + j;
+      if (e >= unit) break;
+      const int64_t c = e / plane, r = e - c * plane;
+      const int y = (int)(r / a.w), x = (int)(r - (int64_t)y * a.w);
+      for (int l = 1; l < nl; ++l) {
+        const float wl = s_wgt[l];
+        if (wl == 0.f) continue;
+        const int lh = s_lh[l], lw = s_lw[l];
+        const float* gl = lv + s_off[l] + c * lh * lw;
+        int y0, y1, xa, xb;
+        float ly, lx;
+        src_index(y, s_sy[l], lh, y0, y1, ly);
+        src_index(x, s_sx[l], lw, xa, xb, lx);
+        const float* r0 = gl + (int64_t)y0 * lw;
+        const float* r1 = gl + (int64_t)y1 * lw;
+        const float top = (1.f - lx) * r0[xa] + lx * r0[xb];
+        const float bot = (1.f - lx) * r1[xa] + lx * r1[xb];
+        v[j] += wl * ((1.f - ly) * top + ly * bot);
+      }
+      dst[e] = v[j];
+      s1 += (double)v[j]; s2 += (double)v[j] * (double)v[j];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int wv = 0; wv < 4; ++wv) { t1 += red[0][wv]; t2 += red[1][wv]; }
+    a.partials[((int64_t)smp * q.n_slots + blockIdx.x) * 2 + 0] = t1;
+    a.partials[((int64_t)smp * q.n_slots + blockIdx.x) * 2 + 1] = t2;
   }
 }
 
@@ -400,6 +516,46 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
     case SKR_F16: hipLaunchKernelGGL(skr::normalise_pass2<_Float16>, grid, dim3(256), 0, s, (_Float16*)out, scratch_f32, partials_f64, lead, unit, batch, -1.0); break;
     case SKR_F32: hipLaunchKernelGGL(skr::normalise_pass2<float>, grid, dim3(256), 0, s, (float*)out, scratch_f32, partials_f64, lead, unit, batch, -1.0); break;
     case SKR_F64: hipLaunchKernelGGL(skr::normalise_pass2<double>, grid, dim3(256), 0, s, (double*)out, scratch_f32, partials_f64, lead, unit, batch, -1.0); break;
+    default: return SKR_ERR_DTYPE;
+  }
+  return status_of_launch();
+}
+
+extern "C" int skr_noise_pyramid_any(void* out, int32_t out_dtype, float* scratch_f32, float* levels_f32, double* partials_f64, int32_t n_slots,
+                                     int32_t* level_ws, const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
+                                     int64_t lead, int64_t h, int64_t w, int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream) {
+  if (batch < 0 || lead < 1 || h < 1 || w < 1 || depth < 0 || n_slots < 1) return SKR_ERR_SHAPE;
+  if (batch == 0) return SKR_OK;
+  if (!out || !scratch_f32 || !levels_f32 || !partials_f64 || !seeds_dev || !level_ws) return SKR_ERR_NULL;
+  if (h > 32767 || w > 32767 || batch > 65535 || n_slots > 65535) return SKR_ERR_UNSUPPORTED;
+  if (!resize_h && h != 1) return SKR_ERR_SHAPE;
+  skr::PyramidAnyArgs q;
+  skr::PyramidArgs& a = q.p;
+  a.scratch = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
+  a.level_hw = level_ws; a.n_levels = level_ws + batch * skr::PYR_MAX_LEVELS * 2;
+  a.stream_base = stream_base; a.stream_levels = stream_levels; a.batch = batch; a.lead = (int32_t)lead; a.h = (int32_t)h; a.w = (int32_t)w;
+  a.resize_h = resize_h; a.depth = depth; a.with_base = with_base; a.strength = (float)strength;
+  const int64_t unit = lead * h * w;
+  q.levels = levels_f32; q.cap = unit; q.n_slots = n_slots;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(skr::pyramid_geometry, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, a);
+  if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
+  int64_t lb = (unit / 16 + 255) / 256;  // levels hold at most unit/3 values
+  if (lb < 1) lb = 1;
+  if (lb > 1024) lb = 1024;
+  hipLaunchKernelGGL(skr::pyramid_levels_any, dim3((unsigned)lb, (unsigned)batch), dim3(256), 0, s, q);
+  if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
+  hipLaunchKernelGGL(skr::pyramid_pass1_any, dim3((unsigned)n_slots, (unsigned)batch), dim3(256), 0, s, q);
+  if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
+  int64_t bx = (unit / 4 + 255) / 256;
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  dim3 grid((unsigned)bx, (unsigned)batch);
+  switch (out_dtype) {
+    case SKR_BF16: hipLaunchKernelGGL(skr::normalise_pass2<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, -1.0); break;
+    case SKR_F16: hipLaunchKernelGGL(skr::normalise_pass2<_Float16>, grid, dim3(256), 0, s, (_Float16*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, -1.0); break;
+    case SKR_F32: hipLaunchKernelGGL(skr::normalise_pass2<float>, grid, dim3(256), 0, s, (float*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, -1.0); break;
+    case SKR_F64: hipLaunchKernelGGL(skr::normalise_pass2<double>, grid, dim3(256), 0, s, (double*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, -1.0); break;
     default: return SKR_ERR_DTYPE;
   }
   return status_of_launch();

@@ -271,7 +271,7 @@ class Pyramid(TensorNoiseCommon):
         key = ("ws", batch, lead, h, w)
         if key not in state:
             for k in [k for k in state if k != "static_stream"]:
-                del state[k]
+                del state[k]  # (also drops the any-shape workspaces of a previous shape)
             state[key] = (
                 torch.empty(batch * lead * h * w, dtype=torch.float32, device=dev),
                 torch.empty(batch * lead * 2, dtype=torch.float64, device=dev),
@@ -280,13 +280,18 @@ class Pyramid(TensorNoiseCommon):
         scratch, partials, levels = state[key]
         out = torch.empty((batch, *unit_shape), dtype=dtype, device=dev)
         lib, hstream = _launch_ctx(seeds)
-        _hip.check(
-            lib.skr_noise_pyramid(
-                out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), partials.data_ptr(), levels.data_ptr(), seeds.data_ptr(), stream,
-                stream_levels, batch, lead, h, w, 1 if resize_h else 0, float(props.strength), int(min(props.depth, 1 << 20)), 1, hstream,
-            ),
-            "skr_noise_pyramid",
-        )
+        tail = (seeds.data_ptr(), stream, stream_levels, batch, lead, h, w, 1 if resize_h else 0, float(props.strength), int(min(props.depth, 1 << 20)), 1, hstream)
+        status = _hip.SKR_ERR_UNSUPPORTED if state.get("any_shape") else lib.skr_noise_pyramid(out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), partials.data_ptr(), levels.data_ptr(), *tail)
+        if status == _hip.SKR_ERR_UNSUPPORTED:
+            # planes too large for the LDS level stage, or a width that is not a multiple of 4: levels in global memory
+            if "any_shape" not in state:
+                slots = max(1, min(1024, -(-(lead * h * w) // (4 * 256 * 8))))
+                state["any_shape"] = (torch.empty(batch * lead * h * w, dtype=torch.float32, device=dev), torch.empty(batch * slots * 2, dtype=torch.float64, device=dev), slots)
+            level_ws, partials_any, slots = state["any_shape"]
+            status = lib.skr_noise_pyramid_any(out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), level_ws.data_ptr(), partials_any.data_ptr(), slots, levels.data_ptr(), *tail)
+            _hip.check(status, "skr_noise_pyramid_any")
+        else:
+            _hip.check(status, "skr_noise_pyramid")
         state["levels"] = levels  # device table of the last draw: [batch][8][2] sizes, then [batch] counts
         return out
 

@@ -225,6 +225,23 @@ def test_pyramid(unit, kw, dev):
         assert (got.reshape(3, -1).std(dim=1) - 1).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize(("unit", "kw"), [((2, 30, 90), {}), ((3, 27, 18), dict(strength=0.6)), ((1, 400, 400), {}), ((2, 7), dict(dims=(-1,))), ((3, 50), dict(dims=(-1,), depth=1)), ((1, 4, 4), {})])
+def test_pyramid_any_shape(unit, kw, dev):
+    "widths that are not multiples of 4 and planes beyond the LDS level stage take the global-memory fallback; same oracle, same bar"
+    seeds = [41, 42]
+    props = PN.PyramidProps(**kw)
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=props, dtype=torch.float32)
+    for n in range(2):
+        got = g.generate(None).cpu()
+        ref = torch.stack([pyramid_reference(unit, s, n * 256, **kw) for s in seeds])
+        assert rel(got, ref) < 2e-5, (unit, kw, n, rel(got, ref))
+    if unit != (1, 4, 4):
+        assert "any_shape" in g._state
+    h16 = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=props, dtype=torch.bfloat16).generate(None)
+    ref = torch.stack([pyramid_reference(unit, s, 0, **kw) for s in seeds])
+    assert (h16.cpu().float() - ref).abs().max() <= 2.0**-6 * max(1.0, ref.abs().max().item())
+
+
 def test_pyramid_static(dev):
     "PyramidProps.static: the pyramid component of the first draw is reused, only the base normal is fresh"
     unit, seeds = (4, 32, 32), [51, 52]
