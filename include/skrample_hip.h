@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 5
+#define SKR_ABI_VERSION 6
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 enum skr_status {
@@ -172,6 +172,12 @@ int skr_error_mean(const void* a_or_null, const void* b, int32_t dtype, int64_t 
 /* raw generator outputs, for parity tests of the RNG itself */
 int skr_philox_u32(uint32_t* out /* [n_blocks*4] device */, uint64_t seed, uint64_t stream_id,
                    uint64_t first_block, int64_t n_blocks, void* stream);
+
+/* SPC's signed-power blend (structured.py:568-572 with common.py:187-190), the one non-linear tensor op of the
+ * samplers: out = spowf(p * spowf(a, P) + c * spowf(b, P), 1/P), spowf(x, f) = |x|^f * sign(x).  out is fp32 or
+ * fp64 (the wrappers' compute_scale; fp64 uses double-precision pow); a and b may be any of the four dtypes.  P != 0. */
+int skr_power_blend(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, const void* b, int32_t b_dtype, double p,
+                    double c, double power, int64_t numel, void* stream);
 
 int skr_abi_version(void);
 const char* skr_strerror(int status);

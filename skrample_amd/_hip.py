@@ -13,7 +13,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 5
+ABI_VERSION = 6
 SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
@@ -33,6 +33,7 @@ EXPORTS = (
     "skr_noise_colored",
     "skr_noise_colored_any",
     "skr_error_mean",
+    "skr_power_blend",
     "skr_philox_u32",
     "skr_abi_version",
     "skr_strerror",
@@ -114,6 +115,8 @@ def load() -> ctypes.CDLL:
         lib.skr_error_mean.restype = ctypes.c_int
         lib.skr_philox_u32.argtypes = [vp, u64, u64, u64, i64, vp]
         lib.skr_philox_u32.restype = ctypes.c_int
+        lib.skr_power_blend.argtypes = [vp, i32, vp, i32, vp, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i64, vp]
+        lib.skr_power_blend.restype = ctypes.c_int
         lib.skr_abi_version.restype = ctypes.c_int
         lib.skr_strerror.argtypes = [ctypes.c_int]
         lib.skr_strerror.restype = ctypes.c_char_p

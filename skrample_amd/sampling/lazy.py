@@ -463,6 +463,21 @@ def error_mean(a, b: torch.Tensor, power: int) -> float:
     return ws[0].item()
 
 
+def power_blend(a: torch.Tensor, b: torch.Tensor, wa: float, wb: float, power: float, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    "spowf(wa * spowf(a, power) + wb * spowf(b, power), 1 / power) as one elementwise launch; fp32 or fp64 result"
+    _check_tensor(a)
+    _check_tensor(b)
+    if a.shape != b.shape:
+        raise SkrampleHipError(f"shape mismatch in sampler operands: {tuple(a.shape)} vs {tuple(b.shape)}")
+    if dtype not in (torch.float32, torch.float64):
+        raise SkrampleHipError("the signed-power blend is evaluated in float32 or float64")
+    a, b = _prepare_tensor(a), _prepare_tensor(b)
+    out = empty_output(a.shape, dtype, a.device)
+    status = _hip.load().skr_power_blend(out.data_ptr(), _hip.DTYPE_CODE[dtype], a.data_ptr(), _hip.DTYPE_CODE[a.dtype], b.data_ptr(), _hip.DTYPE_CODE[b.dtype], float(wa), float(wb), float(power), a.numel(), _hip.current_stream_ptr(a.device))
+    _hip.check(status, "skr_power_blend")
+    return out
+
+
 def settle(value, like=None, dtype: torch.dtype | None = None):
     "number -> number; form -> tensor (one launch)"
     if isinstance(value, Lin):

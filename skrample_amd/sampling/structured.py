@@ -349,8 +349,8 @@ class UniPC(UniP):
 @dataclass(frozen=True)
 class SPC(traits.DerivativeTransform, StructuredSampler):
     """Simple predictor-corrector: re-run the previous step with a corrector sampler, blend it with
-    the incoming sample (softmax of sigma/alpha), then predict.  Only the linear blend (power == 1)
-    is expressible as a fused step; other powers are not supported by this engine."""
+    the incoming sample (softmax of sigma/alpha), then predict.  The linear blend (power == 1) is part of
+    the one fused step; other powers take three launches (corrector, signed-power blend, predictor)."""
 
     predictor: StructuredSampler = Euler()
     corrector: StructuredSampler = Adams(order=4)
@@ -389,7 +389,14 @@ class SPC(traits.DerivativeTransform, StructuredSampler):
                 wp, wc = wc, wp
             if abs(self.power - 1) > 1e-8:
                 if isinstance(corrected, Lin):
-                    raise lazy.SkrampleHipError("SPC(power != 1) is a non-linear blend; not supported by the fused engine")
+                    # the one non-linear tensor op of the samplers: materialise the corrector's result (one launch), blend
+                    # (one elementwise launch), then predict from the blended sample as usual
+                    wide = _state_dtype(result_dtype)  # compute_scale: float32, or float64 when asked for
+                    sample_t = packed.sample if isinstance(packed.sample, torch.Tensor) else lazy.settle(lift(packed.sample), dtype=wide)
+                    blended = lazy.power_blend(sample_t, lazy.settle(corrected, dtype=wide), wp, wc, self.power, wide)
+                    inner = replace(inner, sample=blended)
+                    final = lazy.settle(self.predictor._form(inner, space, schedule, previous), dtype=result_dtype)
+                    return SKSamples(blended, prediction, packed.step, packed.noise, final)
                 blended = common.spowf(common.spowf(packed.sample, self.power) * wp + common.spowf(corrected, self.power) * wc, 1 / self.power)
             else:
                 blended = lift(packed.sample) * wp + corrected * wc

@@ -77,6 +77,8 @@ SAMPLERS = {
     "unipc3_noderiv": (lambda: OA.make("unipc", 3, deriv=None), lambda: PT.UniPC(order=3, derivative_transform=None)),
     "spc": (lambda: OA.make("spc"), lambda: PT.SPC()),
     "spc_bias": (lambda: OA.make("spc", bias=0.3), lambda: PT.SPC(bias=0.3)),
+    "spc_power2": (lambda: OA.make("spc", power=2), lambda: PT.SPC(power=2)),
+    "spc_power_half_dpm": (lambda: OA.make("spc", power=0.5, predictor=OA.make("dpm", 2, eta=0.5), corrector=OA.make("adams", 2)), lambda: PT.SPC(power=0.5, predictor=PT.DPM(order=2, stochasticity=0.5), corrector=PT.Adams(order=2))),
     "spc_dpm_unip": (
         lambda: OA.make("spc", predictor=OA.make("dpm", 2, eta=1), corrector=OA.make("unip", 3), adaptive=False, invert=True),
         lambda: PT.SPC(predictor=PT.DPM(order=2, stochasticity=1), corrector=PT.UniP(order=3), adaptive=False, invert=True),
