@@ -315,11 +315,26 @@ def test_colored_spectrum_slope(dev):
         ok = (power > 0) & (centers > 0)
         return -linregress(np.log(centers[ok]), np.log(power[ok])).slope
 
-    for exponent in (-3, -1.5, 1.5, 3):
-        for unit in ((1024, 1024), (128, 128, 128)):
+    for exponent in (-3, -1.5, 0, 1.5, 3):
+        for unit in ((65536,), (1024, 1024), (128, 128, 128)):
             g = PN.Colored(unit, 5, torch.float32, PN.ColoredProps(color_curve=0, color_start=exponent, color_end=-exponent))
             assert abs(exponent - slope(g.generate(None).cpu().numpy())) < 0.1
             assert abs(-exponent - slope(g.generate(Step(0, 1)).cpu().numpy())) < 0.1
+
+
+@pytest.mark.parametrize("unit", [(65536,), (1024, 1024), (128, 128, 128)])
+def test_colored_energy(unit, dev):
+    "reference tests/self_noise.py:83-103: the output std is |energy| exactly, or ~1 (the white noise's own) without it"
+    rng = np.random.default_rng(3)
+    for energy in (None, -3, -1.5, 0, 1.5, 3):
+        props = PN.ColoredProps(energy=energy, color_start=float(rng.standard_normal()), color_end=float(rng.standard_normal()))
+        g = PN.Colored(unit, 9, torch.float32, props)
+        for st in (None, Step(0, 1)):
+            std = g.generate(st).double().std().item()
+            if energy is None:
+                assert abs(1 - std) < 1e-2, (unit, energy, std)
+            else:
+                assert abs(abs(energy) - std) < 1e-5 * max(1.0, abs(energy)), (unit, energy, std)
 
 
 def test_colored_with_unipc_wrapper(dev):
