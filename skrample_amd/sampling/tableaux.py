@@ -167,6 +167,64 @@ def shu_osher_tableau(alphas: Sequence[Sequence[float]], betas: Sequence[Sequenc
     return Tableau(tuple(Stage(math.fsum(r), tuple(r)) for r in a), tuple(b))
 
 
+@dataclasses.dataclass(frozen=True)
+class ButcherCoeffs:
+    """Mutable scratch form of a tableau: nodes c, strictly lower-triangular rows a (row n has n entries) and weights b,
+    optionally 1-indexed with a dummy leading entry (papers that number stages from 1).  Interface of the reference's
+    tableaux/common.py:30-125 (empty / compute_c / compose / decompose / deserialize / serialize / from_shu_osher)."""
+
+    one_index: bool
+    c: list
+    a: list
+    b: list
+
+    @classmethod
+    def empty(cls, stages: int, fill: float = -math.inf, one_index: bool = False) -> "ButcherCoeffs":
+        n = stages + int(one_index)
+        c = [fill] * n
+        c[int(one_index)] = 0  # the first stage sits at the step start
+        return cls(one_index, c=c, a=[[fill] * k for k in range(n)], b=[fill] * n)
+
+    def compute_c(self) -> None:
+        "row-sum condition: c_i = sum_j a_ij"
+        self.c[:] = [math.fsum(row) for row in self.a]
+
+    def compose(self) -> Tableau:
+        k = int(self.one_index)
+        return Tableau(tuple(Stage(c, tuple(row[k:])) for c, row in zip(self.c[k:], self.a[k:], strict=True)), tuple(self.b[k:]))
+
+    @classmethod
+    def decompose(cls, tableau: Tableau) -> "ButcherCoeffs":
+        return cls(False, c=[st.c for st in tableau.stages], a=[list(st.a) for st in tableau.stages], b=list(tableau.weights))
+
+    @classmethod
+    def deserialize(cls, coeffs: Sequence[float], stages: int, compute_c: bool = False, b_last: bool = True) -> "ButcherCoeffs":
+        "flat list: [c (unless compute_c)] [b if not b_last] [a rows 1..] [b if b_last]"
+        t = cls.empty(stages)
+        n_a = sum(len(row) for row in t.a)
+        if len(coeffs) != (0 if compute_c else stages) + stages + n_a:
+            raise AssertionError(f"{len(coeffs)} coefficients for {stages} stages")
+        it = iter(coeffs)
+        if not compute_c:
+            t.c[:] = [next(it) for _ in range(stages)]
+        if not b_last:
+            t.b[:] = [next(it) for _ in range(stages)]
+        for row in t.a[1:]:
+            row[:] = [next(it) for _ in row]
+        if compute_c:
+            t.compute_c()
+        if b_last:
+            t.b[:] = [next(it) for _ in range(stages)]
+        return t
+
+    def serialize(self) -> list:
+        return [*self.c, *(v for row in self.a for v in row), *self.b]
+
+    @classmethod
+    def from_shu_osher(cls, alphas: Sequence[Sequence[float]], betas: Sequence[Sequence[float]]) -> "ButcherCoeffs":
+        return cls.decompose(shu_osher_tableau(alphas, betas))
+
+
 # ---------------------------------------------------------------------------------------------------
 # providers
 # ---------------------------------------------------------------------------------------------------
@@ -420,8 +478,29 @@ class SSP(_EnumProvider):
     )
 
 
+def _from_table(path_name: str, prefix: str) -> dict[str, Tableau]:
+    "coefficient tables stored as exact float hex (tools/make_tableaux_data.py): members `prefix.<name>`"
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), path_name)) as fh:
+        raw = json.load(fh)
+    h = float.fromhex
+    return {
+        key.split(".", 1)[1]: Tableau(tuple(Stage(h(c), tuple(h(v) for v in row)) for c, row in zip(t["c"], t["a"])), tuple(h(v) for v in t["b"]))
+        for key, t in raw.items()
+        if key.startswith(prefix + ".")
+    }
+
+
+# The reference's "graveyard" (tableaux/__init__.py:39-43): published methods it keeps but does not recommend.
+WSO = _EnumProvider("WSO", _from_table("tableaux_graveyard.json", "WSO"))
+WSO.__doc__ = """Methods with a higher weak stage order, named STAGES_ORDER_WSO (Biswas et al. 2023, "Explicit Runge-Kutta
+methods that alleviate order reduction", arXiv:2310.02817; reference providers.py:641-861)."""
+Shanks1965 = _EnumProvider("Shanks1965", _from_table("tableaux_graveyard.json", "Shanks1965"))
+Shanks1965.__doc__ = """E. B. Shanks, "Higher order approximations of Runge-Kutta type", NASA TN D-2920 (1965); RK5_5, RK6_6, RK7_7
+and RK8_10 only approximate their nominal orders (reference providers.py:863-1000)."""
+
 BUILTIN_TABLEAUX: Sequence = [*RK1, *RK2, *RK3, *RK4, *RKZ, *SSP]
 BUILTIN_EMBEDDED_TABLEAU: Sequence = [*RKE2, *RKE3, *RKE5]
+GRAVEYARD: Sequence = [*WSO, *Shanks1965]
 
 
 def pretty_tableau(tab, label: str | None = None) -> str:
@@ -433,3 +512,9 @@ def pretty_tableau(tab, label: str | None = None) -> str:
     width = max(len(line) for line in (*body, *foot))
     head = [label.rjust((width + len(label)) // 2)] if label is not None else []
     return "\n".join([*head, *body, "-" * width, *foot])
+
+
+# the reference splits this module into a package (tableaux.common / tableaux.providers); both names resolve here
+import sys as _sys  # noqa: E402
+
+common = providers = _sys.modules[__name__]

@@ -109,7 +109,7 @@ def test_effective_order(tables):
 
 
 def test_tableaux(tables):
-    groups = (PTab.RK1, PTab.RK2, PTab.RK3, PTab.RK4, PTab.RKZ, PTab.RKE2, PTab.RKE3, PTab.RKE5, PTab.SSP)
+    groups = (PTab.RK1, PTab.RK2, PTab.RK3, PTab.RK4, PTab.RKZ, PTab.RKE2, PTab.RKE3, PTab.RKE5, PTab.SSP, PTab.WSO, PTab.Shanks1965)
     for grp in groups:
         for member in grp:
             ref = tables["tableaux"][f"{grp.__name__}.{member.name}"]
@@ -126,6 +126,8 @@ def test_tableaux(tables):
         grp, name = v.split(".")
         assert PF.STABLE_PROVIDERS[int(k)] is getattr(getattr(PTab, grp), name)
     assert len(PF.RKUltra(order=99).tableau().stages) == 15  # Stepanov10
+    assert [m.name for m in PTab.GRAVEYARD] == [m.name for m in (*PTab.WSO, *PTab.Shanks1965)] and len(PTab.GRAVEYARD) == 14
+    assert not set(PTab.GRAVEYARD) & set(PTab.BUILTIN_TABLEAUX)  # kept, not recommended (reference tableaux/__init__.py:39-43)
 
 
 def test_rk_points(tables):
@@ -434,3 +436,61 @@ def test_brownian_oracle_is_an_independent_restatement():
     # reference call-site arithmetic: direction-normalised and clamped steps (noise.py:241)
     assert torch.equal(ON.brownian_noise(5, (n,), (0.4, 0.35)), ON.brownian_noise(5, (n,), (0.35, 0.4)))
     assert torch.equal(ON.brownian_noise(5, (n,), (1.0, 1.05)), ON.brownian_noise(5, (n,), (0.95, 1.0)))
+
+
+def test_tableau_constructors():
+    "reference tests/self_sampling.py:675-800: the parametric constructors reproduce the published tableaux"
+    T, S, B = PTab.common.Tableau, PTab.common.Stage, PTab.common.ButcherCoeffs
+
+    def distance(a, b) -> float:
+        return max(abs(x - y) for x, y in zip(PTab.serialize(a), PTab.serialize(b)))
+
+    assert distance(T((S(0.0, ()), S(2 / 3, (2 / 3,))), (1 / 4, 3 / 4)), PTab.providers.rk2_tableau(2 / 3)) < 1e-20  # Ralston
+    wray = T((S(0.0, ()), S(8 / 15, (8 / 15,)), S(2 / 3, (1 / 4, 5 / 12))), (1 / 4, 0.0, 3 / 4))
+    assert distance(wray, PTab.providers.rk3_tableau(8 / 15, 2 / 3)) < 1e-15
+    eighth = T((S(0, ()), S(1 / 3, (1 / 3,)), S(2 / 3, (-1 / 3, 1)), S(1, (1, -1, 1))), (1 / 8, 3 / 8, 3 / 8, 1 / 8))
+    assert distance(eighth, PTab.providers.rk4_tableau(1 / 3, 2 / 3)) < 1e-12
+    ees25 = T((S(0, ()), S(1 / 3, (1 / 3,)), S(5 / 6, (-5 / 48, 15 / 16))), (1 / 10, 1 / 2, 2 / 5))  # arXiv 2507.21006 (8.4)
+    assert distance(ees25, PTab.providers.ees25_tableau(1 / 10)) < 1e-15
+    v2 = math.sqrt(2)
+    ees27 = T(
+        (
+            S(0, ()),
+            S(1 / 3 * (2 - v2), (1 / 3 * (2 - v2),)),
+            S(1 / 6 * (2 + v2), (1 / 24 * (-4 + v2), 1 / 8 * (4 + v2))),
+            S(1 / 6 * (4 + v2), (1 / 168 * (-176 + 145 * v2), 3 / 56 * (8 - 5 * v2), 3 / 7 * (3 - v2))),
+        ),
+        (1 / 14 * (5 - 3 * v2), 1 / 14 * (3 + v2), 3 / 14 * (-1 + 2 * v2), 1 / 14 * (9 - 4 * v2)),
+    )
+    assert distance(ees27, PTab.providers.ees27_tableau(1 / 14 * (5 - 3 * v2))) < 1e-15
+    ssp45 = T(  # SSPRK(5,4) in Butcher form
+        (
+            S(0, ()),
+            S(0.391752226869254, (0.391752226869254,)),
+            S(0.586079689066902, (0.217669096357835, 0.368410592709067)),
+            S(0.474542363162481, (0.082692086683094, 0.139958502107426, 0.251891774371961)),
+            S(0.935010631095793, (0.067966283574048, 0.115034698453668, 0.207034898772937, 0.54497475029514)),
+        ),
+        (0.146811876157876, 0.248482909391317, 0.104258830279481, 0.274438901048481, 0.226007483122845),
+    )
+    alphas = [[1], [0.444370493651235, 0.555629506348765], [0.620101851488403, 0, 0.379898148511597], [0.178079954393132, 0, 0, 0.821920045606868], [0, 0, 0.517231671970585, 0.096059710526147, 0.386708617503269]]
+    betas = [[0.391752226571890], [0, 0.368410593050371], [0, 0, 0.251891774271694], [0, 0, 0, 0.544974750228521], [0, 0, 0, 0.063692468666290, 0.226007483236906]]
+    assert distance(ssp45, B.from_shu_osher(alphas, betas).compose()) < 1e-8
+    # serialisation round trips in every layout
+    ck = PTab.RKE5.CashKarp.tableau()
+    coeffs = B.decompose(T(ck.stages, ck.weights))
+    n = len(coeffs.c)
+    for compute_c, b_last in itertools.product((False, True), (True, False)):
+        flat = ([] if compute_c else list(coeffs.c)) + ([] if b_last else list(coeffs.b)) + [v for row in coeffs.a[1:] for v in row] + (list(coeffs.b) if b_last else [])
+        back = B.deserialize(flat, n, compute_c, b_last).compose()
+        assert distance(back, T(ck.stages, ck.weights)) < 1e-15
+    shifted = B.empty(3, one_index=True)
+    assert len(shifted.c) == 4 and shifted.c[1] == 0 and [len(r) for r in shifted.a] == [0, 1, 2, 3]
+    # no two built-in methods of the same size coincide (reference test_tableau_dupe), graveyard included
+    everything = [m.tableau() for m in (*PTab.BUILTIN_TABLEAUX, *PTab.GRAVEYARD)]
+    for i, a in enumerate(everything):
+        for b in everything[i + 1 :]:
+            if len(a.stages) == len(b.stages):
+                assert distance(a, b) > 1e-2
+    for provider in PF.STABLE_PROVIDERS.values():  # reference test_tableau_preset_nondefault
+        assert provider not in PF.DEFAULT_PROVIDERS.values()

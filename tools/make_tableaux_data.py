@@ -32,3 +32,18 @@ for name in ("Stepanov10", "Ono10", "Harrier10", "Zhang10", "Feagin10", "Feagin1
 path = os.path.join(os.path.dirname(HERE), "skrample_amd", "sampling", "tableaux_high_order.json")
 json.dump(out, open(path, "w"))
 print(path, os.path.getsize(path), {k: len(v["b"]) for k, v in out.items()})
+
+# the "graveyard" groups (reference tableaux/__init__.py:39-43; providers.py:641-861 WSO -- Biswas et al. 2023,
+# arXiv:2310.02817; providers.py:863-1000 Shanks1965 -- E. B. Shanks, NASA TN D-2920): coefficients only
+grave = {}
+for group in ("WSO", "Shanks1965"):
+    for member in getattr(tableaux, group):
+        tab = member.tableau()
+        grave[f"{group}.{member.name}"] = {
+            "c": [float(s.c).hex() for s in tab.stages],
+            "a": [[float(v).hex() for v in s.a] for s in tab.stages],
+            "b": [float(v).hex() for v in tab.weights],
+        }
+path = os.path.join(os.path.dirname(HERE), "skrample_amd", "sampling", "tableaux_graveyard.json")
+json.dump(grave, open(path, "w"))
+print(path, os.path.getsize(path), {k: len(v["b"]) for k, v in grave.items()})
