@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 6
+#define SKR_ABI_VERSION 7
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 enum skr_status {
@@ -172,6 +172,12 @@ int skr_error_mean(const void* a_or_null, const void* b, int32_t dtype, int64_t 
 /* raw generator outputs, for parity tests of the RNG itself */
 int skr_philox_u32(uint32_t* out /* [n_blocks*4] device */, uint64_t seed, uint64_t stream_id,
                    uint64_t first_block, int64_t n_blocks, void* stream);
+
+/* Colored.colorize_noise (noise.py:337-403) on a caller's white noise: white_f32 ([batch * prod(dims)] fp32, used as
+ * the transform workspace and overwritten) is shaped exactly as skr_noise_colored_any shapes its own draws; same
+ * workspaces, any dims (hipFFT).  exponent = 0 is the caller's fast path (plain rescale), not handled here. */
+int skr_colorize(void* out, int32_t out_dtype, void* spec_c64, float* white_f32, double* partials_f64, int64_t batch,
+                 int32_t rank, const int32_t* dims, double exponent, int32_t has_energy, double energy, void* stream);
 
 /* SPC's signed-power blend (structured.py:568-572 with common.py:187-190), the one non-linear tensor op of the
  * samplers: out = spowf(p * spowf(a, P) + c * spowf(b, P), 1/P), spowf(x, f) = |x|^f * sign(x).  out is fp32 or

@@ -13,7 +13,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 6
+ABI_VERSION = 7
 SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
@@ -32,6 +32,7 @@ EXPORTS = (
     "skr_noise_pyramid_any",
     "skr_noise_colored",
     "skr_noise_colored_any",
+    "skr_colorize",
     "skr_error_mean",
     "skr_power_blend",
     "skr_philox_u32",
@@ -111,6 +112,8 @@ def load() -> ctypes.CDLL:
         lib.skr_noise_colored.restype = ctypes.c_int
         lib.skr_noise_colored_any.argtypes = [vp, i32, vp, vp, vp, vp, u64, i64, i32, ctypes.POINTER(i32), ctypes.c_double, i32, ctypes.c_double, vp]
         lib.skr_noise_colored_any.restype = ctypes.c_int
+        lib.skr_colorize.argtypes = [vp, i32, vp, vp, vp, i64, i32, ctypes.POINTER(i32), ctypes.c_double, i32, ctypes.c_double, vp]
+        lib.skr_colorize.restype = ctypes.c_int
         lib.skr_error_mean.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp]
         lib.skr_error_mean.restype = ctypes.c_int
         lib.skr_philox_u32.argtypes = [vp, u64, u64, u64, i64, vp]

@@ -91,6 +91,17 @@ __global__ __launch_bounds__(256) void any_white(const AnyArgs a) {
   block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * SLOTS + blockIdx.x) * 2);
 }
 
+// the white noise is already in a.real (colorize_noise on a caller's tensor): only its statistics are needed
+__global__ __launch_bounds__(256) void any_white_stats(const AnyArgs a) {
+  const int64_t smp = blockIdx.y;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)SLOTS * 256) {
+    const float v = a.real[smp * a.unit + e];
+    s1 += (double)v; s2 += (double)v * (double)v;
+  }
+  block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * SLOTS + blockIdx.x) * 2);
+}
+
 __device__ __forceinline__ float axis_freq(int k, int d) { const int m = k < d - k ? k : d - k; return (float)m / (float)d; }
 
 __global__ __launch_bounds__(256) void any_weights(const AnyArgs a) {
@@ -138,13 +149,13 @@ __global__ __launch_bounds__(256) void any_finish(T* out, const AnyArgs a, int h
 
 }  // namespace
 
-extern "C" int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
-                                     const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
-                                     double exponent, int32_t has_energy, double energy, void* stream) {
+static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
+                            const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
+                            double exponent, int32_t has_energy, double energy, void* stream, bool white_given) {
   if (batch < 0 || rank < 1 || rank > 3 || !dims) return SKR_ERR_SHAPE;
   for (int i = 0; i < rank; ++i) if (dims[i] < 2) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
-  if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || !seeds_dev) return SKR_ERR_NULL;
+  if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || (!white_given && !seeds_dev)) return SKR_ERR_NULL;
   if (batch > 65535) return SKR_ERR_UNSUPPORTED;
   FftApi& f = api();
   if (!f.ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
@@ -181,7 +192,8 @@ extern "C" int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c6
   f.set_stream(plans.fwd, s);
   f.set_stream(plans.inv, s);
 
-  hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+  if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
   if (f.r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
   int64_t wb = ((int64_t)a.d1 * a.d2 * a.d3h * batch + 255) / 256; if (wb > 256 * 32) wb = 256 * 32;
   hipLaunchKernelGGL(any_weights, dim3((unsigned)wb), dim3(256), 0, s, a);
@@ -197,4 +209,15 @@ extern "C" int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c6
     default: return SKR_ERR_DTYPE;
   }
   return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}
+
+extern "C" int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
+                                     const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
+                                     double exponent, int32_t has_energy, double energy, void* stream) {
+  return colored_any_impl(out, out_dtype, spec_c64, scratch_f32, partials_f64, seeds_dev, stream_id, batch, rank, dims, exponent, has_energy, energy, stream, false);
+}
+
+extern "C" int skr_colorize(void* out, int32_t out_dtype, void* spec_c64, float* white_f32, double* partials_f64, int64_t batch, int32_t rank,
+                            const int32_t* dims, double exponent, int32_t has_energy, double energy, void* stream) {
+  return colored_any_impl(out, out_dtype, spec_c64, white_f32, partials_f64, nullptr, 0, batch, rank, dims, exponent, has_energy, energy, stream, true);
 }

@@ -316,6 +316,35 @@ class Colored(TensorNoiseCommon):
         pow2 = len(dims) >= 2 and all(d & (d - 1) == 0 for d in dims) and dims[-1] >= 4 and max(dims) <= 4096
         return dims, pow2
 
+    @staticmethod
+    def colorize_noise(white: torch.Tensor, exponent: float = 0.0, energy: float | None = None) -> torch.Tensor:
+        """Colour an existing white-noise tensor with the power-law spectrum f^(-exponent), normalised back to the
+        input's std (or to `energy`).  Size-1 dimensions are excluded from the transform; no batching -- the whole
+        tensor is one sample (reference noise.py:337-403).  Any shape with 1-3 transform axes (hipFFT)."""
+        import ctypes
+
+        _hip.require_device(white, "white noise")
+        if exponent == 0.0:
+            if energy is None:
+                return white
+            wstd = white.float().std()
+            return white if wstd.item() < 1e-8 else (white.float() * (energy / wstd)).to(white.dtype)
+        dims = [d for d in white.shape if d != 1]
+        if not 1 <= len(dims) <= 3:
+            raise SkrampleHipError(f"colorize_noise needs 1 to 3 transform axes, got shape {tuple(white.shape)}")
+        dev, unit = white.device, math.prod(dims)
+        work = white.detach().to(torch.float32).contiguous().clone().reshape(-1)  # transform workspace, overwritten
+        spec = torch.empty(unit // dims[-1] * (dims[-1] // 2 + 1), dtype=torch.complex64, device=dev)
+        partials = torch.empty(4 * 256, dtype=torch.float64, device=dev)
+        out_dtype = white.dtype if white.dtype in _hip.DTYPE_CODE else torch.float32
+        out = torch.empty(white.shape, dtype=out_dtype, device=dev)
+        status = _hip.load().skr_colorize(
+            out.data_ptr(), _hip.DTYPE_CODE[out_dtype], spec.data_ptr(), work.data_ptr(), partials.data_ptr(), 1, len(dims), (ctypes.c_int32 * len(dims))(*dims),
+            float(exponent), 0 if energy is None else 1, 0.0 if energy is None else float(energy), _hip.current_stream_ptr(dev),
+        )
+        _hip.check(status, "skr_colorize")
+        return out
+
     @classmethod
     def _batch_lazy(cls, unit_shape, seeds, stream, step, props, dtype, state):
         if colored_exponent(step, props) == 0.0 and props.energy is None:

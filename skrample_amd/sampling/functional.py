@@ -158,6 +158,9 @@ def _error_mean(a, b, power: int) -> float:
 class FunctionalAdaptive(FunctionalSampler):
     "samplers that choose their own step size from an error estimate"
 
+    Evaluator = Callable[[Any, Any], float]
+    "signature of an error measure between two samples"
+
     @staticmethod
     def mae(a, b) -> float:
         return _error_mean(a, b, 1)

@@ -436,3 +436,35 @@ def test_rku_brownian(steps, begin, order, schedule_name, dev):
         assert torch.isfinite(out).all()
     assert wrapper._noise_generator is not None and len(wrapper._noise_generator.generators) == 1
     assert isinstance(wrapper._noise_generator.generators[0], PN.Brownian)
+
+
+def test_colorize_noise_equals_reference_fixtures(dev):
+    """Colored.colorize_noise on the white draws the REFERENCE consumed must give the reference's own recorded output
+    (tests/golden/noise.npz, written by tools/make_golden.py from the imported reference) -- reference in, reference out"""
+    from conftest import load_npz
+
+    fx = load_npz("noise.npz")
+    tags = sorted(k.rsplit("/", 1)[0] for k in fx if k.endswith("/out") and k.startswith("colored"))
+    assert len(tags) >= 10
+    steps = [None, Step(0.0, 0.05), Step(0.45, 0.5), Step(0.95, 1.0)]
+    for tag in tags:
+        kind = tag.split("/")[0]
+        if kind == "colored_energy":
+            props, step = PN.ColoredProps(energy=2.5, color_start=1.5, color_end=-3, color_curve=0), Step(0.3, 0.4)
+        else:
+            props, step = PN.ColoredProps(), steps[int(kind[-1])]
+        white = torch.from_numpy(fx[f"{tag}/normal0"]).to(dev)
+        got = PN.Colored.colorize_noise(white, exponent=PN.colored_exponent(step, props), energy=props.energy)
+        ref = torch.from_numpy(fx[f"{tag}/out"])
+        assert got.shape == ref.shape and got.dtype == torch.float32
+        assert rel(got, ref) < 2e-5, (tag, rel(got, ref))
+    # API behaviour of the utility (reference noise.py:337-403)
+    w = torch.randn(1, 8, 1, 12, device=dev)
+    assert PN.Colored.colorize_noise(w) is w
+    e = PN.Colored.colorize_noise(w, exponent=0.0, energy=2.0)
+    assert abs(e.std().item() - 2.0) < 1e-5
+    c = PN.Colored.colorize_noise(w.bfloat16(), exponent=1.0)
+    assert c.shape == w.shape and c.dtype == torch.bfloat16
+    assert abs(c.float().std().item() - w.bfloat16().float().std().item()) < 2e-2
+    with pytest.raises(_hip.SkrampleHipError):
+        PN.Colored.colorize_noise(torch.randn(2, 2, 2, 2, device=dev), exponent=1.0)
