@@ -678,6 +678,13 @@ class RKWrapperCore(SkrampleWrapperCore):
             return space.update_form(base, mix, DeltaPoint(s0, sn))
         raise ValueError
 
+    def step_tableau_inside_out(self, sample: Tensor, output, model_transform: DiffusionModel, S0: Point, S1: Point, SN: Point, generator=None) -> Tensor:
+        """Reference-named entry (diffusers.py:746-796): feed one derivative, get the next stage input (or the step result
+        once every stage is in) as a tensor in compute_scale.  `step` itself uses the lazy form and fuses it with the
+        derivative conversion of the same call."""
+        form = self._stage_form(sample, output if isinstance(output, lazy.Lin) else lift(output), model_transform, S0, S1, SN, generator)
+        return lazy.settle(form, dtype=self.compute_scale)
+
     def step(self, model_output: Tensor, timestep, sample: Tensor, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict: bool = True):
         value = _host_number(timestep)
         expected = self.all_points[self._index].timestep

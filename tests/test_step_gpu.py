@@ -918,6 +918,26 @@ def test_random_sweep_runge_kutta_vs_oracle(seed, dev):
         x = ref
 
 
+def test_step_tableau_inside_out_entry(dev):
+    "the reference-named stage method of the RK wrappers (diffusers.py:746-796) used directly: Heun = two feeds per step"
+    w = PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=2, model=PM.DataModel(), providers={2: PD.tableaux.RKE2.Heun})
+    w.set_timesteps(4)
+    g = torch.Generator().manual_seed(2)
+    x, d0, d1 = (torch.randn(2, 4, 8, 8, generator=g).to(dev) for _ in range(3))
+    pts = [PS.Point(*row) for row in w.schedule_np]
+    s0, s1 = w.schedule.ipoint(0.0), w.schedule.ipoint(0.25)
+    mid = w.step_tableau_inside_out(x, d0, PM.DataModel(), s0, s1, s1, None)
+    fin = w.step_tableau_inside_out(mid, d1, PM.DataModel(), s0, s1, s1, None)
+    from skr_oracle import predictors as OP
+
+    p0, p1 = OS.scaled().ipoint(0.0), OS.scaled().ipoint(0.25)
+    ref_mid = OP.forward("data", x.cpu(), d0.cpu(), p0, p1)
+    ref_fin = OP.forward("data", x.cpu(), 0.5 * d0.cpu() + 0.5 * d1.cpu(), p0, p1)
+    assert_close(mid, ref_mid, torch.float32, "stage input")
+    assert_close(fin, ref_fin, torch.float32, "step result")
+    assert w._derivatives == [] and w._sample is None and len(pts) >= 4
+
+
 def test_img2img_entry_points(dev):
     "scale_noise / add_noise / set_begin_index: the img2img path (reference diffusers.py:375-381,540-543)"
     w = PD.SkrampleWrapperScheduler(PT.DPM(order=2), PS.Scaled())
