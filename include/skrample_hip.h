@@ -128,7 +128,8 @@ int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* seeds_dev, ui
  * per draw, the first draw's id for PyramidProps.static): geometry uniforms = stream_levels+255, level l normals
  * (stream_levels+1+l, shape [lead][h_l][w_l]) are generated into LDS and sampled there; level 0 is full resolution;
  * skip = max(0, n_levels-1-depth).  Workspaces: scratch_f32 [batch*lead*h*w], partials_f64 [batch*lead*2],
- * level_ws int32 [batch*17] (receives the level table, readable for tests).  Limits: w % 4 == 0 and
+ * level_ws int32 [batch*17] (receives the level table, readable for tests).  with_base = 0 returns the un-normalised
+ * pyramid component alone (reference Pyramid.pyramid(), noise.py:146-200).  Limits: w % 4 == 0 and
  * about h*w <= 380*380 (the level stage must fit 152 KiB of LDS); returns SKR_ERR_UNSUPPORTED beyond them --
  * skr_noise_pyramid_any below covers every shape. */
 int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64, int32_t* level_ws,

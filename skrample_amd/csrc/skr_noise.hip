@@ -317,13 +317,13 @@ __global__ __launch_bounds__(PYR_THREADS, STRIP ? 2 : 4) void pyramid_pass1(cons
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void normalise_pass2(T* out, const float* scratch, const double* partials, int64_t lead, int64_t unit, int64_t batch, double target /* <0: unit std */) {
+__global__ __launch_bounds__(256) void normalise_pass2(T* out, const float* scratch, const double* partials, int64_t lead, int64_t unit, int64_t batch, double target /* <0: unit std, 0: no rescale */) {
   const int64_t smp = blockIdx.y;
   double s1 = 0.0, s2 = 0.0;
   for (int64_t c = 0; c < lead; ++c) { s1 += partials[(smp * lead + c) * 2]; s2 += partials[(smp * lead + c) * 2 + 1]; }
   const double n = (double)unit;
   const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, as torch.std
-  const float inv = (float)(1.0 / sqrt(var));
+  const float inv = target == 0.0 ? 1.0f : (float)(1.0 / sqrt(var));  // target 0: the raw sum (Pyramid.pyramid(), no base)
   const float* src = scratch + smp * unit;
   T* dst = out + smp * unit;
   if ((unit & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
@@ -512,10 +512,10 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   if (bx > 64) bx = 64;
   dim3 grid((unsigned)bx, (unsigned)batch);
   switch (out_dtype) {
-    case SKR_BF16: hipLaunchKernelGGL(skr::normalise_pass2<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, scratch_f32, partials_f64, lead, unit, batch, -1.0); break;
-    case SKR_F16: hipLaunchKernelGGL(skr::normalise_pass2<_Float16>, grid, dim3(256), 0, s, (_Float16*)out, scratch_f32, partials_f64, lead, unit, batch, -1.0); break;
-    case SKR_F32: hipLaunchKernelGGL(skr::normalise_pass2<float>, grid, dim3(256), 0, s, (float*)out, scratch_f32, partials_f64, lead, unit, batch, -1.0); break;
-    case SKR_F64: hipLaunchKernelGGL(skr::normalise_pass2<double>, grid, dim3(256), 0, s, (double*)out, scratch_f32, partials_f64, lead, unit, batch, -1.0); break;
+    case SKR_BF16: hipLaunchKernelGGL(skr::normalise_pass2<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, scratch_f32, partials_f64, lead, unit, batch, with_base ? -1.0 : 0.0); break;
+    case SKR_F16: hipLaunchKernelGGL(skr::normalise_pass2<_Float16>, grid, dim3(256), 0, s, (_Float16*)out, scratch_f32, partials_f64, lead, unit, batch, with_base ? -1.0 : 0.0); break;
+    case SKR_F32: hipLaunchKernelGGL(skr::normalise_pass2<float>, grid, dim3(256), 0, s, (float*)out, scratch_f32, partials_f64, lead, unit, batch, with_base ? -1.0 : 0.0); break;
+    case SKR_F64: hipLaunchKernelGGL(skr::normalise_pass2<double>, grid, dim3(256), 0, s, (double*)out, scratch_f32, partials_f64, lead, unit, batch, with_base ? -1.0 : 0.0); break;
     default: return SKR_ERR_DTYPE;
   }
   return status_of_launch();
@@ -552,10 +552,10 @@ extern "C" int skr_noise_pyramid_any(void* out, int32_t out_dtype, float* scratc
   if (bx < 1) bx = 1;
   dim3 grid((unsigned)bx, (unsigned)batch);
   switch (out_dtype) {
-    case SKR_BF16: hipLaunchKernelGGL(skr::normalise_pass2<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, -1.0); break;
-    case SKR_F16: hipLaunchKernelGGL(skr::normalise_pass2<_Float16>, grid, dim3(256), 0, s, (_Float16*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, -1.0); break;
-    case SKR_F32: hipLaunchKernelGGL(skr::normalise_pass2<float>, grid, dim3(256), 0, s, (float*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, -1.0); break;
-    case SKR_F64: hipLaunchKernelGGL(skr::normalise_pass2<double>, grid, dim3(256), 0, s, (double*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, -1.0); break;
+    case SKR_BF16: hipLaunchKernelGGL(skr::normalise_pass2<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, with_base ? -1.0 : 0.0); break;
+    case SKR_F16: hipLaunchKernelGGL(skr::normalise_pass2<_Float16>, grid, dim3(256), 0, s, (_Float16*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, with_base ? -1.0 : 0.0); break;
+    case SKR_F32: hipLaunchKernelGGL(skr::normalise_pass2<float>, grid, dim3(256), 0, s, (float*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, with_base ? -1.0 : 0.0); break;
+    case SKR_F64: hipLaunchKernelGGL(skr::normalise_pass2<double>, grid, dim3(256), 0, s, (double*)out, scratch_f32, partials_f64, (int64_t)n_slots, unit, batch, with_base ? -1.0 : 0.0); break;
     default: return SKR_ERR_DTYPE;
   }
   return status_of_launch();

@@ -156,6 +156,16 @@ class Offset(TensorNoiseCommon):
     def from_inputs(cls, shape, seed, props=OffsetProps(), dtype=torch.float32):
         return cls(tuple(shape), seed, dtype, props)
 
+    def offset(self) -> torch.Tensor:
+        "just the offset component of the next draw: strength^2 * N over the kept dims (reference noise.py:104-106)"
+        from ..sampling import lazy as _lazy
+
+        nd = len(self.shape)
+        kept = {d + nd if d < 0 else d for d in self.props.dims}
+        reduced = tuple(s if i in kept else 1 for i, s in enumerate(self.shape))
+        noise = PhiloxNoise(self._seeds, self._next_stream() + 1, (1, *reduced), self._device)
+        return _lazy.settle(_lazy.lift(noise) * float(self.props.strength) ** 2, dtype=self.dtype)[0]
+
     @classmethod
     def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
         import ctypes
@@ -261,8 +271,14 @@ class Pyramid(TensorNoiseCommon):
             return math.prod(unit_shape[:-1]), 1, unit_shape[-1], False
         raise SkrampleHipError("Pyramid noise resizes the last one or two dimensions (the reference's other `dims` choices fail inside torch.interpolate)")
 
+    def pyramid(self) -> torch.Tensor:
+        "just the added 'pyramid' component of the next draw, un-normalised (reference noise.py:146-200)"
+        if not hasattr(self, "_state"):
+            self._state = {}
+        return self._batch(tuple(self.shape), self._seeds, self._next_stream(), None, self.props, self.dtype, self._state, with_base=False)[0]
+
     @classmethod
-    def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
+    def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state, with_base: bool = True):
         # static: the pyramid component is frozen at the first draw (same streams every time), only the base changes
         stream_levels = state.setdefault("static_stream", stream) if props.static else stream
         lead, h, w, resize_h = cls._geometry(unit_shape, props)
@@ -280,7 +296,7 @@ class Pyramid(TensorNoiseCommon):
         scratch, partials, levels = state[key]
         out = torch.empty((batch, *unit_shape), dtype=dtype, device=dev)
         lib, hstream = _launch_ctx(seeds)
-        tail = (seeds.data_ptr(), stream, stream_levels, batch, lead, h, w, 1 if resize_h else 0, float(props.strength), int(min(props.depth, 1 << 20)), 1, hstream)
+        tail = (seeds.data_ptr(), stream, stream_levels, batch, lead, h, w, 1 if resize_h else 0, float(props.strength), int(min(props.depth, 1 << 20)), 1 if with_base else 0, hstream)
         status = _hip.SKR_ERR_UNSUPPORTED if state.get("any_shape") else lib.skr_noise_pyramid(out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), partials.data_ptr(), levels.data_ptr(), *tail)
         if status == _hip.SKR_ERR_UNSUPPORTED:
             # planes too large for the LDS level stage, or a width that is not a multiple of 4: levels in global memory

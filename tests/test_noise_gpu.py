@@ -468,3 +468,20 @@ def test_colorize_noise_equals_reference_fixtures(dev):
     assert abs(c.float().std().item() - w.bfloat16().float().std().item()) < 2e-2
     with pytest.raises(_hip.SkrampleHipError):
         PN.Colored.colorize_noise(torch.randn(2, 2, 2, 2, device=dev), exponent=1.0)
+
+
+def test_component_methods(dev):
+    "Offset.offset() and Pyramid.pyramid(): the components alone, as the reference exposes them (noise.py:104-106, 146-200)"
+    unit = (4, 16, 24)
+    o = PN.Offset.from_inputs(unit, 77, PN.OffsetProps(dims=(0, 2), strength=0.5), dtype=torch.float32)
+    for n in range(2):
+        got = o.offset().cpu()
+        assert got.shape == (4, 1, 24) and rel(got, spec_normal(77, n * 256 + 1, (4, 1, 24)) * 0.25) < TOL
+    for kw in ({}, dict(strength=0.6, depth=1)):
+        p = PN.Pyramid.from_inputs(unit, 78, PN.PyramidProps(**kw), dtype=torch.float32)
+        for n in range(2):
+            got = p.pyramid().cpu()
+            uniforms = iter(uniform01(np.array([78], dtype=np.uint64), n * 256 + 255, 8)[0].tolist())
+            level = iter(range(8))
+            ref = ON.pyramid_component(unit, lambda shape: spec_normal(78, n * 256 + 1 + next(level), shape), lambda: next(uniforms), **kw)
+            assert got.shape == unit and rel(got, ref) < 2e-5, (kw, n, rel(got, ref))
