@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from .. import common
-from ..common import DeltaPoint, Point, Step, divf, ln, softmax
+from ..common import DeltaPoint, Point, Step, divf, ln, softmax, spowf  # noqa: F401  (spowf re-exported, as in the reference)
 from ..scheduling import SkrampleSchedule, ipoint_lru
 from . import lazy, models, traits
 from .lazy import LazyTensor, Lin, lift

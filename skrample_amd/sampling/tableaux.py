@@ -231,6 +231,16 @@ class ButcherCoeffs:
 class TableauProvider(Protocol):
     def tableau(self): ...
 
+    def pretty(self) -> str:
+        return pretty_tableau(self.tableau())
+
+
+class _Pretty:
+    "mix-in for the dataclass providers: the text rendering every provider offers"
+
+    def pretty(self) -> str:
+        return pretty_tableau(self.tableau())
+
 
 class _EnumProvider(enum.Enum):
     def tableau(self):
@@ -241,7 +251,7 @@ class _EnumProvider(enum.Enum):
 
 
 @dataclasses.dataclass(frozen=True)
-class CustomTableau:
+class CustomTableau(_Pretty):
     custom: object
 
     def tableau(self):
@@ -249,7 +259,7 @@ class CustomTableau:
 
 
 @dataclasses.dataclass(frozen=True)
-class RK2Custom:
+class RK2Custom(_Pretty):
     c1: float = 1.0
 
     def tableau(self) -> Tableau:
@@ -257,7 +267,7 @@ class RK2Custom:
 
 
 @dataclasses.dataclass(frozen=True)
-class RK3Custom:
+class RK3Custom(_Pretty):
     c1: float = 1 / 2
     c2: float = 1.0
 
@@ -266,7 +276,7 @@ class RK3Custom:
 
 
 @dataclasses.dataclass(frozen=True)
-class RK4Custom:
+class RK4Custom(_Pretty):
     c1: float = 1 / 3
     c2: float = 2 / 3
 

@@ -20,7 +20,7 @@ from typing import Sequence
 
 import numpy as np
 
-from .common import DeltaPoint, Point, Step, rescale_positive
+from .common import DeltaPoint, Point, Step, normalize, regularize, rescale_positive, sigmoid  # (normalize / regularize / sigmoid are re-exported, as in the reference)
 
 NPPoints = np.ndarray
 NPSequence = np.ndarray
