@@ -48,7 +48,6 @@ struct StepArgs {
   int64_t vps;          // vectors per sample (per-sample grid only)
   int32_t n_a, n_terms;
   int32_t grid_mode;    // 0 flat grid, 1 per-sample grid (noise kernels, sample_numel % 8 == 0)
-  int32_t aligned;      // sample_numel % 8 == 0
   int32_t conv_to, conv_from;  // rounded pair conversion (CONV kernels): see convert_rounded()
   double ck[4];
 };
@@ -693,7 +692,6 @@ static int launch(StepArgs<Acc>& args, hipStream_t stream) {
   constexpr int UV = uv_for(NOISE, HAS1);
   Geometry g = geometry<UV, NOISE>(args.numel, args.sample_numel);
   args.grid_mode = g.mode;
-  args.aligned = (args.sample_numel % VEC) == 0;
   args.vps = args.sample_numel / VEC;
   constexpr bool HAS32 = std::is_same<Acc, float>::value && (std::is_same<TA, float>::value || std::is_same<TB, float>::value ||
                                                                (ST0 && std::is_same<TO0, float>::value) || (HAS1 && std::is_same<TO1, float>::value));
