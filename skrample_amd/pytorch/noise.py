@@ -170,19 +170,28 @@ class Offset(TensorNoiseCommon):
     def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state):
         import ctypes
 
-        if len(unit_shape) > 4:
-            raise SkrampleHipError("Offset noise supports per-sample shapes of up to 4 dimensions")
         if props.static:  # the offset is drawn once (first call) and reused
             offset_stream = state.setdefault("offset_stream", stream + 1)
         else:
             offset_stream = stream + 1
-        nd = len(unit_shape)
-        mask = 0
-        for d in props.dims:
-            mask |= 1 << (d + nd if d < 0 else d)
+        nd_full = len(unit_shape)
+        kept_dims = {d + nd_full if d < 0 else d for d in props.dims}
+        # neighbouring dimensions that are both kept or both broadcast index the offset tensor as one merged dimension
+        # (row-major), so any rank collapses to its runs; the kernel handles four
+        merged: list[list] = []
+        for i, size in enumerate(unit_shape):
+            keep = i in kept_dims
+            if merged and merged[-1][1] == keep:
+                merged[-1][0] *= size
+            else:
+                merged.append([size, keep])
+        if len(merged) > 4:
+            raise SkrampleHipError("Offset noise supports up to four alternating runs of kept / broadcast dimensions per sample")
+        nd = len(merged)
+        mask = sum(1 << i for i, (_, keep) in enumerate(merged) if keep)
         out = torch.empty((seeds.shape[0], *unit_shape), dtype=dtype, device=seeds.device)
         lib, hstream = _launch_ctx(seeds)
-        shape_arr = (ctypes.c_int64 * nd)(*unit_shape)
+        shape_arr = (ctypes.c_int64 * nd)(*[m[0] for m in merged])
         _hip.check(
             lib.skr_noise_offset(out.data_ptr(), _hip.DTYPE_CODE[dtype], seeds.data_ptr(), stream, offset_stream, seeds.shape[0], shape_arr, nd, mask, float(props.strength), hstream),
             "skr_noise_offset",

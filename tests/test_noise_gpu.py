@@ -66,7 +66,7 @@ def test_random_generator(dev):
     assert abs(big.mean().item()) < 5e-3 and abs(big.std().item() - 1) < 5e-3 and abs((big**4).mean().item() - 3) < 0.05
 
 
-@pytest.mark.parametrize(("unit", "props"), [((4, 16, 16), PN.OffsetProps()), ((4, 33, 20), PN.OffsetProps(dims=(0, 2), strength=0.5)), ((16, 8, 8), PN.OffsetProps(dims=(1,), strength=1.5)), ((3, 5), PN.OffsetProps(dims=(-1,))), ((2, 3, 8, 8), PN.OffsetProps(dims=(0, 1))), ((4, 8, 16), PN.OffsetProps(dims=(-1,))), ((4, 8, 16), PN.OffsetProps(dims=(0, 2), strength=0.7))])
+@pytest.mark.parametrize(("unit", "props"), [((4, 16, 16), PN.OffsetProps()), ((4, 33, 20), PN.OffsetProps(dims=(0, 2), strength=0.5)), ((16, 8, 8), PN.OffsetProps(dims=(1,), strength=1.5)), ((3, 5), PN.OffsetProps(dims=(-1,))), ((2, 3, 8, 8), PN.OffsetProps(dims=(0, 1))), ((4, 8, 16), PN.OffsetProps(dims=(-1,))), ((4, 8, 16), PN.OffsetProps(dims=(0, 2), strength=0.7)), ((2, 3, 2, 4, 8), PN.OffsetProps(dims=(0, 1), strength=0.4)), ((2, 3, 4, 2, 2, 8), PN.OffsetProps(dims=(1, 2, 5)))])
 def test_offset(unit, props, dev):
     seeds = [11, 12]
     g = PN.BatchTensorNoise.from_batch_inputs(PN.Offset, unit, seeds, props=props, dtype=torch.float32)
