@@ -112,9 +112,10 @@ __global__ __launch_bounds__(256) void any_weights(const AnyArgs a) {
     const int k2 = (int)(r % a.d2);
     const int k1 = (int)(r / a.d2);
     const float f1 = a.d1 > 1 ? axis_freq(k1, a.d1) : 0.f, f2 = a.d2 > 1 ? axis_freq(k2, a.d2) : 0.f, f3 = (float)k3 / (float)a.d3;
-    float radius = sqrtf(f1 * f1 + f2 * f2 + f3 * f3) * a.inv_rmax;
+    // clamp(radius, eps)^(-exponent/2) on the raw transcendental units (radius >= eps > 0: never denormal), as in skr_colored.hip
+    float radius = __builtin_amdgcn_sqrtf(f1 * f1 + f2 * f2 + f3 * f3) * a.inv_rmax;
     radius = radius < a.eps_clip ? a.eps_clip : radius;
-    const float w = powf(radius, a.exponent_half_neg);
+    const float w = __builtin_amdgcn_exp2f(a.exponent_half_neg * __builtin_amdgcn_logf(radius));
     float2 v = a.spec[i];
     a.spec[i] = make_float2(v.x * w, v.y * w);
   }
