@@ -3,6 +3,7 @@
 // consecutive stream ids: +0 base normal, +1.. auxiliary normals (offset / pyramid levels), +255 uniforms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
@@ -185,11 +186,12 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
 
 constexpr int PYR_THREADS = 512;  // 8 waves per block: two 70 KiB blocks per CU keep 16 waves in flight
 
-// STRIP: the block width divides PYR_THREADS, so a thread keeps its 4 columns for every row (see below)
-template <bool STRIP>
-__global__ __launch_bounds__(PYR_THREADS, STRIP ? 2 : 4) void pyramid_pass1(const PyramidArgs a) {
+// STRIP: the block width divides THREADS, so a thread keeps its 4 columns for every row (see below).
+// THREADS: 512 for large planes; 256 for small ones, where it doubles the rows a strip thread revisits.
+template <bool STRIP, int THREADS>
+__global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const PyramidArgs a) {
   extern __shared__ float lds[];  // levels >= 1, back to back
-  __shared__ double red[2][PYR_THREADS / 64];
+  __shared__ double red[2][THREADS / 64];
   __shared__ int s_lh[PYR_MAX_LEVELS], s_lw[PYR_MAX_LEVELS], s_off[PYR_MAX_LEVELS];
   __shared__ float s_wgt[PYR_MAX_LEVELS], s_sy[PYR_MAX_LEVELS], s_sx[PYR_MAX_LEVELS];
   const int slice = blockIdx.x;  // smp * lead + c
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(PYR_THREADS, STRIP ? 2 : 4) void pyramid_pass1(cons
     if (s_wgt[l] == 0.f) continue;
     const int n = s_lh[l] * s_lw[l];
     float* g = lds + s_off[l];
-    for (int i4 = threadIdx.x * 4; i4 < n; i4 += PYR_THREADS * 4) {  // level tensor is [lead][lh][lw]; 4 normals per Philox call
+    for (int i4 = threadIdx.x * 4; i4 < n; i4 += THREADS * 4) {  // level tensor is [lead][lh][lw]; 4 normals per Philox call
       const int64_t e = (int64_t)c * n + i4;
       const int64_t blk = e >> 2;
       const int lane0 = (int)(e & 3);
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(PYR_THREADS, STRIP ? 2 : 4) void pyramid_pass1(cons
     // column strips: a thread keeps its 4 columns for every row it visits, so the horizontal taps of the first
     // PYR_CACHED levels are computed once (packed xa | xb << 16 and the blend weight) instead of once per pixel and row
     constexpr int PYR_CACHED = 5;  // levels 1..4 in registers (deeper levels are rare and tiny: computed in place)
-    const int xg = threadIdx.x % w4, x0 = xg * 4, ystep = PYR_THREADS / w4;
+    const int xg = threadIdx.x % w4, x0 = xg * 4, ystep = THREADS / w4;
     int tap_idx[PYR_CACHED][4];
     float tap_lx[PYR_CACHED][4];
 #pragma unroll
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(PYR_THREADS, STRIP ? 2 : 4) void pyramid_pass1(cons
         else src_index(x0 + j, s_sx[l], s_lw[l], xa, xb, lx);
       });
   } else {
-    for (int q = threadIdx.x; q < n4; q += PYR_THREADS) {
+    for (int q = threadIdx.x; q < n4; q += THREADS) {
       const int y = q / w4, x0 = (q - y * w4) * 4;
       pixel_group(y, x0, q, [&](int l, int j, int& xa, int& xb, float& lx) { src_index(x0 + j, s_sx[l], s_lw[l], xa, xb, lx); });
     }
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(PYR_THREADS, STRIP ? 2 : 4) void pyramid_pass1(cons
   __syncthreads();
   if (threadIdx.x == 0) {
     double t1 = 0.0, t2 = 0.0;
-    for (int wv = 0; wv < PYR_THREADS / 64; ++wv) { t1 += red[0][wv]; t2 += red[1][wv]; }
+    for (int wv = 0; wv < THREADS / 64; ++wv) { t1 += red[0][wv]; t2 += red[1][wv]; }
     a.partials[(int64_t)slice * 2 + 0] = t1;
     a.partials[(int64_t)slice * 2 + 1] = t2;
   }
@@ -499,13 +501,19 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
   const size_t lds_bytes = sizeof(float) * (size_t)bound;
   if (lds_bytes > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
   }
   const int64_t w4 = w / 4;
-  // strips pay off when a thread visits enough rows to amortise its tap table
-  if (skr::PYR_THREADS % w4 == 0 && h / (skr::PYR_THREADS / w4) >= 12) hipLaunchKernelGGL(skr::pyramid_pass1<true>, dim3((unsigned)(batch * lead)), dim3(skr::PYR_THREADS), lds_bytes, s, a);
-  else hipLaunchKernelGGL(skr::pyramid_pass1<false>, dim3((unsigned)(batch * lead)), dim3(skr::PYR_THREADS), lds_bytes, s, a);
+  const dim3 grid1((unsigned)(batch * lead));
+  static const int forced = [] { const char* e = getenv("SKR_PYR_MODE"); return e ? atoi(e) : 0; }();  // tuning switch: 1 generic, 2 strip/512, 3 strip/256
+  // strips pay off when a thread visits enough rows to amortise its tap table; small planes get there with 256-lane blocks
+  const bool strip512 = skr::PYR_THREADS % w4 == 0 && h / (skr::PYR_THREADS / w4) >= 12;
+  const bool strip256 = lds_bytes <= 48 * 1024 && 256 % w4 == 0 && h / (256 / w4) >= 12;
+  const int mode = forced ? forced : (strip512 ? 2 : (strip256 ? 3 : 1));
+  if (mode == 2 && strip512) hipLaunchKernelGGL((skr::pyramid_pass1<true, 512>), grid1, dim3(512), lds_bytes, s, a);
+  else if (mode == 3 && strip256) hipLaunchKernelGGL((skr::pyramid_pass1<true, 256>), grid1, dim3(256), lds_bytes, s, a);
+  else hipLaunchKernelGGL((skr::pyramid_pass1<false, 512>), grid1, dim3(512), lds_bytes, s, a);
   if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
   const int64_t unit = lead * h * w;
   int64_t bx = (unit / 4 + 255) / 256;
