@@ -184,6 +184,7 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
   l1 = src - (float)i0;
 }
 
+constexpr int PYR_UNROLLED = 5;  // levels 1..4 are unrolled (and cached per column strip); deeper levels are rare and tiny
 constexpr int PYR_THREADS = 512;  // 8 waves per block: two 70 KiB blocks per CU keep 16 waves in flight
 
 // STRIP: the block width divides THREADS, so a thread keeps its 4 columns for every row (see below).
@@ -248,11 +249,9 @@ __global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const Py
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = fmaf(z[j], w0, v[j]);
     }
-#pragma unroll
-    for (int l = 1; l < PYR_MAX_LEVELS; ++l) {
-      if (l >= nl) break;
+    auto add_level = [&](int l) {
       const float wl = s_wgt[l];
-      if (wl == 0.f) continue;
+      if (wl == 0.f) return;
       const int lh = s_lh[l], lw = s_lw[l];
       const float* g = lds + s_off[l];
       int y0, y1;
@@ -269,7 +268,13 @@ __global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const Py
         const float bot = (1.f - lx) * r1[xa] + lx * r1[xb];
         v[j] += wl * ((1.f - ly) * top + ly * bot);
       }
-    }
+    };
+    // the first levels unrolled (their taps may sit in registers: compile-time l), deeper ones in a rolled loop
+#pragma unroll
+    for (int l = 1; l < PYR_UNROLLED; ++l)
+      if (l < nl) add_level(l);
+#pragma unroll 1
+    for (int l = PYR_UNROLLED; l < nl; ++l) add_level(l);
     const float p1 = (v[0] + v[1]) + (v[2] + v[3]);  // 4 values in fp32, then one widening add: the per-slice totals stay double
     const float p2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
     s1 += (double)p1; s2 += (double)p2;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const Py
   if constexpr (STRIP) {
     // column strips: a thread keeps its 4 columns for every row it visits, so the horizontal taps of the first
     // PYR_CACHED levels are computed once (packed xa | xb << 16 and the blend weight) instead of once per pixel and row
-    constexpr int PYR_CACHED = 5;  // levels 1..4 in registers (deeper levels are rare and tiny: computed in place)
+    constexpr int PYR_CACHED = PYR_UNROLLED;  // levels 1..4 in registers
     const int xg = threadIdx.x % w4, x0 = xg * 4, ystep = THREADS / w4;
     int tap_idx[PYR_CACHED][4];
     float tap_lx[PYR_CACHED][4];
