@@ -60,6 +60,7 @@ struct AnyArgs {
   const uint64_t* seeds;
   uint64_t stream;
   int64_t batch, unit;
+  int32_t d0;           // outermost axis of a 4-axis unit (1 otherwise); d1,d2,d3 are the hipFFT axes
   int32_t d1, d2, d3, d3h;
   float exponent_half_neg, eps_clip, inv_rmax;
 };
@@ -121,6 +122,62 @@ __global__ __launch_bounds__(256) void any_weights(const AnyArgs a) {
   }
 }
 
+// 4-axis units: hipFFT transforms the three inner axes (batched over batch*d0); the outermost axis (length d0 <= 64,
+// e.g. channels or frames) is a direct DFT per spectral column: forward, radial weights of the full 4-D frequency,
+// inverse -- one lane per column, its d0 values staged in LDS (column-private, no barriers after the twiddle table).
+constexpr int AXIS0_THREADS = 64;
+__global__ __launch_bounds__(AXIS0_THREADS) void any_axis0(const AnyArgs a) {
+  extern __shared__ float2 sh[];  // [d0] twiddles, [d0][64] values, [d0][64] weighted spectrum
+  float2* tw = sh;
+  float2* v = tw + a.d0;
+  float2* x = v + a.d0 * AXIS0_THREADS;
+  const int lane = threadIdx.x, d0 = a.d0;
+  for (int j = lane; j < d0; j += AXIS0_THREADS) {
+    float sn, cs;
+    sincospif(-2.0f * (float)j / (float)d0, &sn, &cs);
+    tw[j] = make_float2(cs, sn);
+  }
+  __syncthreads();
+  const int64_t cols = (int64_t)a.d1 * a.d2 * a.d3h;
+  const int64_t smp = blockIdx.y;
+  float2* base = a.spec + smp * d0 * cols;
+  for (int64_t q = (int64_t)blockIdx.x * AXIS0_THREADS + lane; q < cols; q += (int64_t)gridDim.x * AXIS0_THREADS) {
+    for (int n = 0; n < d0; ++n) v[n * AXIS0_THREADS + lane] = base[(int64_t)n * cols + q];
+    int64_t r = q;
+    const int k3 = (int)(r % a.d3h); r /= a.d3h;
+    const int k2 = (int)(r % a.d2);
+    const int k1 = (int)(r / a.d2);
+    const float f1 = a.d1 > 1 ? axis_freq(k1, a.d1) : 0.f, f2 = a.d2 > 1 ? axis_freq(k2, a.d2) : 0.f, f3 = (float)k3 / (float)a.d3;
+    const float rest = f1 * f1 + f2 * f2 + f3 * f3;
+    for (int k = 0; k < d0; ++k) {
+      float2 acc = make_float2(0.f, 0.f);
+      int idx = 0;  // (n * k) mod d0
+      for (int n = 0; n < d0; ++n) {
+        const float2 t = tw[idx], u = v[n * AXIS0_THREADS + lane];
+        acc.x += u.x * t.x - u.y * t.y;
+        acc.y += u.x * t.y + u.y * t.x;
+        idx += k; if (idx >= d0) idx -= d0;
+      }
+      const float f0 = axis_freq(k, d0);
+      float radius = __builtin_amdgcn_sqrtf(f0 * f0 + rest) * a.inv_rmax;
+      radius = radius < a.eps_clip ? a.eps_clip : radius;
+      const float w = __builtin_amdgcn_exp2f(a.exponent_half_neg * __builtin_amdgcn_logf(radius));
+      x[k * AXIS0_THREADS + lane] = make_float2(acc.x * w, acc.y * w);
+    }
+    for (int n = 0; n < d0; ++n) {
+      float2 acc = make_float2(0.f, 0.f);
+      int idx = 0;
+      for (int k = 0; k < d0; ++k) {
+        const float2 t = tw[idx], u = x[k * AXIS0_THREADS + lane];
+        acc.x += u.x * t.x + u.y * t.y;  // conj(t)
+        acc.y += u.y * t.x - u.x * t.y;
+        idx += n; if (idx >= d0) idx -= d0;
+      }
+      base[(int64_t)n * cols + q] = acc;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void any_stats(const AnyArgs a) {
   const int64_t smp = blockIdx.y;
   const float scale = 1.0f / (float)a.unit;
@@ -153,38 +210,48 @@ __global__ __launch_bounds__(256) void any_finish(T* out, const AnyArgs a, int h
 static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
                             const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
                             double exponent, int32_t has_energy, double energy, void* stream, bool white_given) {
-  if (batch < 0 || rank < 1 || rank > 3 || !dims) return SKR_ERR_SHAPE;
+  if (batch < 0 || rank < 1 || rank > 4 || !dims) return SKR_ERR_SHAPE;
   for (int i = 0; i < rank; ++i) if (dims[i] < 2) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
   if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || (!white_given && !seeds_dev)) return SKR_ERR_NULL;
   if (batch > 65535) return SKR_ERR_UNSUPPORTED;
   FftApi& f = api();
   if (!f.ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
+  const int full_rank = rank;
+  const int32_t* full_dims = dims;
+  int d0 = 1;
+  if (rank == 4) {  // outermost axis by direct DFT (any_axis0), the inner three by hipFFT batched over batch*d0
+    d0 = dims[0];
+    if (d0 > 64 || batch * d0 > 0x7fffffffll) return SKR_ERR_UNSUPPORTED;
+    dims += 1; rank = 3;
+  }
   int n[3] = {1, 1, 1};
   for (int i = 0; i < rank; ++i) n[3 - rank + i] = dims[i];
   AnyArgs a;
+  a.d0 = d0;
   a.real = scratch_f32; a.spec = reinterpret_cast<float2*>(spec_c64); a.partials = partials_f64; a.seeds = seeds_dev; a.stream = stream_id;
-  a.batch = batch; a.d1 = n[0]; a.d2 = n[1]; a.d3 = n[2]; a.d3h = n[2] / 2 + 1; a.unit = (int64_t)n[0] * n[1] * n[2];
+  a.batch = batch; a.d1 = n[0]; a.d2 = n[1]; a.d3 = n[2]; a.d3h = n[2] / 2 + 1; a.unit = (int64_t)d0 * n[0] * n[1] * n[2];
   a.exponent_half_neg = (float)(-exponent / 2.0);
   double n_eff = 0;
-  for (int i = 0; i < rank; ++i) n_eff += dims[i];
-  n_eff /= rank;
+  for (int i = 0; i < full_rank; ++i) n_eff += full_dims[i];
+  n_eff /= full_rank;
   a.eps_clip = (float)(0.5 / (n_eff > 4.0 ? n_eff : 4.0));
   float r2 = 0.f;
-  for (int i = 0; i < rank; ++i) { const float m = (float)(dims[i] / 2) / (float)dims[i]; r2 += m * m; }
+  for (int i = 0; i < full_rank; ++i) { const float m = (float)(full_dims[i] / 2) / (float)full_dims[i]; r2 += m * m; }
   a.inv_rmax = r2 > 0.f ? 1.0f / sqrtf(r2) : 1.0f;
 
   Plans plans;
   {
     std::lock_guard<std::mutex> lock(g_mutex);
-    auto key = std::make_tuple(rank, n[0], n[1], n[2], batch);
+    const int64_t fft_batch = batch * d0;
+    auto key = std::make_tuple(rank, n[0], n[1], n[2], fft_batch);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
       int nn[3];
       for (int i = 0; i < rank; ++i) nn[i] = dims[i];
       Plans p;
-      if (f.plan_many(&p.fwd, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, (int)batch) != 0) return SKR_ERR_UNSUPPORTED;
-      if (f.plan_many(&p.inv, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, (int)batch) != 0) return SKR_ERR_UNSUPPORTED;
+      if (f.plan_many(&p.fwd, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, (int)fft_batch) != 0) return SKR_ERR_UNSUPPORTED;
+      if (f.plan_many(&p.inv, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, (int)fft_batch) != 0) return SKR_ERR_UNSUPPORTED;
       it = g_plans.emplace(key, p).first;
     }
     plans = it->second;
@@ -196,8 +263,16 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
   if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
   if (f.r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
-  int64_t wb = ((int64_t)a.d1 * a.d2 * a.d3h * batch + 255) / 256; if (wb > 256 * 32) wb = 256 * 32;
-  hipLaunchKernelGGL(any_weights, dim3((unsigned)wb), dim3(256), 0, s, a);
+  if (d0 > 1) {
+    const int64_t cols = (int64_t)a.d1 * a.d2 * a.d3h;
+    int64_t ab = (cols + AXIS0_THREADS - 1) / AXIS0_THREADS; if (ab > 4096) ab = 4096;
+    const size_t lds = sizeof(float2) * ((size_t)d0 + 2 * (size_t)d0 * AXIS0_THREADS);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(any_axis0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(any_axis0, dim3((unsigned)ab, (unsigned)batch), dim3(AXIS0_THREADS), lds, s, a);
+  } else {
+    int64_t wb = ((int64_t)a.d1 * a.d2 * a.d3h * batch + 255) / 256; if (wb > 256 * 32) wb = 256 * 32;
+    hipLaunchKernelGGL(any_weights, dim3((unsigned)wb), dim3(256), 0, s, a);
+  }
   if (f.c2r(plans.inv, a.spec, a.real) != 0) return SKR_ERR_LAUNCH;
   hipLaunchKernelGGL(any_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
   int64_t fb = (a.unit + 255) / 256; if (fb > 64) fb = 64;

@@ -336,16 +336,16 @@ class Colored(TensorNoiseCommon):
     def _axes(unit_shape) -> tuple[list[int], bool]:
         "(transform dims after dropping size-1 axes, whether the hand-written power-of-two path applies)"
         dims = [d for d in unit_shape if d != 1]
-        if not 1 <= len(dims) <= 3:
-            raise SkrampleHipError(f"Colored noise needs 1 to 3 transform axes per sample, got shape {tuple(unit_shape)}")
-        pow2 = len(dims) >= 2 and all(d & (d - 1) == 0 for d in dims) and dims[-1] >= 4 and max(dims) <= 4096
+        if not 1 <= len(dims) <= 4 or (len(dims) == 4 and dims[0] > 64):
+            raise SkrampleHipError(f"Colored noise needs 1 to 4 transform axes per sample (the first of four at most 64 long), got shape {tuple(unit_shape)}")
+        pow2 = 2 <= len(dims) <= 3 and all(d & (d - 1) == 0 for d in dims) and dims[-1] >= 4 and max(dims) <= 4096
         return dims, pow2
 
     @staticmethod
     def colorize_noise(white: torch.Tensor, exponent: float = 0.0, energy: float | None = None) -> torch.Tensor:
         """Colour an existing white-noise tensor with the power-law spectrum f^(-exponent), normalised back to the
         input's std (or to `energy`).  Size-1 dimensions are excluded from the transform; no batching -- the whole
-        tensor is one sample (reference noise.py:337-403).  Any shape with 1-3 transform axes (hipFFT)."""
+        tensor is one sample (reference noise.py:337-403).  Any shape with 1-4 transform axes (hipFFT)."""
         import ctypes
 
         _hip.require_device(white, "white noise")
@@ -355,8 +355,8 @@ class Colored(TensorNoiseCommon):
             wstd = white.float().std()
             return white if wstd.item() < 1e-8 else (white.float() * (energy / wstd)).to(white.dtype)
         dims = [d for d in white.shape if d != 1]
-        if not 1 <= len(dims) <= 3:
-            raise SkrampleHipError(f"colorize_noise needs 1 to 3 transform axes, got shape {tuple(white.shape)}")
+        if not 1 <= len(dims) <= 4 or (len(dims) == 4 and dims[0] > 64):
+            raise SkrampleHipError(f"colorize_noise needs 1 to 4 transform axes (the first of four at most 64 long), got shape {tuple(white.shape)}")
         dev, unit = white.device, math.prod(dims)
         work = white.detach().to(torch.float32).contiguous().clone().reshape(-1)  # transform workspace, overwritten
         spec = torch.empty(unit // dims[-1] * (dims[-1] // 2 + 1), dtype=torch.complex64, device=dev)

@@ -276,7 +276,7 @@ def test_pyramid_through_wrapper(dev):
     assert torch.isfinite(x.float()).all() and x.dtype == torch.bfloat16
 
 
-@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64)])
+@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10)])
 def test_colored(unit, dev):
     seeds = [31, 32]
     cases = [
@@ -467,7 +467,7 @@ def test_colorize_noise_equals_reference_fixtures(dev):
     assert c.shape == w.shape and c.dtype == torch.bfloat16
     assert abs(c.float().std().item() - w.bfloat16().float().std().item()) < 2e-2
     with pytest.raises(_hip.SkrampleHipError):
-        PN.Colored.colorize_noise(torch.randn(2, 2, 2, 2, device=dev), exponent=1.0)
+        PN.Colored.colorize_noise(torch.randn(2, 2, 2, 2, 2, device=dev), exponent=1.0)
 
 
 def test_component_methods(dev):

@@ -33,12 +33,14 @@ def case_pyramid():
     (T.test_pyramid if w % 4 == 0 else T.test_pyramid_any_shape)(unit, kw, dev)
 
 def case_colored():
-    nd = rng.choice((2, 3, 3))
+    nd = rng.choice((2, 3, 3, 4))
     pow2 = rng.random() < 0.7
     pick = (lambda: rng.choice((4, 8, 16, 32, 64, 128))) if pow2 else (lambda: rng.choice((6, 12, 20, 24, 40, 48, 96)))
     unit = tuple(pick() for _ in range(nd))
     if nd == 3:
         unit = (rng.choice((1, 2, 4, 8, 16, 32)) if pow2 else rng.choice((1, 3, 4, 6)),) + unit[1:]
+    if nd == 4:
+        unit = (rng.choice((2, 3, 4, 16)), rng.choice((2, 5, 8))) + tuple(min(d, 24) for d in unit[2:])
     T.test_colored.__wrapped__(unit, dev) if hasattr(T.test_colored, "__wrapped__") else T.test_colored(unit, dev)
 
 def case_brownian():
