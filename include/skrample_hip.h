@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 7
+#define SKR_ABI_VERSION 8
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 enum skr_status {
@@ -191,6 +191,17 @@ int skr_abi_version(void);
 const char* skr_strerror(int status);
 int skr_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */
 const char* skr_build_info(void);
+
+/* Kernel-selection switches for tests and tuning tools (process-wide, not synchronised with launches in flight on
+ * other threads; results are bit-identical under every setting -- only speed changes):
+ *   "one_trip" 1|0  one-trip loads-first kernels for launches made of whole 2048-element chunks (default 1)
+ *   "xmap"     n    XCD-aware chunk map of the one-trip kernels: every XCD takes runs of 2^n consecutive chunks
+ *                   (0 = identity map)
+ *   "tile"     1|0  whole-line tile layout when a 32-bit tensor takes part (default 1)
+ *   "rk_uv"    0|1|2|4  vectors per lane of the grid-stride Runge-Kutta stage kernel (0 = default)
+ *   "reset"    (value ignored) back to the defaults
+ * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_RK_UV=n. */
+int skr_set_tuning(const char* key, int32_t value);
 
 #ifdef __cplusplus
 }

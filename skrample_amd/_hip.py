@@ -13,7 +13,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 7
+ABI_VERSION = 8
 SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
@@ -40,6 +40,7 @@ EXPORTS = (
     "skr_strerror",
     "skr_last_hip_error",
     "skr_build_info",
+    "skr_set_tuning",
 )
 
 
@@ -125,6 +126,8 @@ def load() -> ctypes.CDLL:
         lib.skr_strerror.restype = ctypes.c_char_p
         lib.skr_last_hip_error.restype = ctypes.c_int
         lib.skr_build_info.restype = ctypes.c_char_p
+        lib.skr_set_tuning.argtypes = [ctypes.c_char_p, i32]
+        lib.skr_set_tuning.restype = ctypes.c_int
         if lib.skr_abi_version() != ABI_VERSION:
             raise SkrampleHipError(f"ABI mismatch: library {lib.skr_abi_version()} != binding {ABI_VERSION}; rebuild")
         _lib = lib

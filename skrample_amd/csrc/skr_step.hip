@@ -6,18 +6,32 @@
 // Memory-bound by construction (<= ~1.5 flop/byte without noise): no LDS, no MFMA.  Each lane owns
 // 8 consecutive elements per trip (16 B of bf16, 32 B of fp32), inputs are issued in batches of four
 // independent 16-byte loads before any FMA so every wave keeps >= 4 KiB in flight, coefficients
-// live in SGPRs (kernarg), outputs use non-temporal stores (they are next read by the model, not
-// by us).  The reference equivalent is ~16 separate aten passes + 17 copies per step
+// live in SGPRs (kernarg), 16-bit outputs and whole-line 32-bit outputs are written through (`sc0 sc1` stores:
+// they are next read by the model, not by us).  The reference equivalent is ~16 separate aten passes + 17 copies per step
 // (SURVEY.md section 8a, rows S2-S12).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
 #include "skr_pack.h"
 
 namespace skr {
+
+// tuning switches (defaults = the measured best; initialised from the environment, changed with skr_set_tuning)
+struct Tuning {
+  int one_trip, xmap, tile, rk_uv;
+  Tuning() {
+    const char* e;
+    one_trip = !((e = getenv("SKR_ONE_TRIP")) && e[0] == '0');
+    xmap = (e = getenv("SKR_XMAP")) ? atoi(e) : 7;
+    tile = getenv("SKR_NO_TILE") == nullptr;
+    rk_uv = (e = getenv("SKR_RK_UV")) ? atoi(e) : 0;
+  }
+};
+static Tuning g_tune;
 
 constexpr int VEC = 8;       // elements per lane per trip
 constexpr int BLOCK = 256;   // 4 waves
@@ -533,6 +547,7 @@ struct RkArgs {
   float chain;
   float ck[4];
   int32_t conv_to, conv_from;
+  int32_t xmap_lr;
   int64_t numel;
 };
 
@@ -578,6 +593,154 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_rk(const RkArgs a) {
   }
 }
 
+
+// ---- one-trip kernels: loads first, XCD-aware chunk map ------------------------------------------------
+// Launches made of whole 2048-element chunks (every BASELINE config) take these.  One workgroup = one chunk of
+// BLOCK lane-vectors, one trip, exactly numel/2048 workgroups on a 1-D grid:
+//  * the operand pointers are the first thing read from the kernarg and the K loads are issued right behind them;
+//    everything else the wave needs (seed, Philox key schedule, coefficients) is fetched while they are in flight.
+//    (The grid-stride kernels above read geometry -> seed pointer -> seed -> key schedule before their first load:
+//    three dependent scalar round trips per wave, 0.7 us on the 26 us headline launch.)
+//  * chunk map: workgroups b and b+8 run on the same XCD (round-robin dispatch), so with the identity map every XCD
+//    walks the tensor with a stride of 8 chunks.  The map hands each XCD runs of 2^lr consecutive chunks inside every
+//    group of 8 runs: -0.2..0.3 us on the headline launch (tools/tune/tune_r2.hip).
+// Arithmetic, lane ownership and Philox block numbering are exactly those of step_kernel_k / step_kernel_rk, so the
+// results are bit-identical (tests/test_step_gpu.py::test_one_trip_kernels_agree_bitwise).
+// Kernarg of the one-trip kernel: what the first instructions need (pointers, chunk map) leads, and launches of <= 4
+// operands carry a 2-line block instead of 3 (every CU's scalar cache misses each line once per launch).
+template <int KMAX>
+struct OneTripArgs {
+  const void* in[KMAX];
+  void* out0;
+  const uint64_t* seeds;
+  int32_t xmap_lr;      // log2(run length) of the XCD chunk map
+  int32_t bps_shift;    // log2(blocks per sample)
+  uint64_t stream0;
+  float c0[KMAX];
+  float zeta0;
+};
+
+__device__ __forceinline__ uint32_t chunk_of(uint32_t b, int lr) {  // lr = log2(run length); 0 = identity
+  const uint32_t g = 3 + lr;
+  return ((b >> g) << g) + ((b & 7u) << lr) + ((b >> 3) & ((1u << lr) - 1u));
+}
+
+template <typename T, int K, bool NOISE, bool TILE>
+__global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 4 ? 4 : 8)> a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
+  const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
+  Raw<T> raw[K];
+  float z[VEC];
+  // Paced issue.  One burst of K loads per wave is not the fastest order on this memory system: on the headline
+  // launch (tools/tune/tune_r2.hip, 256x4x128x128 bf16, K = 4) all loads first runs 26.3 us, loads after the Philox
+  // set-up 27.0 us, and the loads spread over the wave's Philox work -- one before the seed fetch, one after it, one
+  // after each Philox block -- 25.9 us; without noise, ~1000 idle clocks (s_sleep 16) between the loads of a
+  // 4-operand launch give 25.6 instead of 26.1 us (no gain measured for 2-output or 7/8-operand launches, which stay
+  // unpaced).  The order is pinned by data dependencies: each later load takes its lane-vector index from an empty
+  // asm statement that sits behind the work it has to follow (volatile asm statements keep their order), and
+  // sched_barrier stops the machine scheduler from regrouping the segments.
+  if constexpr (NOISE) {
+    int64_t vj = v;
+#define SKR_ISSUE(SLOT)                                                                      \
+    _Pragma("unroll") for (int j = 0; j < K; ++j)                                            \
+      if ((j * 4) / K == SLOT) raw[j] = load_raw<T, TILE>(a.in[j], vj);                      \
+    __builtin_amdgcn_sched_barrier(0)
+    SKR_ISSUE(0);
+    const uint32_t smp = c >> a.bps_shift;
+    const uint64_t seed = a.seeds[smp];
+    uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;  // lane-vector within the sample
+    asm volatile("" : "+v"(vj) : "s"((uint32_t)seed));               // ... behind the seed's arrival
+    SKR_ISSUE(1);
+    normal4(seed, a.stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
+    asm volatile("" : "+v"(vj), "+v"(vs) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]));  // ... behind the first block
+    __builtin_amdgcn_sched_barrier(0);
+    SKR_ISSUE(2);
+    normal4(seed, a.stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
+    asm volatile("" : "+v"(vj) : "v"(z[4]), "v"(z[5]), "v"(z[6]), "v"(z[7]));           // ... behind the second
+    __builtin_amdgcn_sched_barrier(0);
+    SKR_ISSUE(3);
+#undef SKR_ISSUE
+  } else if constexpr (K >= 3 && K <= 5) {
+    int64_t vj = v;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      raw[j] = load_raw<T, TILE>(a.in[j], vj);
+      if (j < K - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_sleep 16" : "+v"(vj));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
+  }
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    float w[VEC];
+    widen<T, float>(raw[j], w);
+    const float cj = a.c0[j];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] = fma_(cj, w[i], s[i]);
+  }
+  if constexpr (NOISE) fma_noise8<float>(a.zeta0, z, s);
+  store8<T, float, TILE>(a.out0, v, s);
+}
+
+template <typename T, int K, bool TILE>
+__global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
+  const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
+  Raw<T> raw[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
+  const float k[4] = {a.ck[0], a.ck[1], a.ck[2], a.ck[3]};
+  float sv[VEC], ov[VEC], d[VEC], s1[VEC];
+  widen<T, float>(raw[0], sv);
+  widen<T, float>(raw[1], ov);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    d[i] = convert_rounded<T, float>(sv[i], ov[i], a.conv_to, a.conv_from, k);
+    s1[i] = fma_(a.c1[1], ov[i], fma_(a.c1[0], sv[i], 0.f));
+  }
+#pragma unroll
+  for (int j = 2; j < K; ++j) {
+    float w[VEC];
+    widen<T, float>(raw[j], w);
+    const float cj = a.c1[j];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = fma_(cj, w[i], s1[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = fma_(a.chain, d[i], s1[i]);
+  store8<T, float, TILE>(a.out1, v, s1);
+  store8<T, float, TILE>(a.out0, v, d);
+}
+
+// one-trip launches: whole chunks, and with in-kernel noise a power-of-two number of whole chunks per sample
+static bool one_trip_ok(int64_t numel, int64_t sample_numel, bool noise, int* bps_shift) {
+  constexpr int64_t CHUNK = (int64_t)BLOCK * VEC;
+  if (!g_tune.one_trip || numel % CHUNK != 0 || numel / CHUNK > 0x7fffffffll) return false;
+  *bps_shift = 0;
+  if (!noise) return true;
+  if (sample_numel % CHUNK != 0) return false;
+  const int64_t bps = sample_numel / CHUNK;
+  if (bps & (bps - 1)) return false;
+  while ((1ll << *bps_shift) < bps) ++*bps_shift;
+  return true;
+}
+// run length of the XCD chunk map: the largest power of two <= the tuned one whose group of 8 runs divides the grid
+static int xmap_lr_for(int64_t chunks) {
+  int lr = g_tune.xmap;
+  if (lr < 0) lr = 0;
+  if (lr > 20) lr = 20;
+  while (lr > 0 && chunks % (8ll << lr) != 0) --lr;
+  return lr;
+}
+
 struct Geometry { dim3 grid; int mode; };
 
 template <int UV, bool NOISE>
@@ -602,8 +765,7 @@ static Geometry geometry(int64_t numel, int64_t sample_numel) {
 
 // whole 512-element tiles everywhere (and, with in-kernel noise, samples made of whole tiles on the per-sample grid)
 static bool tile_ok(int64_t numel, int64_t sample_numel, bool noise, int grid_mode) {
-  static const bool tile_off = getenv("SKR_NO_TILE") != nullptr;  // tuning switch
-  return !tile_off && numel % 512 == 0 && (!noise || (grid_mode == 1 && sample_numel % 512 == 0));
+  return g_tune.tile && numel % 512 == 0 && (!noise || (grid_mode == 1 && sample_numel % 512 == 0));
 }
 
 static int finish_launch() {
@@ -633,10 +795,30 @@ static int launch_k_uv(StepArgs<float>& args, hipStream_t stream, bool& taken) {
   return finish_launch();
 }
 
+template <typename T, bool NOISE, int KMAX>
+static int launch_k1(const StepArgs<float>& args, int bps_shift, hipStream_t stream) {
+  constexpr bool TILE = sizeof(T) == 4;  // whole chunks are whole tiles
+  const int64_t chunks = args.numel / ((int64_t)BLOCK * VEC);
+  OneTripArgs<KMAX> fa;
+  for (int k = 0; k < KMAX; ++k) { fa.in[k] = k < args.n_terms ? args.in[k] : nullptr; fa.c0[k] = k < args.n_terms ? args.c0[k] : 0.f; }
+  fa.out0 = args.out0; fa.seeds = args.seeds; fa.zeta0 = args.zeta0; fa.stream0 = args.stream0;
+  fa.bps_shift = bps_shift; fa.xmap_lr = xmap_lr_for(chunks);
+#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); break
+  if constexpr (KMAX == 4) { switch (args.n_terms) { SKR_K(1); SKR_K(2); SKR_K(3); SKR_K(4); } }
+  else { switch (args.n_terms) { SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); } }
+#undef SKR_K
+  return finish_launch();
+}
+
 template <typename T, bool NOISE>
 static int launch_k(StepArgs<float>& args, hipStream_t stream, bool& taken) {
   taken = false;
   if (args.n_terms < 1 || args.n_terms > 8 || args.numel % VEC != 0) return SKR_OK;
+  int bps_shift = 0;
+  if (one_trip_ok(args.numel, args.sample_numel, NOISE, &bps_shift) && !(sizeof(T) == 4 && !g_tune.tile)) {
+    taken = true;
+    return args.n_terms <= 4 ? launch_k1<T, NOISE, 4>(args, bps_shift, stream) : launch_k1<T, NOISE, 8>(args, bps_shift, stream);
+  }
   if constexpr (NOISE) {
     return launch_k_uv<T, true, 1>(args, stream, taken);
   } else {
@@ -653,7 +835,7 @@ static int launch_rk_uv(const StepArgs<float>& args, hipStream_t stream) {
   for (int k = 0; k < 8; ++k) { ra.in[k] = k < args.n_terms ? args.in[k] : nullptr; ra.c1[k] = k < args.n_terms ? args.c1[k] : 0.f; }
   ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
   for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
-  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel;
+  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel; ra.xmap_lr = 0;
 #define SKR_K(N, TILE) case N: hipLaunchKernelGGL((step_kernel_rk<T, N, UV, TILE>), g.grid, dim3(BLOCK), 0, stream, ra); break
   if constexpr (sizeof(T) == 4) {
     if (tile_ok(args.numel, args.sample_numel, false, g.mode)) {
@@ -667,9 +849,27 @@ static int launch_rk_uv(const StepArgs<float>& args, hipStream_t stream) {
 }
 
 template <typename T>
+static int launch_rk1(const StepArgs<float>& args, unsigned chunks, hipStream_t stream) {
+  constexpr bool TILE = sizeof(T) == 4;
+  RkArgs ra;
+  for (int k = 0; k < 8; ++k) { ra.in[k] = k < args.n_terms ? args.in[k] : nullptr; ra.c1[k] = k < args.n_terms ? args.c1[k] : 0.f; }
+  ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
+  for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
+  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel; ra.xmap_lr = xmap_lr_for(chunks);
+#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE>), dim3(chunks), dim3(BLOCK), 0, stream, ra); break
+  switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
+#undef SKR_K
+  return finish_launch();
+}
+
+template <typename T>
 static int launch_rk(const StepArgs<float>& args, hipStream_t stream) {
-  static const int forced = [] { const char* e = getenv("SKR_RK_UV"); return e ? atoi(e) : 0; }();
-  const int uv = forced ? forced : 1;  // measured on the cfg5 shard: 1, 2 and 4 vectors per lane are within 2 %
+  int unused = 0;
+  if (one_trip_ok(args.numel, args.sample_numel, false, &unused) && !(sizeof(T) == 4 && !g_tune.tile)) {
+    const int64_t chunks = args.numel / ((int64_t)BLOCK * VEC);
+    return launch_rk1<T>(args, (unsigned)chunks, stream);
+  }
+  const int uv = g_tune.rk_uv ? g_tune.rk_uv : 1;  // measured on the cfg5 shard: 1, 2 and 4 vectors per lane are within 2 %
   if (uv == 4) return launch_rk_uv<T, 4>(args, stream);
   if (uv == 2) return launch_rk_uv<T, 2>(args, stream);
   return launch_rk_uv<T, 1>(args, stream);
@@ -817,3 +1017,14 @@ extern "C" int skr_step_launch(const skr_step_plan* plan, const void* const* inp
 }
 
 extern "C" int skr_last_hip_error(void) { return skr::g_last_hip_error; }
+
+extern "C" int skr_set_tuning(const char* key, int32_t value) {
+  if (!key) return SKR_ERR_NULL;
+  if (!strcmp(key, "reset")) skr::g_tune = skr::Tuning();
+  else if (!strcmp(key, "one_trip")) skr::g_tune.one_trip = value;
+  else if (!strcmp(key, "xmap")) skr::g_tune.xmap = value;
+  else if (!strcmp(key, "tile")) skr::g_tune.tile = value;
+  else if (!strcmp(key, "rk_uv")) skr::g_tune.rk_uv = value;
+  else return SKR_ERR_UNSUPPORTED;
+  return SKR_OK;
+}

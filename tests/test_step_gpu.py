@@ -386,6 +386,51 @@ def test_tile_layout_agrees_bitwise(dtypes, n_terms, two_outputs, dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize(("n_terms", "noise", "rk"), [(1, False, False), (4, True, False), (4, False, False), (8, True, False), (2, False, True), (5, False, True), (8, False, True)])
+def test_one_trip_kernels_agree_bitwise(dtype, n_terms, noise, rk, dev):
+    """launches made of whole 2048-element chunks take the one-trip loads-first kernels (XCD-aware chunk map, 1-D grid);
+    the grid-stride kernels they replace (still used for ragged shapes) and the identity chunk map must give the same bits,
+    including the in-kernel Philox draws (same block numbering per sample)."""
+    lib = _hip.load()
+    batch, sample = 6, 2048 * 64  # 64 chunks per sample (a power of two), 384 chunks in all (a multiple of 64: XCD map on)
+    n = batch * sample
+    g = torch.Generator().manual_seed(100 * n_terms + noise)
+    ins = [torch.randn(n, generator=g).to(dtype).to(dev) for _ in range(n_terms)]
+    seeds = torch.arange(batch, dtype=torch.int64, device=dev) * 7919 + 3
+    code = _hip.DTYPE_CODE[dtype]
+    plan = _hip.StepPlanC()
+    plan.n_terms, plan.n_group_a, plan.dtype_a, plan.dtype_b, plan.out0_dtype = n_terms, n_terms, code, code, code
+    plan.out1_dtype = code if rk else -1
+    plan.sample_numel = sample
+    for k in range(n_terms):
+        plan.coef0[k], plan.coef1[k] = (-1) ** k * (0.3 + 0.05 * k), 0.1 * (k + 1) - 0.35
+    if noise:
+        plan.noise_mode, plan.zeta0, plan.stream0 = 1, 0.625, 11
+    if rk:
+        plan.convert_to, plan.convert_from, plan.chain = 1, 2, 0.3125
+        for i, v in enumerate((0.7, 0.9, 0.4, 1.3)):
+            plan.convert_k[i] = v
+    results = []
+    try:
+        for one_trip, xmap in ((1, 3), (1, 0), (1, 1), (0, 0)):
+            assert lib.skr_set_tuning(b"one_trip", one_trip) == 0 and lib.skr_set_tuning(b"xmap", xmap) == 0
+            o0 = torch.full((n,), 5.0, device=dev, dtype=dtype)
+            o1 = torch.full((n,), 5.0, device=dev, dtype=dtype) if rk else None
+            _hip.launch_step(plan, ins, o0, o1, seeds if noise else None, n, dev)
+            torch.cuda.synchronize()
+            results.append((o0, o1))
+    finally:
+        lib.skr_set_tuning(b"reset", 0)
+    for o0, o1 in results[1:]:
+        assert torch.equal(o0, results[0][0])
+        if rk:
+            assert torch.equal(o1, results[0][1])
+    out = results[0][1] if rk else results[0][0]
+    assert torch.isfinite(out.float()).all() and out.float().std() > 0.1
+    assert lib.skr_set_tuning(b"no_such_switch", 1) == 7  # SKR_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("kinds", [(1, 0), (2, 0), (3, 0), (0, 1), (1, 1), (2, 2), (3, 3), (1, 2)])
 def test_rounded_conversion_equals_torch_op_by_op(dtype, kinds, dev):
     """the RK wrapper's derivative (out0 of a CONV launch) must carry exactly the roundings torch applies when the
