@@ -170,8 +170,10 @@ def cpu_baseline(seconds: float) -> dict:
 
 
 def load_traffic() -> float | None:
-    "HBM bytes per launch from the committed PMC pass (profiles/r01_pmc_traffic.json), corrected per the guide"
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per launch of the headline kernel from the committed PMC passes of this same command
+    (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per the guide) -- counters cannot
+    be read from inside an unprofiled run, so this is the round's measured constant, not a per-run reading"""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         return float(json.load(open(path))["hbm_bytes_per_launch"])
     except Exception:
@@ -345,7 +347,7 @@ def main() -> None:
                 "traffic": load_traffic(),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_us_per_launch": kernel_ms * 1e3,
-                "kernel": "skr::step_kernel_k<bf16_t, K=4, NOISE=true, UV=1>",
+                "kernel": "skr::step_kernel_k1<bf16_t, K=4, NOISE=true> (one-trip, paced loads, XCD chunk map)",
                 "measured_d2d_memcpy": copy_gbs,  # hipMemcpy D2D of 512 MiB on this box, read+write GB/s
             },
             "wrapper_steps_per_s": wrapper_rate,

@@ -126,6 +126,13 @@ __device__ __forceinline__ Raw<T> load_raw(const void* base, int64_t vec) {
   return r;
 }
 
+template <typename T>
+__device__ __forceinline__ void pin_raw(Raw<T>& r) {  // "the loaded registers are consumed here": nothing that reads them moves above
+  if constexpr (sizeof(T) == 2) asm volatile("" : "+v"(r.q));
+  else if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(r.q[0]), "+v"(r.q[1]));
+  else asm volatile("" : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]));
+}
+
 template <typename T, typename Acc>
 __device__ __forceinline__ void widen(const Raw<T>& r, Acc v[VEC]) {
   if constexpr (std::is_same<T, bf16_t>::value) {
@@ -660,6 +667,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
     __builtin_amdgcn_sched_barrier(0);
     SKR_ISSUE(3);
 #undef SKR_ISSUE
+    // the operands are first touched here: left alone, the compiler starts unpacking the early ones between the
+    // segments and parks the wave on their arrival (microseconds under load) before the later loads are issued
+#pragma unroll
+    for (int j = 0; j < K; ++j) pin_raw(raw[j]);
   } else if constexpr (K >= 3 && K <= 5) {
     int64_t vj = v;
 #pragma unroll

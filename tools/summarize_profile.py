@@ -13,27 +13,27 @@ import json
 import statistics
 import sys
 
-round_tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k<skr::bf16_t, 4, true, 1, false>"  # headline: K=4 bf16 + Philox
+round_tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k1<skr::bf16_t, 4, true, false>"  # headline: K=4 bf16 + Philox, one-trip kernel
 
 
 def counter(path: str, name: str) -> list[float]:
     return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if needle in r["Kernel_Name"] and r["Counter_Name"] == name]
 
 
-rows = list(csv.DictReader(open("gpurun_out/prof_trace/r01_kernel_stats.csv")))
+rows = list(csv.DictReader(open("gpurun_out/prof_trace/prof_kernel_stats.csv")))
 with open(f"profiles/{round_tag}_kernel_stats.csv", "w", newline="") as fh:
     wr = csv.writer(fh)
     wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
         wr.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
-fetch = counter("gpurun_out/prof_fetch/r01_counter_collection.csv", "FETCH_SIZE")
-write = counter("gpurun_out/prof_write/r01_counter_collection.csv", "WRITE_SIZE")
+fetch = counter("gpurun_out/prof_fetch/prof_counter_collection.csv", "FETCH_SIZE")
+write = counter("gpurun_out/prof_write/prof_counter_collection.csv", "WRITE_SIZE")
 # steady-state launches only (the first, order-1 step of every schedule reads no history)
 fetch = [v for v in fetch if v > 0.75 * max(fetch)]
 out = {
-    "kernel": "skr::step_kernel_k<bf16_t, K=4, NOISE=true, UV=1> (DPM-2 SDE, B=256x4x128x128)",
+    "kernel": "skr::step_kernel_k1<bf16_t, K=4, NOISE=true> (DPM-2 SDE, B=256x4x128x128)",
     "fetch_size_kib_mean": statistics.mean(fetch),
     "write_size_kib_mean": statistics.mean(write),
     "launches": [len(fetch), len(write)],
@@ -46,3 +46,39 @@ out = {
 }
 json.dump(out, open(f"profiles/{round_tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+
+# SQ-level counters of the headline kernel (one or more passes; every counter summed over the launch, mean over launches)
+import glob
+import os
+
+sq = {}
+for path in sorted(glob.glob("gpurun_out/prof_sq*/prof_counter_collection.csv")) + sorted(glob.glob("gpurun_out/prof_misc/prof_counter_collection.csv")):
+    acc: dict[str, list[float]] = {}
+    for r in csv.DictReader(open(path)):
+        if needle in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        sq[k] = {"mean_per_launch": statistics.mean(v), "launches": len(v)}
+if sq:
+    g = lambda k: sq.get(k, {}).get("mean_per_launch")
+    derived = {}
+    if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
+        wc = g("SQ_WAVE_CYCLES")
+        derived["wait_any_frac_of_wave_cycles"] = g("SQ_WAIT_ANY") / wc
+        if g("SQ_ACTIVE_INST_ANY") is not None:
+            derived["active_inst_any_frac_of_wave_cycles"] = g("SQ_ACTIVE_INST_ANY") / wc
+        if g("SQ_WAIT_INST_ANY") is not None:
+            derived["wait_inst_any_frac_of_wave_cycles"] = g("SQ_WAIT_INST_ANY") / wc
+        if g("SQ_ACTIVE_INST_VALU") is not None:
+            derived["active_inst_valu_frac_of_wave_cycles"] = g("SQ_ACTIVE_INST_VALU") / wc
+    if g("SQ_WAVES") and g("SQ_INSTS_VALU"):
+        derived["valu_instructions_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
+    if g("SQ_WAVES") and g("SQ_WAVE_CYCLES"):
+        derived["wave_lifetime_quad_cycles"] = g("SQ_WAVE_CYCLES") / g("SQ_WAVES")
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum"):
+        derived["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    json.dump({"kernel": needle, "counters": sq, "derived": derived,
+               "note": "SQ_* cycle counters are in quad-cycles summed over waves (guides/MI355X_MICROARCH.md); WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES"},
+              open(f"profiles/{round_tag}_sq_counters.json", "w"), indent=1)
+    print(json.dumps(derived, indent=1))
