@@ -198,9 +198,12 @@ const char* skr_build_info(void);
  *   "xmap"     n    XCD-aware chunk map of the one-trip kernels: every XCD takes runs of 2^n consecutive chunks
  *                   (0 = identity map)
  *   "tile"     1|0  whole-line tile layout when a 32-bit tensor takes part (default 1)
+ *   "two_out"  2|1|0  compile-time one-trip kernel for two-output (UniPC / SPC) launches: 1 where it measured faster
+ *                   (default), 2 wherever it is instantiated, 0 never
+ *   "pace"     1|0  paced load issue in the one-trip kernels (default 1)
  *   "rk_uv"    0|1|2|4  vectors per lane of the grid-stride Runge-Kutta stage kernel (0 = default)
  *   "reset"    (value ignored) back to the defaults
- * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_RK_UV=n. */
+ * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_NO_TWO_OUT, SKR_RK_UV=n. */
 int skr_set_tuning(const char* key, int32_t value);
 
 #ifdef __cplusplus

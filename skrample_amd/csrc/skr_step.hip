@@ -9,233 +9,13 @@
 // live in SGPRs (kernarg), 16-bit outputs and whole-line 32-bit outputs are written through (`sc0 sc1` stores:
 // they are next read by the model, not by us).  The reference equivalent is ~16 separate aten passes + 17 copies per step
 // (SURVEY.md section 8a, rows S2-S12).
-#include <hip/hip_runtime.h>
-#include <stdlib.h>
-#include <stdint.h>
-#include <string.h>
 
-#include "../../include/skrample_hip.h"
-#include "skr_philox.h"
-#include "skr_pack.h"
+
+#include "skr_step_common.h"
 
 namespace skr {
 
-// tuning switches (defaults = the measured best; initialised from the environment, changed with skr_set_tuning)
-struct Tuning {
-  int one_trip, xmap, tile, rk_uv;
-  Tuning() {
-    const char* e;
-    one_trip = !((e = getenv("SKR_ONE_TRIP")) && e[0] == '0');
-    xmap = (e = getenv("SKR_XMAP")) ? atoi(e) : 7;
-    tile = getenv("SKR_NO_TILE") == nullptr;
-    rk_uv = (e = getenv("SKR_RK_UV")) ? atoi(e) : 0;
-  }
-};
-static Tuning g_tune;
-
-constexpr int VEC = 8;       // elements per lane per trip
-constexpr int BLOCK = 256;   // 4 waves
-// vectors per lane per trip (spaced BLOCK apart so every wave access stays 1 KiB contiguous).  Measured on
-// MI355X (tools/tune/tune_step.hip, B=256 DPM-2): without Philox more bytes in flight per lane win
-// (UV 1/2/4 -> 29.3/28.2/27.4 us with non-temporal stores; 26.9/26.4/26.7 with the write-through stores used now);
-// with Philox one vector per lane and one trip per lane is best (UV 1/2/4 -> 26.4/27.1/28.0 us): the VALU work then
-// overlaps other waves' loads instead of its own.
-constexpr int uv_for(bool noise, bool has1) { return noise ? 1 : (has1 ? 2 : 4); }
-constexpr int MAXK = SKR_MAX_TERMS;
-
-struct bf16_t { uint16_t v; };
-struct f16_t { _Float16 v; };
-
-template <typename Acc>
-struct StepArgs {
-  const void* in[MAXK];
-  Acc c0[MAXK];
-  Acc c1[MAXK];
-  void* out0;
-  void* out1;
-  const uint64_t* seeds;
-  Acc chain, zeta0, zeta1;
-  uint64_t stream0, stream1;
-  int64_t numel;
-  int64_t sample_numel;
-  double inv_sample_numel;
-  int64_t vps;          // vectors per sample (per-sample grid only)
-  int32_t n_a, n_terms;
-  int32_t grid_mode;    // 0 flat grid, 1 per-sample grid (noise kernels, sample_numel % 8 == 0)
-  int32_t conv_to, conv_from;  // rounded pair conversion (CONV kernels): see convert_rounded()
-  double ck[4];
-};
-
-__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
-// ---- 8-element loads (widening to Acc) ---------------------------------------------------------
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef double f64x2_t __attribute__((ext_vector_type(2)));
-
-template <typename T> struct Raw;  // raw register image of 8 elements
-template <> struct Raw<bf16_t> { u32x4_t q; };
-template <> struct Raw<f16_t> { u32x4_t q; };
-template <> struct Raw<float> { f32x4_t q[2]; };
-template <> struct Raw<double> { f64x2_t q[4]; };
-
-// Which 8 elements lane-slot `v` owns, as two groups of 4 consecutive elements (group index = element / 4):
-//   TILE = false  the 8 consecutive elements 8v .. 8v+7            -> groups 2v, 2v+1
-//   TILE = true   within the wave's 512-element tile, elements 4l..4l+3 and 256+4l..256+4l+3 (l = lane)
-//                 -> groups 128*(v>>6) + l and that + 64
-// With 8 consecutive elements a 16-bit operand is one 16-byte access per lane (a full KiB per wave instruction), but a
-// 32-bit operand is two 16-byte accesses to the lane's own 32 bytes: each wave instruction then covers only HALF of
-// every line it touches, which costs ~20 % on loads and far more on write-through stores.  The tile layout makes
-// every wave instruction cover whole lines for 16- and 32-bit operands alike (16-bit: two 8-byte accesses, 512 B
-// each; 32-bit: two 16-byte accesses, 1 KiB each).  Used whenever a 32-bit tensor takes part and the launch is made of
-// whole tiles (tools/tune/tune_policy.hip: 2 bf16 + 3 fp32 in, fp32 + bf16 out: 66.9 -> 54.7 us).
-template <bool TILE> __device__ __forceinline__ int64_t group0(int64_t v) {
-  if constexpr (TILE) return ((v >> 6) << 7) + (v & 63);
-  else return 2 * v;
-}
-template <bool TILE> __device__ __forceinline__ int64_t group1(int64_t v) {
-  if constexpr (TILE) return ((v >> 6) << 7) + (v & 63) + 64;
-  else return 2 * v + 1;
-}
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-
-template <typename T, bool TILE = false>
-__device__ __forceinline__ Raw<T> load_raw(const void* base, int64_t vec) {
-  Raw<T> r;
-  if constexpr (sizeof(T) == 2) {
-    if constexpr (TILE) {
-      const u32x2_t* p = reinterpret_cast<const u32x2_t*>(base);
-      const u32x2_t lo = __builtin_nontemporal_load(p + group0<true>(vec)), hi = __builtin_nontemporal_load(p + group1<true>(vec));
-      r.q = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
-    } else {
-      r.q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(base) + vec);
-    }
-  } else if constexpr (sizeof(T) == 4) {
-    const f32x4_t* p = reinterpret_cast<const f32x4_t*>(base);
-    r.q[0] = __builtin_nontemporal_load(p + group0<TILE>(vec));
-    r.q[1] = __builtin_nontemporal_load(p + group1<TILE>(vec));
-  } else {
-    const f64x2_t* p = reinterpret_cast<const f64x2_t*>(base);
-    const int64_t g0 = group0<TILE>(vec) * 2, g1 = group1<TILE>(vec) * 2;
-    r.q[0] = __builtin_nontemporal_load(p + g0);
-    r.q[1] = __builtin_nontemporal_load(p + g0 + 1);
-    r.q[2] = __builtin_nontemporal_load(p + g1);
-    r.q[3] = __builtin_nontemporal_load(p + g1 + 1);
-  }
-  return r;
-}
-
-template <typename T>
-__device__ __forceinline__ void pin_raw(Raw<T>& r) {  // "the loaded registers are consumed here": nothing that reads them moves above
-  if constexpr (sizeof(T) == 2) asm volatile("" : "+v"(r.q));
-  else if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(r.q[0]), "+v"(r.q[1]));
-  else asm volatile("" : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]));
-}
-
-template <typename T, typename Acc>
-__device__ __forceinline__ void widen(const Raw<T>& r, Acc v[VEC]) {
-  if constexpr (std::is_same<T, bf16_t>::value) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[2 * i] = (Acc)__uint_as_float(r.q[i] << 16);
-      v[2 * i + 1] = (Acc)__uint_as_float(r.q[i] & 0xFFFF0000u);
-    }
-  } else if constexpr (std::is_same<T, f16_t>::value) {
-    // (bit_cast of a dword to a _Float16x2 vector is mis-compiled by ROCm 7.2 hipcc for lanes 1..3 of a
-    //  dwordx4: go through scalar 16-bit halves instead)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t w = r.q[i];
-      v[2 * i] = (Acc)(float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu));
-      v[2 * i + 1] = (Acc)(float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
-    }
-  } else if constexpr (std::is_same<T, float>::value) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (Acc)r.q[i >> 2][i & 3];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (Acc)r.q[i >> 1][i & 1];
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ float load_scalar(const void* base, int64_t i) {
-  if constexpr (std::is_same<T, bf16_t>::value)
-    return __uint_as_float((uint32_t) reinterpret_cast<const uint16_t*>(base)[i] << 16);
-  else if constexpr (std::is_same<T, f16_t>::value)
-    return (float)reinterpret_cast<const _Float16*>(base)[i];
-  else
-    return (float)reinterpret_cast<const T*>(base)[i];
-}
-template <typename T>
-__device__ __forceinline__ double load_scalar_d(const void* base, int64_t i) {
-  if constexpr (std::is_same<T, double>::value) return reinterpret_cast<const double*>(base)[i];
-  else return (double)load_scalar<T>(base, i);
-}
-
-// ---- stores (single rounding from Acc) --------------------------------------------------------------
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-  f32x2_t f = {a, b};
-  bf16x2_t h = __builtin_convertvector(f, bf16x2_t);  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
-  return __builtin_bit_cast(uint32_t, h);
-}
-__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
-  // round the fp32 accumulator, as the reference does (compute in fp32, then .to(half)): without the pin the compiler
-  // may fuse the last FMA with the conversion (v_fma_mixlo_f16), which rounds the exact sum once
-  asm("" : "+v"(a), "+v"(b));
-  const uint32_t lo = __builtin_bit_cast(uint16_t, (_Float16)a);
-  const uint32_t hi = __builtin_bit_cast(uint16_t, (_Float16)b);
-  return lo | (hi << 16);
-}
-
-template <typename T, typename Acc, bool TILE = false>
-__device__ __forceinline__ void store8(void* base, int64_t vec, const Acc v[VEC]) {
-  if constexpr (sizeof(T) == 2) {
-    u32x4_t q;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if constexpr (std::is_same<T, bf16_t>::value) q[i] = pack_bf16((float)v[2 * i], (float)v[2 * i + 1]);
-      else q[i] = pack_f16((float)v[2 * i], (float)v[2 * i + 1]);
-    }
-    if constexpr (TILE) {
-      u32x2_t* p = reinterpret_cast<u32x2_t*>(base);
-      store8_stream(p + group0<true>(vec), u32x2_t{q[0], q[1]});
-      store8_stream(p + group1<true>(vec), u32x2_t{q[2], q[3]});
-    } else {
-      store16_stream(reinterpret_cast<u32x4_t*>(base) + vec, q);
-    }
-  } else if constexpr (sizeof(T) == 4) {
-    f32x4_t* p = reinterpret_cast<f32x4_t*>(base);
-    f32x4_t a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-    f32x4_t b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
-    if constexpr (TILE) {  // whole lines per wave instruction: write through
-      store16_stream(p + group0<true>(vec), a);
-      store16_stream(p + group1<true>(vec), b);
-    } else {  // 32 B per lane = two half-covered lines per instruction: plain write-back stores, so L2 merges the halves
-      p[2 * vec] = a;  // (measured: plain 33.5 us, non-temporal 41.0 us, write-through 47.2 us for 4 bf16 in -> fp32 out)
-      p[2 * vec + 1] = b;
-    }
-  } else {
-    f64x2_t* p = reinterpret_cast<f64x2_t*>(base);
-    const int64_t g[2] = {group0<TILE>(vec) * 2, group1<TILE>(vec) * 2};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f64x2_t a = {(double)v[2 * i], (double)v[2 * i + 1]};
-      __builtin_nontemporal_store(a, p + g[i >> 1] + (i & 1));
-    }
-  }
-}
-
-template <typename T, typename Acc>
-__device__ __forceinline__ void store_scalar(void* base, int64_t i, Acc v) {
-  if constexpr (std::is_same<T, bf16_t>::value) reinterpret_cast<uint16_t*>(base)[i] = (uint16_t)(pack_bf16((float)v, 0.f) & 0xFFFFu);
-  else if constexpr (std::is_same<T, f16_t>::value) reinterpret_cast<_Float16*>(base)[i] = (_Float16)(float)v;
-  else reinterpret_cast<T*>(base)[i] = (T)v;
-}
+Tuning g_tune;
 
 // ---- accumulate one dtype group: N terms x UV vectors of independent 16-byte loads, then FMAs --------
 template <typename T, typename Acc, bool HAS1, int N, int UV, bool TILE>
@@ -273,76 +53,6 @@ __device__ __forceinline__ void acc_group(const StepArgs<Acc>& a, int k, int ken
   for (; k + 4 <= kend; k += 4) acc_batch<T, Acc, HAS1, 4, UV, TILE>(a, k, v0, vhi, s0, s1);
   if (k + 2 <= kend) { acc_batch<T, Acc, HAS1, 2, UV, TILE>(a, k, v0, vhi, s0, s1); k += 2; }
   if (k < kend) acc_batch<T, Acc, HAS1, 1, UV, TILE>(a, k, v0, vhi, s0, s1);
-}
-
-// ---- rounded pair conversion (Runge-Kutta wrapper) ---------------------------------------------------
-// The reference's RK wrapper converts the network output to derivative space in the INPUT dtype,
-// one rounded tensor op at a time, before any cast to compute_scale (skrample/diffusers.py:819-834 with
-// models.py:92-224).  out0 = from_x(s, to_x(s, o)) is reproduced here op for op with the same roundings,
-// so the stored derivative tensor is bit-identical to the reference's.
-//   to_x   kinds: 0 o | 1 ((s - k0*o) / k1) | 2 (k1*s - k0*o) | 3 (o * k0)
-//   from_x kinds: 0 x | 1 ((s - k2*x) / k3) | 2 ((k2*s - x) / k3) | 3 (x / k2)
-template <typename T> struct OpMath { using type = float; };
-template <> struct OpMath<double> { using type = double; };
-
-template <typename T> __device__ __forceinline__ float rnd(float v) {
-  if constexpr (std::is_same<T, bf16_t>::value) return __uint_as_float(pack_bf16(v, 0.f) << 16);
-  else if constexpr (std::is_same<T, f16_t>::value) {
-    // The reference rounds twice (fp32 op result, then to half).  Left alone, the compiler folds `half(k * float(h))`
-    // into v_fma_mixlo_f16, which rounds the exact product ONCE and differs from torch on fp32 ties (seen as 1-ulp
-    // derivative mismatches in ~4 % of elements).  The empty asm pins the fp32 result in a VGPR first.
-    asm("" : "+v"(v));
-    return (float)(_Float16)v;
-  } else return v;
-}
-__device__ __forceinline__ double rnd_d(double v) { return v; }
-
-// individually rounded ops: hip's __fmul_rn / __fsub_rn are plain operators that the compiler may still contract
-// into an FMA with a neighbour, so contraction is switched off inside these helpers
-__device__ __forceinline__ float mul_(float a, float b) {
-#pragma clang fp contract(off)
-  return a * b;
-}
-__device__ __forceinline__ float sub_(float a, float b) {
-#pragma clang fp contract(off)
-  return a - b;
-}
-__device__ __forceinline__ float div_(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ double mul_(double a, double b) {
-#pragma clang fp contract(off)
-  return a * b;
-}
-__device__ __forceinline__ double sub_(double a, double b) {
-#pragma clang fp contract(off)
-  return a - b;
-}
-__device__ __forceinline__ double div_(double a, double b) { return __ddiv_rn(a, b); }
-
-template <typename T, typename M>
-__device__ __forceinline__ M convert_rounded(M s, M o, int to_kind, int from_kind, const M k[4]) {
-  auto R = [](M v) -> M { if constexpr (std::is_same<M, double>::value) return v; else return rnd<T>(v); };
-  M x;
-  switch (to_kind) {
-    case 1: x = R(div_(R(sub_(s, R(mul_(k[0], o)))), k[1])); break;
-    case 2: x = R(sub_(R(mul_(k[1], s)), R(mul_(k[0], o)))); break;
-    case 3: x = R(mul_(o, k[0])); break;
-    default: x = o; break;
-  }
-  switch (from_kind) {
-    case 1: return R(div_(R(sub_(s, R(mul_(k[2], x)))), k[3]));
-    case 2: return R(div_(R(sub_(R(mul_(k[2], s)), x)), k[3]));
-    case 3: return R(div_(x, k[2]));
-    default: return x;
-  }
-}
-
-// ---- noise ---------------------------------------------------------------------------------------
-// element e of the whole tensor -> sample s = e / sample_numel, r = e % sample_numel,
-// Philox block r >> 2, lane r & 3 (oracle/skr_oracle/noise.py::philox_normal).
-template <typename Acc>
-__device__ __forceinline__ void fma_noise8(Acc zeta, const float z[VEC], Acc s[VEC]) {
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) s[i] = fma_(zeta, (Acc)z[i], s[i]);
 }
 
 // generic placement: any sample_numel.  `smp`/`r` locate element e0 (first of the 8).
@@ -474,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs<Acc> a) {
 }
 
 // ---- host-side dispatch ------------------------------------------------------------------------------
-static thread_local int g_last_hip_error = 0;
+thread_local int g_last_hip_error = 0;
 
 // ---- compile-time-K fast path: uniform dtype, one output, no tail -------------------------------------
 // The generic kernel walks a runtime term list (pointer/coefficient fetched from kernarg at a loop-dependent
@@ -546,17 +256,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k(const FastArgs a) {
 // Same arithmetic, in the same order, as step_kernel<..., CONV> -- but every operand is loaded exactly once
 // (the generic kernel fetches the converted pair a second time), all K loads are issued back to back and the
 // term list is a template constant.
-struct RkArgs {
-  const void* in[8];
-  float c1[8];
-  void* out0;
-  void* out1;
-  float chain;
-  float ck[4];
-  int32_t conv_to, conv_from;
-  int32_t xmap_lr;
-  int64_t numel;
-};
 
 template <typename T, int K, int UV, bool TILE>
 __global__ __launch_bounds__(BLOCK) void step_kernel_rk(const RkArgs a) {
@@ -601,157 +300,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_rk(const RkArgs a) {
 }
 
 
-// ---- one-trip kernels: loads first, XCD-aware chunk map ------------------------------------------------
-// Launches made of whole 2048-element chunks (every BASELINE config) take these.  One workgroup = one chunk of
-// BLOCK lane-vectors, one trip, exactly numel/2048 workgroups on a 1-D grid:
-//  * the operand pointers are the first thing read from the kernarg and the K loads are issued right behind them;
-//    everything else the wave needs (seed, Philox key schedule, coefficients) is fetched while they are in flight.
-//    (The grid-stride kernels above read geometry -> seed pointer -> seed -> key schedule before their first load:
-//    three dependent scalar round trips per wave, 0.7 us on the 26 us headline launch.)
-//  * chunk map: workgroups b and b+8 run on the same XCD (round-robin dispatch), so with the identity map every XCD
-//    walks the tensor with a stride of 8 chunks.  The map hands each XCD runs of 2^lr consecutive chunks inside every
-//    group of 8 runs: -0.2..0.3 us on the headline launch (tools/tune/tune_r2.hip).
-// Arithmetic, lane ownership and Philox block numbering are exactly those of step_kernel_k / step_kernel_rk, so the
-// results are bit-identical (tests/test_step_gpu.py::test_one_trip_kernels_agree_bitwise).
-// Kernarg of the one-trip kernel: what the first instructions need (pointers, chunk map) leads, and launches of <= 4
-// operands carry a 2-line block instead of 3 (every CU's scalar cache misses each line once per launch).
-template <int KMAX>
-struct OneTripArgs {
-  const void* in[KMAX];
-  void* out0;
-  const uint64_t* seeds;
-  int32_t xmap_lr;      // log2(run length) of the XCD chunk map
-  int32_t bps_shift;    // log2(blocks per sample)
-  uint64_t stream0;
-  float c0[KMAX];
-  float zeta0;
-};
-
-__device__ __forceinline__ uint32_t chunk_of(uint32_t b, int lr) {  // lr = log2(run length); 0 = identity
-  const uint32_t g = 3 + lr;
-  return ((b >> g) << g) + ((b & 7u) << lr) + ((b >> 3) & ((1u << lr) - 1u));
-}
-
-template <typename T, int K, bool NOISE, bool TILE>
-__global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 4 ? 4 : 8)> a) {
-  const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
-  const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
-  Raw<T> raw[K];
-  float z[VEC];
-  // Paced issue.  One burst of K loads per wave is not the fastest order on this memory system: on the headline
-  // launch (tools/tune/tune_r2.hip, 256x4x128x128 bf16, K = 4) all loads first runs 26.3 us, loads after the Philox
-  // set-up 27.0 us, and the loads spread over the wave's Philox work -- one before the seed fetch, one after it, one
-  // after each Philox block -- 25.9 us; without noise, ~1000 idle clocks (s_sleep 16) between the loads of a
-  // 4-operand launch give 25.6 instead of 26.1 us (no gain measured for 2-output or 7/8-operand launches, which stay
-  // unpaced).  The order is pinned by data dependencies: each later load takes its lane-vector index from an empty
-  // asm statement that sits behind the work it has to follow (volatile asm statements keep their order), and
-  // sched_barrier stops the machine scheduler from regrouping the segments.
-  if constexpr (NOISE) {
-    int64_t vj = v;
-#define SKR_ISSUE(SLOT)                                                                      \
-    _Pragma("unroll") for (int j = 0; j < K; ++j)                                            \
-      if ((j * 4) / K == SLOT) raw[j] = load_raw<T, TILE>(a.in[j], vj);                      \
-    __builtin_amdgcn_sched_barrier(0)
-    SKR_ISSUE(0);
-    const uint32_t smp = c >> a.bps_shift;
-    const uint64_t seed = a.seeds[smp];
-    uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;  // lane-vector within the sample
-    asm volatile("" : "+v"(vj) : "s"((uint32_t)seed));               // ... behind the seed's arrival
-    SKR_ISSUE(1);
-    normal4(seed, a.stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
-    asm volatile("" : "+v"(vj), "+v"(vs) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]));  // ... behind the first block
-    __builtin_amdgcn_sched_barrier(0);
-    SKR_ISSUE(2);
-    normal4(seed, a.stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
-    asm volatile("" : "+v"(vj) : "v"(z[4]), "v"(z[5]), "v"(z[6]), "v"(z[7]));           // ... behind the second
-    __builtin_amdgcn_sched_barrier(0);
-    SKR_ISSUE(3);
-#undef SKR_ISSUE
-    // the operands are first touched here: left alone, the compiler starts unpacking the early ones between the
-    // segments and parks the wave on their arrival (microseconds under load) before the later loads are issued
-#pragma unroll
-    for (int j = 0; j < K; ++j) pin_raw(raw[j]);
-  } else if constexpr (K >= 3 && K <= 5) {
-    int64_t vj = v;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      raw[j] = load_raw<T, TILE>(a.in[j], vj);
-      if (j < K - 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_sleep 16" : "+v"(vj));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
-  }
-  float s[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    float w[VEC];
-    widen<T, float>(raw[j], w);
-    const float cj = a.c0[j];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) s[i] = fma_(cj, w[i], s[i]);
-  }
-  if constexpr (NOISE) fma_noise8<float>(a.zeta0, z, s);
-  store8<T, float, TILE>(a.out0, v, s);
-}
-
-template <typename T, int K, bool TILE>
-__global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
-  const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
-  const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
-  Raw<T> raw[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
-  const float k[4] = {a.ck[0], a.ck[1], a.ck[2], a.ck[3]};
-  float sv[VEC], ov[VEC], d[VEC], s1[VEC];
-  widen<T, float>(raw[0], sv);
-  widen<T, float>(raw[1], ov);
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    d[i] = convert_rounded<T, float>(sv[i], ov[i], a.conv_to, a.conv_from, k);
-    s1[i] = fma_(a.c1[1], ov[i], fma_(a.c1[0], sv[i], 0.f));
-  }
-#pragma unroll
-  for (int j = 2; j < K; ++j) {
-    float w[VEC];
-    widen<T, float>(raw[j], w);
-    const float cj = a.c1[j];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) s1[i] = fma_(cj, w[i], s1[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) s1[i] = fma_(a.chain, d[i], s1[i]);
-  store8<T, float, TILE>(a.out1, v, s1);
-  store8<T, float, TILE>(a.out0, v, d);
-}
-
-// one-trip launches: whole chunks, and with in-kernel noise a power-of-two number of whole chunks per sample
-static bool one_trip_ok(int64_t numel, int64_t sample_numel, bool noise, int* bps_shift) {
-  constexpr int64_t CHUNK = (int64_t)BLOCK * VEC;
-  if (!g_tune.one_trip || numel % CHUNK != 0 || numel / CHUNK > 0x7fffffffll) return false;
-  *bps_shift = 0;
-  if (!noise) return true;
-  if (sample_numel % CHUNK != 0) return false;
-  const int64_t bps = sample_numel / CHUNK;
-  if (bps & (bps - 1)) return false;
-  while ((1ll << *bps_shift) < bps) ++*bps_shift;
-  return true;
-}
-// run length of the XCD chunk map: the largest power of two <= the tuned one whose group of 8 runs divides the grid
-static int xmap_lr_for(int64_t chunks) {
-  int lr = g_tune.xmap;
-  if (lr < 0) lr = 0;
-  if (lr > 20) lr = 20;
-  while (lr > 0 && chunks % (8ll << lr) != 0) --lr;
-  return lr;
-}
-
 struct Geometry { dim3 grid; int mode; };
 
 template <int UV, bool NOISE>
@@ -779,7 +327,7 @@ static bool tile_ok(int64_t numel, int64_t sample_numel, bool noise, int grid_mo
   return g_tune.tile && numel % 512 == 0 && (!noise || (grid_mode == 1 && sample_numel % 512 == 0));
 }
 
-static int finish_launch() {
+int finish_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_last_hip_error = (int)e; return SKR_ERR_LAUNCH; }
   return SKR_OK;
@@ -806,29 +354,13 @@ static int launch_k_uv(StepArgs<float>& args, hipStream_t stream, bool& taken) {
   return finish_launch();
 }
 
-template <typename T, bool NOISE, int KMAX>
-static int launch_k1(const StepArgs<float>& args, int bps_shift, hipStream_t stream) {
-  constexpr bool TILE = sizeof(T) == 4;  // whole chunks are whole tiles
-  const int64_t chunks = args.numel / ((int64_t)BLOCK * VEC);
-  OneTripArgs<KMAX> fa;
-  for (int k = 0; k < KMAX; ++k) { fa.in[k] = k < args.n_terms ? args.in[k] : nullptr; fa.c0[k] = k < args.n_terms ? args.c0[k] : 0.f; }
-  fa.out0 = args.out0; fa.seeds = args.seeds; fa.zeta0 = args.zeta0; fa.stream0 = args.stream0;
-  fa.bps_shift = bps_shift; fa.xmap_lr = xmap_lr_for(chunks);
-#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); break
-  if constexpr (KMAX == 4) { switch (args.n_terms) { SKR_K(1); SKR_K(2); SKR_K(3); SKR_K(4); } }
-  else { switch (args.n_terms) { SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); } }
-#undef SKR_K
-  return finish_launch();
-}
-
 template <typename T, bool NOISE>
 static int launch_k(StepArgs<float>& args, hipStream_t stream, bool& taken) {
   taken = false;
   if (args.n_terms < 1 || args.n_terms > 8 || args.numel % VEC != 0) return SKR_OK;
-  int bps_shift = 0;
-  if (one_trip_ok(args.numel, args.sample_numel, NOISE, &bps_shift) && !(sizeof(T) == 4 && !g_tune.tile)) {
-    taken = true;
-    return args.n_terms <= 4 ? launch_k1<T, NOISE, 4>(args, bps_shift, stream) : launch_k1<T, NOISE, 8>(args, bps_shift, stream);
+  {
+    const int rc = launch_one_trip_k<T>(args, NOISE, stream, taken);  // whole chunks: one-trip kernel (skr_step_fast.hip)
+    if (taken) return rc;
   }
   if constexpr (NOISE) {
     return launch_k_uv<T, true, 1>(args, stream, taken);
@@ -860,25 +392,11 @@ static int launch_rk_uv(const StepArgs<float>& args, hipStream_t stream) {
 }
 
 template <typename T>
-static int launch_rk1(const StepArgs<float>& args, unsigned chunks, hipStream_t stream) {
-  constexpr bool TILE = sizeof(T) == 4;
-  RkArgs ra;
-  for (int k = 0; k < 8; ++k) { ra.in[k] = k < args.n_terms ? args.in[k] : nullptr; ra.c1[k] = k < args.n_terms ? args.c1[k] : 0.f; }
-  ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
-  for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
-  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel; ra.xmap_lr = xmap_lr_for(chunks);
-#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE>), dim3(chunks), dim3(BLOCK), 0, stream, ra); break
-  switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
-#undef SKR_K
-  return finish_launch();
-}
-
-template <typename T>
 static int launch_rk(const StepArgs<float>& args, hipStream_t stream) {
-  int unused = 0;
-  if (one_trip_ok(args.numel, args.sample_numel, false, &unused) && !(sizeof(T) == 4 && !g_tune.tile)) {
-    const int64_t chunks = args.numel / ((int64_t)BLOCK * VEC);
-    return launch_rk1<T>(args, (unsigned)chunks, stream);
+  {
+    bool taken = false;
+    const int rc = launch_one_trip_rk<T>(args, stream, taken);
+    if (taken) return rc;
   }
   const int uv = g_tune.rk_uv ? g_tune.rk_uv : 1;  // measured on the cfg5 shard: 1, 2 and 4 vectors per lane are within 2 %
   if (uv == 4) return launch_rk_uv<T, 4>(args, stream);
@@ -899,6 +417,13 @@ static int launch(StepArgs<Acc>& args, hipStream_t stream) {
   // Runge-Kutta stage fast path: uniform dtype in and out, conversion + chained result, no in-kernel noise
   if constexpr (std::is_same<Acc, float>::value && std::is_same<TA, TB>::value && std::is_same<TO0, TA>::value && std::is_same<TO1, TA>::value && ST0 && HAS1 && CONV && !NOISE) {
     if (args.n_terms >= 2 && args.n_terms <= 8 && args.numel % VEC == 0) return launch_rk<TA>(args, stream);
+  }
+  // two-output fast path (UniPC / SPC): 16-bit operands (+ at most one fp32 state), fp32 out0 + 16-bit out1
+  if constexpr (std::is_same<Acc, float>::value && sizeof(TA) == 2 && (std::is_same<TB, TA>::value || std::is_same<TB, float>::value) &&
+                std::is_same<TO0, float>::value && std::is_same<TO1, TA>::value && ST0 && HAS1 && !CONV) {
+    bool taken = false;
+    const int rc = launch_one_trip_two<TA>(args, NOISE, std::is_same<TB, float>::value, stream, taken);
+    if (taken) return rc;
   }
   constexpr int UV = uv_for(NOISE, HAS1);
   Geometry g = geometry<UV, NOISE>(args.numel, args.sample_numel);
@@ -1036,6 +561,8 @@ extern "C" int skr_set_tuning(const char* key, int32_t value) {
   else if (!strcmp(key, "xmap")) skr::g_tune.xmap = value;
   else if (!strcmp(key, "tile")) skr::g_tune.tile = value;
   else if (!strcmp(key, "rk_uv")) skr::g_tune.rk_uv = value;
+  else if (!strcmp(key, "two_out")) skr::g_tune.two_out = value;
+  else if (!strcmp(key, "pace")) skr::g_tune.pace = value;
   else return SKR_ERR_UNSUPPORTED;
   return SKR_OK;
 }

@@ -1,0 +1,378 @@
+// One-trip compile-time kernels of the fused solver step for MI355X (gfx950): whole 2048-element chunks, 1-D grid,
+// XCD-aware chunk map, paced load issue.  Bit-identical to the grid-stride / general kernels of skr_step.hip.
+#include "skr_step_common.h"
+
+namespace skr {
+
+// ---- one-trip kernels: loads first, XCD-aware chunk map ------------------------------------------------
+// Launches made of whole 2048-element chunks (every BASELINE config) take these.  One workgroup = one chunk of
+// BLOCK lane-vectors, one trip, exactly numel/2048 workgroups on a 1-D grid:
+//  * the operand pointers are the first thing read from the kernarg and the K loads are issued right behind them;
+//    everything else the wave needs (seed, Philox key schedule, coefficients) is fetched while they are in flight.
+//    (The grid-stride kernels above read geometry -> seed pointer -> seed -> key schedule before their first load:
+//    three dependent scalar round trips per wave, 0.7 us on the 26 us headline launch.)
+//  * chunk map: workgroups b and b+8 run on the same XCD (round-robin dispatch), so with the identity map every XCD
+//    walks the tensor with a stride of 8 chunks.  The map hands each XCD runs of 2^lr consecutive chunks inside every
+//    group of 8 runs: -0.2..0.3 us on the headline launch (tools/tune/tune_r2.hip).
+// Arithmetic, lane ownership and Philox block numbering are exactly those of step_kernel_k / step_kernel_rk, so the
+// results are bit-identical (tests/test_step_gpu.py::test_one_trip_kernels_agree_bitwise).
+// Kernarg of the one-trip kernel: what the first instructions need (pointers, chunk map) leads, and launches of <= 4
+// operands carry a 2-line block instead of 3 (every CU's scalar cache misses each line once per launch).
+template <int KMAX>
+struct OneTripArgs {
+  const void* in[KMAX];
+  void* out0;
+  const uint64_t* seeds;
+  int32_t xmap_lr;      // log2(run length) of the XCD chunk map
+  int32_t bps_shift;    // log2(blocks per sample)
+  uint64_t stream0;
+  float c0[KMAX];
+  float zeta0;
+};
+
+__device__ __forceinline__ uint32_t chunk_of(uint32_t b, int lr) {  // lr = log2(run length); 0 = identity
+  const uint32_t g = 3 + lr;
+  return ((b >> g) << g) + ((b & 7u) << lr) + ((b >> 3) & ((1u << lr) - 1u));
+}
+
+template <typename T, int K, bool NOISE, bool TILE, bool PACE>
+__global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 4 ? 4 : 8)> a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
+  const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
+  Raw<T> raw[K];
+  float z[VEC];
+  // Paced issue.  One burst of K loads per wave is not the fastest order on this memory system: on the headline
+  // launch (tools/tune/tune_r2.hip, 256x4x128x128 bf16, K = 4) all loads first runs 26.3 us, loads after the Philox
+  // set-up 27.0 us, and the loads spread over the wave's Philox work -- one before the seed fetch, one after it, one
+  // after each Philox block -- 25.9 us; without noise, ~1000 idle clocks (s_sleep 16) between the loads of a
+  // 4-operand launch give 25.6 instead of 26.1 us (no gain measured for 2-output or 7/8-operand launches, which stay
+  // unpaced).  The order is pinned by data dependencies: each later load takes its lane-vector index from an empty
+  // asm statement that sits behind the work it has to follow (volatile asm statements keep their order), and
+  // sched_barrier stops the machine scheduler from regrouping the segments.
+  if constexpr (NOISE && PACE) {
+    int64_t vj = v;
+#define SKR_ISSUE(SLOT)                                                                      \
+    _Pragma("unroll") for (int j = 0; j < K; ++j)                                            \
+      if ((j * 4) / K == SLOT) raw[j] = load_raw<T, TILE>(a.in[j], vj);                      \
+    __builtin_amdgcn_sched_barrier(0)
+    SKR_ISSUE(0);
+    const uint32_t smp = c >> a.bps_shift;
+    const uint64_t seed = a.seeds[smp];
+    uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;  // lane-vector within the sample
+    asm volatile("" : "+v"(vj) : "s"((uint32_t)seed));               // ... behind the seed's arrival
+    SKR_ISSUE(1);
+    normal4(seed, a.stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
+    asm volatile("" : "+v"(vj), "+v"(vs) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]));  // ... behind the first block
+    __builtin_amdgcn_sched_barrier(0);
+    SKR_ISSUE(2);
+    normal4(seed, a.stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
+    asm volatile("" : "+v"(vj) : "v"(z[4]), "v"(z[5]), "v"(z[6]), "v"(z[7]));           // ... behind the second
+    __builtin_amdgcn_sched_barrier(0);
+    SKR_ISSUE(3);
+#undef SKR_ISSUE
+    // the operands are first touched here: left alone, the compiler starts unpacking the early ones between the
+    // segments and parks the wave on their arrival (microseconds under load) before the later loads are issued
+#pragma unroll
+    for (int j = 0; j < K; ++j) pin_raw(raw[j]);
+  } else if constexpr (NOISE) {  // unpaced: every load first, then the Philox work
+#pragma unroll
+    for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
+    const uint32_t smp = c >> a.bps_shift;
+    const uint64_t seed = a.seeds[smp];
+    const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
+    normal4(seed, a.stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
+    normal4(seed, a.stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
+  } else if constexpr (PACE && (K == 4 || K == 5)) {  // tools/bench_plan.py: K=4 -1.1 %, K=5 -1.7 %, K=3 +6 % (left unpaced), K>=6 no change
+    int64_t vj = v;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      raw[j] = load_raw<T, TILE>(a.in[j], vj);
+      if (j < K - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_sleep 16" : "+v"(vj));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
+  }
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    float w[VEC];
+    widen<T, float>(raw[j], w);
+    const float cj = a.c0[j];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] = fma_(cj, w[i], s[i]);
+  }
+  if constexpr (NOISE) fma_noise8<float>(a.zeta0, z, s);
+  store8<T, float, TILE>(a.out0, v, s);
+}
+
+template <typename T, int K, bool TILE>
+__global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
+  const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
+  Raw<T> raw[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
+  const float k[4] = {a.ck[0], a.ck[1], a.ck[2], a.ck[3]};
+  float sv[VEC], ov[VEC], d[VEC], s1[VEC];
+  widen<T, float>(raw[0], sv);
+  widen<T, float>(raw[1], ov);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    d[i] = convert_rounded<T, float>(sv[i], ov[i], a.conv_to, a.conv_from, k);
+    s1[i] = fma_(a.c1[1], ov[i], fma_(a.c1[0], sv[i], 0.f));
+  }
+#pragma unroll
+  for (int j = 2; j < K; ++j) {
+    float w[VEC];
+    widen<T, float>(raw[j], w);
+    const float cj = a.c1[j];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = fma_(cj, w[i], s1[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = fma_(a.chain, d[i], s1[i]);
+  store8<T, float, TILE>(a.out1, v, s1);
+  store8<T, float, TILE>(a.out0, v, d);
+}
+
+// one-trip launches: whole chunks, and with in-kernel noise a power-of-two number of whole chunks per sample
+static bool one_trip_ok(int64_t numel, int64_t sample_numel, bool noise, int* bps_shift) {
+  constexpr int64_t CHUNK = (int64_t)BLOCK * VEC;
+  if (!g_tune.one_trip || numel % CHUNK != 0 || numel / CHUNK > 0x7fffffffll) return false;
+  *bps_shift = 0;
+  if (!noise) return true;
+  if (sample_numel % CHUNK != 0) return false;
+  const int64_t bps = sample_numel / CHUNK;
+  if (bps & (bps - 1)) return false;
+  while ((1ll << *bps_shift) < bps) ++*bps_shift;
+  return true;
+}
+// run length of the XCD chunk map: the largest power of two <= the tuned one whose group of 8 runs divides the grid
+static int xmap_lr_for(int64_t chunks) {
+  int lr = g_tune.xmap;
+  if (lr < 0) lr = 0;
+  if (lr > 20) lr = 20;
+  while (lr > 0 && chunks % (8ll << lr) != 0) --lr;
+  return lr;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+template <typename T, bool NOISE, int KMAX>
+static int launch_k1(const StepArgs<float>& args, int bps_shift, hipStream_t stream) {
+  constexpr bool TILE = sizeof(T) == 4;  // whole chunks are whole tiles
+  const int64_t chunks = args.numel / ((int64_t)BLOCK * VEC);
+  OneTripArgs<KMAX> fa;
+  for (int k = 0; k < KMAX; ++k) { fa.in[k] = k < args.n_terms ? args.in[k] : nullptr; fa.c0[k] = k < args.n_terms ? args.c0[k] : 0.f; }
+  fa.out0 = args.out0; fa.seeds = args.seeds; fa.zeta0 = args.zeta0; fa.stream0 = args.stream0;
+  fa.bps_shift = bps_shift; fa.xmap_lr = xmap_lr_for(chunks);
+#define SKR_K(N) case N: if (g_tune.pace) hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, true>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); \
+                        else hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, false>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); break
+  if constexpr (KMAX == 4) { switch (args.n_terms) { SKR_K(1); SKR_K(2); SKR_K(3); SKR_K(4); } }
+  else { switch (args.n_terms) { SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); } }
+#undef SKR_K
+  return finish_launch();
+}
+
+
+template <typename T>
+int launch_one_trip_k(const StepArgs<float>& args, bool noise, hipStream_t stream, bool& taken) {
+  taken = false;
+  int bps_shift = 0;
+  if (!one_trip_ok(args.numel, args.sample_numel, noise, &bps_shift) || (sizeof(T) == 4 && !g_tune.tile)) return SKR_OK;
+  taken = true;
+  if (noise) return args.n_terms <= 4 ? launch_k1<T, true, 4>(args, bps_shift, stream) : launch_k1<T, true, 8>(args, bps_shift, stream);
+  return args.n_terms <= 4 ? launch_k1<T, false, 4>(args, bps_shift, stream) : launch_k1<T, false, 8>(args, bps_shift, stream);
+}
+template int launch_one_trip_k<bf16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
+template int launch_one_trip_k<f16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
+template int launch_one_trip_k<float>(const StepArgs<float>&, bool, hipStream_t, bool&);
+
+template <typename T>
+static int launch_rk1(const StepArgs<float>& args, unsigned chunks, hipStream_t stream) {
+  constexpr bool TILE = sizeof(T) == 4;
+  RkArgs ra;
+  for (int k = 0; k < 8; ++k) { ra.in[k] = k < args.n_terms ? args.in[k] : nullptr; ra.c1[k] = k < args.n_terms ? args.c1[k] : 0.f; }
+  ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
+  for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
+  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel; ra.xmap_lr = xmap_lr_for(chunks);
+#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE>), dim3(chunks), dim3(BLOCK), 0, stream, ra); break
+  switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
+#undef SKR_K
+  return finish_launch();
+}
+
+
+template <typename T>
+int launch_one_trip_rk(const StepArgs<float>& args, hipStream_t stream, bool& taken) {
+  taken = false;
+  int unused = 0;
+  if (!one_trip_ok(args.numel, args.sample_numel, false, &unused) || (sizeof(T) == 4 && !g_tune.tile)) return SKR_OK;
+  taken = true;
+  return launch_rk1<T>(args, (unsigned)(args.numel / ((int64_t)BLOCK * VEC)), stream);
+}
+template int launch_one_trip_rk<bf16_t>(const StepArgs<float>&, hipStream_t, bool&);
+template int launch_one_trip_rk<f16_t>(const StepArgs<float>&, hipStream_t, bool&);
+template int launch_one_trip_rk<float>(const StepArgs<float>&, hipStream_t, bool&);
+
+// ---- two outputs (UniPC / SPC steps): out0 fp32 state, out1 = chain*out0 + ... in the operands' 16-bit dtype ---------
+//   out0 = sum_k c0[k]*in_k + zeta0*N(stream0)          NA 16-bit operands, then NB (0 or 1) fp32 operand
+//   out1 = chain*out0 + sum_k c1[k]*in_k + zeta1*N(stream1)
+// Same FMA order, zero-zeta guards, tile layout and Philox numbering as step_kernel<..., HAS1, TILE = true>, so the bits
+// are the same; what changes is that every pointer and coefficient is in SGPRs before the first load, the term list is
+// a template constant and the launch is one trip over an XCD-mapped 1-D grid.
+template <int NMAX>
+struct TwoOutArgs {
+  const void* in[NMAX];
+  void* out0;
+  void* out1;
+  const uint64_t* seeds;
+  int32_t xmap_lr, bps_shift;
+  uint64_t stream0, stream1;
+  float chain, zeta0, zeta1;
+  float c0[NMAX];
+  float c1[NMAX];
+};
+constexpr int two_out_nmax(int n) { return n <= 4 ? 4 : (n <= 8 ? 8 : 12); }
+
+template <typename TA, int NA, int NB, bool NOISE, bool PACE>
+__global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out_nmax(NA + NB)> a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
+  const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
+  Raw<TA> ra[NA];
+  Raw<float> rb[NB > 0 ? NB : 1];
+  float z0[VEC], z1[VEC];
+  bool n0 = false, n1 = false;
+  if constexpr (NOISE && PACE) {
+    // loads paced over the Philox work (see step_kernel_k1): six slots around the seed fetch and the four blocks
+    int64_t vj = v;
+#define SKR_ISSUE(SLOT)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j)                                                        \
+      if ((j * 6) / (NA + NB) == SLOT) ra[j] = load_raw<TA, true>(a.in[j], vj);                           \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j)                                                        \
+      if (((NA + j) * 6) / (NA + NB) == SLOT) rb[j] = load_raw<float, true>(a.in[NA + j], vj);            \
+    __builtin_amdgcn_sched_barrier(0)
+    SKR_ISSUE(0);
+    const uint32_t smp = c >> a.bps_shift;
+    const uint64_t seed = a.seeds[smp];
+    uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
+    asm volatile("" : "+v"(vj) : "s"((uint32_t)seed));
+    SKR_ISSUE(1);
+    n0 = a.zeta0 != 0.f;
+    n1 = a.zeta1 != 0.f;
+    if (n0) normal4(seed, a.stream0, (uint64_t)group0<true>((int64_t)vs), z0);
+    asm volatile("" : "+v"(vj), "+v"(vs));
+    __builtin_amdgcn_sched_barrier(0);
+    SKR_ISSUE(2);
+    if (n0) normal4(seed, a.stream0, (uint64_t)group1<true>((int64_t)vs), z0 + 4);
+    asm volatile("" : "+v"(vj), "+v"(vs));
+    __builtin_amdgcn_sched_barrier(0);
+    SKR_ISSUE(3);
+    if (n1) normal4(seed, a.stream1, (uint64_t)group0<true>((int64_t)vs), z1);
+    asm volatile("" : "+v"(vj), "+v"(vs));
+    __builtin_amdgcn_sched_barrier(0);
+    SKR_ISSUE(4);
+    if (n1) normal4(seed, a.stream1, (uint64_t)group1<true>((int64_t)vs), z1 + 4);
+    asm volatile("" : "+v"(vj));
+    __builtin_amdgcn_sched_barrier(0);
+    SKR_ISSUE(5);
+#undef SKR_ISSUE
+#pragma unroll
+    for (int j = 0; j < NA; ++j) pin_raw(ra[j]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) pin_raw(rb[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ra[j] = load_raw<TA, true>(a.in[j], v);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = load_raw<float, true>(a.in[NA + j], v);
+    if constexpr (NOISE) {
+      const uint32_t smp = c >> a.bps_shift;
+      const uint64_t seed = a.seeds[smp];
+      const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
+      n0 = a.zeta0 != 0.f;
+      n1 = a.zeta1 != 0.f;
+      if (n0) { normal4(seed, a.stream0, (uint64_t)group0<true>((int64_t)vs), z0); normal4(seed, a.stream0, (uint64_t)group1<true>((int64_t)vs), z0 + 4); }
+      if (n1) { normal4(seed, a.stream1, (uint64_t)group0<true>((int64_t)vs), z1); normal4(seed, a.stream1, (uint64_t)group1<true>((int64_t)vs), z1 + 4); }
+    }
+  }
+  float s0[VEC], s1[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    float w[VEC];
+    widen<TA, float>(ra[j], w);
+    const float w0 = a.c0[j], w1 = a.c1[j];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s0[i] = fma_(w0, w[i], s0[i]);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = fma_(w1, w[i], s1[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    float w[VEC];
+    widen<float, float>(rb[j], w);
+    const float w0 = a.c0[NA + j], w1 = a.c1[NA + j];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s0[i] = fma_(w0, w[i], s0[i]);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = fma_(w1, w[i], s1[i]);
+  }
+  if constexpr (NOISE) { if (n0) fma_noise8<float>(a.zeta0, z0, s0); }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = fma_(a.chain, s0[i], s1[i]);
+  if constexpr (NOISE) { if (n1) fma_noise8<float>(a.zeta1, z1, s1); }
+  store8<TA, float, true>(a.out1, v, s1);
+  store8<float, float, true>(a.out0, v, s0);
+}
+
+template <typename TA, int NA, int NB, bool NOISE, bool PACE>
+static int launch_k2(const StepArgs<float>& args, int bps_shift, hipStream_t stream) {
+  constexpr int NMAX = two_out_nmax(NA + NB);
+  const int64_t chunks = args.numel / ((int64_t)BLOCK * VEC);
+  TwoOutArgs<NMAX> ta;
+  for (int k = 0; k < NMAX; ++k) {
+    const bool live = k < NA + NB;
+    ta.in[k] = live ? args.in[k] : nullptr; ta.c0[k] = live ? args.c0[k] : 0.f; ta.c1[k] = live ? args.c1[k] : 0.f;
+  }
+  ta.out0 = args.out0; ta.out1 = args.out1; ta.seeds = args.seeds;
+  ta.xmap_lr = xmap_lr_for(chunks); ta.bps_shift = bps_shift;
+  ta.stream0 = args.stream0; ta.stream1 = args.stream1;
+  ta.chain = args.chain; ta.zeta0 = args.zeta0; ta.zeta1 = args.zeta1;
+  hipLaunchKernelGGL((step_kernel_k2<TA, NA, NB, NOISE, PACE>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, ta);
+  return finish_launch();
+}
+
+// the operand counts the samplers emit (tools/trace_plans.py): UniPC / SPC of order n give 2n+2 (+2 with a noise
+// tensor) 16-bit operands and the previous corrected state in fp32; their first steps have no fp32 operand yet
+template <typename TA>
+int launch_one_trip_two(const StepArgs<float>& args, bool noise, bool group_b_f32, hipStream_t stream, bool& taken) {
+  taken = false;
+  const int na = args.n_a, nb = args.n_terms - args.n_a;
+  if (nb > 1 || (nb == 1 && !group_b_f32) || !g_tune.tile || !g_tune.two_out) return SKR_OK;
+  // measured (tools/bench_plan.py, 256x16x128x128): with Philox and <= 7 operands the general kernel is 1-2 % faster
+  // (193 vs 197 us at 4+1, 239 vs 241 us at 6+1); from 8+1 on, and without noise, this kernel wins (344 vs 365 us at 10+1)
+  if (noise && na + nb <= 7 && g_tune.two_out != 2) return SKR_OK;
+  int bps_shift = 0;
+  if (!one_trip_ok(args.numel, args.sample_numel, noise, &bps_shift)) return SKR_OK;
+#define SKR_GO(A, B)                                                                             \
+  if (na == A && nb == B) {                                                                      \
+    taken = true;                                                                                \
+    if (!noise) return launch_k2<TA, A, B, false, false>(args, bps_shift, stream);              \
+    return g_tune.pace ? launch_k2<TA, A, B, true, true>(args, bps_shift, stream) : launch_k2<TA, A, B, true, false>(args, bps_shift, stream); \
+  }
+  SKR_GO(2, 0) SKR_GO(3, 0) SKR_GO(4, 0) SKR_GO(4, 1) SKR_GO(6, 1) SKR_GO(7, 1) SKR_GO(8, 1) SKR_GO(10, 1)
+#undef SKR_GO
+  return SKR_OK;
+}
+template int launch_one_trip_two<bf16_t>(const StepArgs<float>&, bool, bool, hipStream_t, bool&);
+template int launch_one_trip_two<f16_t>(const StepArgs<float>&, bool, bool, hipStream_t, bool&);
+
+}  // namespace skr

@@ -430,6 +430,47 @@ def test_one_trip_kernels_agree_bitwise(dtype, n_terms, noise, rk, dev):
     assert lib.skr_set_tuning(b"no_such_switch", 1) == 7  # SKR_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize(("n_a", "n_b", "noise"), [(2, 0, True), (3, 0, False), (4, 0, True), (4, 1, True), (6, 1, False), (7, 1, False), (8, 1, True), (10, 1, False), (8, 1, False)])
+def test_two_output_kernels_agree_bitwise(dtype, n_a, n_b, noise, dev):
+    """UniPC / SPC steps (fp32 state out0 + 16-bit out1, 16-bit operands + at most one fp32 state) take a compile-time
+    one-trip kernel when the launch is made of whole chunks; it must give the bits of the general runtime-term-list kernel,
+    both Philox draws (two streams) included -- and a zero zeta must leave -0.0 sums alone exactly as the general kernel does."""
+    lib = _hip.load()
+    batch, sample = 3, 2048 * 16
+    n = batch * sample
+    g = torch.Generator().manual_seed(10 * n_a + n_b)
+    ins = [torch.randn(n, generator=g).to(dtype).to(dev) for _ in range(n_a)] + [torch.randn(n, generator=g).to(dev) for _ in range(n_b)]
+    ins[0][:64] = 0  # exact zeros in, so some sums are signed zeros
+    seeds = torch.arange(batch, dtype=torch.int64, device=dev) * 104729 + 17
+    code = _hip.DTYPE_CODE[dtype]
+    plan = _hip.StepPlanC()
+    plan.n_terms, plan.n_group_a, plan.dtype_a, plan.dtype_b = n_a + n_b, n_a, code, _hip.F32
+    plan.out0_dtype, plan.out1_dtype, plan.chain, plan.sample_numel = _hip.F32, code, -0.4375, sample
+    for k in range(n_a + n_b):
+        plan.coef0[k], plan.coef1[k] = (-1) ** k * (0.25 + 0.05 * k), 0.3 - 0.07 * k
+    variants = [(0.0, 0.0)]
+    if noise:
+        plan.noise_mode, plan.stream0, plan.stream1 = 1, 5, 6
+        variants = [(0.5, 0.75), (0.0, 0.75), (0.5, 0.0)]
+    try:
+        for z0, z1 in variants:
+            plan.zeta0, plan.zeta1 = z0, z1
+            res = []
+            for fast in (2, 0):  # 2 = take the compile-time kernel for every shape it is instantiated for
+                assert lib.skr_set_tuning(b"two_out", fast) == 0
+                o0 = torch.full((n,), 9.0, device=dev)
+                o1 = torch.full((n,), 9.0, device=dev, dtype=dtype)
+                _hip.launch_step(plan, ins, o0, o1, seeds if noise else None, n, dev)
+                torch.cuda.synchronize()
+                res.append((o0, o1))
+            assert torch.equal(res[0][0].view(torch.int32), res[1][0].view(torch.int32)), (z0, z1)
+            assert torch.equal(res[0][1].view(torch.int16), res[1][1].view(torch.int16)), (z0, z1)
+            assert torch.isfinite(res[0][0]).all() and res[0][0].std() > 0.1
+    finally:
+        lib.skr_set_tuning(b"reset", 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("kinds", [(1, 0), (2, 0), (3, 0), (0, 1), (1, 1), (2, 2), (3, 3), (1, 2)])
 def test_rounded_conversion_equals_torch_op_by_op(dtype, kinds, dev):

@@ -1,0 +1,92 @@
+"""Micro-benchmark of single launch plans through the C ABI under different kernel-selection switches
+(skr_set_tuning), on rotating buffer sets larger than the Infinity Cache.
+
+  python tools/bench_plan.py            # the standard list
+Each line: plan, switches, us per launch (HIP events over 200 launches), algorithmic TB/s, fraction of 8 TB/s."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from skrample_amd import _hip
+
+dev = torch.device("cuda:0")
+lib = _hip.load()
+stream = torch.cuda.current_stream(dev).cuda_stream
+
+
+def bench(name, batch, sample, n_a, n_b, two_out, noise, rk=False, dtype=torch.bfloat16, switches=(), iters=200, footprint=1.2e9):
+    n = batch * sample
+    item = 2 if dtype != torch.float32 else 4
+    per_set = n * (n_a * item + n_b * 4 + (4 + item if two_out else item) + (item if rk else 0))
+    nsets = max(2, min(8, int(footprint // per_set) + 1))
+    g = torch.Generator(device=dev).manual_seed(1)
+    sets = []
+    for _ in range(nsets):
+        ins = [torch.randn(n, device=dev, generator=g).to(dtype) for _ in range(n_a)] + [torch.randn(n, device=dev, generator=g) for _ in range(n_b)]
+        o0 = torch.empty(n, device=dev, dtype=torch.float32 if two_out else dtype)
+        o1 = torch.empty(n, device=dev, dtype=dtype) if (two_out or rk) else None
+        sets.append((ins, o0, o1))
+    seeds = torch.arange(batch, dtype=torch.int64, device=dev) + 42
+    code = _hip.DTYPE_CODE[dtype]
+    plan = _hip.StepPlanC()
+    plan.n_terms, plan.n_group_a, plan.dtype_a, plan.dtype_b = n_a + n_b, n_a, code, _hip.F32 if n_b else code
+    plan.out0_dtype = _hip.F32 if two_out else code
+    plan.out1_dtype = code if (two_out or rk) else -1
+    plan.sample_numel, plan.chain = sample, 0.5
+    for k in range(n_a + n_b):
+        plan.coef0[k], plan.coef1[k] = 0.1 * (k + 1), -0.05 * (k + 1)
+    if noise:
+        plan.noise_mode, plan.zeta0, plan.zeta1, plan.stream0, plan.stream1 = 1, 0.3, 0.2 if two_out else 0.0, 1, 2
+    if rk:
+        plan.convert_to, plan.convert_from = 1, 1
+        for i, v in enumerate((0.7, 0.9, 0.4, 1.3)):
+            plan.convert_k[i] = v
+    calls = []
+    for ins, o0, o1 in sets:
+        ptrs = (ctypes.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
+        calls.append((ptrs, o0.data_ptr(), o1.data_ptr() if o1 is not None else None))
+    bytes_per = per_set
+    out = []
+    for sw in switches or ({},):
+        lib.skr_set_tuning(b"reset", 0)
+        for k, v in sw.items():
+            assert lib.skr_set_tuning(k.encode(), v) == 0
+        def run(count):
+            for i in range(count):
+                ptrs, p0, p1 = calls[i % nsets]
+                st = lib.skr_step_launch(ctypes.byref(plan), ptrs, p0, p1, seeds.data_ptr() if noise else None, n, stream)
+                if st:
+                    _hip.check(st, "skr_step_launch")
+        best = None
+        for rep in range(3):
+            run(20)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(iters); e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            best = us if best is None else min(best, us)
+        tbs = bytes_per / best / 1e6
+        print(f"{name:44s} {str(sw):28s} {best:8.2f} us  {tbs:6.3f} TB/s  {tbs / 8:.3f}", flush=True)
+    lib.skr_set_tuning(b"reset", 0)
+    del sets
+
+
+S4 = 4 * 128 * 128
+S16 = 16 * 128 * 128
+OLD, NEW = {"one_trip": 0, "two_out": 0}, {}
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "k"):
+        for k in (1, 2, 3, 4, 5, 6, 8):
+            bench(f"K={k} bf16 -> bf16", 256, S4, k, 0, False, False, switches=[OLD, NEW, {"pace": 0}])
+        for k in (2, 4, 6):
+            bench(f"K={k} bf16 -> bf16 + philox", 256, S4, k, 0, False, True, switches=[OLD, NEW, {"pace": 0}])
+    if which in ("all", "two"):
+        for na, nb, noise in ((8, 1, True), (8, 1, False), (10, 1, False), (6, 1, True), (4, 1, True), (4, 0, False)):
+            bench(f"two-out NA={na} NB={nb} {'philox' if noise else ''}", 256, S16, na, nb, True, noise, switches=[OLD, NEW, {"pace": 0}])
+    if which in ("all", "rk"):
+        for k in (2, 3, 5, 7):
+            bench(f"rk stage K={k}", 64, 4 * 256 * 256, k, 0, False, False, rk=True, switches=[OLD, NEW])
+    if which in ("all", "f32"):
+        for k in (2, 4):
+            bench(f"K={k} f32 -> f32 + philox", 256, S4, k, 0, False, True, dtype=torch.float32, switches=[OLD, NEW, {"pace": 0}])
+            bench(f"K={k} f32 -> f32", 256, S4, k, 0, False, False, dtype=torch.float32, switches=[OLD, NEW, {"pace": 0}])
