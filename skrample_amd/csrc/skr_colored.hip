@@ -12,6 +12,9 @@
 //   pass D  middle axis inverse                                   (3-D only)
 //   pass E  last axis, half spectrum -> real (fp32 scratch) + per-block sums
 //   pass F  per-sample unbiased std of white (from A) and coloured (from E), rescale, round to out dtype
+// Planes that fit the LDS take the fused kernels instead (colored_plane): A+B in one kernel, D+E+F in another -- the
+// coloured std comes from the weighted spectrum by Parseval (reduced in pass C), so the inverse kernel writes the final
+// dtype itself and the fp32 scratch and pass F disappear; 2-D units are a single kernel.
 // Reductions are per block into fixed slots and summed in a fixed order (bit-reproducible, no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,7 +37,11 @@ struct ColoredArgs {
   uint64_t stream;
   int64_t batch;
   int32_t d1, d2, d3, d3h;   // d1 = 1 for 2-D
-  int32_t n_slots;
+  int32_t n_slots;           // partial slots in use per sample (white half; coloured half of the unfused path)
+  int32_t n_slots_c;         // coloured-half slots written by the Parseval reduction of the fused 3-D path
+  int32_t has_energy;
+  double energy;
+  void* out;                 // fused paths write the result dtype directly
   float exponent_half_neg;   // -exponent / 2
   float eps_clip;
   float inv_rmax;
@@ -143,6 +150,36 @@ __device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
   }
 }
 
+// per-sample rescale factor from the partial sums (reference noise.py:395-403): white std / coloured std (or energy / coloured std)
+__device__ __forceinline__ float rescale_factor(double w1, double w2, double c1, double c2, double n, int has_energy, double energy) {
+  const double wstd = sqrt((w2 - w1 * w1 / n) / (n - 1.0));
+  const double cstd = sqrt((c2 - c1 * c1 / n) / (n - 1.0));
+  float factor = 1.0f;  // only rescale when the coloured std is not degenerate
+  if ((float)cstd > 1e-8f) factor = has_energy ? (float)energy / (float)cstd : (float)wstd / (float)cstd;
+  return factor;
+}
+
+// block-wide sums of four doubles, result broadcast to every thread (fixed order)
+__device__ __forceinline__ void block_sums4_bcast(double v[4]) {
+  __shared__ double red4[4][16];
+  __shared__ double tot4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { for (int i = 0; i < 4; ++i) red4[i][wave] = v[i]; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double acc = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) acc += red4[threadIdx.x][w];
+    tot4[threadIdx.x] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = tot4[i];
+}
+
 // ---- pass A / E: last axis (contiguous lines of d3 reals <-> d3h complex) -------------------------------------
 // Two real lines share one complex transform ("two for one"): z = x_a + i x_b, Z = FFT(z), and
 //   X_a[k] = (Z[k] + conj Z[N-k]) / 2,   X_b[k] = (Z[k] - conj Z[N-k]) / (2i);
@@ -229,10 +266,18 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
 constexpr int PLANE_THREADS = 512;
 constexpr int PLANE_ITEMS = 18;  // staged items per thread: the host keeps (d2/2)*max(d3h, d3) <= PLANE_THREADS * PLANE_ITEMS
 
-template <int MODE>
-__global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs a, int logH, int logW) {
+// MODE 1 and 2 write the result dtype T themselves.  The per-sample rescale factor needs the coloured std of the WHOLE
+// sample before any of it is written; by Parseval it is known from the weighted spectrum -- sum x^2 = (1/N) sum |V|^2 over the
+// full grid (half-spectrum bins off the k3 = 0 / Nyquist planes count twice), sum x = V[0] -- which MODE 2 reduces
+// in place and the outer-axis kernel of the 3-D path reduces per block (partials).  No fp32 scratch, no finishing pass.
+// CH / CW: log2 of the plane's height / width as compile-time constants (0 = runtime).  With them every LDS row pitch
+// (W + 1, H + 1) multiply becomes a shift-add and the loop trip counts are known: the runtime-size kernel spends a quarter
+// of its VALU issue on quarter-rate v_mul_lo_u32 index arithmetic.
+template <int MODE, typename T, int CH, int CW>
+__global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs a, int logH_rt, int logW_rt) {
   extern __shared__ float2 smem[];
-  const int H = a.d2, W = a.d3, WH = a.d3h, ldw = W + 1, ldh = H + 1, pairs = H >> 1;
+  const int logH = CH ? CH : logH_rt, logW = CW ? CW : logW_rt;
+  const int H = CH ? (1 << CH) : a.d2, W = CW ? (1 << CW) : a.d3, WH = CW ? (1 << CW) / 2 + 1 : a.d3h, ldw = W + 1, ldh = H + 1, pairs = H >> 1;
   float2* tw_w = smem;
   float2* tw_h = tw_w + W / 2;
   float2* t1 = tw_h + H / 2;  // row-pair tile
@@ -289,7 +334,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       }
     }
     fft_tile<false>(t2, tw_h, H, logH, WH);
-    block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
+    if (MODE == 0) block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
     if (MODE == 0) {
       for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
         const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
@@ -297,15 +342,25 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       }
       return;
     }
-    // MODE 2: weights in place, then bit-reverse the columns for the inverse transform
+    // MODE 2: weights in place (+ the Parseval sums of the weighted spectrum), then bit-reverse the columns for the inverse
+    double p1 = 0.0, p2 = 0.0;
     for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
       const int k = q >> logH, row = q & (H - 1);
       const float f1 = 0.f, f2 = axis_freq(row, H), f3 = (float)k / (float)W;
       const float wgt = radial_weight(f1 * f1 + f2 * f2 + f3 * f3, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
       float2 v = t2[k * ldh + row];
-      t2[k * ldh + row] = make_float2(v.x * wgt, v.y * wgt);
+      v = make_float2(v.x * wgt, v.y * wgt);
+      t2[k * ldh + row] = v;
+      const float e = __builtin_fmaf(v.x, v.x, v.y * v.y);
+      p2 += (double)((k == 0 || 2 * k == W) ? e : 2.f * e);
+      if (q == 0) p1 = (double)v.x;
     }
-    __syncthreads();
+    {
+      double tot[4] = {s1, s2, p1, p2};
+      block_sums4_bcast(tot);  // (also the barrier between the weighting and the bit reversal)
+      const double n = (double)H * (double)W;
+      s1 = (double)rescale_factor(tot[0], tot[1], tot[2], tot[3] / n, n, a.has_energy, a.energy);  // s1 now carries the factor
+    }
     for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
       const int k = q >> logH, row = q & (H - 1);
       const int r = (int)brev(row, logH);
@@ -363,18 +418,31 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
   }
   fft_tile<true>(t1, tw_w, W, logW, pairs);
   const float scale = 1.0f / ((float)a.d1 * (float)H * (float)W);
-  float* dst = a.real_out + ((smp * a.d1 + i1) * (int64_t)H) * W;
-  s1 = 0.0; s2 = 0.0;
-  for (int q = threadIdx.x; q < pairs * W; q += PLANE_THREADS) {
-    const int pr = q >> logW, n = q & (W - 1);
-    const float2 z = t1[pr * ldw + n];
-    const float va = z.x * scale, vb = z.y * scale;
-    dst[(int64_t)(2 * pr) * W + n] = va;
-    dst[(int64_t)(2 * pr + 1) * W + n] = vb;
-    s1 += (double)(va + vb);
-    s2 += (double)__builtin_fmaf(va, va, vb * vb);
+  float factor;
+  if (MODE == 2) factor = (float)s1;
+  else {
+    double w1 = 0, w2 = 0, c1 = 0, c2 = 0;  // every block sums the sample's partials itself (a few dozen doubles, fixed order)
+    for (int sl = 0; sl < a.n_slots; ++sl) { const double* pw = a.partials + ((0 * a.batch + smp) * a.n_slots + sl) * 2; w1 += pw[0]; w2 += pw[1]; }
+    const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
+    for (int sl = 0; sl < a.n_slots_c; ++sl) { c1 += pc[2 * sl]; c2 += pc[2 * sl + 1]; }
+    const double n = (double)a.d1 * (double)H * (double)W;
+    factor = rescale_factor(w1, w2, c1, c2 / n, n, a.has_energy, a.energy);
   }
-  block_sums(s1, s2, a.partials + ((1 * a.batch + smp) * a.n_slots + i1) * 2);
+  T* dst = reinterpret_cast<T*>(a.out) + ((smp * a.d1 + i1) * (int64_t)H) * W;
+  // 4 consecutive values of one row per item: one 8-byte (16-bit T) or 16-byte (fp32) store
+  for (int q = threadIdx.x; q < pairs * (W / 4); q += PLANE_THREADS) {
+    const int pr = q >> (logW - 2), n4 = (q & (W / 4 - 1)) * 4;
+    const float2 z0 = t1[pr * ldw + n4], z1 = t1[pr * ldw + n4 + 1], z2 = t1[pr * ldw + n4 + 2], z3 = t1[pr * ldw + n4 + 3];
+    if constexpr (sizeof(T) <= 4) {
+      store4_from_f32<T>(dst + (int64_t)(2 * pr) * W + n4, z0.x * scale * factor, z1.x * scale * factor, z2.x * scale * factor, z3.x * scale * factor);
+      store4_from_f32<T>(dst + (int64_t)(2 * pr + 1) * W + n4, z0.y * scale * factor, z1.y * scale * factor, z2.y * scale * factor, z3.y * scale * factor);
+    } else {
+      T* da = dst + (int64_t)(2 * pr) * W + n4;
+      T* db = dst + (int64_t)(2 * pr + 1) * W + n4;
+      da[0] = (T)(z0.x * scale * factor); da[1] = (T)(z1.x * scale * factor); da[2] = (T)(z2.x * scale * factor); da[3] = (T)(z3.x * scale * factor);
+      db[0] = (T)(z0.y * scale * factor); db[1] = (T)(z1.y * scale * factor); db[2] = (T)(z2.y * scale * factor); db[3] = (T)(z3.y * scale * factor);
+    }
+  }
 }
 
 // ---- pass B / C / D: a strided axis of length N; lines start at consecutive complex positions --------------------
@@ -482,6 +550,7 @@ __global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs
   const int64_t cols = (int64_t)a.d2 * a.d3h;  // columns per sample; element n of column q sits at q + n*cols
   const int64_t smp = blockIdx.y;
   float2* base = a.spec + smp * (int64_t)N * cols;
+  double p1 = 0.0, p2 = 0.0;  // Parseval: sum x = V[0,0,0], sum x^2 = (1/N_total) sum mult * |V|^2 (the caller divides)
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < cols; q += (int64_t)gridDim.x * 256) {
     float2 v[N];
 #pragma unroll
@@ -496,10 +565,18 @@ __global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs
       const float wgt = radial_weight(f1 * f1 + rest, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
       v[k] = make_float2(v[k].x * wgt, v[k].y * wgt);
     }
+    {
+      float e = 0.f;
+#pragma unroll
+      for (int k = 0; k < N; ++k) e = __builtin_fmaf(v[k].x, v[k].x, __builtin_fmaf(v[k].y, v[k].y, e));
+      p2 += (double)((k3 == 0 || 2 * k3 == a.d3) ? e : 2.f * e);
+      if (q == 0) p1 = (double)v[0].x;
+    }
     dft_n<N, true>(v);
 #pragma unroll
     for (int n = 0; n < N; ++n) base[q + (int64_t)n * cols] = v[n];
   }
+  if (a.n_slots_c > 0) block_sums(p1, p2, a.partials + (int64_t)a.batch * a.n_slots * 2 + (smp * a.n_slots_c + blockIdx.x) * 2);
 }
 
 // ---- pass F: rescale per sample ---------------------------------------------------------------------------------
@@ -563,6 +640,7 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   a.spec = reinterpret_cast<float2*>(spec_c64); a.real_out = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
   a.stream = stream_id; a.batch = batch; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
   a.exponent_half_neg = (float)(-exponent / 2.0);
+  a.out = out; a.has_energy = has_energy; a.energy = energy; a.n_slots_c = 0;
   const int nd = d1 > 1 ? 3 : 2;
   const double n_eff = nd == 3 ? ((double)d1 + d2 + d3) / 3.0 : ((double)d2 + d3) / 2.0;
   a.eps_clip = (float)(0.5 / (n_eff > 4.0 ? n_eff : 4.0));
@@ -578,12 +656,13 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   const size_t tile_points = (size_t)(d2 / 2) * (d3 + 1) > (size_t)d3h * (d2 + 1) ? (size_t)(d2 / 2) * (d3 + 1) : (size_t)d3h * (d2 + 1);
   const size_t lds_plane = sizeof(float2) * ((size_t)d3 / 2 + d2 / 2 + tile_points);
   const bool fused = lds_plane <= 150 * 1024 && (int64_t)(d2 / 2) * d3 <= PLANE_THREADS * PLANE_ITEMS && (int64_t)(d2 / 2) * d3h <= PLANE_THREADS * PLANE_ITEMS &&
-                     getenv("SKR_FFT_NO_FUSE") == nullptr;
+                     (nd == 2 || d1 <= 16) && d3 % 4 == 0 && getenv("SKR_FFT_NO_FUSE") == nullptr;
   auto outer_axis = [&]() -> int {
     // axis 1 (length d1, stride d2*d3h): forward, radial weights, inverse in one pass
     if (d1 <= 16) {
       const int64_t cols = (int64_t)d2 * d3h;
       int64_t bx = (cols + 255) / 256; if (bx > 4096) bx = 4096;
+      if (a.n_slots_c > 0) { if (bx > a.n_slots_c) bx = a.n_slots_c; a.n_slots_c = (int32_t)bx; }  // one Parseval slot per block
       dim3 grid((unsigned)bx, (unsigned)batch);
       switch (d1) {
         case 2: hipLaunchKernelGGL(colored_outer_axis_regs<2>, grid, dim3(256), 0, s, a); break;
@@ -600,30 +679,34 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     if (d1 > partial_slots) return SKR_ERR_SHAPE;
     a.n_slots = d1;
     dim3 grid((unsigned)d1, (unsigned)batch);
+#define SKR_PLANE_T(MODE, T, CH, CW) do { SKR_ALLOW_LDS((colored_plane<MODE, T, CH, CW>), lds_plane); hipLaunchKernelGGL((colored_plane<MODE, T, CH, CW>), grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3); } while (0)
+#define SKR_PLANE_SZ(MODE, T)                                                    \
+    if (l2 == 7 && l3 == 7) SKR_PLANE_T(MODE, T, 7, 7);                          \
+    else if (l2 == 6 && l3 == 6) SKR_PLANE_T(MODE, T, 6, 6);                     \
+    else SKR_PLANE_T(MODE, T, 0, 0)
+#define SKR_PLANE(MODE)                                                          \
+    switch (out_dtype) {                                                         \
+      case SKR_BF16: SKR_PLANE_SZ(MODE, __bf16); break;                          \
+      case SKR_F16: SKR_PLANE_SZ(MODE, _Float16); break;                         \
+      case SKR_F32: SKR_PLANE_SZ(MODE, float); break;                            \
+      case SKR_F64: SKR_PLANE_T(MODE, double, 0, 0); break;                      \
+      default: return SKR_ERR_DTYPE;                                             \
+    }                                                                            \
+    SKR_CHECK_LAUNCH()
     if (nd == 2) {
-      SKR_ALLOW_LDS(colored_plane<2>, lds_plane);
-      hipLaunchKernelGGL(colored_plane<2>, grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3);
-      SKR_CHECK_LAUNCH();
+      SKR_PLANE(2);
     } else {
-      SKR_ALLOW_LDS(colored_plane<0>, lds_plane);
-      SKR_ALLOW_LDS(colored_plane<1>, lds_plane);
-      hipLaunchKernelGGL(colored_plane<0>, grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3);
+      SKR_PLANE_SZ(0, float);
       SKR_CHECK_LAUNCH();
-      int rc = outer_axis();
-      if (rc == -1) {
-        int logL = 0;
-        const int tile = fft_tile_points();
-        while ((2 << logL) * d1 <= tile && (2 << logL) <= 64) ++logL;
-        const int64_t n_lines = (int64_t)d2 * d3h, blocks = (n_lines + (1 << logL) - 1) >> logL;
-        const size_t lds = sizeof(float2) * ((size_t)d1 / 2 + ((size_t)1 << logL) * (d1 + 1));
-        SKR_ALLOW_LDS(colored_strided_axis<2>, lds);
-        hipLaunchKernelGGL(colored_strided_axis<2>, dim3((unsigned)blocks, (unsigned)batch), dim3(FFT_THREADS), lds, s, a, d1, l1, logL, n_lines, n_lines, (int64_t)0, n_lines, 1);
-        rc = hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
-      }
+      a.n_slots_c = (int32_t)(2 * partial_slots - d1 < 4096 ? 2 * partial_slots - d1 : 4096);  // room left in the partials buffer
+      const int rc = outer_axis();  // d1 <= 16: register kernel, with the Parseval partials of the weighted spectrum
       if (rc != SKR_OK) return rc;
-      hipLaunchKernelGGL(colored_plane<1>, grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3);
-      SKR_CHECK_LAUNCH();
+      SKR_PLANE(1);
     }
+#undef SKR_PLANE
+#undef SKR_PLANE_SZ
+#undef SKR_PLANE_T
+    return SKR_OK;  // the plane kernels wrote `out` themselves
   } else {
   // pass A: last axis forward
   const int64_t lines_last = (int64_t)d1 * d2;
