@@ -39,7 +39,7 @@ from .pytorch.noise import BatchTensorNoise, Random, TensorNoiseCommon, TensorNo
 from . import _hip
 from .sampling import functional, interface, lazy, models, program, tableaux, traits
 from .sampling import structured as sampling
-from .sampling.lazy import LazyTensor, Lin, lift
+from .sampling.lazy import LazyTensor, Lin, SkrampleHipError, lift
 from .sampling.models import DataModel, DiffusionModel, FlowModel, NoiseModel, VelocityModel
 from .sampling.structured import SampleInput, SKSamples, StructuredSampler
 from .scheduling import ScheduleCommon, ScheduleModifier, SkrampleSchedule, SubSchedule
@@ -246,6 +246,41 @@ class SkrampleWrapperCore(abc.ABC):
         self._index: int = 0
         self._device: torch.device = torch.device("cpu")
         self._noise_generator: BatchTensorNoise | None = None
+        self._alias_stamps: list[tuple[Tensor, int, int]] = []  # (caller tensor aliased by history, data_ptr, _version)
+
+    # ---- guard of the aliased history (alias_history=True) -------------------------------------------------------
+    # The reference deep-copies every record (structured.py:113-125); this engine keeps the caller's own tensors as
+    # history operands instead (0 bytes written, 4 B/element read per entry).  That is only sound while the caller
+    # leaves them alone, so every aliased tensor is stamped with (data_ptr, _version) when it enters the history and
+    # checked before it is read again: an in-place write (version bump), a re-bound storage, or a new network output
+    # that occupies a held buffer (a graphed / compiled network with static outputs replays without bumping versions)
+    # raises instead of stepping on overwritten data.
+    _ALIAS_HELP = (
+        "a tensor passed to an earlier step() is still a history operand of this sampler and {what}; the default wrapper "
+        "aliases the caller's `sample` / `model_output` instead of copying them -- construct it with alias_history=False "
+        "(snapshots both tensors per step) when buffers are reused between steps"
+    )
+
+    def _alias_check(self, model_output: Tensor, sample: Tensor) -> None:
+        stamps = self._alias_stamps
+        if not stamps:
+            return
+        for t, ptr, version in stamps:
+            if t._version != version or t.data_ptr() != ptr:
+                raise SkrampleHipError(self._ALIAS_HELP.format(what="was modified in place since"))
+        out_ptr = model_output.data_ptr()
+        for t, ptr, _ in stamps:
+            if ptr == out_ptr:  # same buffer handed back as a new network output (static-output network)
+                raise SkrampleHipError(self._ALIAS_HELP.format(what="its buffer now holds this step's model_output"))
+            if ptr == sample.data_ptr() and t is not sample:
+                raise SkrampleHipError(self._ALIAS_HELP.format(what="its buffer now holds this step's sample"))
+
+    def _alias_hold(self, tensors, keep: int) -> None:
+        "stamp this call's caller-owned tensors; `keep` = how many of the most recent stamps stay live"
+        for t in tensors:
+            if isinstance(t, Tensor):
+                self._alias_stamps.append((t, t.data_ptr(), t._version))
+        self._alias_stamps = self._alias_stamps[max(len(self._alias_stamps) - keep, 0):] if keep > 0 else []
 
     @property
     @abc.abstractmethod
@@ -464,6 +499,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._previous = []
         self._raw_outputs = []
         self._raw_samples = []
+        self._alias_stamps = []
         self._noise_generator = None
         self._timestep_list = None
         if device is not None:
@@ -475,6 +511,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         lowered step programs stay.  Used by skrample_amd.graphs to re-run a loop inside a HIP-graph capture."""
         self._calls = 0
         self._previous, self._raw_outputs, self._raw_samples = [], [], []
+        self._alias_stamps = []
         if self._noise_generator is not None:
             self._noise_generator._draws = 0
 
@@ -500,6 +537,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         step = Step.from_int(idx, len(table))
         if not self.alias_history and self.sampler.require_previous > 0:
             sample, model_output = sample.clone(), model_output.clone()
+        elif self.alias_history:
+            self._alias_check(model_output, sample)
 
         prediction = LazyTensor(-Lin.leaf(model_output), model_output.dtype) if self.invert_prediction else model_output
         noise = None
@@ -544,6 +583,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._previous = self._previous[max(len(self._previous) - keep, 0) :]
         self._raw_outputs = self._raw_outputs[max(len(self._raw_outputs) - keep, 0) :]
         self._raw_samples = self._raw_samples[max(len(self._raw_samples) - keep, 0) :]
+        if self.alias_history:
+            self._alias_hold((sample, model_output), 2 * keep)
         return self._finish(record.final, record.prediction, model_output, return_dict)
 
 
@@ -628,6 +669,7 @@ class RKWrapperCore(SkrampleWrapperCore):
         self._index = 0
         self._derivatives.clear()
         self._sample = None
+        self._alias_stamps = []
         with contextlib.suppress(AttributeError):
             del self.all_points
         with contextlib.suppress(AttributeError):
@@ -647,6 +689,7 @@ class RKWrapperCore(SkrampleWrapperCore):
         "(not in the reference) see SkrampleWrapperScheduler.reset_run"
         self._index = 0
         self._derivatives, self._sample = [], None
+        self._alias_stamps = []
         if self._noise_generator is not None:
             self._noise_generator._draws = 0
 
@@ -692,7 +735,20 @@ class RKWrapperCore(SkrampleWrapperCore):
             assert value == expected, f"Expected timestep {expected} for step {self._index}, got {timestep=}!"
         if not self.alias_history and self.order > 1:
             sample, model_output = sample.clone(), model_output.clone()
+        elif self.alias_history:
+            self._alias_check(model_output, sample)
+            try:
+                return self._step_stage(model_output, sample, generator, return_dict)
+            finally:
+                # between stages the step's base sample and (without a rounded conversion) the earlier network outputs
+                # stay operands; nothing of the caller's is held once the step is complete
+                if self._sample is None and not self._derivatives:
+                    self._alias_stamps = []
+                else:
+                    self._alias_hold((sample, model_output), 2 * self.order)
+        return self._step_stage(model_output, sample, generator, return_dict)
 
+    def _step_stage(self, model_output: Tensor, sample: Tensor, generator, return_dict: bool):
         # stage programs: the same lower-once / replay-by-binding scheme as SkrampleWrapperScheduler.step
         owner = (self.schedule, self._steps, self.sampler_order, self.stochasticity, self.model, self.derivative_transform, self.compute_scale, self.invert_prediction)
         if self._rk_programs_for != owner:

@@ -845,6 +845,60 @@ def test_alias_history_off_survives_buffer_reuse(dev):
             assert torch.equal(res, x_ref), i
 
 
+def test_aliased_history_is_guarded(dev):
+    """the default wrapper keeps the caller's tensors as history operands (the reference deep-copies, structured.py:113-125):
+    a caller that reuses its buffers must get an error, never a silently wrong step; alias_history=False snapshots and must
+    then reproduce the result of a run on fresh tensors bit for bit."""
+    shape, steps = (2, 4, 16, 16), 6
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps)]
+    mk = lambda **kw: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), **kw)  # noqa: E731
+
+    def run(w, reuse):
+        w.set_timesteps(steps)
+        x, buf = x0, torch.empty_like(outs[0])
+        for i, t in enumerate(w.timesteps.tolist()):
+            out = outs[i]
+            if reuse == "copy_":  # one network-output buffer, rewritten in place every step (version bump)
+                buf.copy_(out)
+                out = buf
+            elif reuse == "static":  # a graphed network: same storage, new tensor object, no version bump
+                buf.view(torch.int16).untyped_storage().copy_(out.view(torch.int16).untyped_storage())
+                out = buf.view(shape)
+            x = w.step(out, t, x, generator=[1, 2], return_dict=False)[0]
+        return x
+
+    fresh = run(mk(), None)
+    for reuse in ("copy_", "static"):
+        with pytest.raises(_hip.SkrampleHipError, match="alias_history=False"):
+            run(mk(), reuse)
+        assert torch.equal(run(mk(alias_history=False), reuse), fresh)
+    # in-place edit of the latents between steps
+    w = mk()
+    w.set_timesteps(steps)
+    ts = w.timesteps.tolist()
+    x = w.step(outs[0], ts[0], x0.clone(), generator=[1, 2], return_dict=False)[0]
+    w._alias_stamps[0][0].mul_(1.0)  # the first step's sample, touched in place by the caller
+    with pytest.raises(_hip.SkrampleHipError, match="modified in place"):
+        w.step(outs[1], ts[1], x, generator=[1, 2], return_dict=False)
+    # samplers without history hold nothing
+    w = PD.SkrampleWrapperScheduler(PT.Euler(), PS.Scaled())
+    w.set_timesteps(3)
+    buf, x = outs[0].clone(), x0
+    for t in w.timesteps.tolist():
+        x = w.step(buf, t, x, return_dict=False)[0]
+    # Runge-Kutta stages: the step's base sample is held until the last stage
+    rk = PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=4)
+    rk.set_timesteps(3)
+    ts = rk.timesteps.tolist()
+    base = x0.clone()
+    nxt = rk.step(outs[0], ts[0], base, return_dict=False)[0]
+    base.add_(1.0)
+    with pytest.raises(_hip.SkrampleHipError, match="modified in place"):
+        rk.step(outs[1], ts[1], nxt, return_dict=False)
+
+
 def test_whole_loop_graph_capture(dev):
     "an N-step loop (toy network + fused DPM-2 SDE steps) recorded into one HIP graph replays bit-identically"
     from skrample_amd.graphs import capture_sampling_loop
