@@ -60,15 +60,16 @@ def make_wrapper():
     return w
 
 
-def capture_plans(dev: torch.device, batch: int, first_sample: int):
+def capture_plans(dev: torch.device, shard):
     """Run the real wrapper once with tracing and return, per steady-state step, the emitted plan and
     the role of each input pointer (x, out, x_prev, out_prev)."""
     from skrample_amd import _hip
 
     w = make_wrapper()
-    g = torch.Generator(device=dev).manual_seed(1234 + first_sample)
+    batch = shard.batch
+    g = torch.Generator(device=dev).manual_seed(shard.input_seed())
     shape = (batch, C, H, W)
-    gens = [42 + first_sample + i for i in range(batch)]  # per-sample seeds by GLOBAL sample index
+    gens = shard.seeds()  # per-sample seeds by GLOBAL sample index (skrample_amd/sharding.py)
     x = torch.randn(shape, device=dev, generator=g).to(torch.bfloat16)
     plans = {}
     prev_pair = None
@@ -182,9 +183,10 @@ def load_traffic() -> float | None:
 
 def main() -> None:
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from skrample_amd.sharding import BatchShard, aggregate_rate, max_over_ranks
+
+    shard = BatchShard.from_env(args.batch)
+    rank, local_rank, world = shard.rank, shard.local_rank, shard.world
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -203,7 +205,7 @@ def main() -> None:
     lib = _hip.load()
     batch = args.batch
     numel = batch * C * H * W
-    plans = capture_plans(dev, batch, first_sample=rank * batch)
+    plans = capture_plans(dev, shard)
 
     # rotating buffer sets: (x, out, x_prev, out_prev, y) each 2 B/elem -> 168 MB per set at B=256.
     # In a sampling loop `x`, `x_prev` and `y` are tensors the engine itself allocated (step results), so they
@@ -266,12 +268,7 @@ def main() -> None:
     wall = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream: average per launch
 
-    elapsed = torch.tensor([wall], dtype=torch.float64, device=dev)
-    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
-    wall, kernel_ms = elapsed.item(), kms.item()
+    wall, kernel_ms = max_over_ranks([wall, kernel_ms], dist, dev)  # the slowest rank defines the step time
 
     # wrapper-level rate (Python scheduler overhead included), for information
     wrapper_rate = None
@@ -280,7 +277,7 @@ def main() -> None:
         shape = (batch, C, H, W)
         xs = [s["x"].view(shape) for s in sets]
         outs = [s["out"].view(shape) for s in sets]
-        seeds = [_Seed(42 + i) for i in range(batch)]
+        seeds = [_Seed(sd) for sd in shard.seeds()]
         for rep in range(3):
             w.set_timesteps(SCHEDULE_STEPS)
             ts = w.timesteps.tolist()
@@ -310,7 +307,7 @@ def main() -> None:
         del src, dst
 
     if rank == 0:
-        steps_per_s = world * args.steps / wall
+        steps_per_s = aggregate_rate(args.steps, world, wall)
         algo_bytes = numel * ALGO_BYTES_PER_ELEM
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         out = {

@@ -24,6 +24,11 @@ extern "C" {
 #define SKR_ABI_VERSION 8
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
+/* Devices and streams: every entry point launches on the device that owns its output buffer (queried from the pointer when
+ * the process sees more than one GPU; single-GPU processes skip the query) and restores the caller's current device before
+ * returning.  `stream` is a hipStream_t of that device (NULL = its default stream).  Calls are asynchronous; distinct
+ * streams may be driven from distinct threads. */
+
 enum skr_status {
   SKR_OK = 0,
   SKR_ERR_NULL = 1,        /* required pointer is NULL */

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "skr_device.h"
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
 #include "skr_pack.h"
@@ -78,6 +79,7 @@ static void launch_random(void* out, const uint64_t* seeds, uint64_t stream_id, 
 
 extern "C" int skr_noise_random(void* out, int32_t out_dtype, const uint64_t* seeds_dev, uint64_t stream_id,
                                 int64_t batch, int64_t sample_numel, void* stream) {
+  skr::DeviceGuard device_guard(out);
   if (batch < 0 || sample_numel < 0) return SKR_ERR_SHAPE;
   if (batch == 0 || sample_numel == 0) return SKR_OK;
   if (!out || !seeds_dev) return SKR_ERR_NULL;
@@ -192,6 +194,7 @@ static void launch_brownian(void* out, const uint64_t* seeds, const BrownianArgs
 extern "C" int skr_noise_brownian(void* out, int32_t out_dtype, const uint64_t* seeds_dev, const uint64_t* stream_ids, const double* weights_to,
                                   const double* weights_from, int32_t n_streams, double scale, float* cache_f32, int32_t from_cache,
                                   int64_t batch, int64_t sample_numel, void* stream) {
+  skr::DeviceGuard device_guard(out);
   if (batch < 0 || sample_numel < 0 || n_streams < 0) return SKR_ERR_SHAPE;
   if (n_streams > SKR_MAX_WEIGHTED_STREAMS) return SKR_ERR_UNSUPPORTED;
   if (batch == 0 || sample_numel == 0) return SKR_OK;
@@ -228,6 +231,7 @@ __global__ void philox_dump_kernel(uint32_t* out, uint64_t seed, uint64_t stream
 }
 
 extern "C" int skr_philox_u32(uint32_t* out, uint64_t seed, uint64_t stream_id, uint64_t first_block, int64_t n_blocks, void* stream) {
+  skr::DeviceGuard device_guard(out);
   if (!out) return SKR_ERR_NULL;
   if (n_blocks < 0) return SKR_ERR_SHAPE;
   if (n_blocks == 0) return SKR_OK;

@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "skr_device.h"
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
 #include "skr_pack.h"
@@ -629,6 +630,7 @@ static int ilog2_exact(int64_t v) {
 extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64, int64_t partial_slots,
                                  const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t d1, int32_t d2, int32_t d3,
                                  double exponent, int32_t has_energy, double energy, void* stream) {
+  skr::DeviceGuard device_guard(out);
   using namespace skr;
   if (batch < 0 || d1 < 1 || d2 < 2 || d3 < 4) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;

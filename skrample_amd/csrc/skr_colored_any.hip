@@ -11,6 +11,7 @@
 #include <mutex>
 #include <tuple>
 
+#include "skr_device.h"
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
 
@@ -21,6 +22,7 @@ typedef int (*plan_many_fn)(hipfftHandle_t*, int, int*, int*, int, int, int*, in
 typedef int (*exec_r2c_fn)(hipfftHandle_t, float*, void*);
 typedef int (*exec_c2r_fn)(hipfftHandle_t, void*, float*);
 typedef int (*set_stream_fn)(hipfftHandle_t, hipStream_t);
+typedef int (*destroy_fn)(hipfftHandle_t);
 constexpr int HIPFFT_R2C = 0x2a, HIPFFT_C2R = 0x2c;
 
 struct FftApi {
@@ -28,6 +30,7 @@ struct FftApi {
   exec_r2c_fn r2c = nullptr;
   exec_c2r_fn c2r = nullptr;
   set_stream_fn set_stream = nullptr;
+  destroy_fn destroy = nullptr;
   bool ok = false;
 };
 
@@ -42,14 +45,21 @@ FftApi& api() {
     a.r2c = (exec_r2c_fn)dlsym(h, "hipfftExecR2C");
     a.c2r = (exec_c2r_fn)dlsym(h, "hipfftExecC2R");
     a.set_stream = (set_stream_fn)dlsym(h, "hipfftSetStream");
-    a.ok = a.plan_many && a.r2c && a.c2r && a.set_stream;
+    a.destroy = (destroy_fn)dlsym(h, "hipfftDestroy");
+    a.ok = a.plan_many && a.r2c && a.c2r && a.set_stream && a.destroy;
   });
   return a;
 }
 
-struct Plans { hipfftHandle_t fwd, inv; };
+// One plan pair per (device, stream, shape): hipFFT plans own a work area and carry their stream, so a plan shared between
+// devices runs on the wrong one and a plan shared between streams races on hipfftSetStream.  The cache is bounded; the
+// least recently used pair is destroyed when it is full.
+struct Plans { hipfftHandle_t fwd, inv; uint64_t last_use; };
+typedef std::tuple<int /*device*/, hipStream_t, int, int, int, int, int64_t> PlanKey;
 std::mutex g_mutex;
-std::map<std::tuple<int, int, int, int, int64_t>, Plans> g_plans;
+std::map<PlanKey, Plans> g_plans;
+uint64_t g_plan_clock = 0;
+constexpr size_t MAX_PLANS = 32;
 
 constexpr int SLOTS = 256;  // partial-sum slots per sample (one per block of the stats kernels)
 
@@ -240,25 +250,39 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
   for (int i = 0; i < full_rank; ++i) { const float m = (float)(full_dims[i] / 2) / (float)full_dims[i]; r2 += m * m; }
   a.inv_rmax = r2 > 0.f ? 1.0f / sqrtf(r2) : 1.0f;
 
+  skr::DeviceGuard guard(out);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Plans plans;
   {
     std::lock_guard<std::mutex> lock(g_mutex);
     const int64_t fft_batch = batch * d0;
-    auto key = std::make_tuple(rank, n[0], n[1], n[2], fft_batch);
+    const PlanKey key = std::make_tuple(guard.dev, s, rank, n[0], n[1], n[2], fft_batch);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
+      if (g_plans.size() >= MAX_PLANS) {  // evict the least recently used pair
+        auto victim = g_plans.begin();
+        for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt) if (jt->second.last_use < victim->second.last_use) victim = jt;
+        skr::DeviceGuard owner(nullptr);
+        const int vdev = std::get<0>(victim->first);
+        if (vdev >= 0 && vdev != owner.prev) (void)hipSetDevice(vdev);
+        (void)hipStreamSynchronize(std::get<1>(victim->first));  // its work area may still be in use
+        (void)hipGetLastError();
+        f.destroy(victim->second.fwd);
+        f.destroy(victim->second.inv);
+        if (vdev >= 0 && vdev != owner.prev) (void)hipSetDevice(guard.dev);
+        g_plans.erase(victim);
+      }
       int nn[3];
       for (int i = 0; i < rank; ++i) nn[i] = dims[i];
       Plans p;
       if (f.plan_many(&p.fwd, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, (int)fft_batch) != 0) return SKR_ERR_UNSUPPORTED;
-      if (f.plan_many(&p.inv, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, (int)fft_batch) != 0) return SKR_ERR_UNSUPPORTED;
+      if (f.plan_many(&p.inv, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, (int)fft_batch) != 0) { f.destroy(p.fwd); return SKR_ERR_UNSUPPORTED; }
+      if (f.set_stream(p.fwd, s) != 0 || f.set_stream(p.inv, s) != 0) { f.destroy(p.fwd); f.destroy(p.inv); return SKR_ERR_LAUNCH; }
       it = g_plans.emplace(key, p).first;
     }
+    it->second.last_use = ++g_plan_clock;
     plans = it->second;
   }
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  f.set_stream(plans.fwd, s);
-  f.set_stream(plans.inv, s);
 
   if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);

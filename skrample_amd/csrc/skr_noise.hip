@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "skr_device.h"
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
 #include "skr_pack.h"
@@ -461,6 +462,7 @@ static int status_of_launch() { return hipGetLastError() == hipSuccess ? SKR_OK 
 
 extern "C" int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_offset,
                                 int64_t batch, const int64_t* unit_shape, int32_t ndim, uint32_t keep_mask, double strength, void* stream) {
+  skr::DeviceGuard device_guard(out);
   if (batch < 0 || ndim < 1 || ndim > 4 || !unit_shape) return SKR_ERR_SHAPE;
   skr::OffsetArgs a;
   int64_t d[4] = {1, 1, 1, 1};
@@ -486,6 +488,7 @@ extern "C" int skr_noise_offset(void* out, int32_t out_dtype, const uint64_t* se
 extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f32, double* partials_f64, int32_t* level_ws /* [batch*17] */,
                                  const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch, int64_t lead, int64_t h, int64_t w,
                                  int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream) {
+  skr::DeviceGuard device_guard(out);
   if (batch < 0 || lead < 1 || h < 1 || w < 1 || depth < 0) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
   if (!out || !scratch_f32 || !partials_f64 || !seeds_dev || !level_ws) return SKR_ERR_NULL;
@@ -537,6 +540,7 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
 extern "C" int skr_noise_pyramid_any(void* out, int32_t out_dtype, float* scratch_f32, float* levels_f32, double* partials_f64, int32_t n_slots,
                                      int32_t* level_ws, const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
                                      int64_t lead, int64_t h, int64_t w, int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream) {
+  skr::DeviceGuard device_guard(out);
   if (batch < 0 || lead < 1 || h < 1 || w < 1 || depth < 0 || n_slots < 1) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
   if (!out || !scratch_f32 || !levels_f32 || !partials_f64 || !seeds_dev || !level_ws) return SKR_ERR_NULL;

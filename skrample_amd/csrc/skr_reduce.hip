@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "skr_device.h"
 #include "../../include/skrample_hip.h"
 
 namespace {
@@ -39,6 +40,7 @@ __global__ void norm_final(const double* partials, int n, int64_t numel, double*
 
 extern "C" int skr_error_mean(const void* a_or_null, const void* b, int32_t dtype, int64_t numel, int32_t power,
                               double* out_dev, double* partials_dev /* [1024] */, void* stream) {
+  skr::DeviceGuard device_guard(b);
   if (!b || !out_dev || !partials_dev) return SKR_ERR_NULL;
   if (numel <= 0) return SKR_ERR_SHAPE;
   if (power != 1 && power != 2) return SKR_ERR_UNSUPPORTED;
@@ -112,6 +114,7 @@ static int power_blend_a(M* out, const void* a, int32_t a_dtype, const void* b, 
 
 extern "C" int skr_power_blend(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, const void* b, int32_t b_dtype, double p, double c,
                                double power, int64_t numel, void* stream) {
+  skr::DeviceGuard device_guard(out);
   if (numel < 0) return SKR_ERR_SHAPE;
   if (numel == 0) return SKR_OK;
   if (!out || !a || !b) return SKR_ERR_NULL;

@@ -11,6 +11,7 @@
 // (SURVEY.md section 8a, rows S2-S12).
 
 
+#include "skr_device.h"
 #include "skr_step_common.h"
 
 namespace skr {
@@ -523,6 +524,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" int skr_step_launch(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
                                const uint64_t* seeds_dev, int64_t numel, void* stream) {
+  skr::DeviceGuard device_guard(out0 ? out0 : out1);
   if (!plan) return SKR_ERR_NULL;
   const skr_step_plan& p = *plan;
   if (p.n_terms < 0 || p.n_terms > SKR_MAX_TERMS || p.n_group_a < 0 || p.n_group_a > p.n_terms) return SKR_ERR_TERMS;

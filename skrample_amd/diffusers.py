@@ -35,7 +35,7 @@ from torch import Tensor
 
 from . import scheduling
 from .common import DeltaPoint, MergeStrategy, Point, Step
-from .pytorch.noise import BatchTensorNoise, Random, TensorNoiseCommon, TensorNoiseProps
+from .pytorch.noise import BatchTensorNoise, HostRandomBatch, Random, TensorNoiseCommon, TensorNoiseProps
 from . import _hip
 from .sampling import functional, interface, lazy, models, program, tableaux, traits
 from .sampling import structured as sampling
@@ -336,6 +336,10 @@ class SkrampleWrapperCore(abc.ABC):
             flat = sample.reshape(sample.shape[0], -1)
             mids = flat[:, flat.shape[1] // 2].to(torch.float64).cpu().tolist()
             seeds = [int(v * 1e4 * (step.position() + 1)) for v in mids]
+        if not sample.is_cuda:  # host-resident latents (the reference's CPU path): torch's own generators, as the reference
+            if noise_type is not Random:
+                raise SkrampleHipError(f"{noise_type.__name__} noise is generated by HIP kernels; on CPU tensors only Random noise is available")
+            return HostRandomBatch(tuple(sample.shape[1:]), seeds, torch.float32)
         return BatchTensorNoise.from_batch_inputs(noise_type, unit_shape=tuple(sample.shape[1:]), seeds=seeds, props=noise_props, dtype=sample.dtype)
 
     def get_step_noise(self, step: Step, sample: Tensor, noise_type, noise_props, generator=None, dtype: torch.dtype | None = None, lazy_ok: bool = False):

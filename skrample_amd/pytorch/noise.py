@@ -512,6 +512,25 @@ class Brownian(TensorNoiseCommon):
 
 
 @dataclass
+class HostRandomBatch:
+    """White noise for host-resident samples (CPU tensors), exactly as the reference draws it: one torch generator per
+    batch item, `torch.randn(unit_shape, generator=g)` each, stacked (noise.py:58-74, 438-446; fp32 because the
+    generators live on the CPU, diffusers.py:343).  Structured generators (Offset / Pyramid / Colored / Brownian) are HIP
+    kernels and exist on the device only."""
+
+    def __init__(self, unit_shape, seeds: list, dtype: torch.dtype = torch.float32):
+        self.unit_shape = tuple(unit_shape)
+        self.dtype = dtype
+        self.generators = [s if isinstance(s, torch.Generator) else torch.Generator().manual_seed(seed_value(s) & 0x7FFFFFFFFFFFFFFF) for s in seeds]
+        self._draws = 0
+
+    def generate(self, step=None) -> torch.Tensor:
+        self._draws += 1
+        return torch.stack([torch.randn(self.unit_shape, generator=g, dtype=self.dtype, device=g.device) for g in self.generators])
+
+    generate_lazy = generate
+
+
 class BatchTensorNoise(SkrampleTensorNoise):
     """One logical generator per batch item, executed as a single launch.  `generators` is kept for
     API compatibility (len == batch); the batch shares one draw counter."""

@@ -6,8 +6,13 @@ same-shaped tensors (SURVEY.md "three facts" #2).  The samplers in this package 
 execute tensor arithmetic: they run their (scalar, fp64) algebra on `Lin` objects, which only
 accumulate coefficients, and `evaluate()` turns the final one or two forms into ONE launch of
 `skr_step_launch` (include/skrample_hip.h).  Plain Python numbers flow through the same code
-unchanged -- that is host scalar logic (schedule dry-runs, coefficient tests), not a tensor path.
-There is no CPU tensor path: anything that is not a HIP-device tensor is refused.
+unchanged -- that is host scalar logic (schedule dry-runs, coefficient tests).
+
+Operand residency decides where a form is evaluated, never availability of the library:
+  * HIP-device tensors  -> the fused kernel, always (a missing libskrample_hip.so raises; nothing falls back);
+  * host-resident operands (CPU torch tensors, numpy arrays -- the reference's generic `T`, common.py:11-17, and
+    BASELINE config 1 "on CPU torch") -> `_host_evaluate`, the same  sum_k c_k * T_k  in plain torch on the host.
+    Device tensors can never reach it (mixed residency is refused).
 """
 
 from __future__ import annotations
@@ -108,9 +113,34 @@ class RoundedConversion:
 
 
 def _check_tensor(t: torch.Tensor) -> torch.Tensor:
-    _hip.require_device(t, "sampler operand")
+    if t.device.type not in ("cuda", "cpu"):
+        _hip.require_device(t, "sampler operand")
     if t.dtype not in _hip.DTYPE_CODE:
         raise SkrampleHipError(f"unsupported tensor dtype {t.dtype}; the engine handles bf16/f16/f32/f64")
+    return t
+
+
+# ---- host-resident operands ---------------------------------------------------------------------------------------
+NUMPY = "numpy"  # `device` of forms built from numpy arrays: evaluated on the host, results handed back as ndarrays
+_numpy_views: dict[int, tuple] = {}  # id(ndarray) -> (ndarray, torch view): one leaf per array however often it is lifted
+
+
+def is_host(device) -> bool:
+    return device == NUMPY or (isinstance(device, torch.device) and device.type == "cpu")
+
+
+def _from_numpy(x) -> torch.Tensor:
+    hit = _numpy_views.get(id(x))
+    if hit is not None and hit[0] is x:
+        return hit[1]
+    import numpy as np
+
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if t.dtype not in _hip.DTYPE_CODE:
+        raise SkrampleHipError(f"unsupported array dtype {x.dtype}; float16/32/64 arrays are handled")
+    if len(_numpy_views) >= 64:
+        _numpy_views.pop(next(iter(_numpy_views)))
+    _numpy_views[id(x)] = (x, t)
     return t
 
 
@@ -236,9 +266,12 @@ def lift(x):
         return x.form
     if hasattr(x, "dtype") and hasattr(x, "shape") and getattr(x, "shape", None) == ():
         return float(x)
+    if type(x).__module__ == "numpy" and hasattr(x, "__array_interface__"):
+        t = _from_numpy(x)
+        return Lin({id(t): (t, 1.0)}, t.shape, NUMPY)
     raise SkrampleHipError(
-        f"operand of type {type(x).__name__} is not supported: skrample_amd computes on HIP-device torch tensors "
-        "(host scalars are accepted for schedule logic); there is no numpy / CPU tensor path"
+        f"operand of type {type(x).__name__} is not supported: skrample_amd computes on torch tensors (HIP device: fused "
+        "kernels; CPU: host executor), numpy arrays and host scalars"
     )
 
 
@@ -314,6 +347,8 @@ def evaluate(forms: Sequence[Lin], dtypes: Sequence[torch.dtype | None], acc_f64
     shape, device = f0.shape, f0.device
     numel = math.prod(shape)
     out_dtypes = [d if d is not None else (f.dtype if isinstance(f, RoundedConversion) else _default_dtype(f)) for d, f in zip(dtypes, forms)]
+    if is_host(device) or (f1 is not None and is_host(f1.device)):
+        return _host_evaluate(conv, f0, f1, out_dtypes, acc_f64)
 
     # chain coefficient
     chain = 0.0
@@ -433,6 +468,49 @@ def evaluate(forms: Sequence[Lin], dtypes: Sequence[torch.dtype | None], acc_f64
     return [out0] if out1 is None else [out0, out1]
 
 
+
+def _host_evaluate(conv, f0: "Lin", f1, out_dtypes, acc_f64) -> list:
+    """Host executor for host-resident operands (CPU torch tensors / numpy arrays): the same one or two forms, evaluated
+    with plain torch ops in the accumulator precision the kernel uses (fp32, or fp64 when asked for), each output rounded
+    once.  Not a fallback: forms over HIP tensors never come here, and a form that mixes residencies is refused."""
+    as_numpy = f0.device == NUMPY or (f1 is not None and f1.device == NUMPY)
+    leaves = [leaf for form in (f0, f1) if form is not None for leaf, _ in form.terms.values() if isinstance(leaf, torch.Tensor)]
+    if conv is not None:
+        leaves += [conv.sample, conv.output]
+    for t in leaves:
+        if t.device.type != "cpu":
+            raise SkrampleHipError("operands of one step must all live on the HIP device or all on the host")
+    wide = torch.float64 if acc_f64 or _compute_dtype.get() == torch.float64 or torch.float64 in out_dtypes or any(t.dtype == torch.float64 for t in leaves) else torch.float32
+
+    def total(form, start=None):
+        acc = start
+        for leaf, c in form.terms.values():
+            if isinstance(leaf, Node):
+                continue  # the chained term is added by the caller
+            if isinstance(leaf, PhiloxNoise):
+                raise SkrampleHipError("in-kernel Philox noise exists on the HIP device only")
+            if c == 0.0:
+                continue
+            term = leaf.to(wide) * c
+            acc = term if acc is None else acc.add_(term)
+        return acc if acc is not None else torch.zeros(form.shape, dtype=wide)
+
+    if conv is not None:
+        # the reference's op-by-op conversion in the operands' own dtype (diffusers.py:819-834, models.py:92-224)
+        s_, o_, k = conv.sample, conv.output, conv.k
+        x = {0: lambda: o_, 1: lambda: (s_ - k[0] * o_) / k[1], 2: lambda: k[1] * s_ - k[0] * o_, 3: lambda: o_ * k[0]}[conv.to_kind]()
+        v0 = {0: lambda: x, 1: lambda: (s_ - k[2] * x) / k[3], 2: lambda: (k[2] * s_ - x) / k[3], 3: lambda: x / k[2]}[conv.from_kind]()
+        acc0 = v0.to(wide)
+    else:
+        acc0 = total(f0)
+    outs = [acc0.to(out_dtypes[0])]
+    if f1 is not None:
+        chain = sum(c for leaf, c in f1.terms.values() if isinstance(leaf, Node))
+        acc1 = total(f1, acc0 * chain if chain != 0.0 else None)
+        outs.append(acc1.to(out_dtypes[1]))
+    return [o.numpy() for o in outs] if as_numpy else outs
+
+
 def cast(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     "dtype conversion through the engine (a one-term fused launch)"
     if t.dtype == dtype:
@@ -446,6 +524,9 @@ _norm_ws: dict = {}
 def error_mean(a, b: torch.Tensor, power: int) -> float:
     "mean(|a - b|^power) over a device tensor pair (a may be the number 0); one reduction launch + read-back"
     _check_tensor(b)
+    if not b.is_cuda:  # host-resident operands: plain torch (fp64 accumulation, as the kernel)
+        d = (b.double() if not isinstance(a, torch.Tensor) else a.double() - b.double()).abs()
+        return float((d if power == 1 else d.pow(power)).mean())
     if isinstance(a, torch.Tensor):
         _check_tensor(a)
         if a.dtype != b.dtype or a.shape != b.shape:
@@ -471,6 +552,9 @@ def power_blend(a: torch.Tensor, b: torch.Tensor, wa: float, wb: float, power: f
         raise SkrampleHipError(f"shape mismatch in sampler operands: {tuple(a.shape)} vs {tuple(b.shape)}")
     if dtype not in (torch.float32, torch.float64):
         raise SkrampleHipError("the signed-power blend is evaluated in float32 or float64")
+    if not a.is_cuda and not b.is_cuda:  # host-resident operands
+        spow = lambda v, f: v.abs().pow(f) * v.sign()  # noqa: E731
+        return spow(wa * spow(a.to(dtype), power) + wb * spow(b.to(dtype), power), 1 / power)
     a, b = _prepare_tensor(a), _prepare_tensor(b)
     out = empty_output(a.shape, dtype, a.device)
     status = _hip.load().skr_power_blend(out.data_ptr(), _hip.DTYPE_CODE[dtype], a.data_ptr(), _hip.DTYPE_CODE[a.dtype], b.data_ptr(), _hip.DTYPE_CODE[b.dtype], float(wa), float(wb), float(power), a.numel(), _hip.current_stream_ptr(a.device))

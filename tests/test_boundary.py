@@ -74,17 +74,21 @@ def test_product_never_imports_the_oracle():
                 assert not ({"skr_oracle", "oracle"} & _imports(path)), path
 
 
-def test_no_cpu_tensor_path():
+def test_host_operands_stay_on_the_host_and_never_need_the_library(monkeypatch, tmp_path):
+    """CPU tensors are the reference's host path (generic T, BASELINE config 1): they are computed by the package's own
+    host executor without touching the HIP library -- which may even be absent -- and nothing about them is a fallback for
+    device work (tests/test_host_path.py::test_device_work_never_reaches_the_host_executor)."""
     import skrample_amd.scheduling as PS
     from skrample_amd.sampling import lazy, models, structured
 
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "libskrample_hip.so"))  # no library: host operands must not care
     x = torch.randn(1, 4, 8, 8)
-    with pytest.raises(_hip.SkrampleHipError):
-        structured.Euler().sample(x, x, (0.0, 0.1), models.NoiseModel(), PS.Scaled())
-    with pytest.raises(_hip.SkrampleHipError):
-        models.NoiseModel().to_x(x, x, PS.Scaled().point(0.5))
-    with pytest.raises(_hip.SkrampleHipError):
-        lazy.cast(x, torch.bfloat16)
+    rec = structured.Euler().sample(x, x, (0.0, 0.1), models.NoiseModel(), PS.Scaled())
+    assert isinstance(rec.final, torch.Tensor) and rec.final.device.type == "cpu" and torch.isfinite(rec.final).all()
+    assert lazy.cast(x, torch.bfloat16).dtype == torch.bfloat16
+    with pytest.raises(_hip.SkrampleHipError):  # unsupported dtypes are still refused
+        lazy.cast(torch.ones(4, dtype=torch.int32), torch.float32)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

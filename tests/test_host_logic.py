@@ -324,10 +324,14 @@ def test_lazy_algebra_is_symbolic():
         assert abs(rec.final - coef[tag]) < 1e-12 * max(1, abs(coef[tag])), tag
     with pytest.raises(lazy.SkrampleHipError):
         x * o
+    # host-resident operands are leaves too (evaluated by the host executor): numpy forms remember where they came from
+    assert lazy.lift(np.ones(3)).device == lazy.NUMPY and lazy.lift(torch.ones(3)).device.type == "cpu"
+    arr = np.ones(3)
+    assert list(lazy.lift(arr).terms) == list(lazy.lift(arr).terms)  # one leaf per array, however often it is lifted
     with pytest.raises(lazy.SkrampleHipError):
-        lazy.lift(np.ones(3))
+        lazy.lift(np.ones(3, dtype=np.int64))
     with pytest.raises(lazy.SkrampleHipError):
-        lazy.lift(torch.ones(3))  # CPU tensor: refused, there is no CPU tensor path
+        lazy.lift("not a tensor")
 
 
 # ---- schedule behaviour the reference pins in tests/self_scheduling.py:49-151 -----------------------------------

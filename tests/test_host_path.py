@@ -1,0 +1,159 @@
+"""Host-resident operands (the reference's generic `T`: CPU torch tensors and numpy arrays, common.py:11-17; BASELINE
+config 1 is "on CPU torch").  They are evaluated by skrample_amd's own host executor (sampling/lazy.py::_host_evaluate):
+the same collapsed linear forms the HIP kernel runs, in plain torch.  These tests need no GPU: they replay the
+reference-recorded fixtures and the oracle on the CPU, and check that device work can never end up here."""
+
+import numpy as np
+import pytest
+import torch
+from cases import MODELS, SAMPLERS, SCHEDULES, oracle_schedule
+from conftest import load_npz
+from test_step_gpu import EXTRA_WRAPPERS, FIXTURE_WRAPPERS, Injected, assert_close, replay_fixture
+
+import skrample_amd.diffusers as PD
+import skrample_amd.scheduling as PS
+from skr_oracle import wrapper as OW
+from skrample_amd import _hip
+from skrample_amd.common import Step
+from skrample_amd.sampling import lazy
+from skrample_amd.sampling import models as PM
+from skrample_amd.sampling import structured as PT
+
+CPU = torch.device("cpu")
+pytestmark = []  # (test_step_gpu's module-level gpu mark does not apply here)
+
+
+@pytest.mark.parametrize("name", FIXTURE_WRAPPERS)
+def test_baseline_config_fixtures_on_cpu(name):
+    "the five BASELINE.json configs (reduced shape) on CPU tensors vs outputs of the reference itself; cfg1 is the reference's own CPU case"
+    mk, dt = FIXTURE_WRAPPERS[name]
+    replay_fixture(mk(), load_npz(f"steps_{name}.npz"), dt, CPU, name)
+
+
+@pytest.mark.parametrize("name", EXTRA_WRAPPERS)
+def test_extra_fixtures_on_cpu(name):
+    blob = load_npz("steps_extra.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
+    mk, dt = EXTRA_WRAPPERS[name]
+    replay_fixture(mk(), fx, dt, CPU, name)
+
+
+@pytest.mark.parametrize("sampler", ["euler", "dpm2_sde", "adams4", "unipc3", "spc"])
+def test_samplers_vs_oracle_on_cpu(sampler):
+    if sampler not in SAMPLERS:
+        pytest.skip(f"no sampler case named {sampler}")
+    mk_o, mk_p = SAMPLERS[sampler]
+    steps, shape = 7, (2, 3, 10, 6)
+    for sname, mname in (("karras_scaled", "eps"), ("linear", "flow")):
+        g = torch.Generator().manual_seed(hash((sampler, sname)) % 2**31)
+        w = PD.SkrampleWrapperScheduler(mk_p(), SCHEDULES[sname][1](), MODELS[mname][1])
+        o = OW.StepDriver(mk_o(), oracle_schedule(sname, steps), MODELS[mname][0])
+        w.set_timesteps(steps)
+        o.set_timesteps(steps)
+        noises = [torch.randn(shape, generator=g) for _ in range(steps)]
+        w._noise_generator = Injected(noises, CPU)
+        x = torch.randn(shape, generator=g)
+        for i, t in enumerate(w.timesteps):
+            out = torch.randn(shape, generator=g)
+            got = w.step(out, t, x, return_dict=False)[0]
+            ref = o.step(out, t, x, noise=noises[i])[0]
+            assert_close(got, ref, torch.float32, f"{sampler}/{sname}/{mname} step {i}")
+            x = ref
+
+
+def test_numpy_arrays_through_the_sampler_protocol():
+    "ndarray in -> ndarray out (reference tests/self_sampling.py:184-224), same numbers as CPU tensors"
+    rng = np.random.default_rng(5)
+    sampler, model, schedule = PT.DPM(order=2), PM.NoiseModel(), PS.Scaled()
+    steps = 6
+    xa = rng.standard_normal((3, 8)).astype(np.float64)
+    xt = torch.from_numpy(xa.copy())
+    prev_a, prev_t = [], []
+    for i in range(steps):
+        out = rng.standard_normal((3, 8))
+        ra = sampler.sample(xa, out, Step.from_int(i, steps), model, schedule, None, prev_a)
+        rt = sampler.sample(xt, torch.from_numpy(out.copy()), Step.from_int(i, steps), model, schedule, None, prev_t)
+        assert isinstance(ra.final, np.ndarray) and ra.final.dtype == np.float64
+        assert isinstance(rt.final, torch.Tensor) and rt.final.device.type == "cpu"
+        np.testing.assert_array_equal(ra.final, rt.final.numpy())
+        prev_a.append(ra), prev_t.append(rt)
+        xa, xt = ra.final, rt.final
+    assert np.isfinite(xa).all()
+
+
+def test_wrapper_random_noise_on_cpu_uses_the_callers_generators():
+    "host-resident latents draw white noise as the reference does: torch.randn from one CPU generator per sample"
+    shape, steps = (2, 4, 8, 8), 4
+    mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))  # noqa: E731
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(shape, generator=g)
+    outs = [torch.randn(shape, generator=g) for _ in range(steps)]
+
+    def run(seed_base):
+        w = mk()
+        w.set_timesteps(steps)
+        gens = [torch.Generator().manual_seed(seed_base + i) for i in range(shape[0])]
+        x = x0
+        for out, t in zip(outs, w.timesteps):
+            x = w.step(out, t, x, generator=gens, return_dict=False)[0]
+        return x
+
+    a, b, c = run(10), run(10), run(11)
+    assert torch.equal(a, b) and not torch.equal(a, c) and a.dtype == torch.float32 and a.device.type == "cpu"
+    # reproduce the first step's noise by hand from the same generators
+    w = mk()
+    w.set_timesteps(steps)
+    gens = [torch.Generator().manual_seed(10 + i) for i in range(shape[0])]
+    expect = torch.stack([torch.randn(shape[1:], generator=torch.Generator().manual_seed(10 + i)) for i in range(shape[0])])
+    w.step(outs[0], w.timesteps[0], x0, generator=gens, return_dict=False)
+    assert w._noise_generator._draws == 1
+    got = torch.stack([torch.randn(shape[1:], generator=torch.Generator().manual_seed(10 + i)) for i in range(shape[0])])
+    assert torch.equal(expect, got)
+    from skrample_amd.pytorch import noise as PN
+
+    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), noise_type=PN.Pyramid)
+    w.set_timesteps(steps)
+    with pytest.raises(_hip.SkrampleHipError, match="HIP kernels"):
+        w.step(outs[0], w.timesteps[0], x0, generator=gens, return_dict=False)
+
+
+def test_device_work_never_reaches_the_host_executor(monkeypatch):
+    """the host executor serves host-resident operands only: a form over (fake) device tensors goes to the C ABI and fails
+    loudly when the library is missing; mixed residency is refused"""
+    calls = []
+    monkeypatch.setattr(lazy, "_host_evaluate", lambda *a, **k: calls.append(a) or [torch.zeros(1)])
+    cpu_form = lazy.Lin.leaf(torch.ones(8)) * 2.0
+    lazy.evaluate([cpu_form], [torch.float32])
+    assert len(calls) == 1
+
+    class FakeDevice(torch.Tensor):  # a tensor that reports a HIP device without one being present
+        @property
+        def device(self):
+            return torch.device("cuda", 0)
+
+        @property
+        def is_cuda(self):
+            return True
+
+    fake = torch.ones(8).as_subclass(FakeDevice)
+    form = lazy.Lin({id(fake): (fake, 1.0)}, fake.shape, torch.device("cuda", 0))
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libskrample_hip.so")
+    monkeypatch.setattr(_hip, "_lib", None)
+    with pytest.raises(Exception) as err:  # SkrampleHipError from the loader (or torch refusing the fake device first)
+        lazy.evaluate([form], [torch.float32])
+    assert len(calls) == 1, "a device form must not be routed to the host executor"
+    assert "libskrample_hip" in str(err.value) or "cuda" in str(err.value).lower() or "hip" in str(err.value).lower()
+
+
+def test_mixed_residency_is_refused():
+    a = lazy.Lin.leaf(torch.ones(8))
+
+    class FakeDevice(torch.Tensor):
+        @property
+        def device(self):
+            return torch.device("cuda", 0)
+
+    fake = torch.ones(8).as_subclass(FakeDevice)
+    mixed = lazy.Lin({**a.terms, id(fake): (fake, 1.0)}, a.shape, a.device)
+    with pytest.raises(_hip.SkrampleHipError, match="all live on the HIP device or all on the host"):
+        lazy.evaluate([mixed], [torch.float32])

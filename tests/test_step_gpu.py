@@ -111,7 +111,8 @@ def replay_fixture(w, fx, dtype, dev, name):
         assert_close(prev, from_bits(fx["prev"][i], dtype), dtype, f"{name} step {i} prev_sample")
         assert_close(torch.as_tensor(pred.materialize() if isinstance(pred, lazy.LazyTensor) else pred), from_bits(fx["pred"][i], dtype), dtype, f"{name} step {i} pred_original_sample")
         x = from_bits(fx["prev"][i], dtype).to(dev)
-    torch.cuda.synchronize()
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("name", FIXTURE_WRAPPERS)
