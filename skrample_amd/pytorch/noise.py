@@ -511,7 +511,8 @@ class Brownian(TensorNoiseCommon):
         return out
 
 
-@dataclass
+
+
 class HostRandomBatch:
     """White noise for host-resident samples (CPU tensors), exactly as the reference draws it: one torch generator per
     batch item, `torch.randn(unit_shape, generator=g)` each, stacked (noise.py:58-74, 438-446; fp32 because the
@@ -531,6 +532,7 @@ class HostRandomBatch:
     generate_lazy = generate
 
 
+@dataclass
 class BatchTensorNoise(SkrampleTensorNoise):
     """One logical generator per batch item, executed as a single launch.  `generators` is kept for
     API compatibility (len == batch); the batch shares one draw counter."""
