@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 8
+#define SKR_ABI_VERSION 9
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 /* Devices and streams: every entry point launches on the device that owns its output buffer (queried from the pointer when
@@ -92,6 +92,35 @@ typedef struct skr_step_plan {
 int skr_step_launch(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
                     const uint64_t* seeds_dev /* [batch] device, may be NULL if noise_mode==0 */,
                     int64_t numel, void* stream);
+
+/*
+ * Device-resident step scalars -- SURVEY.md 8(f) rank 1; replaces the per-step host work of
+ * SkrampleWrapperScheduler.step (skrample/diffusers.py:565-567: timestep -> index lookup with an .item() sync) and of the
+ * schedule evaluation inside every sampler step (skrample/scheduling.py:51-62, skrample/sampling/interface.py:34-59).
+ *
+ * A launch recorded into a HIP graph freezes its kernel arguments, so a graph built on skr_step_launch serves exactly one
+ * schedule.  skr_step_launch_indexed takes the step's scalars from device memory instead: the kernel reads
+ *     row = rows_dev[(index_dev ? index_dev[0] : 0) + row_offset]
+ * when it runs.  `plan` fixes the structure only (operand count and dtypes, outputs, noise_mode, whether a rounded conversion
+ * exists); its coef0 / coef1 / chain / zeta / stream / convert_k values are ignored, and convert_to / convert_from must be
+ * the row's kinds.  One captured loop therefore serves any schedule of its length (rewrite the rows: new sigmas, shift,
+ * begin index, stochasticity) and several resident schedules (move index_dev), with no re-capture and no host sync.
+ * Rows with zeta = 0 skip the draw exactly as a launch without noise does.  Covered: launches the one-trip kernels take
+ * (whole 2048-element chunks, <= 16 operands, fp32 accumulation); anything else returns SKR_ERR_UNSUPPORTED.
+ */
+#define SKR_ROW_TERMS 16
+typedef struct skr_step_row {
+  double coef0[SKR_ROW_TERMS];
+  double coef1[SKR_ROW_TERMS];
+  double chain;
+  double zeta0, zeta1;
+  uint64_t stream0, stream1;
+  double convert_k[4];
+} skr_step_row;
+
+int skr_step_launch_indexed(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
+                            const uint64_t* seeds_dev, int64_t numel, const skr_step_row* rows_dev,
+                            const int32_t* index_dev /* device int32, may be NULL */, int32_t row_offset, void* stream);
 
 /*
  * Noise generators -- replace skrample/pytorch/noise.py behind BatchTensorNoise.generate

@@ -13,7 +13,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 8
+ABI_VERSION = 9
 SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
@@ -25,6 +25,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_
 
 EXPORTS = (
     "skr_step_launch",
+    "skr_step_launch_indexed",
     "skr_noise_random",
     "skr_noise_offset",
     "skr_noise_brownian",
@@ -74,6 +75,109 @@ class StepPlanC(ctypes.Structure):
     ]
 
 
+ROW_TERMS = 16  # include/skrample_hip.h SKR_ROW_TERMS
+
+
+class StepRowC(ctypes.Structure):
+    "mirror of `skr_step_row`: the scalars of one launch, resident on the device for indexed launches"
+
+    _fields_ = [
+        ("coef0", ctypes.c_double * ROW_TERMS),
+        ("coef1", ctypes.c_double * ROW_TERMS),
+        ("chain", ctypes.c_double),
+        ("zeta0", ctypes.c_double),
+        ("zeta1", ctypes.c_double),
+        ("stream0", ctypes.c_uint64),
+        ("stream1", ctypes.c_uint64),
+        ("convert_k", ctypes.c_double * 4),
+    ]
+
+
+def plan_structure(plan: StepPlanC) -> tuple:
+    "what a captured launch freezes: everything of a plan except the scalars a row carries"
+    return (plan.n_terms, plan.n_group_a, plan.dtype_a, plan.dtype_b, plan.out0_dtype, plan.out1_dtype, plan.acc_f64, plan.noise_mode,
+            plan.sample_numel, plan.convert_to, plan.convert_from)  # fmt: skip
+
+
+class IndexedRows:
+    """Device-resident step scalars of a captured sampling loop (skr_step_launch_indexed).
+
+    mode "record": launches run normally and append one row each (their structure is remembered);
+    mode "emit"  : launches become indexed launches reading row `base + k` (k = position in the loop) -- used under graph capture;
+    mode "refill": launches run normally (on whatever tensors the dry run uses) and overwrite row `slot*length + k` after checking
+                   that the structure is the captured one -- how a captured loop is re-targeted to another schedule."""
+
+    def __init__(self, device: torch.device, slots: int = 4):
+        self.device, self.slots = device, slots
+        self.mode, self.cursor, self.length = "record", 0, 0
+        self.structures: list[tuple] = []
+        self.host: list[StepRowC] = []
+        self.rows_dev: torch.Tensor | None = None
+        self.index_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.slot = 0
+
+    @staticmethod
+    def row_from(plan: StepPlanC) -> StepRowC:
+        if plan.n_terms > ROW_TERMS:
+            raise SkrampleHipError(f"a launch with {plan.n_terms} operands does not fit a device-resident row ({ROW_TERMS})")
+        row = StepRowC()
+        for k in range(plan.n_terms):
+            row.coef0[k], row.coef1[k] = plan.coef0[k], plan.coef1[k]
+        row.chain, row.zeta0, row.zeta1, row.stream0, row.stream1 = plan.chain, plan.zeta0, plan.zeta1, plan.stream0, plan.stream1
+        for k in range(4):
+            row.convert_k[k] = plan.convert_k[k]
+        return row
+
+    def finish_recording(self) -> None:
+        self.length = len(self.host)
+        size = ctypes.sizeof(StepRowC)
+        self.rows_dev = torch.zeros(self.slots * self.length * size, dtype=torch.uint8, device=self.device)
+        self.upload(0)
+
+    def upload(self, slot: int) -> None:
+        "copy the host rows of `slot` to the device (stream-ordered)"
+        size = ctypes.sizeof(StepRowC)
+        blob = b"".join(bytes(r) for r in self.host[slot * self.length : (slot + 1) * self.length])
+        staging = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        self.rows_dev[slot * self.length * size : (slot + 1) * self.length * size].copy_(staging, non_blocking=False)
+
+    def begin(self, mode: str, slot: int = 0) -> None:
+        self.mode, self.cursor, self.slot = mode, 0, slot
+        if mode == "refill":
+            need = (slot + 1) * self.length
+            while len(self.host) < need:
+                self.host.append(StepRowC())
+
+    def launch(self, lib, plan: StepPlanC, arr, out0_ptr, out1_ptr, seeds_ptr, numel: int, stream_ptr: int) -> int:
+        k = self.cursor
+        self.cursor += 1
+        if self.mode == "record":
+            self.structures.append(plan_structure(plan))
+            self.host.append(self.row_from(plan))
+            return lib.skr_step_launch(ctypes.byref(plan), arr, out0_ptr, out1_ptr, seeds_ptr, numel, stream_ptr)
+        if k >= self.length:
+            raise SkrampleHipError("more launches than the captured loop has")
+        if self.mode == "refill":
+            if plan_structure(plan)[:8] + plan_structure(plan)[9:] != self.structures[k][:8] + self.structures[k][9:]:
+                raise SkrampleHipError(f"launch {k} of the new schedule has a different structure than the captured loop: re-capture")
+            self.host[self.slot * self.length + k] = self.row_from(plan)
+            return lib.skr_step_launch(ctypes.byref(plan), arr, out0_ptr, out1_ptr, seeds_ptr, numel, stream_ptr)
+        if plan_structure(plan) != self.structures[k]:
+            raise SkrampleHipError(f"launch {k} differs in structure between the recording pass and the capture")
+        return lib.skr_step_launch_indexed(ctypes.byref(plan), arr, out0_ptr, out1_ptr, seeds_ptr, numel, self.rows_dev.data_ptr(), self.index_dev.data_ptr(), k, stream_ptr)
+
+
+indexed: IndexedRows | None = None  # installed by skrample_amd.graphs while it records / captures / re-targets a loop
+
+
+def step_launch_raw(plan: StepPlanC, arr, out0_ptr, out1_ptr, seeds_ptr, numel: int, stream_ptr: int) -> int:
+    "every skr_step_launch of the package goes through here (status returned, not checked)"
+    lib = load()
+    if indexed is not None:
+        return indexed.launch(lib, plan, arr, out0_ptr, out1_ptr, seeds_ptr, numel, stream_ptr)
+    return lib.skr_step_launch(ctypes.byref(plan), arr, out0_ptr, out1_ptr, seeds_ptr, numel, stream_ptr)
+
+
 _lock = threading.Lock()
 _lib: ctypes.CDLL | None = None
 
@@ -99,6 +203,8 @@ def load() -> ctypes.CDLL:
         vp, i64, u64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32
         lib.skr_step_launch.argtypes = [ctypes.POINTER(StepPlanC), ctypes.POINTER(vp), vp, vp, vp, i64, vp]
         lib.skr_step_launch.restype = ctypes.c_int
+        lib.skr_step_launch_indexed.argtypes = [ctypes.POINTER(StepPlanC), ctypes.POINTER(vp), vp, vp, vp, i64, vp, vp, i32, vp]
+        lib.skr_step_launch_indexed.restype = ctypes.c_int
         lib.skr_noise_random.argtypes = [vp, i32, vp, u64, i64, i64, vp]
         lib.skr_noise_random.restype = ctypes.c_int
         lib.skr_noise_offset.argtypes = [vp, i32, vp, u64, u64, i64, ctypes.POINTER(i64), i32, ctypes.c_uint32, ctypes.c_double, vp]
@@ -166,8 +272,8 @@ def launch_step(plan: StepPlanC, inputs: list[torch.Tensor], out0, out1, seeds, 
         trace.append((plan, list(inputs), out0, out1, seeds, numel))
     n = len(inputs)
     arr = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in inputs])
-    status = lib.skr_step_launch(
-        ctypes.byref(plan),
+    status = step_launch_raw(
+        plan,
         arr,
         out0.data_ptr() if out0 is not None else None,
         out1.data_ptr() if out1 is not None else None,

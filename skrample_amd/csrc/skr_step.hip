@@ -363,6 +363,7 @@ static int launch_k(StepArgs<float>& args, hipStream_t stream, bool& taken) {
     const int rc = launch_one_trip_k<T>(args, NOISE, stream, taken);  // whole chunks: one-trip kernel (skr_step_fast.hip)
     if (taken) return rc;
   }
+  if (args.rows != nullptr) { taken = true; return SKR_ERR_UNSUPPORTED; }  // indexed launches: one-trip kernels only
   if constexpr (NOISE) {
     return launch_k_uv<T, true, 1>(args, stream, taken);
   } else {
@@ -396,9 +397,10 @@ template <typename T>
 static int launch_rk(const StepArgs<float>& args, hipStream_t stream) {
   {
     bool taken = false;
-    const int rc = launch_one_trip_rk<T>(args, stream, taken);
+    const int rc = launch_one_trip_rk<T>(args, false, stream, taken);
     if (taken) return rc;
   }
+  if (args.rows != nullptr) return SKR_ERR_UNSUPPORTED;
   const int uv = g_tune.rk_uv ? g_tune.rk_uv : 1;  // measured on the cfg5 shard: 1, 2 and 4 vectors per lane are within 2 %
   if (uv == 4) return launch_rk_uv<T, 4>(args, stream);
   if (uv == 2) return launch_rk_uv<T, 2>(args, stream);
@@ -409,15 +411,23 @@ template <typename TA, typename TB, typename TO0, typename TO1, typename Acc, bo
 static int launch(StepArgs<Acc>& args, hipStream_t stream) {
   // fast path: uniform 16/32-bit dtype, single output of the same dtype, fp32 accumulate
   if constexpr (std::is_same<Acc, float>::value && std::is_same<TA, TB>::value && std::is_same<TO0, TA>::value && ST0 && !HAS1 && !CONV) {
-    if (args.n_a == args.n_terms && (!NOISE || args.zeta0 != 0.f)) {
+    if (args.n_a == args.n_terms && (!NOISE || args.zeta0 != 0.f || args.rows != nullptr)) {
       bool taken = false;
       const int rc = launch_k<TA, NOISE>(args, stream, taken);
       if (taken) return rc;
     }
   }
-  // Runge-Kutta stage fast path: uniform dtype in and out, conversion + chained result, no in-kernel noise
-  if constexpr (std::is_same<Acc, float>::value && std::is_same<TA, TB>::value && std::is_same<TO0, TA>::value && std::is_same<TO1, TA>::value && ST0 && HAS1 && CONV && !NOISE) {
-    if (args.n_terms >= 2 && args.n_terms <= 8 && args.numel % VEC == 0) return launch_rk<TA>(args, stream);
+  // Runge-Kutta stage fast path: uniform dtype in and out, conversion + chained result; with in-kernel noise (the last
+  // stage of a stochastic step) only the one-trip kernel has a variant
+  if constexpr (std::is_same<Acc, float>::value && std::is_same<TA, TB>::value && std::is_same<TO0, TA>::value && std::is_same<TO1, TA>::value && ST0 && HAS1 && CONV) {
+    if (args.n_terms >= 2 && args.n_terms <= 8 && args.numel % VEC == 0) {
+      if constexpr (!NOISE) return launch_rk<TA>(args, stream);
+      else {
+        bool taken = false;
+        const int rc = launch_one_trip_rk<TA>(args, true, stream, taken);
+        if (taken) return rc;
+      }
+    }
   }
   // two-output fast path (UniPC / SPC): 16-bit operands (+ at most one fp32 state), fp32 out0 + 16-bit out1
   if constexpr (std::is_same<Acc, float>::value && sizeof(TA) == 2 && (std::is_same<TB, TA>::value || std::is_same<TB, float>::value) &&
@@ -426,6 +436,7 @@ static int launch(StepArgs<Acc>& args, hipStream_t stream) {
     const int rc = launch_one_trip_two<TA>(args, NOISE, std::is_same<TB, float>::value, stream, taken);
     if (taken) return rc;
   }
+  if (args.rows != nullptr) return SKR_ERR_UNSUPPORTED;  // device-resident rows are read by the one-trip kernels only
   constexpr int UV = uv_for(NOISE, HAS1);
   Geometry g = geometry<UV, NOISE>(args.numel, args.sample_numel);
   args.grid_mode = g.mode;
@@ -477,7 +488,8 @@ static int pick_out(StepArgs<Acc>& a, int dt_a, int o0, int o1, bool noise, bool
 
 template <typename Acc>
 static int pick_in(StepArgs<Acc>& a, const skr_step_plan& p, hipStream_t s) {
-  const bool noise = p.noise_mode == 1 && (p.zeta0 != 0.0 || (p.out1_dtype != SKR_NONE && p.zeta1 != 0.0));
+  // (indexed launches: whether a draw happens is the row's business -- a zero zeta skips it at run time)
+  const bool noise = p.noise_mode == 1 && (a.rows != nullptr || p.zeta0 != 0.0 || (p.out1_dtype != SKR_NONE && p.zeta1 != 0.0));
   const int da = p.dtype_a, db = (p.n_group_a == p.n_terms) ? p.dtype_a : p.dtype_b;
   const bool conv = p.convert_to != 0 || p.convert_from != 0;
   if constexpr (std::is_same<Acc, double>::value) {
@@ -495,8 +507,10 @@ static int pick_in(StepArgs<Acc>& a, const skr_step_plan& p, hipStream_t s) {
 }
 
 template <typename Acc>
-static int run(const skr_step_plan& p, const void* const* inputs, void* out0, void* out1, const uint64_t* seeds, int64_t numel, hipStream_t s) {
+static int run(const skr_step_plan& p, const void* const* inputs, void* out0, void* out1, const uint64_t* seeds, int64_t numel, hipStream_t s,
+               const skr_step_row* rows = nullptr, const int32_t* index = nullptr, int32_t row_offset = 0) {
   StepArgs<Acc> a;
+  a.rows = rows; a.index = index; a.row_offset = row_offset;
   for (int k = 0; k < p.n_terms; ++k) {
     a.in[k] = inputs[k];
     a.c0[k] = (Acc)p.coef0[k];
@@ -522,8 +536,8 @@ static int run(const skr_step_plan& p, const void* const* inputs, void* out0, vo
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-extern "C" int skr_step_launch(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
-                               const uint64_t* seeds_dev, int64_t numel, void* stream) {
+static int step_launch_impl(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1, const uint64_t* seeds_dev, int64_t numel,
+                            void* stream, const skr_step_row* rows, const int32_t* index, int32_t row_offset) {
   skr::DeviceGuard device_guard(out0 ? out0 : out1);
   if (!plan) return SKR_ERR_NULL;
   const skr_step_plan& p = *plan;
@@ -538,7 +552,7 @@ extern "C" int skr_step_launch(const skr_step_plan* plan, const void* const* inp
     if (!aligned16(inputs[k])) return SKR_ERR_ALIGN;
   }
   if ((st0 && !aligned16(out0)) || (has1 && !aligned16(out1))) return SKR_ERR_ALIGN;
-  const bool wants_noise = p.noise_mode == 1 && (p.zeta0 != 0.0 || (has1 && p.zeta1 != 0.0));
+  const bool wants_noise = p.noise_mode == 1 && (rows != nullptr || p.zeta0 != 0.0 || (has1 && p.zeta1 != 0.0));
   if (p.noise_mode != 0 && p.noise_mode != 1) return SKR_ERR_UNSUPPORTED;
   if (p.convert_to < 0 || p.convert_to > 3 || p.convert_from < 0 || p.convert_from > 3) return SKR_ERR_UNSUPPORTED;
   if ((p.convert_to || p.convert_from) && (p.n_group_a < 2 || !has1)) return SKR_ERR_TERMS;
@@ -550,9 +564,26 @@ extern "C" int skr_step_launch(const skr_step_plan* plan, const void* const* inp
     if (p.sample_numel % 8 != 0) return SKR_ERR_UNSUPPORTED;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (rows != nullptr) {
+    if (p.acc_f64 || p.n_terms > SKR_ROW_TERMS || row_offset < 0) return SKR_ERR_UNSUPPORTED;
+    return skr::run<float>(p, inputs, out0, out1, seeds_dev, numel, s, rows, index, row_offset);
+  }
   return p.acc_f64 ? skr::run<double>(p, inputs, out0, out1, seeds_dev, numel, s)
                    : skr::run<float>(p, inputs, out0, out1, seeds_dev, numel, s);
 }
+
+extern "C" int skr_step_launch(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
+                               const uint64_t* seeds_dev, int64_t numel, void* stream) {
+  return step_launch_impl(plan, inputs, out0, out1, seeds_dev, numel, stream, nullptr, nullptr, 0);
+}
+
+extern "C" int skr_step_launch_indexed(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
+                                       const uint64_t* seeds_dev, int64_t numel, const skr_step_row* rows_dev,
+                                       const int32_t* index_dev, int32_t row_offset, void* stream) {
+  if (!rows_dev) return SKR_ERR_NULL;
+  return step_launch_impl(plan, inputs, out0, out1, seeds_dev, numel, stream, rows_dev, index_dev, row_offset);
+}
+
 
 extern "C" int skr_last_hip_error(void) { return skr::g_last_hip_error; }
 

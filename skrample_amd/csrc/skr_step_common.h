@@ -57,7 +57,22 @@ struct StepArgs {
   int32_t grid_mode;    // 0 flat grid, 1 per-sample grid (noise kernels, sample_numel % 8 == 0)
   int32_t conv_to, conv_from;  // rounded pair conversion (CONV kernels): see convert_rounded()
   double ck[4];
+  // skr_step_launch_indexed: the scalars above are read from rows[index[0] + row_offset] by the kernel (one-trip kernels only)
+  const skr_step_row* rows;
+  const int32_t* index;
+  int32_t row_offset;
 };
+
+// device-resident scalars of a launch (skr_step_launch_indexed); rows == nullptr: use the kernarg values
+struct RowRef {
+  const skr_step_row* rows;
+  const int32_t* index;
+  int32_t row_offset;
+};
+__device__ __forceinline__ const skr_step_row* row_of(const RowRef& r) {
+  if (r.rows == nullptr) return nullptr;
+  return r.rows + ((r.index != nullptr ? r.index[0] : 0) + r.row_offset);
+}
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -311,6 +326,12 @@ struct RkArgs {
   int32_t conv_to, conv_from;
   int32_t xmap_lr;
   int64_t numel;
+  RowRef tab;
+  // stochastic final stage (one-trip kernel only): out1 += zeta1 * N(stream1)
+  const uint64_t* seeds;
+  float zeta1;
+  int32_t bps_shift;
+  uint64_t stream1;
 };
 
 extern thread_local int g_last_hip_error;
@@ -318,7 +339,7 @@ int finish_launch();
 
 // one-trip launches (skr_step_fast.hip); `taken` = false when the plan is outside what they cover
 template <typename T> int launch_one_trip_k(const StepArgs<float>& args, bool noise, hipStream_t stream, bool& taken);
-template <typename T> int launch_one_trip_rk(const StepArgs<float>& args, hipStream_t stream, bool& taken);
+template <typename T> int launch_one_trip_rk(const StepArgs<float>& args, bool noise, hipStream_t stream, bool& taken);
 template <typename TA> int launch_one_trip_two(const StepArgs<float>& args, bool noise, bool group_b_f32, hipStream_t stream, bool& taken);
 
 }  // namespace skr

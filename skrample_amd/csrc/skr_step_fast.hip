@@ -28,6 +28,7 @@ struct OneTripArgs {
   uint64_t stream0;
   float c0[KMAX];
   float zeta0;
+  RowRef tab;
 };
 
 __device__ __forceinline__ uint32_t chunk_of(uint32_t b, int lr) {  // lr = log2(run length); 0 = identity
@@ -41,6 +42,17 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
   const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
   Raw<T> raw[K];
   float z[VEC];
+  // the step's scalars: kernarg, or the device-resident row of an indexed launch (uniform branch, scalar loads)
+  float cf[K], zeta0 = a.zeta0;
+  uint64_t stream0 = a.stream0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) cf[j] = a.c0[j];
+  if (const skr_step_row* row = row_of(a.tab)) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) cf[j] = (float)row->coef0[j];
+    zeta0 = (float)row->zeta0;
+    stream0 = row->stream0;
+  }
   // Paced issue.  One burst of K loads per wave is not the fastest order on this memory system: on the headline
   // launch (tools/tune/tune_r2.hip, 256x4x128x128 bf16, K = 4) all loads first runs 26.3 us, loads after the Philox
   // set-up 27.0 us, and the loads spread over the wave's Philox work -- one before the seed fetch, one after it, one
@@ -61,11 +73,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
     uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;  // lane-vector within the sample
     asm volatile("" : "+v"(vj) : "s"((uint32_t)seed));               // ... behind the seed's arrival
     SKR_ISSUE(1);
-    normal4(seed, a.stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
+    normal4(seed, stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
     asm volatile("" : "+v"(vj), "+v"(vs) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]));  // ... behind the first block
     __builtin_amdgcn_sched_barrier(0);
     SKR_ISSUE(2);
-    normal4(seed, a.stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
+    normal4(seed, stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
     asm volatile("" : "+v"(vj) : "v"(z[4]), "v"(z[5]), "v"(z[6]), "v"(z[7]));           // ... behind the second
     __builtin_amdgcn_sched_barrier(0);
     SKR_ISSUE(3);
@@ -80,8 +92,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
     const uint32_t smp = c >> a.bps_shift;
     const uint64_t seed = a.seeds[smp];
     const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
-    normal4(seed, a.stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
-    normal4(seed, a.stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
+    normal4(seed, stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
+    normal4(seed, stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
   } else if constexpr (PACE && (K == 4 || K == 5)) {  // tools/bench_plan.py: K=4 -1.1 %, K=5 -1.7 %, K=3 +6 % (left unpaced), K>=6 no change
     int64_t vj = v;
 #pragma unroll
@@ -104,48 +116,74 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
   for (int j = 0; j < K; ++j) {
     float w[VEC];
     widen<T, float>(raw[j], w);
-    const float cj = a.c0[j];
+    const float cj = cf[j];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s[i] = fma_(cj, w[i], s[i]);
   }
-  if constexpr (NOISE) fma_noise8<float>(a.zeta0, z, s);
+  if constexpr (NOISE) { if (zeta0 != 0.f) fma_noise8<float>(zeta0, z, s); }  // (a zero row skips the draw, as a launch without noise does)
   store8<T, float, TILE>(a.out0, v, s);
 }
 
-template <typename T, int K, bool TILE>
+// NOISE: the step's last stage of a stochastic tableau step adds zeta1 * N(stream1) to out1 (the derivative out0 is never noisy)
+template <typename T, int K, bool TILE, bool NOISE>
 __global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
   const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
   const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
   Raw<T> raw[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
-  const float k[4] = {a.ck[0], a.ck[1], a.ck[2], a.ck[3]};
+  float k[4] = {a.ck[0], a.ck[1], a.ck[2], a.ck[3]}, cf[K], chain = a.chain, zeta1 = a.zeta1;
+  uint64_t stream1 = a.stream1;
+#pragma unroll
+  for (int j = 0; j < K; ++j) cf[j] = a.c1[j];
+  if (const skr_step_row* row = row_of(a.tab)) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) cf[j] = (float)row->coef1[j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[i] = (float)row->convert_k[i];
+    chain = (float)row->chain;
+    zeta1 = (float)row->zeta1;
+    stream1 = row->stream1;
+  }
+  float z1[VEC];
+  bool n1 = false;
+  if constexpr (NOISE) {
+    n1 = zeta1 != 0.f;
+    if (n1) {
+      const uint32_t smp = c >> a.bps_shift;
+      const uint64_t seed = a.seeds[smp];
+      const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
+      normal4(seed, stream1, (uint64_t)group0<TILE>((int64_t)vs), z1);
+      normal4(seed, stream1, (uint64_t)group1<TILE>((int64_t)vs), z1 + 4);
+    }
+  }
   float sv[VEC], ov[VEC], d[VEC], s1[VEC];
   widen<T, float>(raw[0], sv);
   widen<T, float>(raw[1], ov);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     d[i] = convert_rounded<T, float>(sv[i], ov[i], a.conv_to, a.conv_from, k);
-    s1[i] = fma_(a.c1[1], ov[i], fma_(a.c1[0], sv[i], 0.f));
+    s1[i] = fma_(cf[1], ov[i], fma_(cf[0], sv[i], 0.f));
   }
 #pragma unroll
   for (int j = 2; j < K; ++j) {
     float w[VEC];
     widen<T, float>(raw[j], w);
-    const float cj = a.c1[j];
+    const float cj = cf[j];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s1[i] = fma_(cj, w[i], s1[i]);
   }
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) s1[i] = fma_(a.chain, d[i], s1[i]);
+  for (int i = 0; i < VEC; ++i) s1[i] = fma_(chain, d[i], s1[i]);
+  if constexpr (NOISE) { if (n1) fma_noise8<float>(zeta1, z1, s1); }
   store8<T, float, TILE>(a.out1, v, s1);
   store8<T, float, TILE>(a.out0, v, d);
 }
 
 // one-trip launches: whole chunks, and with in-kernel noise a power-of-two number of whole chunks per sample
-static bool one_trip_ok(int64_t numel, int64_t sample_numel, bool noise, int* bps_shift) {
+static bool one_trip_ok(int64_t numel, int64_t sample_numel, bool noise, int* bps_shift, bool forced = false) {
   constexpr int64_t CHUNK = (int64_t)BLOCK * VEC;
-  if (!g_tune.one_trip || numel % CHUNK != 0 || numel / CHUNK > 0x7fffffffll) return false;
+  if ((!g_tune.one_trip && !forced) || numel % CHUNK != 0 || numel / CHUNK > 0x7fffffffll) return false;
   *bps_shift = 0;
   if (!noise) return true;
   if (sample_numel % CHUNK != 0) return false;
@@ -172,6 +210,7 @@ static int launch_k1(const StepArgs<float>& args, int bps_shift, hipStream_t str
   for (int k = 0; k < KMAX; ++k) { fa.in[k] = k < args.n_terms ? args.in[k] : nullptr; fa.c0[k] = k < args.n_terms ? args.c0[k] : 0.f; }
   fa.out0 = args.out0; fa.seeds = args.seeds; fa.zeta0 = args.zeta0; fa.stream0 = args.stream0;
   fa.bps_shift = bps_shift; fa.xmap_lr = xmap_lr_for(chunks);
+  fa.tab = RowRef{args.rows, args.index, args.row_offset};
 #define SKR_K(N) case N: if (g_tune.pace) hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, true>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); \
                         else hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, false>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); break
   if constexpr (KMAX == 4) { switch (args.n_terms) { SKR_K(1); SKR_K(2); SKR_K(3); SKR_K(4); } }
@@ -185,7 +224,7 @@ template <typename T>
 int launch_one_trip_k(const StepArgs<float>& args, bool noise, hipStream_t stream, bool& taken) {
   taken = false;
   int bps_shift = 0;
-  if (!one_trip_ok(args.numel, args.sample_numel, noise, &bps_shift) || (sizeof(T) == 4 && !g_tune.tile)) return SKR_OK;
+  if (!one_trip_ok(args.numel, args.sample_numel, noise, &bps_shift, args.rows != nullptr) || (sizeof(T) == 4 && !g_tune.tile && args.rows == nullptr)) return SKR_OK;
   taken = true;
   if (noise) return args.n_terms <= 4 ? launch_k1<T, true, 4>(args, bps_shift, stream) : launch_k1<T, true, 8>(args, bps_shift, stream);
   return args.n_terms <= 4 ? launch_k1<T, false, 4>(args, bps_shift, stream) : launch_k1<T, false, 8>(args, bps_shift, stream);
@@ -194,15 +233,16 @@ template int launch_one_trip_k<bf16_t>(const StepArgs<float>&, bool, hipStream_t
 template int launch_one_trip_k<f16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
 template int launch_one_trip_k<float>(const StepArgs<float>&, bool, hipStream_t, bool&);
 
-template <typename T>
-static int launch_rk1(const StepArgs<float>& args, unsigned chunks, hipStream_t stream) {
+template <typename T, bool NOISE>
+static int launch_rk1(const StepArgs<float>& args, unsigned chunks, int bps_shift, hipStream_t stream) {
   constexpr bool TILE = sizeof(T) == 4;
   RkArgs ra;
+  ra.seeds = args.seeds; ra.zeta1 = args.zeta1; ra.stream1 = args.stream1; ra.bps_shift = bps_shift;
   for (int k = 0; k < 8; ++k) { ra.in[k] = k < args.n_terms ? args.in[k] : nullptr; ra.c1[k] = k < args.n_terms ? args.c1[k] : 0.f; }
   ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
   for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
-  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel; ra.xmap_lr = xmap_lr_for(chunks);
-#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE>), dim3(chunks), dim3(BLOCK), 0, stream, ra); break
+  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel; ra.xmap_lr = xmap_lr_for(chunks); ra.tab = RowRef{args.rows, args.index, args.row_offset};
+#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE, NOISE>), dim3(chunks), dim3(BLOCK), 0, stream, ra); break
   switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
 #undef SKR_K
   return finish_launch();
@@ -210,16 +250,18 @@ static int launch_rk1(const StepArgs<float>& args, unsigned chunks, hipStream_t 
 
 
 template <typename T>
-int launch_one_trip_rk(const StepArgs<float>& args, hipStream_t stream, bool& taken) {
+int launch_one_trip_rk(const StepArgs<float>& args, bool noise, hipStream_t stream, bool& taken) {
   taken = false;
-  int unused = 0;
-  if (!one_trip_ok(args.numel, args.sample_numel, false, &unused) || (sizeof(T) == 4 && !g_tune.tile)) return SKR_OK;
+  int bps_shift = 0;
+  if (!one_trip_ok(args.numel, args.sample_numel, noise, &bps_shift, args.rows != nullptr) || (sizeof(T) == 4 && !g_tune.tile && args.rows == nullptr)) return SKR_OK;
+  if (noise && args.rows == nullptr && args.zeta0 != 0.f) return SKR_OK;  // (a noisy derivative does not occur; left to the general kernel)
   taken = true;
-  return launch_rk1<T>(args, (unsigned)(args.numel / ((int64_t)BLOCK * VEC)), stream);
+  const unsigned chunks = (unsigned)(args.numel / ((int64_t)BLOCK * VEC));
+  return noise ? launch_rk1<T, true>(args, chunks, bps_shift, stream) : launch_rk1<T, false>(args, chunks, bps_shift, stream);
 }
-template int launch_one_trip_rk<bf16_t>(const StepArgs<float>&, hipStream_t, bool&);
-template int launch_one_trip_rk<f16_t>(const StepArgs<float>&, hipStream_t, bool&);
-template int launch_one_trip_rk<float>(const StepArgs<float>&, hipStream_t, bool&);
+template int launch_one_trip_rk<bf16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
+template int launch_one_trip_rk<f16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
+template int launch_one_trip_rk<float>(const StepArgs<float>&, bool, hipStream_t, bool&);
 
 // ---- two outputs (UniPC / SPC steps): out0 fp32 state, out1 = chain*out0 + ... in the operands' 16-bit dtype ---------
 //   out0 = sum_k c0[k]*in_k + zeta0*N(stream0)          NA 16-bit operands, then NB (0 or 1) fp32 operand
@@ -238,6 +280,7 @@ struct TwoOutArgs {
   float chain, zeta0, zeta1;
   float c0[NMAX];
   float c1[NMAX];
+  RowRef tab;
 };
 constexpr int two_out_nmax(int n) { return n <= 4 ? 4 : (n <= 8 ? 8 : 12); }
 
@@ -249,6 +292,16 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
   Raw<float> rb[NB > 0 ? NB : 1];
   float z0[VEC], z1[VEC];
   bool n0 = false, n1 = false;
+  float cf0[NA + NB], cf1[NA + NB], chain = a.chain, zeta0 = a.zeta0, zeta1 = a.zeta1;
+  uint64_t stream0 = a.stream0, stream1 = a.stream1;
+#pragma unroll
+  for (int j = 0; j < NA + NB; ++j) { cf0[j] = a.c0[j]; cf1[j] = a.c1[j]; }
+  if (const skr_step_row* row = row_of(a.tab)) {
+#pragma unroll
+    for (int j = 0; j < NA + NB; ++j) { cf0[j] = (float)row->coef0[j]; cf1[j] = (float)row->coef1[j]; }
+    chain = (float)row->chain; zeta0 = (float)row->zeta0; zeta1 = (float)row->zeta1;
+    stream0 = row->stream0; stream1 = row->stream1;
+  }
   if constexpr (NOISE && PACE) {
     // loads paced over the Philox work (see step_kernel_k1): six slots around the seed fetch and the four blocks
     int64_t vj = v;
@@ -264,21 +317,21 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
     uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
     asm volatile("" : "+v"(vj) : "s"((uint32_t)seed));
     SKR_ISSUE(1);
-    n0 = a.zeta0 != 0.f;
-    n1 = a.zeta1 != 0.f;
-    if (n0) normal4(seed, a.stream0, (uint64_t)group0<true>((int64_t)vs), z0);
+    n0 = zeta0 != 0.f;
+    n1 = zeta1 != 0.f;
+    if (n0) normal4(seed, stream0, (uint64_t)group0<true>((int64_t)vs), z0);
     asm volatile("" : "+v"(vj), "+v"(vs));
     __builtin_amdgcn_sched_barrier(0);
     SKR_ISSUE(2);
-    if (n0) normal4(seed, a.stream0, (uint64_t)group1<true>((int64_t)vs), z0 + 4);
+    if (n0) normal4(seed, stream0, (uint64_t)group1<true>((int64_t)vs), z0 + 4);
     asm volatile("" : "+v"(vj), "+v"(vs));
     __builtin_amdgcn_sched_barrier(0);
     SKR_ISSUE(3);
-    if (n1) normal4(seed, a.stream1, (uint64_t)group0<true>((int64_t)vs), z1);
+    if (n1) normal4(seed, stream1, (uint64_t)group0<true>((int64_t)vs), z1);
     asm volatile("" : "+v"(vj), "+v"(vs));
     __builtin_amdgcn_sched_barrier(0);
     SKR_ISSUE(4);
-    if (n1) normal4(seed, a.stream1, (uint64_t)group1<true>((int64_t)vs), z1 + 4);
+    if (n1) normal4(seed, stream1, (uint64_t)group1<true>((int64_t)vs), z1 + 4);
     asm volatile("" : "+v"(vj));
     __builtin_amdgcn_sched_barrier(0);
     SKR_ISSUE(5);
@@ -296,10 +349,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
       const uint32_t smp = c >> a.bps_shift;
       const uint64_t seed = a.seeds[smp];
       const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
-      n0 = a.zeta0 != 0.f;
-      n1 = a.zeta1 != 0.f;
-      if (n0) { normal4(seed, a.stream0, (uint64_t)group0<true>((int64_t)vs), z0); normal4(seed, a.stream0, (uint64_t)group1<true>((int64_t)vs), z0 + 4); }
-      if (n1) { normal4(seed, a.stream1, (uint64_t)group0<true>((int64_t)vs), z1); normal4(seed, a.stream1, (uint64_t)group1<true>((int64_t)vs), z1 + 4); }
+      n0 = zeta0 != 0.f;
+      n1 = zeta1 != 0.f;
+      if (n0) { normal4(seed, stream0, (uint64_t)group0<true>((int64_t)vs), z0); normal4(seed, stream0, (uint64_t)group1<true>((int64_t)vs), z0 + 4); }
+      if (n1) { normal4(seed, stream1, (uint64_t)group0<true>((int64_t)vs), z1); normal4(seed, stream1, (uint64_t)group1<true>((int64_t)vs), z1 + 4); }
     }
   }
   float s0[VEC], s1[VEC];
@@ -309,7 +362,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
   for (int j = 0; j < NA; ++j) {
     float w[VEC];
     widen<TA, float>(ra[j], w);
-    const float w0 = a.c0[j], w1 = a.c1[j];
+    const float w0 = cf0[j], w1 = cf1[j];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s0[i] = fma_(w0, w[i], s0[i]);
 #pragma unroll
@@ -319,16 +372,16 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
   for (int j = 0; j < NB; ++j) {
     float w[VEC];
     widen<float, float>(rb[j], w);
-    const float w0 = a.c0[NA + j], w1 = a.c1[NA + j];
+    const float w0 = cf0[NA + j], w1 = cf1[NA + j];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s0[i] = fma_(w0, w[i], s0[i]);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s1[i] = fma_(w1, w[i], s1[i]);
   }
-  if constexpr (NOISE) { if (n0) fma_noise8<float>(a.zeta0, z0, s0); }
+  if constexpr (NOISE) { if (n0) fma_noise8<float>(zeta0, z0, s0); }
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) s1[i] = fma_(a.chain, s0[i], s1[i]);
-  if constexpr (NOISE) { if (n1) fma_noise8<float>(a.zeta1, z1, s1); }
+  for (int i = 0; i < VEC; ++i) s1[i] = fma_(chain, s0[i], s1[i]);
+  if constexpr (NOISE) { if (n1) fma_noise8<float>(zeta1, z1, s1); }
   store8<TA, float, true>(a.out1, v, s1);
   store8<float, float, true>(a.out0, v, s0);
 }
@@ -346,6 +399,7 @@ static int launch_k2(const StepArgs<float>& args, int bps_shift, hipStream_t str
   ta.xmap_lr = xmap_lr_for(chunks); ta.bps_shift = bps_shift;
   ta.stream0 = args.stream0; ta.stream1 = args.stream1;
   ta.chain = args.chain; ta.zeta0 = args.zeta0; ta.zeta1 = args.zeta1;
+  ta.tab = RowRef{args.rows, args.index, args.row_offset};
   hipLaunchKernelGGL((step_kernel_k2<TA, NA, NB, NOISE, PACE>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, ta);
   return finish_launch();
 }
@@ -356,12 +410,12 @@ template <typename TA>
 int launch_one_trip_two(const StepArgs<float>& args, bool noise, bool group_b_f32, hipStream_t stream, bool& taken) {
   taken = false;
   const int na = args.n_a, nb = args.n_terms - args.n_a;
-  if (nb > 1 || (nb == 1 && !group_b_f32) || !g_tune.tile || !g_tune.two_out) return SKR_OK;
+  if (nb > 1 || (nb == 1 && !group_b_f32) || ((!g_tune.tile || !g_tune.two_out) && args.rows == nullptr)) return SKR_OK;
   // measured (tools/bench_plan.py, 256x16x128x128): with Philox and <= 7 operands the general kernel is 1-2 % faster
   // (193 vs 197 us at 4+1, 239 vs 241 us at 6+1); from 8+1 on, and without noise, this kernel wins (344 vs 365 us at 10+1)
-  if (noise && na + nb <= 7 && g_tune.two_out != 2) return SKR_OK;
+  if (noise && na + nb <= 7 && g_tune.two_out != 2 && args.rows == nullptr) return SKR_OK;
   int bps_shift = 0;
-  if (!one_trip_ok(args.numel, args.sample_numel, noise, &bps_shift)) return SKR_OK;
+  if (!one_trip_ok(args.numel, args.sample_numel, noise, &bps_shift, args.rows != nullptr)) return SKR_OK;
 #define SKR_GO(A, B)                                                                             \
   if (na == A && nb == B) {                                                                      \
     taken = true;                                                                                \

@@ -901,7 +901,7 @@ class RKWrapperCore(SkrampleWrapperCore):
         arr = prog["ptrs"]
         for i, t in enumerate(ops):
             arr[i] = t.data_ptr()
-        status = _hip.load().skr_step_launch(ctypes.byref(plan), arr, out0.data_ptr(), out1.data_ptr() if out1 is not None else None, seeds_ptr, prog["numel"], torch.cuda.current_stream(dev).cuda_stream)
+        status = _hip.step_launch_raw(plan, arr, out0.data_ptr(), out1.data_ptr() if out1 is not None else None, seeds_ptr, prog["numel"], torch.cuda.current_stream(dev).cuda_stream)
         _hip.check(status, "skr_step_launch")
         result = out1 if prog["converted"] else out0
         pred = out0 if prog["converted"] else model_output

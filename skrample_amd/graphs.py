@@ -5,6 +5,14 @@ caller's stream: no allocation, no synchronisation, no host read-back; per-sampl
 read from device memory at run time), so a sampling loop whose network is itself capturable can be recorded
 with `torch.cuda.graph` and replayed with new inputs / new seeds at ~10 us of host cost for the whole loop.
 This removes the per-step Python + launch overhead that dominates small batches.
+
+`indexed=True` additionally moves every step's scalars (coefficients, zeta, Philox stream ids, conversion constants) out
+of the frozen kernel arguments into a device-resident table (`skr_step_launch_indexed`, include/skrample_hip.h): the kernels
+read row `index + k` when they run.  The captured loop then serves ANY schedule of its length -- other sigmas, flow shift
+(`mu`), begin index, stochasticity -- by rewriting the table (`CapturedLoop.retarget`, a dry run of the new scheduler on one
+sample plus one small copy; no re-capture), and keeps several schedules resident at once, selected per replay by moving the
+device-resident index (`loop(latents, slot=k)`).  The reference redoes this work on the host every step, with a device sync
+(skrample/diffusers.py:565-567, skrample/scheduling.py:51-62, skrample/sampling/interface.py:34-59).
 """
 
 from __future__ import annotations
@@ -17,11 +25,40 @@ import torch
 class CapturedLoop:
     "replayable sampling loop: `out = loop(initial_latents, seeds=None)`"
 
-    def __init__(self, graph: torch.cuda.CUDAGraph, static_in: torch.Tensor, static_out: torch.Tensor, seeds_dev: torch.Tensor | None):
+    def __init__(self, graph: torch.cuda.CUDAGraph, static_in: torch.Tensor, static_out: torch.Tensor, seeds_dev: torch.Tensor | None, rows=None, runner=None):
         self.graph, self.static_in, self.static_out, self.seeds_dev = graph, static_in, static_out, seeds_dev
+        self.rows, self._runner = rows, runner  # _hip.IndexedRows of an indexed capture; runner(wrapper, x) = the captured loop body
 
-    def __call__(self, latents: torch.Tensor, seeds: Sequence[int] | None = None) -> torch.Tensor:
+    @property
+    def slots(self) -> int:
+        return self.rows.slots if self.rows is not None else 1
+
+    def retarget(self, wrapper, slot: int = 0) -> None:
+        """Load the step scalars of `wrapper` (same sampler structure and number of steps as the captured one, any schedule /
+        shift / begin index / stochasticity) into table slot `slot`: a dry run of its loop on one sample fills the rows, one
+        small host-to-device copy publishes them.  The graph itself is untouched."""
+        from . import _hip
+
+        if self.rows is None:
+            raise ValueError("capture the loop with indexed=True to re-target it")
+        if not 0 <= slot < self.rows.slots:
+            raise ValueError(f"slot {slot} outside 0..{self.rows.slots - 1}")
+        self.rows.begin("refill", slot)
+        _hip.indexed = self.rows
+        try:
+            self._runner(wrapper, self.static_in[:1].clone())
+        finally:
+            _hip.indexed = None
+        if self.rows.cursor != self.rows.length:
+            raise _hip.SkrampleHipError(f"the new schedule issued {self.rows.cursor} launches, the captured loop has {self.rows.length}: re-capture")
+        self.rows.upload(slot)
+
+    def __call__(self, latents: torch.Tensor, seeds: Sequence[int] | None = None, slot: int | None = None) -> torch.Tensor:
         self.static_in.copy_(latents)
+        if slot is not None:
+            if self.rows is None or not 0 <= slot < self.rows.slots:
+                raise ValueError("no such schedule slot")
+            self.rows.index_dev.fill_(slot * self.rows.length)  # the device-resident step index: row = index + position in the loop
         if seeds is not None:
             if self.seeds_dev is None:
                 raise ValueError("this loop draws no noise")
@@ -32,7 +69,8 @@ class CapturedLoop:
         return self.static_out.clone()
 
 
-def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], example: torch.Tensor, steps: int, seeds: Sequence[int] | None = None, warmup: int = 2) -> CapturedLoop:
+def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], example: torch.Tensor, steps: int, seeds: Sequence[int] | None = None, warmup: int = 2,
+                          indexed: bool = False, slots: int = 4) -> CapturedLoop:
     """Capture `for t in wrapper.timesteps: x = wrapper.step(model(x, t), t, x)` for `steps` steps.
 
     `wrapper` is any scheduler wrapper of skrample_amd.diffusers; `model(x, t)` must be capturable (pure device
@@ -52,6 +90,13 @@ def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor],
             x = wrapper.step(model(x, t), t, x, generator=gen, return_dict=False)[0]
         return x
 
+    def run_other(other, x):  # the same loop body on another scheduler instance (re-targeting dry run, one sample)
+        other.set_timesteps(steps)
+        sub = gen[: x.shape[0]] if gen is not None else None
+        for t in other.timesteps.tolist():
+            x = other.step(model(x, t), t, x, generator=sub, return_dict=False)[0]
+        return x
+
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
@@ -60,8 +105,28 @@ def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor],
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
 
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        static_out = run(static_in)
+    rows = None
+    if indexed:
+        from . import _hip
+
+        rows = _hip.IndexedRows(dev, slots=slots)
+        _hip.indexed = rows
+        try:
+            rows.begin("record")
+            run(static_in)  # recording pass: one row per launch, in launch order
+            torch.cuda.synchronize(dev)
+            rows.finish_recording()
+            rows.begin("emit")
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = run(static_in)
+        finally:
+            _hip.indexed = None
+        if rows.cursor != rows.length:
+            raise _hip.SkrampleHipError("the captured loop issued a different number of launches than the recording pass")
+    else:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = run(static_in)
     seeds_dev = getattr(getattr(wrapper, "_noise_generator", None), "_seeds", None)
-    return CapturedLoop(graph, static_in, static_out, seeds_dev)
+    return CapturedLoop(graph, static_in, static_out, seeds_dev, rows, run_other)

@@ -387,7 +387,7 @@ def test_tile_layout_agrees_bitwise(dtypes, n_terms, two_outputs, dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
-@pytest.mark.parametrize(("n_terms", "noise", "rk"), [(1, False, False), (4, True, False), (4, False, False), (8, True, False), (2, False, True), (5, False, True), (8, False, True)])
+@pytest.mark.parametrize(("n_terms", "noise", "rk"), [(1, False, False), (4, True, False), (4, False, False), (8, True, False), (2, False, True), (5, False, True), (8, False, True), (3, True, True), (6, True, True)])
 def test_one_trip_kernels_agree_bitwise(dtype, n_terms, noise, rk, dev):
     """launches made of whole 2048-element chunks take the one-trip loads-first kernels (XCD-aware chunk map, 1-D grid);
     the grid-stride kernels they replace (still used for ragged shapes) and the identity chunk map must give the same bits,
@@ -408,6 +408,8 @@ def test_one_trip_kernels_agree_bitwise(dtype, n_terms, noise, rk, dev):
     if noise:
         plan.noise_mode, plan.zeta0, plan.stream0 = 1, 0.625, 11
     if rk:
+        if noise:  # the stochastic last stage: the draw lands on out1, the derivative (out0) stays clean
+            plan.zeta0, plan.zeta1, plan.stream1 = 0.0, 0.625, 11
         plan.convert_to, plan.convert_from, plan.chain = 1, 2, 0.3125
         for i, v in enumerate((0.7, 0.9, 0.4, 1.3)):
             plan.convert_k[i] = v
@@ -923,6 +925,126 @@ def test_whole_loop_graph_capture(dev):
     x1 = torch.randn(shape, generator=g).bfloat16().to(dev)
     assert torch.equal(loop(x1), eager(x1, seeds))  # new latents, same graph
     assert torch.equal(loop(x1, seeds=[9, 8, 7, 6]), eager(x1, [9, 8, 7, 6]))  # new seeds are read from device memory
+
+
+def _oracle_loop(cfg, sched_name, pred, net, x0, steps, seeds):
+    "the same N-step loop on the oracle (CPU), fed the Philox normals the kernels draw (stream = 256 * step)"
+    o = OW.StepDriver(cfg, oracle_schedule(sched_name, steps), pred)
+    o.set_timesteps(steps)
+    x, n = x0.clone(), x0[0].numel()
+    for i, t in enumerate(o.timesteps.tolist()):
+        noise = torch.from_numpy(np.stack([ON.philox_normal(sd, i * 256, n) for sd in seeds])).reshape(x0.shape)
+        x = o.step(net(x, t), t, x, noise=noise)[0]
+    return x
+
+
+@pytest.mark.parametrize("indexed", [False, True])
+def test_whole_loop_graph_capture_vs_oracle(indexed, dev):
+    """the captured loop (frozen kernel arguments, or device-resident step scalars) against the ORACLE's trajectory of the same
+    loop -- fp32 latents and an elementwise network, so both sides carry only fp32 rounding -- and bitwise against eager"""
+    from skrample_amd.graphs import capture_sampling_loop
+
+    shape, steps, seeds = (4, 4, 32, 32), 9, [3, 4, 5, 6]
+    g = torch.Generator().manual_seed(21)
+    net = lambda x, t: x * 0.75 - (t / 2000) * x.abs()  # noqa: E731
+    x0 = torch.randn(shape, generator=g)
+    mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))  # noqa: E731
+    loop = capture_sampling_loop(mk(), net, x0.to(dev), steps, seeds=seeds, indexed=indexed)
+    got = loop(x0.to(dev))
+    w = mk()
+    w.set_timesteps(steps)
+    x = x0.to(dev)
+    for t in w.timesteps.tolist():
+        x = w.step(net(x, t), t, x, generator=seeds, return_dict=False)[0]
+    assert torch.equal(got, x)
+    ref = _oracle_loop(OA.make("dpm", 2, eta=1), "karras_scaled", "eps", net, x0, steps, seeds)
+    assert rel_err(got, ref) < 5e-5, rel_err(got, ref)  # 9 chained steps of <= 1e-5 each (Philox normals within 2e-6)
+
+
+@pytest.mark.parametrize("kind", ["dpm2_sde", "unipc3_sde", "adams4", "rk4_sde"])
+def test_indexed_graph_serves_other_schedules(kind, dev):
+    """skr_step_launch_indexed: one captured loop, step scalars resident on the device.  Re-targeting it to other schedules of
+    the same length (other sigmas, other base schedule, other stochasticity) only rewrites rows -- no re-capture -- and must
+    reproduce the eager run of that scheduler bit for bit; several schedules stay resident and are picked by the device index."""
+    from skrample_amd.graphs import capture_sampling_loop
+
+    shape, steps, seeds = (4, 4, 32, 32), 6, [11, 12, 13, 14]
+    g = torch.Generator().manual_seed(31)
+    # (the toy network ignores t: a host float t would be frozen into the graph; real pipelines feed the device-resident
+    #  `scheduler.timesteps`, which is data like the rows)
+    net = lambda x, t: x * 0.5 + 0.3 * x.abs()  # noqa: E731
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    makers = {
+        "dpm2_sde": lambda sch, eta=1.0: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=eta), sch),
+        "unipc3_sde": lambda sch, eta=1.0: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=eta), sch),
+        "adams4": lambda sch, eta=0.0: PD.SkrampleWrapperScheduler(PT.Adams(order=4), sch),
+        "rk4_sde": lambda sch, eta=1.0: PD.RKUltraWrapperScheduler(sch, sampler_order=4, stochasticity=eta),
+    }
+    mk = makers[kind]
+    variants = [PS.Karras(PS.Scaled()), PS.Scaled(), PS.Karras(PS.Scaled(), rho=3.0), PS.Exponential(PS.Scaled())]
+
+    def eager(w, x):
+        w.set_timesteps(steps)
+        for t in w.timesteps.tolist():
+            x = w.step(net(x, t), t, x, generator=seeds, return_dict=False)[0]
+        return x
+
+    loop = capture_sampling_loop(mk(variants[0]), net, x0, steps, seeds=seeds, indexed=True, slots=4)
+    assert torch.equal(loop(x0), eager(mk(variants[0]), x0))
+    for slot, sch in enumerate(variants[1:], start=1):
+        loop.retarget(mk(sch), slot=slot)
+    outs = [loop(x0, slot=k) for k in range(4)]
+    for k, sch in enumerate(variants):
+        assert torch.equal(outs[k], eager(mk(sch), x0)), (kind, k)
+    assert not torch.equal(outs[0], outs[1])
+    if kind != "adams4":  # another stochasticity is just other zeta / gamma values in the rows
+        loop.retarget(mk(variants[1], 0.5), slot=0)
+        assert torch.equal(loop(x0, slot=0), eager(mk(variants[1], 0.5), x0))
+    x1 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    assert torch.equal(loop(x1, slot=2), eager(mk(variants[2]), x1))  # new latents, resident schedule 2
+    with pytest.raises(_hip.SkrampleHipError):  # a structurally different sampler cannot reuse the capture
+        loop.retarget(PD.SkrampleWrapperScheduler(PT.Euler(), PS.Scaled()), slot=3)
+
+
+def test_indexed_launch_through_the_c_abi(dev):
+    "skr_step_launch_indexed directly: rows on the device, the index picks the row at run time; unsupported shapes are refused"
+    lib = _hip.load()
+    batch, sample = 2, 4096
+    n = batch * sample
+    g = torch.Generator().manual_seed(5)
+    ins = [torch.randn(n, generator=g).bfloat16().to(dev) for _ in range(3)]
+    seeds = torch.tensor([7, 8], dtype=torch.int64, device=dev)
+    plan = _hip.StepPlanC()
+    plan.n_terms, plan.n_group_a, plan.dtype_a, plan.dtype_b, plan.out0_dtype, plan.out1_dtype = 3, 3, _hip.BF16, _hip.BF16, _hip.BF16, -1
+    plan.noise_mode, plan.sample_numel = 1, sample
+    rows = (_hip.StepRowC * 3)()
+    for r, row in enumerate(rows):
+        for k in range(3):
+            row.coef0[k] = 0.25 * (k + 1) * (-1) ** r
+        row.zeta0, row.stream0 = (0.5, 4 + r) if r < 2 else (0.0, 0)
+    rows_dev = torch.frombuffer(bytearray(bytes(rows)), dtype=torch.uint8).to(dev)
+    index = torch.zeros(1, dtype=torch.int32, device=dev)
+    ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ins])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for idx, off in ((0, 0), (1, 0), (0, 2), (1, 1)):
+        index.fill_(idx)
+        r = idx + off
+        got = torch.empty(n, device=dev, dtype=torch.bfloat16)
+        assert lib.skr_step_launch_indexed(ctypes.byref(plan), ptrs, got.data_ptr(), None, seeds.data_ptr(), n, rows_dev.data_ptr(), index.data_ptr(), off, stream) == 0
+        ref_plan = _hip.StepPlanC()
+        ctypes.memmove(ctypes.byref(ref_plan), ctypes.byref(plan), ctypes.sizeof(plan))
+        for k in range(3):
+            ref_plan.coef0[k] = rows[r].coef0[k]
+        ref_plan.zeta0, ref_plan.stream0 = rows[r].zeta0, rows[r].stream0
+        ref = torch.empty_like(got)
+        _hip.launch_step(ref_plan, ins, ref, None, seeds, n, dev)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), (idx, off)
+    ragged = n - 8  # not made of whole chunks: the one-trip kernels do not cover it
+    assert lib.skr_step_launch_indexed(ctypes.byref(plan), ptrs, got.data_ptr(), None, seeds.data_ptr(), ragged - ragged % sample, rows_dev.data_ptr(), index.data_ptr(), 0, stream) in (0, 7)
+    plan.sample_numel = 8 * 33
+    assert lib.skr_step_launch_indexed(ctypes.byref(plan), ptrs, got.data_ptr(), None, seeds.data_ptr(), 8 * 33 * 2, rows_dev.data_ptr(), index.data_ptr(), 0, stream) == 7  # SKR_ERR_UNSUPPORTED
+    assert lib.skr_step_launch_indexed(ctypes.byref(plan), ptrs, got.data_ptr(), None, seeds.data_ptr(), n, None, None, 0, stream) == 1  # SKR_ERR_NULL
 
 
 @pytest.mark.parametrize("noise", ["Offset", "Pyramid", "Colored", "Brownian"])
