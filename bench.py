@@ -170,6 +170,68 @@ def cpu_baseline(seconds: float) -> dict:
     }
 
 
+def graph_loop_rate(dev: torch.device) -> dict | None:
+    """SURVEY 8(f) rank 1, reported beside the headline: BASELINE config 2 itself (B=64x4x128x128, DPM-2 SDE, Karras, 20 steps)
+    as ONE HIP graph of the whole sampler loop with device-resident step scalars (skr_step_launch_indexed) -- the launch-bound
+    regime where the eager wrapper is host-limited.  Sampler only: the "network" hands back pre-generated tensors."""
+    try:
+        import skrample_amd.diffusers as PD
+        import skrample_amd.scheduling as PS
+        from skrample_amd.graphs import capture_sampling_loop
+        from skrample_amd.sampling import structured as PT
+
+        batch, steps = 64, SCHEDULE_STEPS
+        shape = (batch, C, H, W)
+        g = torch.Generator(device=dev).manual_seed(7)
+        x0 = torch.randn(shape, device=dev, generator=g).to(torch.bfloat16)
+        outs = [torch.randn(shape, device=dev, generator=g).to(torch.bfloat16) for _ in range(4)]
+        calls = [0]
+
+        def net(x, t):  # distinct buffers in turn (the wrapper guards its aliased history against reused output buffers)
+            calls[0] += 1
+            return outs[calls[0] % len(outs)]
+
+        seeds = list(range(42, 42 + batch))
+        mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))  # noqa: E731
+        w = mk()
+
+        def eager():
+            w.set_timesteps(steps)
+            x = x0
+            for t in w.timesteps.tolist():
+                x = w.step(net(x, t), t, x, generator=seeds, return_dict=False)[0]
+            return x
+
+        for _ in range(3):
+            eager()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            eager()
+        torch.cuda.synchronize(dev)
+        eager_s = (time.perf_counter() - t0) / 10
+        loop = capture_sampling_loop(mk(), net, x0, steps, seeds=seeds, indexed=True)
+        for _ in range(5):
+            loop.graph.replay()
+        torch.cuda.synchronize(dev)
+        reps = 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            loop.graph.replay()
+        torch.cuda.synchronize(dev)
+        graph_s = (time.perf_counter() - t0) / reps
+        return {
+            "workload": f"BASELINE config 2: DPM-2 SDE + Karras, eps-pred, B={batch}x{C}x{H}x{W} bf16, {steps}-step loop, sampler only",
+            "graph_steps_per_s": steps / graph_s,
+            "graph_us_per_step": graph_s / steps * 1e6,
+            "eager_steps_per_s": steps / eager_s,
+            "eager_us_per_step": eager_s / steps * 1e6,
+            "mode": "one HIP graph per loop, step scalars read from a device-resident table (skr_step_launch_indexed)",
+        }
+    except Exception as exc:  # informational key: never take the headline down
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
 def load_traffic() -> float | None:
     """HBM bytes per launch of the headline kernel from the committed PMC passes of this same command
     (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per the guide) -- counters cannot
@@ -348,6 +410,7 @@ def main() -> None:
                 "measured_d2d_memcpy": copy_gbs,  # hipMemcpy D2D of 512 MiB on this box, read+write GB/s
             },
             "wrapper_steps_per_s": wrapper_rate,
+            "graph_loop_cfg2": graph_loop_rate(dev),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
