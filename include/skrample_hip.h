@@ -180,6 +180,16 @@ int skr_noise_pyramid_any(void* out, int32_t out_dtype, float* scratch_f32, floa
                           uint64_t stream_levels, int64_t batch, int64_t lead, int64_t h, int64_t w, int32_t resize_h,
                           double strength, int32_t depth, int32_t with_base, void* stream);
 
+/* Pyramid over ANY one or two axes of the unit (reference noise.py:146-193: the resized axes are permuted to the end,
+ * interpolated slice by slice and permuted back; level l normals are drawn in the unit's own axis order, reduced sizes on the
+ * resized axes).  unit_shape[ndim] (ndim <= 4; merge adjacent untouched axes), axis_a < axis_b the resized axes (axis_a = -1:
+ * only axis_b).  Same streams, level geometry, workspaces and normalisation as skr_noise_pyramid_any, which is the special
+ * case unit_shape = (lead, h, w), axes (1, 2). */
+int skr_noise_pyramid_nd(void* out, int32_t out_dtype, float* scratch_f32, float* levels_f32, double* partials_f64, int32_t n_slots,
+                         int32_t* level_ws, const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
+                         int32_t ndim, const int64_t* unit_shape, int32_t axis_a, int32_t axis_b, double strength, int32_t depth,
+                         int32_t with_base, void* stream);
+
 /* Colored.generate / colorize_noise (noise.py:337-425): white Philox noise shaped in the Fourier domain by
  * clamp(radial_frequency, eps)^(-exponent/2) and rescaled per sample to the white noise's std (or `energy`).
  * The per-sample transform is over (d1, d2, d3) (d1 = 1 for a 2-D unit), each a power of two <= 4096.

@@ -31,6 +31,7 @@ EXPORTS = (
     "skr_noise_brownian",
     "skr_noise_pyramid",
     "skr_noise_pyramid_any",
+    "skr_noise_pyramid_nd",
     "skr_noise_colored",
     "skr_noise_colored_any",
     "skr_colorize",
@@ -215,6 +216,8 @@ def load() -> ctypes.CDLL:
         lib.skr_noise_pyramid.restype = ctypes.c_int
         lib.skr_noise_pyramid_any.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, u64, u64, i64, i64, i64, i64, i32, ctypes.c_double, i32, i32, vp]
         lib.skr_noise_pyramid_any.restype = ctypes.c_int
+        lib.skr_noise_pyramid_nd.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, u64, u64, i64, i32, ctypes.POINTER(i64), i32, i32, ctypes.c_double, i32, i32, vp]
+        lib.skr_noise_pyramid_nd.restype = ctypes.c_int
         lib.skr_noise_colored.argtypes = [vp, i32, vp, vp, vp, i64, vp, u64, i64, i32, i32, i32, ctypes.c_double, i32, ctypes.c_double, vp]
         lib.skr_noise_colored.restype = ctypes.c_int
         lib.skr_noise_colored_any.argtypes = [vp, i32, vp, vp, vp, vp, u64, i64, i32, ctypes.POINTER(i32), ctypes.c_double, i32, ctypes.c_double, vp]

@@ -146,6 +146,11 @@ struct PyramidArgs {
   int32_t lead, h, w;
   int32_t resize_h, depth, with_base;
   float strength;
+  // any-dims path (pyramid_pass1_any): the unit as up to four axes, h = dim[axis_a] (axis_a = -1: one resized axis),
+  // w = dim[axis_b], lead = product of the other axes.  Level tensors keep the unit's axis ORDER (reference
+  // noise.py:162-165 draws `randn(running_shape)` before permuting), so level l, element (i0..i3) is normal number
+  // sum_j i_j * stride_l[j] of that level's stream.
+  int32_t nd, dim[4], axis_a, axis_b;
 };
 
 // level geometry (reference noise.py:157-162,195-196): level i shrinks the RUNNING size by r_i**i,
@@ -423,21 +428,37 @@ __global__ __launch_bounds__(256) void pyramid_pass1_any(const PyramidAnyArgs q)
     for (int j = 0; j < 4; ++j) {
       const int64_t e = g * 4 + j;
       if (e >= unit) break;
-      const int64_t c = e / plane, r = e - c * plane;
-      const int y = (int)(r / a.w), x = (int)(r - (int64_t)y * a.w);
+      // coordinates of e in the unit's own axis order; (y, x) = the resized axes, the rest select the slice
+      int idx[4];
+      {
+        int64_t r = e;
+#pragma unroll
+        for (int ax = 3; ax >= 0; --ax) { const int d = a.dim[ax]; idx[ax] = (int)(r % d); r /= d; }
+      }
+      int y = 0, x = 0;
+#pragma unroll
+      for (int ax = 0; ax < 4; ++ax) { if (ax == a.axis_a) y = idx[ax]; if (ax == a.axis_b) x = idx[ax]; }
       for (int l = 1; l < nl; ++l) {
         const float wl = s_wgt[l];
         if (wl == 0.f) continue;
         const int lh = s_lh[l], lw = s_lw[l];
-        const float* gl = lv + s_off[l] + c * lh * lw;
+        // row-major strides of this level's tensor (axis_a -> lh, axis_b -> lw, other axes unchanged)
+        int64_t stride = 1, base_off = 0, str_a = 0, str_b = 0;
+#pragma unroll
+        for (int ax = 3; ax >= 0; --ax) {
+          if (ax == a.axis_b) { str_b = stride; stride *= lw; }
+          else if (ax == a.axis_a) { str_a = stride; stride *= lh; }
+          else { base_off += idx[ax] * stride; stride *= a.dim[ax]; }
+        }
+        const float* gl = lv + s_off[l] + base_off;
         int y0, y1, xa, xb;
         float ly, lx;
         src_index(y, s_sy[l], lh, y0, y1, ly);
         src_index(x, s_sx[l], lw, xa, xb, lx);
-        const float* r0 = gl + (int64_t)y0 * lw;
-        const float* r1 = gl + (int64_t)y1 * lw;
-        const float top = (1.f - lx) * r0[xa] + lx * r0[xb];
-        const float bot = (1.f - lx) * r1[xa] + lx * r1[xb];
+        const float* r0 = gl + (int64_t)y0 * str_a;
+        const float* r1 = gl + (int64_t)y1 * str_a;
+        const float top = (1.f - lx) * r0[xa * str_b] + lx * r0[xb * str_b];
+        const float bot = (1.f - lx) * r1[xa * str_b] + lx * r1[xb * str_b];
         v[j] += wl * ((1.f - ly) * top + ly * bot);
       }
       dst[e] = v[j];
@@ -537,27 +558,35 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   return status_of_launch();
 }
 
-extern "C" int skr_noise_pyramid_any(void* out, int32_t out_dtype, float* scratch_f32, float* levels_f32, double* partials_f64, int32_t n_slots,
-                                     int32_t* level_ws, const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
-                                     int64_t lead, int64_t h, int64_t w, int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream) {
+static int pyramid_nd_impl(void* out, int32_t out_dtype, float* scratch_f32, float* levels_f32, double* partials_f64, int32_t n_slots,
+                           int32_t* level_ws, const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
+                           int32_t nd, const int64_t* shape, int32_t axis_a, int32_t axis_b, double strength, int32_t depth, int32_t with_base, void* stream) {
   skr::DeviceGuard device_guard(out);
-  if (batch < 0 || lead < 1 || h < 1 || w < 1 || depth < 0 || n_slots < 1) return SKR_ERR_SHAPE;
+  if (batch < 0 || depth < 0 || n_slots < 1 || nd < 1 || nd > 4 || !shape) return SKR_ERR_SHAPE;
+  if (axis_b < 0 || axis_b >= nd || axis_a >= axis_b || axis_a < -1) return SKR_ERR_SHAPE;
+  for (int i = 0; i < nd; ++i) if (shape[i] < 1 || shape[i] > 0x7fffffffll) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
   if (!out || !scratch_f32 || !levels_f32 || !partials_f64 || !seeds_dev || !level_ws) return SKR_ERR_NULL;
-  if (h > 32767 || w > 32767 || batch > 65535 || n_slots > 65535) return SKR_ERR_UNSUPPORTED;
-  if (!resize_h && h != 1) return SKR_ERR_SHAPE;
   skr::PyramidAnyArgs q;
   skr::PyramidArgs& a = q.p;
+  // right-align the axes in the 4-slot descriptor
+  const int pad = 4 - nd;
+  for (int i = 0; i < 4; ++i) a.dim[i] = i < pad ? 1 : (int32_t)shape[i - pad];
+  a.nd = nd; a.axis_a = axis_a < 0 ? -1 : axis_a + pad; a.axis_b = axis_b + pad;
+  const int64_t h = axis_a < 0 ? 1 : shape[axis_a], w = shape[axis_b];
+  int64_t unit = 1;
+  for (int i = 0; i < nd; ++i) unit *= shape[i];
+  const int64_t lead = unit / (h * w);
+  if (h > 32767 || w > 32767 || batch > 65535 || n_slots > 65535 || lead > 0x7fffffffll) return SKR_ERR_UNSUPPORTED;
   a.scratch = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
   a.level_hw = level_ws; a.n_levels = level_ws + batch * skr::PYR_MAX_LEVELS * 2;
   a.stream_base = stream_base; a.stream_levels = stream_levels; a.batch = batch; a.lead = (int32_t)lead; a.h = (int32_t)h; a.w = (int32_t)w;
-  a.resize_h = resize_h; a.depth = depth; a.with_base = with_base; a.strength = (float)strength;
-  const int64_t unit = lead * h * w;
+  a.resize_h = axis_a >= 0 ? 1 : 0; a.depth = depth; a.with_base = with_base; a.strength = (float)strength;
   q.levels = levels_f32; q.cap = unit; q.n_slots = n_slots;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(skr::pyramid_geometry, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, a);
   if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
-  int64_t lb = (unit / 16 + 255) / 256;  // levels hold at most unit/3 values
+  int64_t lb = (unit / 16 + 255) / 256;  // the levels >= 1 together hold fewer than `unit` values
   if (lb < 1) lb = 1;
   if (lb > 1024) lb = 1024;
   hipLaunchKernelGGL(skr::pyramid_levels_any, dim3((unsigned)lb, (unsigned)batch), dim3(256), 0, s, q);
@@ -576,4 +605,22 @@ extern "C" int skr_noise_pyramid_any(void* out, int32_t out_dtype, float* scratc
     default: return SKR_ERR_DTYPE;
   }
   return status_of_launch();
+}
+
+extern "C" int skr_noise_pyramid_any(void* out, int32_t out_dtype, float* scratch_f32, float* levels_f32, double* partials_f64, int32_t n_slots,
+                                     int32_t* level_ws, const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
+                                     int64_t lead, int64_t h, int64_t w, int32_t resize_h, double strength, int32_t depth, int32_t with_base, void* stream) {
+  if (lead < 1 || h < 1 || w < 1) return SKR_ERR_SHAPE;
+  if (!resize_h && h != 1) return SKR_ERR_SHAPE;
+  const int64_t shape[3] = {lead, h, w};
+  return pyramid_nd_impl(out, out_dtype, scratch_f32, levels_f32, partials_f64, n_slots, level_ws, seeds_dev, stream_base, stream_levels, batch,
+                         3, shape, resize_h ? 1 : -1, 2, strength, depth, with_base, stream);
+}
+
+extern "C" int skr_noise_pyramid_nd(void* out, int32_t out_dtype, float* scratch_f32, float* levels_f32, double* partials_f64, int32_t n_slots,
+                                    int32_t* level_ws, const uint64_t* seeds_dev, uint64_t stream_base, uint64_t stream_levels, int64_t batch,
+                                    int32_t ndim, const int64_t* unit_shape, int32_t axis_a, int32_t axis_b, double strength, int32_t depth,
+                                    int32_t with_base, void* stream) {
+  return pyramid_nd_impl(out, out_dtype, scratch_f32, levels_f32, partials_f64, n_slots, level_ws, seeds_dev, stream_base, stream_levels, batch,
+                         ndim, unit_shape, axis_a, axis_b, strength, depth, with_base, stream);
 }

@@ -22,6 +22,7 @@ W(t) is a fixed linear function of Philox-keyed node normals, walked on the host
 
 from __future__ import annotations
 
+import ctypes
 import math
 from abc import ABC, abstractmethod
 from dataclasses import dataclass, field
@@ -272,13 +273,43 @@ class Pyramid(TensorNoiseCommon):
 
     @staticmethod
     def _geometry(unit_shape, props) -> tuple[int, int, int, bool]:
+        "(lead, h, w, resize_h) when the resized axes are the trailing one or two (the fast LDS kernels); else None"
         nd = len(unit_shape)
-        dims = sorted((d + nd if d < 0 else d) for d in props.dims)
+        dims = sorted({(d + nd if d < 0 else d) for d in props.dims})
         if dims == [nd - 2, nd - 1] and nd >= 2:
             return math.prod(unit_shape[:-2]), unit_shape[-2], unit_shape[-1], True
         if dims == [nd - 1]:
             return math.prod(unit_shape[:-1]), 1, unit_shape[-1], False
-        raise SkrampleHipError("Pyramid noise resizes the last one or two dimensions (the reference's other `dims` choices fail inside torch.interpolate)")
+        return None
+
+    @staticmethod
+    def _axes_nd(unit_shape, props) -> tuple[list[int], int, int]:
+        """Any pair of resized axes (reference noise.py:146-193: resized axes are permuted to the end, interpolated slice by
+        slice and permuted back; level tensors are drawn in the unit's own axis order).  Adjacent kept axes are merged so
+        that the kernel sees at most four: (shape, axis_a, axis_b)."""
+        nd = len(unit_shape)
+        dims = sorted({(d + nd if d < 0 else d) for d in props.dims})
+        if any(not 0 <= d < nd for d in dims):
+            raise SkrampleHipError(f"Pyramid dims {tuple(props.dims)} outside a {nd}-axis unit")
+        if len(dims) == 1:
+            # (the trailing axis alone is the linear case handled by _geometry)
+            raise SkrampleHipError("Pyramid over a single non-trailing axis: the reference itself fails there (RuntimeError in its permute, noise.py:176); resize the last axis or two axes")
+        if len(dims) != 2:
+            raise SkrampleHipError("Pyramid resizes one or two axes (three would be the reference's 'bicubic' on 5-D input, which torch.interpolate rejects)")
+        shape, axes, run = [], [], None
+        for ax, size in enumerate(unit_shape):
+            if ax in dims:
+                axes.append(len(shape))
+                shape.append(size)
+                run = None
+            elif run is None:
+                run = len(shape)
+                shape.append(size)
+            else:
+                shape[run] *= size
+        if len(shape) > 4:
+            raise SkrampleHipError(f"Pyramid dims {tuple(props.dims)} split the unit {tuple(unit_shape)} into more than four axis groups")
+        return shape, axes[0], axes[1]
 
     def pyramid(self) -> torch.Tensor:
         "just the added 'pyramid' component of the next draw, un-normalised (reference noise.py:146-200)"
@@ -290,7 +321,10 @@ class Pyramid(TensorNoiseCommon):
     def _batch(cls, unit_shape, seeds, stream, step, props, dtype, state, with_base: bool = True):
         # static: the pyramid component is frozen at the first draw (same streams every time), only the base changes
         stream_levels = state.setdefault("static_stream", stream) if props.static else stream
-        lead, h, w, resize_h = cls._geometry(unit_shape, props)
+        geometry = cls._geometry(unit_shape, props)
+        if geometry is None:
+            return cls._batch_nd(unit_shape, seeds, stream, stream_levels, props, dtype, state, with_base)
+        lead, h, w, resize_h = geometry
         batch = seeds.shape[0]
         dev = seeds.device
         key = ("ws", batch, lead, h, w)
@@ -318,6 +352,35 @@ class Pyramid(TensorNoiseCommon):
         else:
             _hip.check(status, "skr_noise_pyramid")
         state["levels"] = levels  # device table of the last draw: [batch][8][2] sizes, then [batch] counts
+        return out
+
+    @classmethod
+    def _batch_nd(cls, unit_shape, seeds, stream, stream_levels, props, dtype, state, with_base: bool):
+        "resized axes anywhere in the unit: the any-shape kernels with an axis descriptor (skr_noise_pyramid_nd)"
+        shape, axis_a, axis_b = cls._axes_nd(unit_shape, props)
+        batch, dev, unit = seeds.shape[0], seeds.device, math.prod(unit_shape)
+        key = ("ws_nd", batch, tuple(shape), axis_a, axis_b)
+        if key not in state:
+            for k in [k for k in state if k != "static_stream"]:
+                del state[k]
+            slots = max(1, min(1024, -(-unit // (4 * 256 * 8))))
+            state[key] = (
+                torch.empty(batch * unit, dtype=torch.float32, device=dev),  # scratch
+                torch.empty(batch * unit, dtype=torch.float32, device=dev),  # level normals
+                torch.empty(batch * slots * 2, dtype=torch.float64, device=dev),
+                torch.empty(batch * (PYRAMID_MAX_LEVELS * 2 + 1), dtype=torch.int32, device=dev),
+                slots,
+            )
+        scratch, level_ws, partials, levels, slots = state[key]
+        out = torch.empty((batch, *unit_shape), dtype=dtype, device=dev)
+        lib, hstream = _launch_ctx(seeds)
+        status = lib.skr_noise_pyramid_nd(
+            out.data_ptr(), _hip.DTYPE_CODE[dtype], scratch.data_ptr(), level_ws.data_ptr(), partials.data_ptr(), slots, levels.data_ptr(), seeds.data_ptr(),
+            stream, stream_levels, batch, len(shape), (ctypes.c_int64 * len(shape))(*shape), axis_a, axis_b, float(props.strength), int(min(props.depth, 1 << 20)),
+            1 if with_base else 0, hstream,
+        )  # fmt: skip
+        _hip.check(status, "skr_noise_pyramid_nd")
+        state["levels"] = levels
         return out
 
 

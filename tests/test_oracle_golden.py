@@ -152,6 +152,24 @@ def test_step_fixtures(name):
         x = prev
 
 
+def test_pyramid_dims_fixtures():
+    """Pyramid over other `dims` subsets (reference noise.py:146-193): the oracle reproduces what the reference returned for the
+    axis pairs it accepts; the single non-trailing axes it rejects (RuntimeError inside its own permute) are recorded as such"""
+    fx = load_npz("noise_dims.npz")
+    tags = sorted({k.rsplit("/", 1)[0] for k in fx if k.endswith("/out")})
+    assert len(tags) == 6
+    for tag in tags:
+        unit = tuple(int(v) for v in tag.split("/")[1].split("x"))
+        dims = tuple(int(d) for d in fx[f"{tag}/dims"])
+        normals = [torch.from_numpy(fx[f"{tag}/normal{i}"]) for i in range(int(fx[f"{tag}/n_normals"]))]
+        rp = ON.Replay(normals, fx[f"{tag}/uniforms"].tolist())
+        got = ON.pyramid_noise(unit, rp.randn, rp.rand1, dims=dims)
+        assert torch.equal(got, torch.from_numpy(fx[f"{tag}/out"])), tag
+        assert not rp.normals
+    rejected = sorted(k.split("/")[0] for k in fx if k.endswith("/reference_error"))
+    assert rejected == ["pyramid_d0", "pyramid_d0", "pyramid_d1", "pyramid_d1"]
+
+
 def test_step_fixture_rk():
     "oracle == reference RKUltraWrapperScheduler.step (Cash-Karp, SDE) bit for bit"
     fx = load_npz("steps_cfg5.npz")

@@ -300,6 +300,21 @@ def noise() -> None:
     )
     np.savez_compressed(os.path.join(OUT, "noise.npz"), **blob)
 
+    # noise_dims.npz: Pyramid over other `dims` subsets (noise.py:146-193 permutes the resized axes to the end, interpolates
+    # slice by slice and permutes back; the level normals are drawn in the unit's own axis order)
+    blob = {}
+    for unit in ((4, 16, 24), (6, 10, 12)):
+        u = "x".join(map(str, unit))
+        for k, dims in enumerate(((0, 1), (0, 2), (0,), (1,), (-2,), (1, 2))):
+            tag = "d" + "".join(str(d % len(unit)) for d in dims)
+            gen = RN.Pyramid.from_inputs(unit, g(40 + k), RN.PyramidProps(dims=dims))
+            try:
+                put(f"pyramid_{tag}/{u}", *record(lambda: gen.generate(None)))
+                blob[f"pyramid_{tag}/{u}/dims"] = np.asarray(dims)
+            except Exception as exc:  # the reference itself rejects this choice: recorded, so the product may refuse it too
+                blob[f"pyramid_{tag}/{u}/reference_error"] = np.asarray(type(exc).__name__)
+    np.savez_compressed(os.path.join(OUT, "noise_dims.npz"), **blob)
+
 
 def _exp(step) -> float:
     seen = {}
