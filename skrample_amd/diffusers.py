@@ -24,6 +24,7 @@ import ctypes
 import dataclasses
 import functools
 import math
+import weakref
 from collections import OrderedDict
 from collections.abc import Hashable, Mapping, Sequence
 from types import MappingProxyType
@@ -300,7 +301,27 @@ class SkrampleWrapperCore(abc.ABC):
 
     @property
     def timesteps(self) -> Tensor:
-        return torch.from_numpy(self.schedule_np[:, 0]).to(self._device)
+        out = torch.from_numpy(self.schedule_np[:, 0]).to(self._device)
+        if out.is_cuda:
+            # remember what was handed out: a 0-d slice of it (`for t in scheduler.timesteps`) is then recognised by its storage
+            # offset -- the index without the reference's .item() synchronisation (diffusers.py:565-567)
+            issued = [ref for ref in getattr(self, "_issued_timesteps", []) if ref() is not None][-3:]
+            issued.append(weakref.ref(out))
+            self._issued_timesteps = issued
+        return out
+
+    def _device_timestep_index(self, timestep: Tensor) -> int | None:
+        "index of a device-resident timestep that is an element of a `timesteps` tensor this scheduler handed out; else None"
+        if timestep.numel() != 1:
+            return None
+        ptr = timestep.data_ptr()
+        for ref in getattr(self, "_issued_timesteps", ()):
+            base = ref()
+            if base is not None and base.dtype == timestep.dtype and base.device == timestep.device:
+                off = ptr - base.data_ptr()
+                if 0 <= off < base.numel() * base.element_size() and off % base.element_size() == 0:
+                    return off // base.element_size()
+        return None
 
     @property
     def sigmas(self) -> Tensor:
@@ -345,6 +366,12 @@ class SkrampleWrapperCore(abc.ABC):
     def get_step_noise(self, step: Step, sample: Tensor, noise_type, noise_props, generator=None, dtype: torch.dtype | None = None, lazy_ok: bool = False):
         """noise for this step: [B, *unit].  With `lazy_ok` plain white noise comes back symbolic
         (drawn inside the step kernel); otherwise a tensor of `dtype or sample.dtype`."""
+        handed = getattr(self, "_predrawn_noise", None)
+        if handed is not None:  # drawn by a stage replay that then fell back to the normal path
+            self._predrawn_noise = None
+            if lazy_ok or not isinstance(handed, lazy.PhiloxNoise):
+                return handed if lazy_ok else lazy.cast(handed, dtype or sample.dtype)
+            return lazy.cast(handed.realize(torch.float32), dtype or sample.dtype)
         if self._noise_generator is None:
             self._noise_generator = self._make_noise_generator(step, sample, noise_type, noise_props, generator)
         if lazy_ok:
@@ -387,10 +414,20 @@ class SkrampleWrapperCore(abc.ABC):
 
     def _lookup(self, table: Sequence[float], timestep, expected: int) -> int:
         value = _host_number(timestep)
-        if value is None:  # device tensor: trust the schedule order, no sync
-            if not 0 <= expected < len(table):
-                raise ValueError(f"step {expected} is outside the {len(table)}-step schedule")
-            return expected
+        if value is None:
+            # device tensor.  An element of the `timesteps` tensor this scheduler handed out is located by its storage
+            # offset (no sync).  A foreign device scalar is read back once, as the reference does (diffusers.py:566) --
+            # except under stream capture, where a read-back is impossible and the schedule order is authoritative.
+            idx = self._device_timestep_index(timestep)
+            if idx is not None:
+                if not 0 <= idx < len(table):
+                    raise ValueError(f"timestep index {idx} is outside the {len(table)}-step schedule")
+                return idx
+            if torch.cuda.is_current_stream_capturing():
+                if not 0 <= expected < len(table):
+                    raise ValueError(f"step {expected} is outside the {len(table)}-step schedule")
+                return expected
+            value = timestep.item()
         return table.index(value)
 
     @staticmethod
@@ -735,6 +772,10 @@ class RKWrapperCore(SkrampleWrapperCore):
     def step(self, model_output: Tensor, timestep, sample: Tensor, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict: bool = True):
         value = _host_number(timestep)
         expected = self.all_points[self._index].timestep
+        if value is None:  # device timestep: checked through its position in the `timesteps` tensor we handed out (no sync)
+            idx = self._device_timestep_index(timestep)
+            if idx is not None:
+                assert idx == self._index, f"Expected timestep {expected} for step {self._index}, got element {idx} of the schedule!"
         if value is not None:
             assert value == expected, f"Expected timestep {expected} for step {self._index}, got {timestep=}!"
         if not self.alias_history and self.order > 1:
@@ -872,29 +913,39 @@ class RKWrapperCore(SkrampleWrapperCore):
         pending = [self._single_tensor(d) for d in self._derivatives]
         if any(t is None for t in pending):
             return None
+        def fits(t, dt) -> bool:
+            return isinstance(t, Tensor) and t.dtype == dt and t.numel() == prog["numel"] and t.is_contiguous() and t.data_ptr() % 16 == 0
+
+        # every operand that exists before the draw is validated BEFORE the draw: a fallback to the normal path must not find
+        # the noise generator one draw further than a run that never tried the replay
+        for role, dt in zip(prog["roles"], prog["dtypes"]):
+            kind = role[0]
+            if kind != "n" and not fits(sample if kind == "x" else model_output if kind == "o" else self._sample if kind == "b" else pending[role[1]], dt):
+                return None
         noise = None
         if prog["noise"] is not None:
             base = sample if self._sample is None else self._sample
             noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), base, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
-        ops = []
-        for role, dt in zip(prog["roles"], prog["dtypes"]):
-            kind = role[0]
-            t = sample if kind == "x" else model_output if kind == "o" else self._sample if kind == "b" else noise if kind == "n" else pending[role[1]]
-            if not isinstance(t, Tensor) or t.dtype != dt or t.numel() != prog["numel"] or not t.is_contiguous() or t.data_ptr() % 16:
-                return None
-            ops.append(t)
         plan = prog["plan"]
         seeds_ptr = None
+        ok = True
         if prog["noise"] == "philox":
-            if not isinstance(noise, lazy.PhiloxNoise) or not noise.fusable() or noise.shape != prog["shape"]:
-                return None
+            ok = isinstance(noise, lazy.PhiloxNoise) and noise.fusable() and noise.shape == prog["shape"]
+        elif prog["noise"] == "tensor":
+            ok = isinstance(noise, Tensor) and all(fits(noise, dt) for role, dt in zip(prog["roles"], prog["dtypes"]) if role[0] == "n")
+        if not ok:
+            self._predrawn_noise = noise  # the normal path consumes this draw instead of making another
+            return None
+        if prog["noise"] == "philox":
             if prog["converted"]:
                 plan.stream1 = noise.stream
             else:
                 plan.stream0 = noise.stream
             seeds_ptr = noise.seeds.data_ptr()
-        elif prog["noise"] == "tensor" and not isinstance(noise, Tensor):
-            return None
+        ops = []
+        for role, dt in zip(prog["roles"], prog["dtypes"]):
+            kind = role[0]
+            ops.append(sample if kind == "x" else model_output if kind == "o" else self._sample if kind == "b" else noise if kind == "n" else pending[role[1]])
         dev = sample.device
         out0 = lazy.empty_output(prog["shape"], prog["out_dtypes"][0], dev)
         out1 = lazy.empty_output(prog["shape"], prog["out_dtypes"][1], dev) if prog["out_dtypes"][1] is not None else None

@@ -574,11 +574,18 @@ def settle(value, like=None, dtype: torch.dtype | None = None):
 class LazyTensor:
     """A form that is evaluated on first use.  Returned where the reference returns a tensor that
     callers rarely read (e.g. `pred_original_sample`): unused, it costs no HBM traffic; used in any
-    torch function or via `.materialize()`, it becomes an ordinary tensor."""
+    torch function, arithmetic, indexing or via `.materialize()`, it becomes an ordinary tensor.
 
-    def __init__(self, form: Lin | None, dtype: torch.dtype, form_fn=None, shape=None, device=None):
+    The form's leaves are the caller's own tensors, so a late evaluation would silently use whatever they hold by
+    then: every leaf is stamped (data_ptr, _version) at creation and `materialize()` refuses to run once one of them
+    has been modified in place -- read the value before reusing the buffers, as with any view."""
+
+    def __init__(self, form: Lin | None, dtype: torch.dtype, form_fn=None, shape=None, device=None, leaves=None):
         self._form, self._form_fn, self.dtype, self._value = form, form_fn, dtype, None
         self._shape, self._device = shape, device
+        if leaves is None and form is not None and isinstance(form, Lin):
+            leaves = [leaf for leaf, _ in form.terms.values() if isinstance(leaf, torch.Tensor)]
+        self._stamps = [(t, t.data_ptr(), t._version) for t in (leaves or ()) if isinstance(t, torch.Tensor)]
 
     @property
     def form(self) -> Lin:
@@ -596,7 +603,11 @@ class LazyTensor:
 
     def materialize(self) -> torch.Tensor:
         if self._value is None:
+            for t, ptr, version in self._stamps:
+                if t._version != version or t.data_ptr() != ptr:
+                    raise SkrampleHipError("an operand of this lazily evaluated tensor was modified in place before it was read; materialize() it (or use it) before reusing the buffers it was computed from")
             self._value = evaluate([self.form], [self.dtype])[0]
+            self._stamps = []
         return self._value
 
     def to(self, *args, **kwargs):
@@ -606,6 +617,26 @@ class LazyTensor:
         if name.startswith("__"):
             raise AttributeError(name)
         return getattr(self.materialize(), name)
+
+    # python operators and the container protocol are looked up on the type, not through __getattr__
+    def __len__(self):
+        return len(self.materialize())
+
+    def __getitem__(self, key):
+        return self.materialize()[key]
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __neg__(self):
+        return -self.materialize()
+
+    def __abs__(self):
+        return abs(self.materialize())
+
+    def __array__(self, dtype=None):
+        v = self.materialize().detach().cpu()
+        return v.float().numpy() if v.dtype in (torch.bfloat16,) else (v.numpy() if dtype is None else v.numpy().astype(dtype))
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -617,6 +648,20 @@ class LazyTensor:
             return a
 
         return func(*unwrap(args), **{k: unwrap(v) for k, v in (kwargs or {}).items()})
+
+
+def _lazy_binary(name: str):
+    def op(self, other):
+        other = other.materialize() if isinstance(other, LazyTensor) else other
+        return getattr(self.materialize(), name)(other)
+
+    op.__name__ = name
+    return op
+
+
+for _name in ("add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "pow", "rpow", "matmul", "rmatmul", "floordiv", "mod", "eq", "ne", "lt", "le", "gt", "ge"):
+    setattr(LazyTensor, f"__{_name}__", _lazy_binary(f"__{_name}__"))
+LazyTensor.__hash__ = object.__hash__  # (defining __eq__ would otherwise drop hashability)
 
 
 def is_number(x: Any) -> bool:

@@ -179,5 +179,5 @@ class StepProgram:
                     form = piece if form is None else form + piece
                 return form
 
-            prediction = LazyTensor(None, dtype, form_fn=make_form, shape=self.shape, device=device)
+            prediction = LazyTensor(None, dtype, form_fn=make_form, shape=self.shape, device=device, leaves=[leaf for leaf, _ in bound])
         return SKSamples(sample, prediction, step, roles.noise, final)

@@ -848,6 +848,41 @@ def test_alias_history_off_survives_buffer_reuse(dev):
             assert torch.equal(res, x_ref), i
 
 
+def test_device_timesteps_are_located_not_assumed(dev):
+    """device-resident timesteps used to be trusted to arrive in schedule order.  An element of the `timesteps`
+    tensor the scheduler handed out is now recognised by its storage offset (no .item() sync), so a pipeline that slices,
+    repeats or skips steps gets the coefficients of the step it names; a foreign device scalar is read back once, as in the
+    reference (diffusers.py:565-567)."""
+    shape, steps = (2, 4, 16, 16), 8
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(shape, generator=g).to(dev)
+    outs = [torch.randn(shape, generator=g).to(dev) for _ in range(steps)]
+    mk = lambda: PD.SkrampleWrapperScheduler(PT.Euler(), PS.Scaled())  # noqa: E731
+
+    def run(kind):
+        w = mk()
+        w.set_timesteps(steps, device=dev)
+        ts_dev, ts_host = w.timesteps, w.timesteps.tolist()
+        x = x0
+        for i in (0, 1, 2, 5, 6):  # a pipeline that skips steps 3-4 without set_begin_index
+            t = {"host": ts_host[i], "view": ts_dev[i], "foreign": torch.tensor(ts_host[i], dtype=ts_dev.dtype, device=dev)}[kind]
+            x = w.step(outs[i], t, x, return_dict=False)[0]
+        return x
+
+    ref = run("host")
+    assert torch.equal(run("view"), ref) and torch.equal(run("foreign"), ref)
+    w = mk()
+    w.set_timesteps(steps, device=dev)
+    with pytest.raises(ValueError):
+        w.step(outs[0], torch.tensor(123.456, dtype=torch.float64, device=dev), x0)  # not a timestep of this schedule
+    rk = PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=2)
+    rk.set_timesteps(4, device=dev)
+    ts = rk.timesteps
+    rk.step(outs[0], ts[0], x0)
+    with pytest.raises(AssertionError):
+        rk.step(outs[1], ts[2], x0)  # out of order: the reference asserts on the value, here the position is checked
+
+
 def test_aliased_history_is_guarded(dev):
     """the default wrapper keeps the caller's tensors as history operands (the reference deep-copies, structured.py:113-125):
     a caller that reuses its buffers must get an error, never a silently wrong step; alias_history=False snapshots and must
