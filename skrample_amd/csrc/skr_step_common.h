@@ -69,8 +69,7 @@ struct RowRef {
   const int32_t* index;
   int32_t row_offset;
 };
-__device__ __forceinline__ const skr_step_row* row_of(const RowRef& r) {
-  if (r.rows == nullptr) return nullptr;
+__device__ __forceinline__ const skr_step_row* row_of(const RowRef& r) {  // (only called by the TAB instantiations: rows != nullptr)
   return r.rows + ((r.index != nullptr ? r.index[0] : 0) + r.row_offset);
 }
 

@@ -36,22 +36,27 @@ __device__ __forceinline__ uint32_t chunk_of(uint32_t b, int lr) {  // lr = log2
   return ((b >> g) << g) + ((b & 7u) << lr) + ((b >> 3) & ((1u << lr) - 1u));
 }
 
-template <typename T, int K, bool NOISE, bool TILE, bool PACE>
+template <typename T, int K, bool NOISE, bool TILE, bool PACE, bool TAB>
 __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 4 ? 4 : 8)> a) {
   const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
   const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
   Raw<T> raw[K];
   float z[VEC];
-  // the step's scalars: kernarg, or the device-resident row of an indexed launch (uniform branch, scalar loads)
-  float cf[K], zeta0 = a.zeta0;
-  uint64_t stream0 = a.stream0;
-#pragma unroll
-  for (int j = 0; j < K; ++j) cf[j] = a.c0[j];
-  if (const skr_step_row* row = row_of(a.tab)) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) cf[j] = (float)row->coef0[j];
-    zeta0 = (float)row->zeta0;
-    stream0 = row->stream0;
+  // The step's scalars come from the kernarg or, in the TAB instantiation (indexed launches), from the device-resident row
+  // (two dependent scalar loads).  They are fetched AFTER the first global loads have been issued, and the choice is a
+  // template parameter: as a run-time branch in front it put three scalar round trips before the first load of every wave
+  // (+0.3 us on the headline launch), and the compiler sank the loads behind the branch wherever it stood.
+  float cf[K], zeta0;
+  uint64_t stream0;
+#define SKR_SCALARS()                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                         \
+  zeta0 = a.zeta0; stream0 = a.stream0;                                      \
+  _Pragma("unroll") for (int j = 0; j < K; ++j) cf[j] = a.c0[j];             \
+  if constexpr (TAB) {                                                       \
+    const skr_step_row* row = row_of(a.tab);                                 \
+    _Pragma("unroll") for (int j = 0; j < K; ++j) cf[j] = (float)row->coef0[j]; \
+    zeta0 = (float)row->zeta0;                                               \
+    stream0 = row->stream0;                                                  \
   }
   // Paced issue.  One burst of K loads per wave is not the fastest order on this memory system: on the headline
   // launch (tools/tune/tune_r2.hip, 256x4x128x128 bf16, K = 4) all loads first runs 26.3 us, loads after the Philox
@@ -68,11 +73,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
       if ((j * 4) / K == SLOT) raw[j] = load_raw<T, TILE>(a.in[j], vj);                      \
     __builtin_amdgcn_sched_barrier(0)
     SKR_ISSUE(0);
+    SKR_ISSUE(1);  // (both before the wave parks on its scalar fetches: holding the second one back behind them cost 0.3 us)
+    SKR_SCALARS();
     const uint32_t smp = c >> a.bps_shift;
     const uint64_t seed = a.seeds[smp];
     uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;  // lane-vector within the sample
-    asm volatile("" : "+v"(vj) : "s"((uint32_t)seed));               // ... behind the seed's arrival
-    SKR_ISSUE(1);
     normal4(seed, stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
     asm volatile("" : "+v"(vj), "+v"(vs) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]));  // ... behind the first block
     __builtin_amdgcn_sched_barrier(0);
@@ -89,6 +94,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
   } else if constexpr (NOISE) {  // unpaced: every load first, then the Philox work
 #pragma unroll
     for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
+    SKR_SCALARS();
     const uint32_t smp = c >> a.bps_shift;
     const uint64_t seed = a.seeds[smp];
     const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
@@ -105,10 +111,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    SKR_SCALARS();
   } else {
 #pragma unroll
     for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
+    SKR_SCALARS();
   }
+#undef SKR_SCALARS
   float s[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) s[i] = 0.f;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
 }
 
 // NOISE: the step's last stage of a stochastic tableau step adds zeta1 * N(stream1) to out1 (the derivative out0 is never noisy)
-template <typename T, int K, bool TILE, bool NOISE>
+template <typename T, int K, bool TILE, bool NOISE, bool TAB>
 __global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
   const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
   const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
@@ -136,7 +145,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
   uint64_t stream1 = a.stream1;
 #pragma unroll
   for (int j = 0; j < K; ++j) cf[j] = a.c1[j];
-  if (const skr_step_row* row = row_of(a.tab)) {
+  if constexpr (TAB) {
+    const skr_step_row* row = row_of(a.tab);
 #pragma unroll
     for (int j = 0; j < K; ++j) cf[j] = (float)row->coef1[j];
 #pragma unroll
@@ -211,8 +221,9 @@ static int launch_k1(const StepArgs<float>& args, int bps_shift, hipStream_t str
   fa.out0 = args.out0; fa.seeds = args.seeds; fa.zeta0 = args.zeta0; fa.stream0 = args.stream0;
   fa.bps_shift = bps_shift; fa.xmap_lr = xmap_lr_for(chunks);
   fa.tab = RowRef{args.rows, args.index, args.row_offset};
-#define SKR_K(N) case N: if (g_tune.pace) hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, true>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); \
-                        else hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, false>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); break
+#define SKR_K(N) case N: if (args.rows != nullptr) hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, true, true>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); \
+                        else if (g_tune.pace) hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, true, false>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); \
+                        else hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, false, false>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); break
   if constexpr (KMAX == 4) { switch (args.n_terms) { SKR_K(1); SKR_K(2); SKR_K(3); SKR_K(4); } }
   else { switch (args.n_terms) { SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); } }
 #undef SKR_K
@@ -242,7 +253,8 @@ static int launch_rk1(const StepArgs<float>& args, unsigned chunks, int bps_shif
   ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
   for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
   ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel; ra.xmap_lr = xmap_lr_for(chunks); ra.tab = RowRef{args.rows, args.index, args.row_offset};
-#define SKR_K(N) case N: hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE, NOISE>), dim3(chunks), dim3(BLOCK), 0, stream, ra); break
+#define SKR_K(N) case N: if (args.rows != nullptr) hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE, NOISE, true>), dim3(chunks), dim3(BLOCK), 0, stream, ra); \
+                        else hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE, NOISE, false>), dim3(chunks), dim3(BLOCK), 0, stream, ra); break
   switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
 #undef SKR_K
   return finish_launch();
@@ -284,7 +296,7 @@ struct TwoOutArgs {
 };
 constexpr int two_out_nmax(int n) { return n <= 4 ? 4 : (n <= 8 ? 8 : 12); }
 
-template <typename TA, int NA, int NB, bool NOISE, bool PACE>
+template <typename TA, int NA, int NB, bool NOISE, bool PACE, bool TAB>
 __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out_nmax(NA + NB)> a) {
   const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
   const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
@@ -292,15 +304,17 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
   Raw<float> rb[NB > 0 ? NB : 1];
   float z0[VEC], z1[VEC];
   bool n0 = false, n1 = false;
-  float cf0[NA + NB], cf1[NA + NB], chain = a.chain, zeta0 = a.zeta0, zeta1 = a.zeta1;
-  uint64_t stream0 = a.stream0, stream1 = a.stream1;
-#pragma unroll
-  for (int j = 0; j < NA + NB; ++j) { cf0[j] = a.c0[j]; cf1[j] = a.c1[j]; }
-  if (const skr_step_row* row = row_of(a.tab)) {
-#pragma unroll
-    for (int j = 0; j < NA + NB; ++j) { cf0[j] = (float)row->coef0[j]; cf1[j] = (float)row->coef1[j]; }
-    chain = (float)row->chain; zeta0 = (float)row->zeta0; zeta1 = (float)row->zeta1;
-    stream0 = row->stream0; stream1 = row->stream1;
+  float cf0[NA + NB], cf1[NA + NB], chain, zeta0, zeta1;  // kernarg or device-resident row, fetched behind the first loads
+  uint64_t stream0, stream1;
+#define SKR_SCALARS()                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                       \
+  chain = a.chain; zeta0 = a.zeta0; zeta1 = a.zeta1; stream0 = a.stream0; stream1 = a.stream1; \
+  _Pragma("unroll") for (int j = 0; j < NA + NB; ++j) { cf0[j] = a.c0[j]; cf1[j] = a.c1[j]; } \
+  if constexpr (TAB) {                                                                     \
+    const skr_step_row* row = row_of(a.tab);                                               \
+    _Pragma("unroll") for (int j = 0; j < NA + NB; ++j) { cf0[j] = (float)row->coef0[j]; cf1[j] = (float)row->coef1[j]; } \
+    chain = (float)row->chain; zeta0 = (float)row->zeta0; zeta1 = (float)row->zeta1;       \
+    stream0 = row->stream0; stream1 = row->stream1;                                        \
   }
   if constexpr (NOISE && PACE) {
     // loads paced over the Philox work (see step_kernel_k1): six slots around the seed fetch and the four blocks
@@ -312,11 +326,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
       if (((NA + j) * 6) / (NA + NB) == SLOT) rb[j] = load_raw<float, true>(a.in[NA + j], vj);            \
     __builtin_amdgcn_sched_barrier(0)
     SKR_ISSUE(0);
+    SKR_ISSUE(1);
+    SKR_SCALARS();
     const uint32_t smp = c >> a.bps_shift;
     const uint64_t seed = a.seeds[smp];
     uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
-    asm volatile("" : "+v"(vj) : "s"((uint32_t)seed));
-    SKR_ISSUE(1);
     n0 = zeta0 != 0.f;
     n1 = zeta1 != 0.f;
     if (n0) normal4(seed, stream0, (uint64_t)group0<true>((int64_t)vs), z0);
@@ -345,6 +359,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
     for (int j = 0; j < NA; ++j) ra[j] = load_raw<TA, true>(a.in[j], v);
 #pragma unroll
     for (int j = 0; j < NB; ++j) rb[j] = load_raw<float, true>(a.in[NA + j], v);
+    SKR_SCALARS();
     if constexpr (NOISE) {
       const uint32_t smp = c >> a.bps_shift;
       const uint64_t seed = a.seeds[smp];
@@ -355,6 +370,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
       if (n1) { normal4(seed, stream1, (uint64_t)group0<true>((int64_t)vs), z1); normal4(seed, stream1, (uint64_t)group1<true>((int64_t)vs), z1 + 4); }
     }
   }
+#undef SKR_SCALARS
   float s0[VEC], s1[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
   store8<float, float, true>(a.out0, v, s0);
 }
 
-template <typename TA, int NA, int NB, bool NOISE, bool PACE>
+template <typename TA, int NA, int NB, bool NOISE, bool PACE, bool TAB>
 static int launch_k2(const StepArgs<float>& args, int bps_shift, hipStream_t stream) {
   constexpr int NMAX = two_out_nmax(NA + NB);
   const int64_t chunks = args.numel / ((int64_t)BLOCK * VEC);
@@ -400,7 +416,7 @@ static int launch_k2(const StepArgs<float>& args, int bps_shift, hipStream_t str
   ta.stream0 = args.stream0; ta.stream1 = args.stream1;
   ta.chain = args.chain; ta.zeta0 = args.zeta0; ta.zeta1 = args.zeta1;
   ta.tab = RowRef{args.rows, args.index, args.row_offset};
-  hipLaunchKernelGGL((step_kernel_k2<TA, NA, NB, NOISE, PACE>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, ta);
+  hipLaunchKernelGGL((step_kernel_k2<TA, NA, NB, NOISE, PACE, TAB>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, ta);
   return finish_launch();
 }
 
@@ -419,8 +435,9 @@ int launch_one_trip_two(const StepArgs<float>& args, bool noise, bool group_b_f3
 #define SKR_GO(A, B)                                                                             \
   if (na == A && nb == B) {                                                                      \
     taken = true;                                                                                \
-    if (!noise) return launch_k2<TA, A, B, false, false>(args, bps_shift, stream);              \
-    return g_tune.pace ? launch_k2<TA, A, B, true, true>(args, bps_shift, stream) : launch_k2<TA, A, B, true, false>(args, bps_shift, stream); \
+    if (args.rows != nullptr) return noise ? launch_k2<TA, A, B, true, true, true>(args, bps_shift, stream) : launch_k2<TA, A, B, false, false, true>(args, bps_shift, stream); \
+    if (!noise) return launch_k2<TA, A, B, false, false, false>(args, bps_shift, stream);       \
+    return g_tune.pace ? launch_k2<TA, A, B, true, true, false>(args, bps_shift, stream) : launch_k2<TA, A, B, true, false, false>(args, bps_shift, stream); \
   }
   SKR_GO(2, 0) SKR_GO(3, 0) SKR_GO(4, 0) SKR_GO(4, 1) SKR_GO(6, 1) SKR_GO(7, 1) SKR_GO(8, 1) SKR_GO(10, 1)
 #undef SKR_GO

@@ -785,12 +785,19 @@ class RKWrapperCore(SkrampleWrapperCore):
             try:
                 return self._step_stage(model_output, sample, generator, return_dict)
             finally:
-                # between stages the step's base sample and (without a rounded conversion) the earlier network outputs
-                # stay operands; nothing of the caller's is held once the step is complete
-                if self._sample is None and not self._derivatives:
-                    self._alias_stamps = []
-                else:
-                    self._alias_hold((sample, model_output), 2 * self.order)
+                # between stages exactly the tensors the pending state still reads are held: the step's base sample and the
+                # leaves of the stored derivative forms (the caller's own network outputs only when no rounded conversion
+                # produced an engine-owned derivative tensor); nothing once the step is complete
+                live: dict[int, Tensor] = {}
+                if self._sample is not None and isinstance(self._sample, Tensor):
+                    live[id(self._sample)] = self._sample
+                for form in self._derivatives:
+                    if isinstance(form, Lin):
+                        for leaf, _ in form.terms.values():
+                            if isinstance(leaf, Tensor):
+                                live[id(leaf)] = leaf
+                known = {id(t): (t, ptr, ver) for t, ptr, ver in self._alias_stamps}
+                self._alias_stamps = [known.get(i) or (t, t.data_ptr(), t._version) for i, t in live.items()]
         return self._step_stage(model_output, sample, generator, return_dict)
 
     def _step_stage(self, model_output: Tensor, sample: Tensor, generator, return_dict: bool):

@@ -14,19 +14,29 @@ import statistics
 import sys
 
 round_tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k1<skr::bf16_t, 4, true, false>"  # headline: K=4 bf16 + Philox, one-trip kernel
+needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k1<skr::bf16_t, 4, true, false, true>"  # headline: K=4 bf16 + Philox, one-trip paced kernel
+HEADLINE_GRID = 256 * 4 * 128 * 128 // 8  # threads of a B=256 launch: bench.py's extra graph-loop key runs the same kernel at B=64
 
 
 def counter(path: str, name: str) -> list[float]:
-    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if needle in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if needle in r["Kernel_Name"] and r["Counter_Name"] == name and int(r["Grid_Size"]) == HEADLINE_GRID]
 
 
-rows = list(csv.DictReader(open("gpurun_out/prof_trace/prof_kernel_stats.csv")))
+# kernel stats rebuilt from the per-dispatch trace, one row per (kernel, grid size): the same kernel runs at B=256 (the timed
+# headline launches) and at B=64 (the graph-loop key of the same bench command), which rocprofv3's own --stats table lumps together
+import collections
+
+groups: dict = collections.defaultdict(list)
+for r in csv.DictReader(open("gpurun_out/prof_trace/prof_kernel_trace.csv")):
+    wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+    groups[(r["Kernel_Name"], grid // wg, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+total = sum(sum(v) for v in groups.values())
 with open(f"profiles/{round_tag}_kernel_stats.csv", "w", newline="") as fh:
     wr = csv.writer(fh)
-    wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for r in rows:
-        wr.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    wr.writerow(["Name", "Workgroups", "WorkgroupSize", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for (name, wgs, wg), d in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        wr.writerow([name[:160], wgs, wg, len(d), sum(d), f"{statistics.mean(d):.3f}", f"{100 * sum(d) / total:.2f}", min(d), max(d), f"{statistics.pstdev(d):.3f}"])
 
 fetch = counter("gpurun_out/prof_fetch/prof_counter_collection.csv", "FETCH_SIZE")
 write = counter("gpurun_out/prof_write/prof_counter_collection.csv", "WRITE_SIZE")
@@ -42,7 +52,7 @@ out = {
     "hbm_bytes_per_launch": 2 * statistics.mean(fetch) * 1024 + statistics.mean(write) * 1024,
     "algorithmic_bytes_per_launch": 256 * 4 * 128 * 128 * 10,
     "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B on wide coalesced streams), WRITE_SIZE x1, KiB -> bytes",
-    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline (one counter per pass)",
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline (one counter per pass; B=256 launches only)",
 }
 json.dump(out, open(f"profiles/{round_tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
@@ -56,7 +66,7 @@ sq = {}
 for path in sorted(glob.glob("gpurun_out/prof_sq*/prof_counter_collection.csv")) + sorted(glob.glob("gpurun_out/prof_misc/prof_counter_collection.csv")):
     acc: dict[str, list[float]] = {}
     for r in csv.DictReader(open(path)):
-        if needle in r["Kernel_Name"]:
+        if needle in r["Kernel_Name"] and int(r["Grid_Size"]) == HEADLINE_GRID:
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in acc.items():
         sq[k] = {"mean_per_launch": statistics.mean(v), "launches": len(v)}
