@@ -103,6 +103,46 @@ def capture_plans(dev: torch.device, shard):
     return plans
 
 
+class _HipEvent:
+    """A raw HIP event created with hipEventDisableSystemFence.  torch.cuda.Event records carry a system-scope release (cache
+    write-back + invalidate): harmless at the ends of the timed region, but as a marker BETWEEN two launches it opens a bubble of
+    several microseconds (24 us under rocprofv3) that would be billed to the kernels.  Same API subset as torch.cuda.Event."""
+
+    _hip = None
+
+    @classmethod
+    def runtime(cls):
+        if cls._hip is None:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+            hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            hip.hipEventQuery.argtypes = [ctypes.c_void_p]
+            hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+            hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+            cls._hip = hip
+        return cls._hip
+
+    def __init__(self, stream: int):
+        self.stream = stream
+        self.handle = ctypes.c_void_p()
+        if self.runtime().hipEventCreateWithFlags(ctypes.byref(self.handle), 0x20000000) != 0:  # hipEventDisableSystemFence
+            raise RuntimeError("hipEventCreateWithFlags failed")
+
+    def record(self) -> None:
+        if self._hip.hipEventRecord(self.handle, self.stream) != 0:
+            raise RuntimeError("hipEventRecord failed")
+
+    def query(self) -> bool:
+        return self._hip.hipEventQuery(self.handle) == 0
+
+    def elapsed_time(self, other: "_HipEvent") -> float:
+        ms = ctypes.c_float()
+        self._hip.hipEventSynchronize(other.handle)
+        if self._hip.hipEventElapsedTime(ctypes.byref(ms), self.handle, other.handle) != 0:
+            raise RuntimeError("hipEventElapsedTime failed")
+        return ms.value
+
+
 class _Seed:
     "minimal stand-in for torch.Generator as a seed carrier (initial_seed only)"
 
@@ -298,7 +338,7 @@ def main() -> None:
         ptrs = (ctypes.c_void_p * len(roles))(*[bufs[r].data_ptr() for r in roles])
         calls.append((ctypes.byref(plan), ptrs, bufs["y"].data_ptr(), seeds.data_ptr()))
 
-    def run(count: int, offset: int = 0) -> None:
+    def run(count: int, offset: int = 0, mark=None) -> None:
         launch = lib.skr_step_launch
         ncalls = len(calls)
         for i in range(count):
@@ -306,20 +346,30 @@ def main() -> None:
             status = launch(p, ptrs, y, None, sd, numel, stream)
             if status:
                 _hip.check(status, "skr_step_launch")
+            if i == 0 and mark is not None:
+                mark.record()  # behind the first timed launch: the kernel clock excludes the cold-queue start of the region
 
+    try:  # HIP events on the launch stream, without the system-scope fence of torch's events (see _HipEvent)
+        e0, e1, e_first, e_warm = (_HipEvent(stream) for _ in range(4))
+    except Exception:
+        e0, e1, e_first, e_warm = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+    for ev in (e0, e1, e_first, e_warm):  # (torch creates its HIP event at the first record: do that outside the timed region)
+        ev.record()
     # conditioning (untimed, before the contract's W warm-up steps): ~8 ms of back-to-back launches so that clocks and
     # the page tables of all buffer sets are in their steady state however small W is
     run(args.precondition)
     torch.cuda.synchronize(dev)
     run(args.warmup)
+    e_warm.record()
+    while not e_warm.query():  # poll, then synchronize: a blocking wait returns tens of us late, and the GPU would sit idle
+        pass                   # (and start the timed region from a colder state) for that long
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     e0.record()
-    run(args.steps, offset=args.warmup)
+    run(args.steps, offset=args.warmup, mark=e_first)
     e1.record()
     while not e1.query():  # poll for completion (a blocking synchronize wakes up tens of us late), then synchronize
         pass
@@ -328,7 +378,11 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    kernel_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream: average per launch
+    # HIP events on the launch stream.  Average launch duration over the timed region = launches 2..K, back to back behind the
+    # first one (the stream is empty when the region starts, so e0 -> first kernel also contains the cold-queue dispatch latency,
+    # which is in `value` / ms_per_step but is not kernel time); K = 1 falls back to the whole span.
+    kernel_ms = e_first.elapsed_time(e1) / (args.steps - 1) if args.steps > 1 else e0.elapsed_time(e1)
+    span_ms = e0.elapsed_time(e1) / args.steps
 
     wall, kernel_ms = max_over_ranks([wall, kernel_ms], dist, dev)  # the slowest rank defines the step time
 
@@ -406,6 +460,7 @@ def main() -> None:
                 "traffic": load_traffic(),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_us_per_launch": kernel_ms * 1e3,
+                "event_span_us_per_launch": span_ms * 1e3,  # e0 -> e1 over all K launches, cold-queue start included
                 "kernel": "skr::step_kernel_k1<bf16_t, K=4, NOISE=true> (one-trip, paced loads, XCD chunk map)",
                 "measured_d2d_memcpy": copy_gbs,  # hipMemcpy D2D of 512 MiB on this box, read+write GB/s
             },

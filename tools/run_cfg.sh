@@ -1,7 +1,6 @@
 set -e
 export TMPDIR=/tmp
-python -m pytest tests/test_step_gpu.py -x -q -m gpu -k "one_trip or baseline_config or two_output or indexed" > gpurun_out/pytest_quick.log 2>&1 || { tail -30 gpurun_out/pytest_quick.log; exit 1; }
-tail -1 gpurun_out/pytest_quick.log
-tools/tune/tune_r2 place=torch > gpurun_out/tune_x.log 2>&1
-cat gpurun_out/tune_x.log
-for i in 1 2 3; do python bench.py --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_us_per_launch'], d['roofline']['frac'], d['graph_loop_cfg2']['graph_steps_per_s'])"; done
+for k in 20 20 400; do python bench.py --steps $k --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['steps'], round(d['value']), round(d['ms_per_step']*1e3,2), round(r['kernel_us_per_launch'],2), round(r['event_span_us_per_launch'],2), round(r['frac'],4))"; done
+cd /tmp
+rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_k20 -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_k20.log 2>&1
+tail -1 $GRAFT_REPO_ROOT/gpurun_out/prof_k20.log | cut -c1-50
