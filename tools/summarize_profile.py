@@ -14,7 +14,7 @@ import statistics
 import sys
 
 round_tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k1<skr::bf16_t, 4, true, false, true>"  # headline: K=4 bf16 + Philox, one-trip paced kernel
+needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k1<skr::bf16_t, 4, true, false, true, false>"  # headline: K=4 bf16 + Philox, one-trip paced kernel, kernarg scalars
 HEADLINE_GRID = 256 * 4 * 128 * 128 // 8  # threads of a B=256 launch: bench.py's extra graph-loop key runs the same kernel at B=64
 
 

@@ -688,10 +688,11 @@ int main(int argc, char** argv) {
   //            BLK  UV MAP PRIO SYNC NOISE
   run_ks<3>("ks stag3 1|1|pa|1|pb|1", sets);
   lib("LIB skr_step_launch");
-  run_kn<16>("kn no-noise sleep16", sets);
-  p.noise_mode = 0; p.zeta0 = 0;
-  lib("LIB skr_step_launch no-noise");
-  p.noise_mode = 1; p.zeta0 = 0.3;
+  run_kv< 256, 1, 107, 0, 0, true>("kv blk256  uv1 R128", sets);
+  run_kv< 128, 1, 108, 0, 0, true>("kv blk128  uv1 R256", sets);
+  run_kv<  64, 1, 109, 0, 0, true>("kv blk64   uv1 R512", sets);
+  run_kv< 128, 1, 107, 0, 0, true>("kv blk128  uv1 R128", sets);
+  run_kv< 512, 1, 106, 0, 0, true>("kv blk512  uv1 R64", sets);
   run_ks<3>("ks stag3 (again)", sets);
   lib("LIB skr_step_launch (again)");
   return 0;
