@@ -222,6 +222,39 @@ def test_inner_boundary_sample_packed(dev):
     assert_close(sched.ipoint(0.3).add_noise(xd, od), x * p.alpha + out * p.sigma, torch.float32, "add_noise")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind", ["dpm2_sde", "adams3", "euler"])
+def test_sampler_level_api_on_16_bit_tensors(dtype, kind, dev):
+    """Called directly (no wrapper), the reference's samplers compute in the TENSOR dtype, rounding after every op
+    (structured.py:209-283 -- only its wrappers widen to compute_scale); this engine accumulates the collapsed form in fp32 and
+    rounds once.  Stated difference, pinned here: the results differ by a few last-place units of the 16-bit type, and the
+    engine's is never farther from the exact (fp64) answer than the reference's native-dtype chain is."""
+    mk_o, mk_p = {"dpm2_sde": (OA.make("dpm", 2, eta=1), PT.DPM(order=2, stochasticity=1)), "adams3": (OA.make("adams", 3), PT.Adams(order=3)),
+                  "euler": (OA.make("euler"), PT.Euler())}[kind]  # fmt: skip
+    sched, model, osched = PS.Scaled(), PM.NoiseModel(), OS.scaled()
+    g = torch.Generator().manual_seed(17)
+    shape, steps = (2, 4, 16, 16), 12
+    xs = [torch.randn(shape, generator=g).to(dtype) for _ in range(4)]
+    outs = [torch.randn(shape, generator=g).to(dtype) for _ in range(4)]
+    nzs = [torch.randn(shape, generator=g).to(dtype) for _ in range(4)]
+    step_of = lambda i: (i / steps, (i + 1) / steps)  # noqa: E731
+    hist = [(xs[k], outs[k], 5 + k) for k in range(3)]  # three earlier steps as history
+    cur = 8
+    prev_p = [PT.SKSamples(x.to(dev), o.to(dev), PT.Step.from_int(i, steps), None, None) for x, o, i in hist]
+    got = mk_p.sample(xs[3].to(dev), outs[3].to(dev), PT.Step.from_int(cur, steps), model, sched, nzs[3].to(dev), prev_p).final.cpu()
+    assert got.dtype == dtype
+    native = OA.sample(mk_o, xs[3], outs[3], step_of(cur), "eps", osched, nzs[3], [OA.Rec(x, o, step_of(i)) for x, o, i in hist]).final
+    exact = OA.sample(mk_o, xs[3].double(), outs[3].double(), step_of(cur), "eps", osched, nzs[3].double(), [OA.Rec(x.double(), o.double(), step_of(i)) for x, o, i in hist]).final
+    assert native.dtype == dtype  # the oracle, like the reference, stayed in the tensor dtype
+    ulp = bf16_ulp(exact.float()) * (1 if dtype == torch.bfloat16 else 2.0**-3)
+    scale = exact.abs().max().item()
+    err_engine = ((got.double() - exact).abs() / (ulp.double() + 1e-5 * scale)).max().item()
+    err_native = ((native.double() - exact).abs() / (ulp.double() + 1e-5 * scale)).max().item()
+    assert err_engine <= 0.51 + 1e-3, err_engine  # one rounding of the exact result (+ the fp32 noise floor of the operands)
+    assert err_engine <= err_native + 1e-9  # never worse than the reference's own native-dtype chain ...
+    assert ((got.double() - native.double()).abs() / (ulp.double() + 1e-5 * scale)).max().item() <= err_native + 0.51 + 1e-3  # ... and close to it
+
+
 @pytest.mark.parametrize("shape", [(3, 4, 32, 32), (2, 3, 16, 16), (2, 6, 16, 16), (3, 1, 8, 8)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_in_kernel_philox_matches_oracle_spec(dtype, shape, dev):
