@@ -913,6 +913,7 @@ class RKWrapperCore(SkrampleWrapperCore):
             "plan": plan, "roles": roles, "dtypes": [t.dtype for t in inputs], "numel": numel, "shape": tuple(sample.shape),
             "out_dtypes": (out0.dtype, out1.dtype if out1 is not None else None), "converted": converted, "finished": finished,
             "noise": "philox" if philox else ("tensor" if isinstance(noise, Tensor) else None), "ptrs": (ctypes.c_void_p * max(len(inputs), 1))(),
+            "drawn": noise is not None,  # the normal path drew for this stage even if the draw's coefficient is zero (last step: zeta = 0)
         }  # fmt: skip
 
     def _replay_stage(self, prog: dict, model_output: Tensor, sample: Tensor, generator):
@@ -930,7 +931,9 @@ class RKWrapperCore(SkrampleWrapperCore):
             if kind != "n" and not fits(sample if kind == "x" else model_output if kind == "o" else self._sample if kind == "b" else pending[role[1]], dt):
                 return None
         noise = None
-        if prog["noise"] is not None:
+        if prog["noise"] is not None or prog.get("drawn"):
+            # (a stage whose draw has a zero coefficient still consumes the draw, as the normal path and the reference do:
+            #  the generator's stream position must not depend on which path ran)
             base = sample if self._sample is None else self._sample
             noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), base, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
         plan = prog["plan"]

@@ -916,6 +916,39 @@ def test_device_timesteps_are_located_not_assumed(dev):
         rk.step(outs[1], ts[2], x0)  # out of order: the reference asserts on the value, here the position is checked
 
 
+def test_stage_replay_fallback_keeps_the_noise_stream(dev):
+    """a stage replay that bailed out AFTER drawing the step noise left the generator one draw ahead, so the normal
+    path drew stream (n+1)*256.  Operands are now validated before the draw (and a draw already made is handed over): a run whose
+    final stages cannot be replayed (non-contiguous network output) must equal the run that replays everything, bit for bit."""
+    shape, steps, seeds = (2, 4, 32, 32), 3, [5, 6]
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    n_calls = 3 * steps * 4
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(n_calls)]
+    wide = [torch.randn(shape[0], shape[1], shape[2], 2 * shape[3], generator=g).bfloat16().to(dev) for _ in range(n_calls)]
+    for o, wd in zip(outs, wide):
+        wd[..., ::2] = o  # the same values behind a strided (non-contiguous) view
+
+    def run(strided_final: bool):
+        w = PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=4, stochasticity=1.0)
+        result = None
+        for rep in range(2):  # second pass: every stage has a recorded program
+            w.set_timesteps(steps)
+            x = x0
+            ts = w.timesteps.tolist()
+            for i, t in enumerate(ts):
+                final_stage = (i + 1) % w.order == 0
+                out = wide[i][..., ::2] if (strided_final and final_stage and rep == 1) else outs[i]
+                x = w.step(out, t, x, generator=seeds, return_dict=False)[0]
+            result = x
+        return result, w._noise_generator._draws
+
+    ref, draws_ref = run(False)
+    got, draws_got = run(True)
+    assert draws_got == draws_ref
+    assert torch.equal(got, ref)
+
+
 def test_aliased_history_is_guarded(dev):
     """the default wrapper keeps the caller's tensors as history operands (the reference deep-copies, structured.py:113-125):
     a caller that reuses its buffers must get an error, never a silently wrong step; alias_history=False snapshots and must

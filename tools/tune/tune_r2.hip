@@ -573,6 +573,55 @@ static void run_kq(const char* name, std::vector<Args>& sets) {
   fflush(stdout);
 }
 
+// few operands: UV vectors per lane (consecutive 4 KiB pieces of one workgroup-owned span), BLK threads
+template <int NIN, int UV, int BLK, int MAPLR>
+__global__ __launch_bounds__(BLK) void kw(const Args a) {
+  const int64_t c = chunk_of<100 + MAPLR>(blockIdx.x, gridDim.x);
+  const int64_t v0 = c * (BLK * UV) + threadIdx.x;
+  u32x4_t r[UV][NIN];
+#pragma unroll
+  for (int u = 0; u < UV; ++u)
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) r[u][j] = ldg(a.in[j] + v0 + u * BLK);
+#pragma unroll
+  for (int u = 0; u < UV; ++u) {
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NIN; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[2 * i] = __builtin_fmaf(a.c[j], __uint_as_float(r[u][j][i] << 16), s[2 * i]);
+        s[2 * i + 1] = __builtin_fmaf(a.c[j], __uint_as_float(r[u][j][i] & 0xFFFF0000u), s[2 * i + 1]);
+      }
+    u32x4_t q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = pack_bf16(s[2 * i], s[2 * i + 1]);
+    stg(a.out + v0 + u * BLK, q);
+  }
+}
+template <int NIN, int UV, int BLK, int MAPLR>
+static void run_kw(const char* name, std::vector<Args>& sets) {
+  const unsigned grid = (unsigned)(sets[0].nvec / (BLK * UV));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double best = 1e9, sum = 0;
+  const int NS = (int)sets.size();
+  auto go = [&](int i) { hipLaunchKernelGGL((kw<NIN, UV, BLK, MAPLR>), dim3(grid), dim3(BLK), 0, 0, sets[i % NS]); };
+  for (int rep = 0; rep < g.reps; ++rep) {
+    for (int i = 0; i < 12; ++i) go(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < g.iters; ++i) go(i);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / g.iters; sum += us; if (us < best) best = us;
+  }
+  const double bytes = (double)g_n * 2 * (NIN + 1);
+  printf("%-44s avg %7.2f us  best %7.2f us  %6.3f TB/s  frac8=%.3f\n", name, sum / g.reps, best, bytes / best / 1e6, bytes / best / 1e6 / 8.0);
+  fflush(stdout);
+}
+
 template <int BLK, int UV, int MAP, int PRIO, int SYNC, bool NOISE>
 static void run_kv(const char* name, std::vector<Args>& sets) {
   const unsigned grid = (unsigned)(sets[0].nvec / (BLK * UV));
@@ -686,14 +735,21 @@ int main(int argc, char** argv) {
     return 0;
   }
   //            BLK  UV MAP PRIO SYNC NOISE
-  run_ks<3>("ks stag3 1|1|pa|1|pb|1", sets);
-  lib("LIB skr_step_launch");
-  run_kv< 256, 1, 107, 0, 0, true>("kv blk256  uv1 R128", sets);
-  run_kv< 128, 1, 108, 0, 0, true>("kv blk128  uv1 R256", sets);
-  run_kv<  64, 1, 109, 0, 0, true>("kv blk64   uv1 R512", sets);
-  run_kv< 128, 1, 107, 0, 0, true>("kv blk128  uv1 R128", sets);
-  run_kv< 512, 1, 106, 0, 0, true>("kv blk512  uv1 R64", sets);
-  run_ks<3>("ks stag3 (again)", sets);
-  lib("LIB skr_step_launch (again)");
+  run_kw<1, 1, 256, 7>("kw 1in uv1 blk256 R128", sets);
+  run_kw<1, 2, 256, 6>("kw 1in uv2 blk256 R64", sets);
+  run_kw<1, 4, 256, 5>("kw 1in uv4 blk256 R32", sets);
+  run_kw<1, 8, 256, 4>("kw 1in uv8 blk256 R16", sets);
+  run_kw<1, 1, 512, 6>("kw 1in uv1 blk512 R64", sets);
+  run_kw<1, 1, 1024, 5>("kw 1in uv1 blk1024 R32", sets);
+  run_kw<1, 2, 512, 5>("kw 1in uv2 blk512 R32", sets);
+  run_kw<2, 1, 256, 7>("kw 2in uv1 blk256 R128", sets);
+  run_kw<2, 2, 256, 6>("kw 2in uv2 blk256 R64", sets);
+  run_kw<2, 4, 256, 5>("kw 2in uv4 blk256 R32", sets);
+  run_kw<2, 1, 512, 6>("kw 2in uv1 blk512 R64", sets);
+  run_kw<2, 2, 512, 5>("kw 2in uv2 blk512 R32", sets);
+  run_kw<3, 1, 256, 7>("kw 3in uv1 blk256 R128", sets);
+  run_kw<3, 2, 256, 6>("kw 3in uv2 blk256 R64", sets);
+  run_kw<4, 1, 256, 7>("kw 4in uv1 blk256 R128", sets);
+  run_kw<4, 2, 256, 6>("kw 4in uv2 blk256 R64", sets);
   return 0;
 }
