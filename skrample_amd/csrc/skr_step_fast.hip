@@ -31,6 +31,13 @@ struct OneTripArgs {
   RowRef tab;
 };
 
+// chunk -> (sample, chunk within the sample).  bps_shift >= 0: a power-of-two number of chunks per sample (shift);
+// bps_shift < 0: -bps_shift chunks per sample (e.g. 18 for 4x96x96 latents), one uniform integer division per wave.
+__device__ __forceinline__ void sample_of(uint32_t c, int32_t bps_shift, uint32_t& smp, uint32_t& within) {
+  if (bps_shift >= 0) { smp = c >> bps_shift; within = c - (smp << bps_shift); }
+  else { const uint32_t bps = (uint32_t)(-bps_shift); smp = c / bps; within = c - smp * bps; }
+}
+
 __device__ __forceinline__ uint32_t chunk_of(uint32_t b, int lr) {  // lr = log2(run length); 0 = identity
   const uint32_t g = 3 + lr;
   return ((b >> g) << g) + ((b & 7u) << lr) + ((b >> 3) & ((1u << lr) - 1u));
@@ -75,9 +82,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
     SKR_ISSUE(0);
     SKR_ISSUE(1);  // (both before the wave parks on its scalar fetches: holding the second one back behind them cost 0.3 us)
     SKR_SCALARS();
-    const uint32_t smp = c >> a.bps_shift;
+    uint32_t smp, within;
+    sample_of(c, a.bps_shift, smp, within);
     const uint64_t seed = a.seeds[smp];
-    uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;  // lane-vector within the sample
+    uint32_t vs = within * BLOCK + threadIdx.x;  // lane-vector within the sample
     normal4(seed, stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
     asm volatile("" : "+v"(vj), "+v"(vs) : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]));  // ... behind the first block
     __builtin_amdgcn_sched_barrier(0);
@@ -95,9 +103,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
 #pragma unroll
     for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
     SKR_SCALARS();
-    const uint32_t smp = c >> a.bps_shift;
+    uint32_t smp, within;
+    sample_of(c, a.bps_shift, smp, within);
     const uint64_t seed = a.seeds[smp];
-    const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
+    const uint32_t vs = within * BLOCK + threadIdx.x;
     normal4(seed, stream0, (uint64_t)group0<TILE>((int64_t)vs), z);
     normal4(seed, stream0, (uint64_t)group1<TILE>((int64_t)vs), z + 4);
   } else if constexpr (PACE && (K == 4 || K == 5)) {  // tools/bench_plan.py: K=4 -1.1 %, K=5 -1.7 %, K=3 +6 % (left unpaced), K>=6 no change
@@ -160,9 +169,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
   if constexpr (NOISE) {
     n1 = zeta1 != 0.f;
     if (n1) {
-      const uint32_t smp = c >> a.bps_shift;
+      uint32_t smp, within;
+      sample_of(c, a.bps_shift, smp, within);
       const uint64_t seed = a.seeds[smp];
-      const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
+      const uint32_t vs = within * BLOCK + threadIdx.x;
       normal4(seed, stream1, (uint64_t)group0<TILE>((int64_t)vs), z1);
       normal4(seed, stream1, (uint64_t)group1<TILE>((int64_t)vs), z1 + 4);
     }
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
   store8<T, float, TILE>(a.out0, v, d);
 }
 
-// one-trip launches: whole chunks, and with in-kernel noise a power-of-two number of whole chunks per sample
+// one-trip launches: whole chunks, and with in-kernel noise samples made of whole chunks (any number of them)
 static bool one_trip_ok(int64_t numel, int64_t sample_numel, bool noise, int* bps_shift, bool forced = false) {
   constexpr int64_t CHUNK = (int64_t)BLOCK * VEC;
   if ((!g_tune.one_trip && !forced) || numel % CHUNK != 0 || numel / CHUNK > 0x7fffffffll) return false;
@@ -198,10 +208,12 @@ static bool one_trip_ok(int64_t numel, int64_t sample_numel, bool noise, int* bp
   if (!noise) return true;
   if (sample_numel % CHUNK != 0) return false;
   const int64_t bps = sample_numel / CHUNK;
-  if (bps & (bps - 1)) return false;
-  while ((1ll << *bps_shift) < bps) ++*bps_shift;
+  if (bps > 0x3fffffffll) return false;
+  if ((bps & (bps - 1)) == 0) { while ((1ll << *bps_shift) < bps) ++*bps_shift; }
+  else *bps_shift = -(int)bps;  // any chunk count per sample: the kernel divides
   return true;
 }
+
 // run length of the XCD chunk map: the largest power of two <= the tuned one whose group of 8 runs divides the grid
 static int xmap_lr_for(int64_t chunks) {
   int lr = g_tune.xmap;
@@ -328,9 +340,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
     SKR_ISSUE(0);
     SKR_ISSUE(1);
     SKR_SCALARS();
-    const uint32_t smp = c >> a.bps_shift;
+    uint32_t smp, within;
+    sample_of(c, a.bps_shift, smp, within);
     const uint64_t seed = a.seeds[smp];
-    uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
+    uint32_t vs = within * BLOCK + threadIdx.x;
     n0 = zeta0 != 0.f;
     n1 = zeta1 != 0.f;
     if (n0) normal4(seed, stream0, (uint64_t)group0<true>((int64_t)vs), z0);
@@ -361,9 +374,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
     for (int j = 0; j < NB; ++j) rb[j] = load_raw<float, true>(a.in[NA + j], v);
     SKR_SCALARS();
     if constexpr (NOISE) {
-      const uint32_t smp = c >> a.bps_shift;
+      uint32_t smp, within;
+      sample_of(c, a.bps_shift, smp, within);
       const uint64_t seed = a.seeds[smp];
-      const uint32_t vs = (c - (smp << a.bps_shift)) * BLOCK + threadIdx.x;
+      const uint32_t vs = within * BLOCK + threadIdx.x;
       n0 = zeta0 != 0.f;
       n1 = zeta1 != 0.f;
       if (n0) { normal4(seed, stream0, (uint64_t)group0<true>((int64_t)vs), z0); normal4(seed, stream0, (uint64_t)group1<true>((int64_t)vs), z0 + 4); }

@@ -421,12 +421,14 @@ def test_tile_layout_agrees_bitwise(dtypes, n_terms, two_outputs, dev):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize(("n_terms", "noise", "rk"), [(1, False, False), (4, True, False), (4, False, False), (8, True, False), (2, False, True), (5, False, True), (8, False, True), (3, True, True), (6, True, True)])
-def test_one_trip_kernels_agree_bitwise(dtype, n_terms, noise, rk, dev):
+@pytest.mark.parametrize("chunks_per_sample", [64, 18])
+def test_one_trip_kernels_agree_bitwise(dtype, n_terms, noise, rk, chunks_per_sample, dev):
     """launches made of whole 2048-element chunks take the one-trip loads-first kernels (XCD-aware chunk map, 1-D grid);
     the grid-stride kernels they replace (still used for ragged shapes) and the identity chunk map must give the same bits,
     including the in-kernel Philox draws (same block numbering per sample)."""
     lib = _hip.load()
-    batch, sample = 6, 2048 * 64  # 64 chunks per sample (a power of two), 384 chunks in all (a multiple of 64: XCD map on)
+    # 64 chunks per sample (a power of two: shift) or 18 (4x96x96 latents: the kernel divides); 384 / 108 chunks in all
+    batch, sample = 6, 2048 * chunks_per_sample
     n = batch * sample
     g = torch.Generator().manual_seed(100 * n_terms + noise)
     ins = [torch.randn(n, generator=g).to(dtype).to(dev) for _ in range(n_terms)]
