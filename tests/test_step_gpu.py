@@ -198,6 +198,57 @@ def test_random_sweep_vs_oracle(seed, dev):
         x = ref
 
 
+def chunked_sweep_case(seed: int, dev) -> None:
+    """one seeded draw over (sampler x schedule x predictor x dtype x run length) on shapes made of whole 2048-element chunks --
+    the domain of the one-trip kernels (k1 / k2) -- with the step noise drawn INSIDE the kernel: checked step by step against the
+    oracle fed the Philox normals the specification assigns (stream 256 * draw)"""
+    import random
+
+    rng = random.Random(7000 + seed)
+    sampler = rng.choice(sorted(SAMPLERS))
+    mk_o, mk_p = SAMPLERS[sampler]
+    if rng.random() < 0.4:
+        sname, mname = rng.choice(FLOW_SCHEDULES), rng.choice(("flow", "data", "v"))
+    else:
+        sname = rng.choice(VP_SCHEDULES)
+        mname = rng.choice(("v", "data") if sname in ("zsnr", "beta_zsnr_flowshift") else ("eps", "v", "data"))
+    dtype = rng.choice((torch.float32, torch.bfloat16, torch.bfloat16, torch.float16))
+    batch = rng.randint(1, 3)
+    chunks = rng.choice((1, 2, 3, 4, 6, 9))  # chunks per sample: powers of two (shift) and others (division)
+    shape = (batch, chunks * 2, 32, 32)
+    steps = rng.randint(2, 10)
+    seeds = [rng.randrange(2**62) for _ in range(batch)]
+    g = torch.Generator().manual_seed(seed)
+    w = PD.SkrampleWrapperScheduler(mk_p(), SCHEDULES[sname][1](), MODELS[mname][1])
+    o = OW.StepDriver(mk_o(), oracle_schedule(sname, steps), MODELS[mname][0])
+    w.set_timesteps(steps)
+    o.set_timesteps(steps)
+    x = torch.randn(shape, generator=g).to(dtype)
+    n = shape[1] * shape[2] * shape[3]
+    what = f"{sampler}/{sname}/{mname}/{dtype}/{shape}/{steps}"
+    draws = 0
+    for i, t in enumerate(w.timesteps):
+        out = torch.randn(shape, generator=g).to(dtype)
+        noise = None
+        if w.sampler.require_noise:
+            noise = torch.from_numpy(np.stack([ON.philox_normal(sd, draws * 256, n) for sd in seeds])).reshape(shape)
+            draws += 1
+        try:
+            ref = o.step(out, t, x, noise=noise)[0]
+        except ZeroDivisionError:
+            return
+        if not torch.isfinite(ref.float()).all():
+            return
+        got = w.step(out.to(dev), t, x.to(dev), generator=seeds, return_dict=False)[0]
+        assert_close(got, ref, dtype, f"{what} step {i}", flips=0.10)
+        x = ref
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_chunked_shapes_sweep_vs_oracle(seed, dev):
+    chunked_sweep_case(seed, dev)
+
+
 def test_inner_boundary_sample_packed(dev):
     "StructuredSampler.sample on HIP tensors: aliases in the record, fresh result tensor, inputs untouched"
     sched, model = PS.Karras(PS.Scaled()), PM.NoiseModel()

@@ -86,7 +86,7 @@ def sweep_in_kernel_philox(seed, dev):
 
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (48, 700)
 for seed in range(lo, hi):
-    for fn in (T.test_random_sweep_vs_oracle, T.test_random_sweep_runge_kutta_vs_oracle, sweep_in_kernel_philox, sweep_float64):
+    for fn in (T.test_random_sweep_vs_oracle, T.test_random_sweep_runge_kutta_vs_oracle, sweep_in_kernel_philox, sweep_float64, T.chunked_sweep_case):
         try:
             fn.__wrapped__(seed, dev) if hasattr(fn, "__wrapped__") else fn(seed, dev)
         except Exception as e:
