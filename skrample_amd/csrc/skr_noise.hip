@@ -193,8 +193,10 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
 constexpr int PYR_UNROLLED = 5;  // levels 1..4 are unrolled (and cached per column strip); deeper levels are rare and tiny
 constexpr int PYR_THREADS = 512;  // 8 waves per block: two 70 KiB blocks per CU keep 16 waves in flight
 
-// STRIP: the block width divides THREADS, so a thread keeps its 4 columns for every row (see below).
-// THREADS: 512 for large planes; 256 for small ones, where it doubles the rows a strip thread revisits.
+// STRIP: the block width divides THREADS, so a thread keeps its 4 columns for a RUN of consecutive rows: the
+// horizontally interpolated level rows (top / bottom) stay in registers while the coarse source row does not change
+// and slide (bottom -> top) when it advances by one.
+// THREADS: 512 for large planes; 256 for small ones, where it doubles the rows of a run.
 template <bool STRIP, int THREADS>
 __global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const PyramidArgs a) {
   extern __shared__ float lds[];  // levels >= 1, back to back
@@ -288,14 +290,17 @@ __global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const Py
   };
 
   if constexpr (STRIP) {
-    // column strips: a thread keeps its 4 columns for every row it visits, so the horizontal taps of the first
-    // PYR_CACHED levels are computed once (packed xa | xb << 16 and the blend weight) instead of once per pixel and row
-    constexpr int PYR_CACHED = PYR_UNROLLED;  // levels 1..4 in registers
-    const int xg = threadIdx.x % w4, x0 = xg * 4, ystep = THREADS / w4;
-    int tap_idx[PYR_CACHED][4];
-    float tap_lx[PYR_CACHED][4];
+    // column strips over a run of consecutive rows: the horizontal taps of the first PYR_CACHED levels (packed
+    // xa | xb << 16 and the blend weight) are computed once per thread, and the horizontally interpolated source rows
+    // (top / bottom) once per coarse row instead of once per pixel
+    constexpr int PYR_CACHED = PYR_UNROLLED;
+    const int xg = threadIdx.x % w4, x0 = xg * 4, groups = THREADS / w4;
+    const int run = (a.h + groups - 1) / groups, ya = (threadIdx.x / w4) * run, yz = ya + run < a.h ? ya + run : a.h;
+    int tap_idx[PYR_CACHED][4], cy0[PYR_CACHED], cy1[PYR_CACHED];
+    float tap_lx[PYR_CACHED][4], top[PYR_CACHED][4], bot[PYR_CACHED][4];
 #pragma unroll
     for (int l = 1; l < PYR_CACHED; ++l) {
+      cy0[l] = -1; cy1[l] = -1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int xa = 0, xb = 0;
@@ -303,13 +308,80 @@ __global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const Py
         if (l < nl) src_index(x0 + j, s_sx[l], s_lw[l], xa, xb, lx);
         tap_idx[l][j] = xa | (xb << 16);
         tap_lx[l][j] = lx;
+        top[l][j] = 0.f; bot[l][j] = 0.f;
       }
     }
-    for (int y = threadIdx.x / w4; y < a.h; y += ystep)
-      pixel_group(y, x0, y * w4 + xg, [&](int l, int j, int& xa, int& xb, float& lx) {
-        if (l < PYR_CACHED) { xa = tap_idx[l][j] & 0xFFFF; xb = tap_idx[l][j] >> 16; lx = tap_lx[l][j]; }
-        else src_index(x0 + j, s_sx[l], s_lw[l], xa, xb, lx);
-      });
+    for (int y = ya; y < yz; ++y) {
+      const int64_t e0 = ((int64_t)c * a.h + y) * a.w + x0;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.with_base) normal4(seed, a.stream_base, (uint64_t)e0 >> 2, v);
+      if (w0 != 0.f) {
+        float z[4];
+        normal4(seed, a.stream_levels + 1, (uint64_t)e0 >> 2, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(z[j], w0, v[j]);
+      }
+#pragma unroll
+      for (int l = 1; l < PYR_CACHED; ++l) {
+        if (l >= nl) break;
+        const float wl = s_wgt[l];
+        if (wl == 0.f) continue;
+        const int lw = s_lw[l];
+        const float* g = lds + s_off[l];
+        int y0, y1;
+        float ly;
+        src_index(y, s_sy[l], s_lh[l], y0, y1, ly);
+        auto row_taps = [&](int row, float* dstv) {
+          const float* r = g + row * lw;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lx = tap_lx[l][j];
+            dstv[j] = (1.f - lx) * r[tap_idx[l][j] & 0xFFFF] + lx * r[tap_idx[l][j] >> 16];
+          }
+        };
+        if (y0 != cy0[l]) {
+          if (y0 == cy1[l]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) top[l][j] = bot[l][j];
+          } else row_taps(y0, top[l]);
+          cy0[l] = y0;
+        }
+        if (y1 != cy1[l]) {
+          if (y1 == y0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bot[l][j] = top[l][j];
+          } else row_taps(y1, bot[l]);
+          cy1[l] = y1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += wl * ((1.f - ly) * top[l][j] + ly * bot[l][j]);
+      }
+#pragma unroll 1
+      for (int l = PYR_CACHED; l < nl; ++l) {  // deeper levels: rare and tiny, sampled directly
+        const float wl = s_wgt[l];
+        if (wl == 0.f) continue;
+        const int lh = s_lh[l], lw = s_lw[l];
+        const float* g = lds + s_off[l];
+        int y0, y1;
+        float ly;
+        src_index(y, s_sy[l], lh, y0, y1, ly);
+        const float* r0 = g + y0 * lw;
+        const float* r1 = g + y1 * lw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int xa, xb;
+          float lx;
+          src_index(x0 + j, s_sx[l], lw, xa, xb, lx);
+          const float tp = (1.f - lx) * r0[xa] + lx * r0[xb];
+          const float bt = (1.f - lx) * r1[xa] + lx * r1[xb];
+          v[j] += wl * ((1.f - ly) * tp + ly * bt);
+        }
+      }
+      const float p1 = (v[0] + v[1]) + (v[2] + v[3]);
+      const float p2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+      s1 += (double)p1; s2 += (double)p2;
+      *reinterpret_cast<float4*>(dst + ((int64_t)y * w4 + xg) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   } else {
     for (int q = threadIdx.x; q < n4; q += THREADS) {
       const int y = q / w4, x0 = (q - y * w4) * 4;
