@@ -47,6 +47,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--precondition", type=int, default=300, help="untimed conditioning launches before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 FETCH_SIZE / WRITE_SIZE passes (roofline.traffic falls back to the committed summary)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no wrapper-rate and graph-loop keys (used by the counter passes)")
     return ap.parse_args()
 
 
@@ -274,13 +276,66 @@ def graph_loop_rate(dev: torch.device) -> dict | None:
 
 def load_traffic() -> float | None:
     """HBM bytes per launch of the headline kernel from the committed PMC passes of this same command
-    (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per the guide) -- counters cannot
-    be read from inside an unprofiled run, so this is the round's measured constant, not a per-run reading"""
+    (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per the guide): the fallback when
+    the live passes below cannot run"""
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         return float(json.load(open(path))["hbm_bytes_per_launch"])
     except Exception:
         return None
+
+
+HEADLINE_KERNEL = "step_kernel_k1<skr::bf16_t, 4, true"  # K=4 bf16 operands + in-kernel Philox (DPM-2 SDE steady state)
+
+
+def measure_traffic(batch: int) -> tuple[float | None, str]:
+    """HBM bytes per launch of the headline kernel, measured now: this command is re-run twice as a child process under
+    `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE and WRITE_SIZE in separate passes, as the guide's HBM section
+    prescribes), the counter rows of the B=`batch` launches of the headline kernel are averaged, and the guide's gfx950
+    corrections are applied (values are KiB; FETCH_SIZE counts the 128-B requests of wide coalesced streams as 64 B -> x2;
+    WRITE_SIZE is exact).  Returns (bytes, provenance); (None, reason) when the profiler is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    grid = batch * C * H * W // 8  # threads of one headline launch (8 elements each)
+    tmp = tempfile.mkdtemp(prefix="skr_pmc_", dir="/tmp")
+    means, counts = {}, {}
+    try:
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, name)
+            cmd = [exe, "--pmc", name, "--kernel-trace", "-d", out_dir, "-o", "prof", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "60", "--warmup", "5", "--precondition", "0",
+                   "--batch", str(batch), "--no-cpu-baseline", "--no-traffic", "--no-extras"]  # fmt: skip
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+            env["TMPDIR"] = "/tmp"
+            proc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if proc.returncode != 0 or not files:
+                return None, f"{name} pass failed (rc {proc.returncode}): {proc.stderr.decode(errors='replace')[-160:]}"
+            vals = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
+                    if HEADLINE_KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name and int(r["Grid_Size"]) == grid]  # fmt: skip
+            vals = [v for v in vals if v > 0.75 * max(vals)] if vals else vals  # steady-state launches (order-1 steps read no history)
+            if len(vals) < 10:
+                return None, f"{name} pass: only {len(vals)} headline launches found"
+            means[name], counts[name] = statistics.mean(vals), len(vals)
+    except subprocess.TimeoutExpired:
+        return None, "counter pass timed out"
+    except Exception as exc:
+        return None, f"{type(exc).__name__}: {exc}"[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = 2.0 * means["FETCH_SIZE"] * 1024.0 + means["WRITE_SIZE"] * 1024.0
+    return total, (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in child processes "
+                   f"({counts['FETCH_SIZE']} / {counts['WRITE_SIZE']} launches; KiB, FETCH x2 on gfx950)")
 
 
 def main() -> None:
@@ -400,7 +455,7 @@ def main() -> None:
 
     # wrapper-level rate (Python scheduler overhead included), for information
     wrapper_rate = None
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         w = make_wrapper()
         shape = (batch, C, H, W)
         xs = [s["x"].view(shape) for s in sets]
@@ -438,6 +493,9 @@ def main() -> None:
         steps_per_s = aggregate_rate(args.steps, world, wall)
         algo_bytes = numel * ALGO_BYTES_PER_ELEM
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = (None, "skipped (--no-traffic)") if args.no_traffic or world > 1 else measure_traffic(batch)
+        if traffic is None:
+            traffic, traffic_source = load_traffic(), f"profiles/r02_pmc_traffic.json (committed summary of the same passes; live: {traffic_source})"
         out = {
             "metric": "sampler steps/sec (fused DPM-2 SDE step, eps-pred, Karras sigmas, Bx4x128x128 bf16) + achieved HBM GB/s",
             "value": steps_per_s,
@@ -469,7 +527,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_us_per_launch": kernel_ms * 1e3,
                 "event_span_us_per_launch": span_ms * 1e3,  # e0 -> e1 over all K launches, cold-queue start included
@@ -477,7 +536,7 @@ def main() -> None:
                 "measured_d2d_memcpy": copy_gbs,  # hipMemcpy D2D of 512 MiB on this box, read+write GB/s
             },
             "wrapper_steps_per_s": wrapper_rate,
-            "graph_loop_cfg2": graph_loop_rate(dev),
+            "graph_loop_cfg2": None if args.no_extras else graph_loop_rate(dev),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
