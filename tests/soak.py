@@ -1,7 +1,7 @@
 """GPU box: run the seeded random parity sweeps of tests/test_step_gpu.py over many more seeds than the test-suite does
-(usage: python tools/soak.py [first_seed last_seed]).  Found the fp16 fused multiply-convert double-rounding mismatch."""
+(usage: python tests/soak.py [first_seed last_seed]).  Found the fp16 fused multiply-convert double-rounding mismatch."""
 import sys, os, traceback
-root = os.environ.get("GRAFT_REPO_ROOT", ".")
+root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
 import torch
 import test_step_gpu as T

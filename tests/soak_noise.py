@@ -1,5 +1,5 @@
 """GPU box: randomised shapes / properties for the Offset, Pyramid, Colored and Brownian generators against the oracle
-(usage: python tools/soak_noise.py [n_cases]); the fixed cases live in tests/test_noise_gpu.py."""
+(usage: python tests/soak_noise.py [n_cases]); the fixed cases live in tests/test_noise_gpu.py."""
 import os, random, sys, traceback
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
