@@ -72,6 +72,11 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 path = os.path.join(dirpath, f)
                 assert not ({"skr_oracle", "oracle"} & _imports(path)), path
+    # nor do the tools (benchmarks, profilers, fixture generators): the checker scripts that call the oracle live in tests/
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            text = open(os.path.join(ROOT, "tools", f)).read()
+            assert "skr_oracle" not in text and '"oracle"' not in text and "'oracle'" not in text, f
 
 
 def test_host_operands_stay_on_the_host_and_never_need_the_library(monkeypatch, tmp_path):
