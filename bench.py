@@ -348,7 +348,10 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs for a one-GPU box (the multi-GPU run proper is one rank per GPU over RCCL): SKR_BENCH_DEVICE pins every
+    # rank to one device index, SKR_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
+    backend = os.environ.get("SKR_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", int(os.environ.get("SKR_BENCH_DEVICE", local_rank)))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torchrun, also for a single rank
@@ -361,7 +364,7 @@ def main() -> None:
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
             dist.barrier()
             torch.cuda.synchronize(dev)
         finally:
@@ -451,7 +454,7 @@ def main() -> None:
     kernel_ms = e_first.elapsed_time(e1) / (args.steps - 1) if args.steps > 1 else e0.elapsed_time(e1)
     span_ms = e0.elapsed_time(e1) / args.steps
 
-    wall, kernel_ms = max_over_ranks([wall, kernel_ms], dist, dev)  # the slowest rank defines the step time
+    wall, kernel_ms = max_over_ranks([wall, kernel_ms], dist, dev if backend == "nccl" else None)  # the slowest rank defines the step time
 
     # wrapper-level rate (Python scheduler overhead included), for information
     wrapper_rate = None
