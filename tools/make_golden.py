@@ -19,6 +19,7 @@ Outputs
 from __future__ import annotations
 
 import ast
+import dataclasses
 import json
 import math
 import os
@@ -316,6 +317,141 @@ def noise() -> None:
     np.savez_compressed(os.path.join(OUT, "noise_dims.npz"), **blob)
 
 
+# ---------------------------------------------------------------------------------------------------
+def _norm(v):
+    "JSON-able, class-identity-free rendering of config values (types by name, dataclasses by repr)"
+    if isinstance(v, type):
+        return f"<{v.__name__}>"
+    if isinstance(v, dict):
+        return {str(k): _norm(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_norm(x) for x in v]
+    if isinstance(v, (bool, int, float, str)) or v is None:
+        return v
+    if isinstance(v, torch.dtype):
+        return str(v)
+    return repr(v)
+
+
+def wrapper_api() -> None:
+    """The scheduler protocol around step(): set_timesteps in its four calling forms, timesteps / sigmas / init_noise_sigma / order /
+    config, add_noise / scale_noise / scale_model_input / time_shift / set_begin_index on CPU tensors, the diffusers-config
+    round trip (parse_diffusers_config, from_diffusers_config, as_diffusers_config) and the functional bridge."""
+    out: dict = {"timesteps": {}, "scale": {}, "configs": {}, "functional": {}}
+    mk = {
+        "euler_scaled": lambda: RD.SkrampleWrapperScheduler(structured.Euler(), RS.Scaled()),
+        "dpm2_karras": lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2, stochasticity=1), RS.Karras(RS.Scaled())),
+        "unipc_flowshift": lambda: RD.SkrampleWrapperScheduler(structured.UniPC(order=3), RS.FlowShift(RS.Linear()), models.FlowModel()),
+        "adams_zsnr_v": lambda: RD.SkrampleWrapperScheduler(structured.Adams(order=4), RS.ZSNR(), models.VelocityModel()),
+        "euler_beta_flowshift": lambda: RD.SkrampleWrapperScheduler(structured.Euler(), RS.FlowShift(RS.Beta(RS.ZSNR()))),
+        "euler_exp_static": lambda: RD.SkrampleWrapperScheduler(structured.Euler(), RS.Exponential(RS.Scaled()), allow_dynamic=False),
+        "rku3_scaled": lambda: RD.RKUltraWrapperScheduler(RS.Scaled(), sampler_order=3),
+        "dyn3_linear": lambda: RD.DynasauRKWrapperScheduler(RS.Linear(), sampler_order=3, model=models.FlowModel()),
+    }
+    forms = {
+        "n7": dict(num_inference_steps=7),
+        "n1": dict(num_inference_steps=1),
+        "timesteps5": dict(timesteps=[900, 700, 500, 300, 100]),
+        "sigmas4": dict(sigmas=[1.0, 0.7, 0.4, 0.1]),
+        "n6_mu": dict(num_inference_steps=6, mu=0.8),
+        "none": dict(),
+    }
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn([2, 3, 4, 4], generator=g, dtype=torch.float64)
+    nz = torch.randn([2, 3, 4, 4], generator=g, dtype=torch.float64)
+    out["x"], out["noise"] = x.flatten().tolist(), nz.flatten().tolist()
+    for name, make in mk.items():
+        for fname, kw in forms.items():
+            w = make()
+            w.set_timesteps(7)  # a previous run's state must not leak into the next call form
+            rec: dict = {}
+            try:
+                w.set_timesteps(**kw)
+                rec = {
+                    "timesteps": w.timesteps.tolist(), "sigmas": w.sigmas.tolist(), "init_noise_sigma": float(w.init_noise_sigma),
+                    "order": int(w.order), "schedule_np": w.schedule_np.tolist(), "config": _norm(dict(w.config)),
+                    "schedule": repr(w.schedule),
+                }  # fmt: skip
+            except Exception as exc:
+                rec = {"error": type(exc).__name__}
+            out["timesteps"][f"{name}/{fname}"] = rec
+        w = make()
+        w.set_timesteps(6)
+        ts = w.timesteps
+        sc: dict = {"time_shift": [float(w.time_shift(0.7, 1.3, torch.tensor(t, dtype=torch.float64))) for t in (0.1, 0.5, 0.9)]}
+        for k in (0, 2, len(ts) - 1):
+            sc[f"scale_noise/{k}"] = w.scale_noise(x, ts[k], nz).flatten().tolist()
+            sc[f"scale_model_input/{k}"] = w.scale_model_input(x, ts[k]).flatten().tolist()
+            sc[f"scale_model_input_float/{k}"] = w.scale_model_input(x, float(ts[k])).flatten().tolist()
+            sc[f"add_noise/{k}"] = w.add_noise(x, nz, ts[k : k + 2]).flatten().tolist()
+        sc["add_noise/empty"] = w.add_noise(x, nz, ts[:0]).flatten().tolist()
+        try:
+            w.set_begin_index(2 * w.order)
+            sc["begin_index/config"] = _norm(dict(w.config)).get("begin_index")
+            sc["begin_index/add_noise"] = w.add_noise(x, nz, ts[2 * w.order : 2 * w.order + 1]).flatten().tolist()
+        except Exception as exc:
+            sc["begin_index/error"] = type(exc).__name__
+        out["scale"][name] = sc
+
+    # diffusers config round trip
+    base_cfgs = []
+    for cls_name in RD.DIFFUSERS_CLASS_MAP:
+        base_cfgs.append({"_class_name": cls_name})
+    variants = [
+        {},
+        {"prediction_type": "v_prediction", "beta_schedule": "scaled_linear", "use_karras_sigmas": True, "solver_order": 3},
+        {"prediction_type": "sample", "beta_schedule": "linear", "use_exponential_sigmas": True, "algorithm_type": "sde-dpmsolver++", "num_train_timesteps": 500},
+        {"prediction_type": "epsilon", "use_beta_sigmas": True, "rescale_betas_zero_snr": True, "timestep_spacing": "trailing"},
+        {"prediction_type": "flow", "shift": 3.0, "use_dynamic_shifting": False},
+        {"flow_shift": 2.0, "use_flow_sigmas": True, "solver_order": 2, "algorithm_type": "dpmsolver++"},
+        {"shift": 1.5, "use_dynamic_shifting": True, "base_shift": 0.5, "max_shift": 1.15, "use_karras_sigmas": True},
+    ]
+    for bc in base_cfgs:
+        for vi, var in enumerate(variants):
+            cfg = {**bc, **var}
+            key = f"{bc['_class_name']}/{vi}"
+            rec = {"config": cfg}
+            try:
+                parsed = RD.parse_diffusers_config(cfg)
+                rec["parsed"] = _norm(dataclasses.asdict(parsed) if False else {f.name: getattr(parsed, f.name) for f in dataclasses.fields(parsed)})
+                w = RD.SkrampleWrapperScheduler.from_diffusers_config(cfg)
+                rec["wrapper"] = {"sampler": repr(w.sampler), "schedule": repr(w.schedule), "model": repr(w.model), "invert": bool(w.invert_prediction)}
+                rec["as_config"] = _norm(RD.as_diffusers_config(w.sampler, w.schedule, w.model))
+                w.set_timesteps(5)
+                rec["timesteps"] = w.timesteps.tolist()
+                rec["sigmas"] = w.sigmas.tolist()
+            except Exception as exc:
+                rec["error"] = type(exc).__name__
+            out["configs"][key] = rec
+    # explicit sampler / schedule arguments override what the config names
+    for key, kw in {
+        "override_sampler": dict(sampler=structured.Adams),
+        "override_schedule": dict(schedule=RS.Linear),
+    }.items():
+        cfg = {"_class_name": "DPMSolverMultistepScheduler", "solver_order": 3, "prediction_type": "epsilon"}
+        parsed = RD.parse_diffusers_config(cfg, **kw)
+        out["configs"][key] = {"config": cfg, "parsed": _norm({f.name: getattr(parsed, f.name) for f in dataclasses.fields(parsed)})}
+
+    # functional bridge on CPU float64 tensors with a linear toy model
+    def toy(xx, t, s, a):
+        return xx * 0.3 - 0.1 * s + 0.05 * a
+
+    for name in ("euler_scaled", "dpm2_karras", "adams_zsnr_v", "rku3_scaled"):
+        w = mk[name]()
+        draws = [torch.randn([2, 3, 4, 4], generator=g, dtype=torch.float64) for _ in range(24)]
+        pool = list(draws)
+        res = w.functional_sample_model(x.clone(), toy, 5, rng=lambda *_: pool.pop(0))
+        used = len(draws) - len(pool)
+        pool2 = list(draws)
+        gen = w.functional_generate_model(toy, lambda *_: pool2.pop(0), 5)
+        out["functional"][name] = {
+            "draws": [d.flatten().tolist() for d in draws[: max(used, len(draws) - len(pool2))]],
+            "sample_model": res.flatten().tolist(), "used": used,
+            "generate_model": gen.flatten().tolist(), "used_generate": len(draws) - len(pool2),
+        }  # fmt: skip
+    json.dump(out, open(os.path.join(OUT, "wrapper_api.json"), "w"))
+
+
 def _exp(step) -> float:
     seen = {}
     orig = RN.Colored.colorize_noise
@@ -334,5 +470,6 @@ if __name__ == "__main__":
     tables()
     steps()
     noise()
+    wrapper_api()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
