@@ -8,7 +8,7 @@ import pytest
 import torch
 from cases import MODELS, SAMPLERS, SCHEDULES, oracle_schedule
 from conftest import load_npz
-from test_step_gpu import EXTRA_WRAPPERS, FIXTURE_WRAPPERS, Injected, assert_close, replay_fixture
+from test_step_gpu import EXTRA2_WRAPPERS, EXTRA_WRAPPERS, FIXTURE_WRAPPERS, Injected, assert_close, replay_fixture
 
 import skrample_amd.diffusers as PD
 import skrample_amd.scheduling as PS
@@ -35,6 +35,14 @@ def test_extra_fixtures_on_cpu(name):
     blob = load_npz("steps_extra.npz")
     fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
     mk, dt = EXTRA_WRAPPERS[name]
+    replay_fixture(mk(), fx, dt, CPU, name)
+
+
+@pytest.mark.parametrize("name", EXTRA2_WRAPPERS)
+def test_extra2_fixtures_on_cpu(name):
+    blob = load_npz("steps_extra2.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
+    mk, dt = EXTRA2_WRAPPERS[name]
     replay_fixture(mk(), fx, dt, CPU, name)
 
 

@@ -96,6 +96,24 @@ EXTRA_WRAPPERS = {
     "rku5_noderiv": (lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=5, derivative_transform=None), torch.float32),
 }
 
+# round 2 (tests/golden/steps_extra2.npz): the predictor-corrector blend, DynasauRK, nested predictors, the other sub-schedules
+EXTRA2_WRAPPERS = {
+    "spc_default": (lambda: PD.SkrampleWrapperScheduler(PT.SPC(), PS.Scaled()), torch.bfloat16),
+    "spc_power2_bias": (lambda: PD.SkrampleWrapperScheduler(PT.SPC(power=2, bias=0.3, adaptive=False), PS.Scaled()), torch.float32),
+    "spc_invert_dpm_unip": (lambda: PD.SkrampleWrapperScheduler(PT.SPC(predictor=PT.DPM(order=2), corrector=PT.UniP(order=3), invert=True), PS.Karras(PS.Scaled())), torch.float32),
+    "spc_sde_v": (lambda: PD.SkrampleWrapperScheduler(PT.SPC(predictor=PT.Euler(stochasticity=1)), PS.ZSNR(), PM.VelocityModel()), torch.bfloat16),
+    "spc_flow_power_half": (lambda: PD.SkrampleWrapperScheduler(PT.SPC(power=0.5, bias=-0.2), PS.Linear(), PM.FlowModel()), torch.float32),
+    "unipc3_dpm_pred_sde": (lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1, predictor=PT.DPM(order=2, stochasticity=1)), PS.Karras(PS.Scaled())), torch.bfloat16),
+    "dpm2_exponential": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2), PS.Exponential(PS.Scaled())), torch.float32),
+    "adams2_beta_zsnr": (lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=2), PS.Beta(PS.ZSNR()), PM.VelocityModel()), torch.float32),
+    "euler_probit_flow": (lambda: PD.SkrampleWrapperScheduler(PT.Euler(), PS.Probit(PS.Linear()), PM.FlowModel()), torch.bfloat16),
+    "dpm2_hyper": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=0.3), PS.Hyper(PS.Scaled())), torch.float32),
+    "unip2_sinner_flow": (lambda: PD.SkrampleWrapperScheduler(PT.UniP(order=2), PS.Sinner(PS.Linear()), PM.FlowModel()), torch.float32),
+    "dyn3_flow": (lambda: PD.DynasauRKWrapperScheduler(PS.Linear(), sampler_order=3, model=PM.FlowModel()), torch.float32),
+    "dyn2_sde_eps": (lambda: PD.DynasauRKWrapperScheduler(PS.Scaled(), sampler_order=2, stochasticity=0.5), torch.bfloat16),
+    "dyn4_v": (lambda: PD.DynasauRKWrapperScheduler(PS.Scaled(), sampler_order=4, model=PM.VelocityModel()), torch.float32),
+}
+
 
 def replay_fixture(w, fx, dtype, dev, name):
     "teacher-forced replay: every step sees exactly the inputs the reference saw"
@@ -127,6 +145,14 @@ def test_extra_fixtures(name, dev):
     blob = load_npz("steps_extra.npz")
     fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
     mk, dt = EXTRA_WRAPPERS[name]
+    replay_fixture(mk(), fx, dt, dev, name)
+
+
+@pytest.mark.parametrize("name", EXTRA2_WRAPPERS)
+def test_extra2_fixtures(name, dev):
+    blob = load_npz("steps_extra2.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
+    mk, dt = EXTRA2_WRAPPERS[name]
     replay_fixture(mk(), fx, dt, dev, name)
 
 

@@ -238,6 +238,30 @@ def steps() -> None:
             blob[f"{name}/{k}"] = v
     np.savez_compressed(os.path.join(OUT, "steps_extra.npz"), **blob)
 
+    # round 2: the predictor-corrector blend (SPC), DynasauRK, nested predictors, the remaining sub-schedules / modifiers
+    extra2 = {
+        "spc_default": (lambda: RD.SkrampleWrapperScheduler(structured.SPC(), RS.Scaled()), bf16),
+        "spc_power2_bias": (lambda: RD.SkrampleWrapperScheduler(structured.SPC(power=2, bias=0.3, adaptive=False), RS.Scaled()), f32),
+        "spc_invert_dpm_unip": (lambda: RD.SkrampleWrapperScheduler(structured.SPC(predictor=structured.DPM(order=2), corrector=structured.UniP(order=3), invert=True), RS.Karras(RS.Scaled())), f32),
+        "spc_sde_v": (lambda: RD.SkrampleWrapperScheduler(structured.SPC(predictor=structured.Euler(stochasticity=1)), RS.ZSNR(), models.VelocityModel()), bf16),
+        "spc_flow_power_half": (lambda: RD.SkrampleWrapperScheduler(structured.SPC(power=0.5, bias=-0.2), RS.Linear(), models.FlowModel()), f32),
+        "unipc3_dpm_pred_sde": (lambda: RD.SkrampleWrapperScheduler(structured.UniPC(order=3, stochasticity=1, predictor=structured.DPM(order=2, stochasticity=1)), RS.Karras(RS.Scaled())), bf16),
+        "dpm2_exponential": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2), RS.Exponential(RS.Scaled())), f32),
+        "adams2_beta_zsnr": (lambda: RD.SkrampleWrapperScheduler(structured.Adams(order=2), RS.Beta(RS.ZSNR()), models.VelocityModel()), f32),
+        "euler_probit_flow": (lambda: RD.SkrampleWrapperScheduler(structured.Euler(), RS.Probit(RS.Linear()), models.FlowModel()), bf16),
+        "dpm2_hyper": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2, stochasticity=0.3), RS.Hyper(RS.Scaled())), f32),
+        "unip2_sinner_flow": (lambda: RD.SkrampleWrapperScheduler(structured.UniP(order=2), RS.Sinner(RS.Linear()), models.FlowModel()), f32),
+        "dyn3_flow": (lambda: RD.DynasauRKWrapperScheduler(RS.Linear(), sampler_order=3, model=models.FlowModel()), f32),
+        "dyn2_sde_eps": (lambda: RD.DynasauRKWrapperScheduler(RS.Scaled(), sampler_order=2, stochasticity=0.5), bf16),
+        "dyn4_v": (lambda: RD.DynasauRKWrapperScheduler(RS.Scaled(), sampler_order=4, model=models.VelocityModel()), f32),
+    }
+    blob = {}
+    for i, (name, (mk, dt)) in enumerate(extra2.items()):
+        rec = run_wrapper(mk(), 2, (4, 8, 8), 7 if "dyn" not in name else 3, dt, seed=3000 + i)
+        for k, v in rec.items():
+            blob[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "steps_extra2.npz"), **blob)
+
 
 # ---------------------------------------------------------------------------------------------------
 class _RecGen:
