@@ -476,6 +476,67 @@ def wrapper_api() -> None:
     json.dump(out, open(os.path.join(OUT, "wrapper_api.json"), "w"))
 
 
+# ---------------------------------------------------------------------------------------------------
+FUNCTIONAL_CASES = {
+    # name: (sampler factory as text evaluated in the test too, model name, schedule name, steps, include)
+    "rku1_eps": ("F.RKUltra(order=1)", "eps", "scaled", 6, (None, None)),
+    "rku2_flow": ("F.RKUltra(order=2)", "flow", "linear", 6, (None, None)),
+    "rku3_sde_eps": ("F.RKUltra(order=3, stochasticity=0.5)", "eps", "karras_scaled", 6, (None, None)),
+    "rku4_v_slice": ("F.RKUltra(order=4)", "v", "zsnr", 7, (2, 5)),
+    "rku6_sde_flow": ("F.RKUltra(order=6, stochasticity=1)", "flow", "linear", 4, (None, None)),
+    "rku5_noderiv": ("F.RKUltra(order=5, derivative_transform=None)", "eps", "scaled", 4, (None, None)),
+    "dyn2_eps": ("F.DynasauRK(order=2)", "eps", "scaled", 6, (None, None)),
+    "dyn3_flow_invert": ("F.DynasauRK(order=3, invert=True)", "flow", "linear", 5, (None, None)),
+    "dyn4_decay": ("F.DynasauRK(order=4, per_step_decay=0.1, total_step_decay=-0.02, stochasticity=0.3)", "eps", "scaled", 5, (1, None)),
+    "moire2": ("F.RKMoire(order=2)", "eps", "scaled", 6, (None, None)),
+    "moire3_flow": ("F.RKMoire(order=3, threshold=1e-3, initial=1 / 20)", "flow", "linear", 6, (None, None)),
+    "moire5_mae": ("F.RKMoire(order=5, evaluator=F.FunctionalAdaptive.mae, adaption=0.5, rescale_max=True)", "eps", "scaled", 8, (None, None)),
+    "moire2_slice_discard": ("F.RKMoire(order=2, discard=2.0, maximum=1 / 3)", "v", "zsnr", 8, (1, 6)),
+    "adapter_dpm2_sde": ("I.StructuredFunctionalAdapter(S.DPM(order=2, stochasticity=1))", "eps", "karras_scaled", 7, (None, None)),
+    "adapter_unipc3_slice": ("I.StructuredFunctionalAdapter(S.UniPC(order=3))", "flow", "linear", 8, (2, 7)),
+    "adapter_spc": ("I.StructuredFunctionalAdapter(S.SPC())", "eps", "scaled", 6, (None, None)),
+}
+
+
+def functional_api() -> None:
+    """The functional samplers (RKUltra, DynasauRK, adaptive RKMoire, the structured adapter) driving a toy model on CPU float64
+    tensors: the result, every (t, sigma, alpha) the model was called at, the callback trace and the draws consumed."""
+    from skrample.sampling import interface
+
+    env = {"F": functional, "S": structured, "I": interface}
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randn([2, 3, 4], generator=g, dtype=torch.float64)
+    out: dict = {"x": x.flatten().tolist(), "cases": {}}
+    for name, (expr, mname, sname, steps, (lo, hi)) in FUNCTIONAL_CASES.items():
+        sampler = eval(expr, env)
+        sched, model_t = CFG_SCHEDULES[sname](), MODELS[mname]
+        draws = [torch.randn([2, 3, 4], generator=g, dtype=torch.float64) for _ in range(40)]
+        pool = list(draws)
+        seen, trace = [], []
+
+        def toy(xx, t, s, a):
+            seen.append([float(t), float(s), float(a)])
+            return xx * 0.3 - 0.1 * s + 0.05 * a + 0.01 * torch.sin(xx * 3.0)
+
+        def cb(sample, n, dp):
+            trace.append([int(n), *[float(v) for v in dp.point_from], *[float(v) for v in dp.point_to], float(sample.sum())])
+
+        rec: dict = {"expr": expr, "model": mname, "schedule": sname, "steps": steps, "include": [lo, hi], "adjust_steps": sampler.adjust_steps(steps) if hasattr(sampler, "adjust_steps") else None}
+        try:
+            res = sampler.sample_model(x.clone(), toy, model_t, sched, steps, slice(lo, hi), lambda *_: pool.pop(0), cb)
+            rec.update(result=res.flatten().tolist(), seen=list(seen), trace=list(trace), used=len(draws) - len(pool))
+            rec["draws"] = [d.flatten().tolist() for d in draws[: rec["used"]]]
+            seen.clear(); trace.clear()
+            pool2 = list(draws)
+            gen = sampler.generate_model(toy, model_t, sched, lambda *_: pool2.pop(0), steps, slice(lo, hi), None if lo is None else x.clone())
+            rec.update(generate=gen.flatten().tolist(), generate_used=len(draws) - len(pool2), generate_nfe=len(seen))
+            rec["generate_draws"] = [d.flatten().tolist() for d in draws[: rec["generate_used"]]]
+        except Exception as exc:
+            rec["error"] = type(exc).__name__
+        out["cases"][name] = rec
+    json.dump(out, open(os.path.join(OUT, "functional_api.json"), "w"))
+
+
 def _exp(step) -> float:
     seen = {}
     orig = RN.Colored.colorize_noise
@@ -495,5 +556,6 @@ if __name__ == "__main__":
     steps()
     noise()
     wrapper_api()
+    functional_api()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
