@@ -104,3 +104,23 @@ def bf16_ulp(ref: torch.Tensor) -> torch.Tensor:
     "one bf16 unit in the last place at |ref|"
     mag = ref.float().abs().clamp_min(2.0**-126)
     return torch.exp2(torch.floor(torch.log2(mag)) - 7)
+
+
+# ---- tests/golden/native16.npz: the sampler-level API called directly on 16-bit tensors (reference-recorded) ----------------
+NATIVE16_ORACLE = {
+    "euler": lambda OA: OA.make("euler"),
+    "euler_sde_v": lambda OA: OA.make("euler", eta=1),
+    "dpm2_sde": lambda OA: OA.make("dpm", 2, eta=1),
+    "dpm3_flow": lambda OA: OA.make("dpm", 3),
+    "adams3": lambda OA: OA.make("adams", 3),
+    "unipc3_flow": lambda OA: OA.make("unipc", 3),
+}
+NATIVE16_TAGS = [f"{n}/{d}" for n in NATIVE16_ORACLE for d in ("bf16", "f16")]
+
+
+def native16_case(blob, tag):
+    "(dtype, steps, model name, schedule name, sampler constructor text, per-step tensors as 16-bit torch tensors)"
+    dt = torch.bfloat16 if tag.endswith("/bf16") else torch.float16
+    expr, mname, sname, steps = (str(v) for v in blob[tag + "/meta"])
+    view = lambda key: [torch.from_numpy(a.copy()).view(dt) for a in blob[f"{tag}/{key}"]]  # noqa: E731
+    return dt, int(steps), mname, sname, expr, {k: view(k) for k in ("x", "out", "noise", "final", "prediction")}

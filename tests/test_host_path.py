@@ -6,9 +6,9 @@ reference-recorded fixtures and the oracle on the CPU, and check that device wor
 import numpy as np
 import pytest
 import torch
-from cases import MODELS, SAMPLERS, SCHEDULES, oracle_schedule
+from cases import MODELS, NATIVE16_TAGS, SAMPLERS, SCHEDULES, oracle_schedule
 from conftest import load_npz
-from test_step_gpu import EXTRA2_WRAPPERS, EXTRA_WRAPPERS, FIXTURE_WRAPPERS, Injected, assert_close, replay_fixture
+from test_step_gpu import EXTRA2_WRAPPERS, EXTRA_WRAPPERS, FIXTURE_WRAPPERS, Injected, assert_close, native16_engine_vs_reference, replay_fixture
 
 import skrample_amd.diffusers as PD
 import skrample_amd.scheduling as PS
@@ -44,6 +44,11 @@ def test_extra2_fixtures_on_cpu(name):
     fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
     mk, dt = EXTRA2_WRAPPERS[name]
     replay_fixture(mk(), fx, dt, CPU, name)
+
+
+@pytest.mark.parametrize("tag", NATIVE16_TAGS)
+def test_sampler_level_api_vs_reference_recorded_16_bit_runs_on_cpu(tag):
+    native16_engine_vs_reference(tag, CPU)
 
 
 @pytest.mark.parametrize("sampler", ["euler", "dpm2_sde", "adams4", "unipc3", "spc"])

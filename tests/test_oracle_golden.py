@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 import torch
-from cases import SCHEDULES, from_bits, oracle_schedule
+from cases import MODELS, NATIVE16_ORACLE, NATIVE16_TAGS, SCHEDULES, from_bits, native16_case, oracle_schedule
 from conftest import eq_nan, load_npz
 
 from skr_oracle import noise as ON
@@ -260,3 +260,21 @@ def test_identities():
                     noisy = OC.pt_add_noise(p, s, n)
                     clean = OC.pt_remove_noise(p, noisy, n)
                     assert abs((s if alpha != 0 else noisy) - clean) < 1e-15
+
+
+@pytest.mark.parametrize("tag", NATIVE16_TAGS)
+def test_native_dtype_chain_equals_the_reference_bit_for_bit(tag):
+    """Called directly on 16-bit tensors the reference's samplers compute in the tensor dtype, rounding after every torch op
+    (structured.py:209-283).  The oracle restates that op order: its chain over the recorded inputs (tests/golden/native16.npz,
+    outputs of the reference itself) reproduces every recorded `final` and `prediction` bit for bit, bf16 and fp16."""
+    dt, steps, mname, sname, _, t = native16_case(load_npz("native16.npz"), tag)
+    cfg, sched = NATIVE16_ORACLE[tag.split("/")[0]](OA), SCHEDULES[sname][0]()
+    previous: list = []
+    for i in range(steps):
+        rec = OA.sample(cfg, t["x"][i], t["out"][i], (i / steps, (i + 1) / steps), MODELS[mname][0], sched, t["noise"][i] if OA.require_noise(cfg) else None, previous)
+        assert rec.final.dtype == dt
+        assert torch.equal(rec.final.view(torch.int16), t["final"][i].view(torch.int16)), (tag, i)
+        assert torch.equal(torch.as_tensor(rec.prediction).view(torch.int16), t["prediction"][i].view(torch.int16)), (tag, i)
+        previous.append(rec)
+        keep = OA.require_previous(cfg)
+        previous = previous[max(len(previous) - keep, 0) :] if keep else []

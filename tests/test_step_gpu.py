@@ -11,7 +11,7 @@ import itertools
 import numpy as np
 import pytest
 import torch
-from cases import MODELS, SAMPLERS, SCHEDULES, bf16_ulp, from_bits, oracle_schedule
+from cases import MODELS, NATIVE16_ORACLE, NATIVE16_TAGS, SAMPLERS, SCHEDULES, bf16_ulp, from_bits, native16_case, oracle_schedule
 from conftest import load_npz
 
 import skrample_amd.diffusers as PD
@@ -330,6 +330,39 @@ def test_sampler_level_api_on_16_bit_tensors(dtype, kind, dev):
     assert err_engine <= 0.51 + 1e-3, err_engine  # one rounding of the exact result (+ the fp32 noise floor of the operands)
     assert err_engine <= err_native + 1e-9  # never worse than the reference's own native-dtype chain ...
     assert ((got.double() - native.double()).abs() / (ulp.double() + 1e-5 * scale)).max().item() <= err_native + 0.51 + 1e-3  # ... and close to it
+
+
+def native16_engine_vs_reference(tag, device):
+    """The reference's recorded native-dtype chain (tests/golden/native16.npz) is 4-47 units away from the exact (fp64) result of
+    the same inputs, a unit being the 16-bit ulp of the exact value + 1e-5 of its range; this engine, accumulating the collapsed
+    form in fp32 and rounding once, stays within half a unit on every step -- never farther from exact than the reference is."""
+    dt, steps, mname, sname, expr, t = native16_case(load_npz("native16.npz"), tag)
+    sampler, sched, model = eval(expr, {"S": PT}), SCHEDULES[sname][1](), MODELS[mname][1]
+    cfg, osched = NATIVE16_ORACLE[tag.split("/")[0]](OA), SCHEDULES[sname][0]()
+    previous, exact_previous = [], []
+    worst_engine = worst_reference = 0.0
+    for i in range(steps):
+        x, out, nz = t["x"][i], t["out"][i], t["noise"][i]
+        rec = sampler.sample(x.to(device), out.to(device), PT.Step.from_int(i, steps), model, sched, nz.to(device) if sampler.require_noise else None, tuple(previous))
+        assert rec.final.dtype == dt
+        exact_rec = OA.sample(cfg, x.double(), out.double(), (i / steps, (i + 1) / steps), MODELS[mname][0], osched, nz.double() if OA.require_noise(cfg) else None, exact_previous)
+        exact = exact_rec.final
+        unit = (bf16_ulp(exact.float()) * (1 if dt == torch.bfloat16 else 2.0**-3)).double() + 1e-5 * exact.abs().max().item()
+        worst_engine = max(worst_engine, ((torch.as_tensor(rec.final).double().cpu() - exact).abs() / unit).max().item())
+        worst_reference = max(worst_reference, ((t["final"][i].double() - exact).abs() / unit).max().item())
+        previous.append(rec)
+        exact_previous.append(exact_rec)
+        keep = sampler.require_previous
+        previous = previous[max(len(previous) - keep, 0) :] if keep else []
+        exact_previous = exact_previous[max(len(exact_previous) - keep, 0) :] if keep else []
+    assert worst_engine <= 0.51, (tag, worst_engine)
+    assert worst_engine <= worst_reference, (tag, worst_engine, worst_reference)
+    assert worst_reference >= 2.0, (tag, worst_reference)  # the stated difference is real: the reference's chain is not an exact rounding
+
+
+@pytest.mark.parametrize("tag", NATIVE16_TAGS)
+def test_sampler_level_api_vs_reference_recorded_16_bit_runs(tag, dev):
+    native16_engine_vs_reference(tag, dev)
 
 
 @pytest.mark.parametrize("shape", [(3, 4, 32, 32), (2, 3, 16, 16), (2, 6, 16, 16), (3, 1, 8, 8)])

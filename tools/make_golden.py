@@ -537,6 +537,49 @@ def functional_api() -> None:
     json.dump(out, open(os.path.join(OUT, "functional_api.json"), "w"))
 
 
+# ---------------------------------------------------------------------------------------------------
+NATIVE16_CASES = {
+    # name: (sampler text, model, schedule)
+    "euler": ("S.Euler()", "eps", "scaled"),
+    "euler_sde_v": ("S.Euler(stochasticity=1)", "v", "zsnr"),
+    "dpm2_sde": ("S.DPM(order=2, stochasticity=1)", "eps", "karras_scaled"),
+    "dpm3_flow": ("S.DPM(order=3)", "flow", "linear"),
+    "adams3": ("S.Adams(order=3)", "eps", "scaled"),
+    "unipc3_flow": ("S.UniPC(order=3)", "flow", "linear"),
+}
+
+
+def native16() -> None:
+    """The sampler-level API called directly on 16-bit tensors (no wrapper): the reference then computes in the TENSOR dtype,
+    rounding after every torch op (structured.py:209-283).  Six samplers x {bf16, fp16}, 7 teacher-forced steps each."""
+    env = {"S": structured}
+    blob = {}
+    for ci, (name, (expr, mname, sname)) in enumerate(NATIVE16_CASES.items()):
+        for dt in (torch.bfloat16, torch.float16):
+            sampler = eval(expr, env)
+            sched, model_t = CFG_SCHEDULES[sname](), MODELS[mname]
+            g = torch.Generator().manual_seed(5000 + ci)
+            steps, shape = 7, (2, 4, 8, 8)
+            x = torch.randn(shape, generator=g).to(dt)
+            previous: list = []
+            tag = f"{name}/{'bf16' if dt == torch.bfloat16 else 'f16'}"
+            xs, outs, nzs, finals, preds = [], [], [], [], []
+            for i in range(steps):
+                out = torch.randn(shape, generator=g).to(dt)
+                nz = torch.randn(shape, generator=g).to(dt)
+                rec = sampler.sample(x, out, Step.from_int(i, steps), model_t, sched, nz if sampler.require_noise else None, tuple(previous))
+                assert rec.final.dtype == dt
+                xs.append(x); outs.append(out); nzs.append(nz); finals.append(rec.final); preds.append(rec.prediction)
+                previous.append(rec)
+                previous = previous[max(len(previous) - sampler.require_previous, 0) :] if sampler.require_previous else []
+                x = rec.final
+            as16 = lambda ts: np.stack([t.contiguous().view(torch.int16).numpy().copy() for t in ts])  # noqa: E731
+            blob[f"{tag}/x"], blob[f"{tag}/out"], blob[f"{tag}/noise"] = as16(xs), as16(outs), as16(nzs)
+            blob[f"{tag}/final"], blob[f"{tag}/prediction"] = as16(finals), as16(preds)
+            blob[f"{tag}/meta"] = np.asarray([expr, mname, sname, str(steps)])
+    np.savez_compressed(os.path.join(OUT, "native16.npz"), **blob)
+
+
 def _exp(step) -> float:
     seen = {}
     orig = RN.Colored.colorize_noise
@@ -557,5 +600,6 @@ if __name__ == "__main__":
     noise()
     wrapper_api()
     functional_api()
+    native16()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
