@@ -580,6 +580,66 @@ def native16() -> None:
     np.savez_compressed(os.path.join(OUT, "native16.npz"), **blob)
 
 
+# ---------------------------------------------------------------------------------------------------
+def common_api() -> None:
+    "skrample/common.py's helpers on floats, numpy arrays and tensors, edge values included (common.py:24-213)"
+    import skrample.common as C
+
+    def num(v):
+        if isinstance(v, (tuple, list)):
+            return [num(x) for x in v]
+        if isinstance(v, torch.Tensor):
+            return num(v.tolist())
+        if isinstance(v, np.ndarray):
+            return num(v.tolist())
+        v = float(v)
+        return v if math.isfinite(v) else repr(v)
+
+    def attempt(fn):
+        try:
+            return num(fn())
+        except Exception as exc:
+            return {"error": type(exc).__name__}
+
+    xs = [-3.5, -1.0, -0.25, -0.0, 0.0, 1e-12, 0.5, 1.0, 2.0, 40.0, 1e30, float("inf")]
+    arr = np.asarray([-2.0, -0.5, 0.0, 0.3, 1.7])
+    ten = torch.tensor(arr)
+    out: dict = {"xs": num(xs), "arr": arr.tolist()}
+    out["divf"] = [[attempt(lambda a=a, b=b: C.divf(a, b)) for b in (-2.0, -0.0, 0.0, 3.0)] for a in (-1.5, 0.0, 2.0)]
+    out["ln"] = [attempt(lambda x=x: C.ln(x)) for x in xs]
+    out["rescale_positive"] = [attempt(lambda x=x: C.rescale_positive(x)) for x in xs[:-1]]
+    out["rescale_subnormal"] = [attempt(lambda x=x: C.rescale_subnormal(x)) for x in xs]
+    out["exp"] = [attempt(lambda x=x: C.exp(x)) for x in xs[:10]] + [attempt(lambda: C.exp(arr)), attempt(lambda: C.exp(ten))]
+    out["sigmoid"] = [attempt(lambda x=x: C.sigmoid(x)) for x in xs[:10]] + [attempt(lambda: C.sigmoid(arr)), attempt(lambda: C.sigmoid(ten))]
+    out["softmax"] = [attempt(lambda: C.softmax((0.1, -2.0, 3.0))), attempt(lambda: C.softmax((arr, arr * 0.5, arr - 1))), attempt(lambda: C.softmax((ten, ten * 2)))]
+    out["spowf"] = [[attempt(lambda x=x, f=f: C.spowf(x, f)) for f in (0.5, 1.0, 2.0, -1.0)] for x in xs[:10]] + [[attempt(lambda f=f: C.spowf(arr, f)), attempt(lambda f=f: C.spowf(ten, f))] for f in (0.5, 2.0)]
+    out["mean"] = [attempt(lambda: C.mean(0.75)), attempt(lambda: C.mean(arr)), attempt(lambda: C.mean(ten))]
+    out["clamp"] = [attempt(lambda x=x: C.clamp(x)) for x in xs] + [attempt(lambda: C.clamp(5.0, 2, 3)), attempt(lambda: C.clamp(-5.0, -1, 3))]
+    out["normalize"] = [attempt(lambda: C.normalize(0.3, 2.0)), attempt(lambda: C.normalize(arr, 4.0, 1.0)), attempt(lambda: C.normalize(ten, 0.5, -0.5))]
+    out["regularize"] = [attempt(lambda: C.regularize(0.3, 2.0)), attempt(lambda: C.regularize(arr, 4.0, 1.0)), attempt(lambda: C.regularize(ten, 0.5, -0.5))]
+    out["bashforth"] = [attempt(lambda n=n: C.bashforth(n)) for n in range(1, 10)]
+    p = C.Point(700.0, 1.3, 0.4)
+    p0 = C.Point(0.0, 0.0, 1.0)
+    pz = C.Point(999.0, 1.0, 0.0)
+    out["point"] = {
+        "add_noise": [attempt(lambda: p.add_noise(0.5, -2.0)), attempt(lambda: p.add_noise(arr, arr[::-1].copy())), attempt(lambda: p.add_noise(ten, ten * 3))],
+        "remove_noise": [attempt(lambda: p.remove_noise(0.5, -2.0)), attempt(lambda: p.remove_noise(arr, arr[::-1].copy())), attempt(lambda: pz.remove_noise(0.5, -2.0)), attempt(lambda: p0.remove_noise(ten, ten * 3))],
+        "difference": attempt(lambda: C.DeltaPoint(p, p0).difference()),
+    }
+    steps = []
+    for n, amount in ((0, 1), (0, 7), (3, 7), (6, 7), (19, 20)):
+        st = C.Step.from_int(n, amount)
+        steps.append({
+            "from_int": [n, amount], "step": num(st), "distance": attempt(st.distance), "position": attempt(st.position), "amount": attempt(st.amount),
+            "offset": [attempt(lambda k=k: st.offset(k)) for k in (-2, 0.5, 3)], "clamp": [attempt(lambda k=k: st.offset(k).clamp()) for k in (-9, 0, 9.5)],
+            "normal": attempt(lambda: C.Step(st.time_to, st.time_from).normal()),
+        })  # fmt: skip
+    out["step"] = steps
+    a, b = list(range(0, 11)), list(range(0, 15, 2))
+    out["merge"] = {m.name: {"value": str(m.value), "ab": m.merge(a, b), "ba": m.merge(b, a), "cmp": m.merge(a, b, lambda u, v: u // 2 == v // 2)} for m in C.MergeStrategy}
+    json.dump(out, open(os.path.join(OUT, "common_api.json"), "w"))
+
+
 def _exp(step) -> float:
     seen = {}
     orig = RN.Colored.colorize_noise
@@ -601,5 +661,6 @@ if __name__ == "__main__":
     wrapper_api()
     functional_api()
     native16()
+    common_api()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
