@@ -640,6 +640,64 @@ def common_api() -> None:
     json.dump(out, open(os.path.join(OUT, "common_api.json"), "w"))
 
 
+# ---------------------------------------------------------------------------------------------------
+SCHEDULE_EXPRS = [
+    "R.Scaled()", "R.Scaled(base_timesteps=500, beta_start=0.0001, beta_end=0.02, beta_scale=1)", "R.Scaled(beta_scale=3)", "R.ZSNR()",
+    "R.ZSNR(beta_scale=1, base_timesteps=200)", "R.Linear()", "R.Linear(sigma_start=14.6)", "R.Linear(base_timesteps=250, sigma_start=0.8)",
+    "R.Karras(R.Scaled())", "R.Karras(R.Scaled(), rho=3.0, steps=9)", "R.Karras(R.Linear())", "R.Karras(R.ZSNR(), steps=31)",
+    "R.Exponential(R.Scaled())", "R.Exponential(R.Scaled(), rho=2.5, steps=7)", "R.Exponential(R.Linear())",
+    "R.Beta(R.Scaled())", "R.Beta(R.ZSNR(), alpha=0.4, beta=1.3)", "R.Beta(R.Linear(), alpha=2.0, beta=0.5)",
+    "R.Probit(R.Linear())", "R.Probit(R.Scaled(), scale=1.5)", "R.NoSub(R.Scaled())",
+    "R.FlowShift(R.Linear())", "R.FlowShift(R.Linear(), shift=0.5)", "R.FlowShift(R.Scaled(), shift=7.0)", "R.FlowShift(R.Beta(R.ZSNR()))",
+    "R.Hyper(R.Scaled())", "R.Hyper(R.Linear(), scale=-1.5, tail=False)", "R.Hyper(R.Karras(R.Scaled()), scale=0.5)",
+    "R.Sinner(R.Linear())", "R.Sinner(R.Scaled(), count=3, scale=-0.7)", "R.NoMod(R.Linear())",
+    "R.FlowShift(R.Hyper(R.Sinner(R.Karras(R.Scaled()))), shift=2.0)", "R.Hyper(R.FlowShift(R.Probit(R.Linear()), shift=1.7), scale=3)",
+]
+
+
+def scheduling_api() -> None:
+    """Every schedule class, sub-schedule and modifier (defaults and non-default parameters, nested stacks): schedule_np for four
+    run lengths, points / ipoints at fixed abscissae, step / istep, the end points, the sigma space, the modifier-stack
+    introspection (all_split, lowest, find, find_split, stack round trip)."""
+    env = {"R": RS}
+    ts = [0.0, 1e-9, 0.013, 0.25, 0.5, 0.77, 0.999, 1.0]
+    out: dict = {"t": ts, "cases": {}}
+    for expr in SCHEDULE_EXPRS:
+        sch = eval(expr, env)
+        rec: dict = {"repr": repr(sch), "space": type(sch.space).__name__}
+        for n in (1, 2, 9, 30):
+            rec[f"schedule_np/{n}"] = sch.schedule_np(n).tolist()
+        rec["points"] = [list(map(float, p)) for p in sch.points(ts)]
+        rec["ipoints"] = [list(map(float, p)) for p in sch.ipoints(ts)]
+        rec["point_0"], rec["point_1"] = list(map(float, sch.point_0)), list(map(float, sch.point_1))
+        st = Step.from_int(2, 9)
+        rec["step"] = [list(map(float, p)) for p in sch.step(st)]
+        rec["istep"] = [list(map(float, p)) for p in sch.istep(st)]
+        if isinstance(sch, RS.ScheduleModifier):
+            mods, sub, base = sch.all_split
+            rec["all_split"] = [[repr(m) for m in mods], repr(sub), repr(base)]
+            rec["lowest"] = repr(sch.lowest)
+            rec["all"] = [repr(v) for v in sch.all]
+            rec["find_flowshift"] = repr(sch.find(RS.FlowShift))
+            rec["find_hyper_exact"] = repr(sch.find(RS.Hyper, exact=True))
+            found = sch.find_split(RS.FlowShift)
+            rec["find_split_flowshift"] = None if found is None else [[repr(m) for m in found[0]], repr(found[1]), [repr(m) for m in found[2]], repr(found[3]), repr(found[4])]
+            rec["restacked"] = repr(sch.stack(mods, sub, base))
+        out["cases"][expr] = rec
+    # a fixed table of (timestep, sigma) pairs behaves as a schedule too
+    fixed = RS.FixedSchedule.from_regular(np.asarray([900.0, 600.0, 300.0, 50.0]), np.asarray([10.0, 3.0, 0.8, 0.05]), RS.VariancePreserving())
+    out["fixed"] = {"repr": repr(fixed), "schedule_np/4": fixed.schedule_np(4).tolist(), "points": [list(map(float, p)) for p in fixed.points([0.0, 0.3, 1.0])]}
+    for name, space in (("vp", RS.VariancePreserving()), ("flow", RS.FlowMatching())):
+        sig = np.asarray([0.0, 0.05, 0.7, 1.0, 14.6])
+        try:
+            out[f"space/{name}"] = {"normalize": [np.asarray(a).tolist() for a in space.normalize(sig)], "regularize": np.asarray(space.regularize(np.asarray([0.0, 0.05, 0.5, 0.9]))).tolist()}
+        except Exception as exc:
+            out[f"space/{name}"] = {"error": type(exc).__name__}
+    sch = RS.Karras(RS.Scaled())
+    out["lru"] = {"np": RS.np_schedule_lru(sch, 6).tolist(), "points": [list(map(float, p)) for p in RS.schedule_lru(sch, 6)]}
+    json.dump(out, open(os.path.join(OUT, "scheduling_api.json"), "w"))
+
+
 def _exp(step) -> float:
     seen = {}
     orig = RN.Colored.colorize_noise
@@ -662,5 +720,6 @@ if __name__ == "__main__":
     functional_api()
     native16()
     common_api()
+    scheduling_api()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
