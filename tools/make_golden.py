@@ -698,6 +698,66 @@ def scheduling_api() -> None:
     json.dump(out, open(os.path.join(OUT, "scheduling_api.json"), "w"))
 
 
+# ---------------------------------------------------------------------------------------------------
+MODEL_EXPRS = ["M.DataModel()", "M.NoiseModel()", "M.FlowModel()", "M.VelocityModel()", "M.ScaleX()", "M.ScaleX(bias=-1.5)"]
+
+
+def models_api() -> None:
+    """models.py on CPU float64 tensors and floats: to_x / from_x, gamma / delta / zeta / zeta_ts / eta_transform, forward /
+    backward with and without noise, ModelConvert between every pair (output_to, output_from, wrap_model_call)."""
+    env = {"M": models}
+    g = torch.Generator().manual_seed(99)
+    x, o, nz = (torch.randn([2, 3], generator=g, dtype=torch.float64) for _ in range(3))
+    out: dict = {"x": x.flatten().tolist(), "o": o.flatten().tolist(), "noise": nz.flatten().tolist(), "cases": {}, "convert": {}}
+    scheds = {"scaled": RS.Scaled(), "linear": RS.Linear(), "zsnr": RS.ZSNR()}
+    spans = [(0.0, 0.1), (0.45, 0.5), (0.3, 0.8), (0.9, 1.0)]
+
+    def num(v):
+        v = float(v)
+        return v if math.isfinite(v) else repr(v)
+
+    def attempt(fn):
+        try:
+            r = fn()
+            if isinstance(r, torch.Tensor):
+                return [num(v) for v in r.flatten().tolist()]
+            if isinstance(r, tuple):
+                return [[num(q) for q in p] for p in r]
+            return num(r)
+        except Exception as exc:
+            return {"error": type(exc).__name__}
+
+    for expr in MODEL_EXPRS:
+        m = eval(expr, env)
+        for sname, sch in scheds.items():
+            for a, b in spans:
+                dp = DeltaPoint(*sch.ipoints([a, b]))
+                key = f"{expr}|{sname}|{a}|{b}"
+                rec = {"repr": repr(m)}
+                rec["to_x"] = attempt(lambda: m.to_x(x, o, dp.point_from))
+                rec["from_x"] = attempt(lambda: m.from_x(x, o, dp.point_from))
+                rec["to_x_float"] = attempt(lambda: m.to_x(0.7, -0.4, dp.point_from))
+                for eta in (0.0, 0.5, 1.0, -1.5):
+                    rec[f"gdz/{eta}"] = [attempt(lambda: m.gamma(dp, eta)), attempt(lambda: m.delta(dp, eta)), attempt(lambda: m.zeta(dp, eta)), attempt(lambda: m.zeta_ts(dp, eta))]
+                    rec[f"eta_transform/{eta}"] = attempt(lambda: m.eta_transform(dp, eta))
+                    rec[f"forward/{eta}"] = attempt(lambda: m.forward(x, o, dp, nz, eta))
+                    rec[f"backward/{eta}"] = attempt(lambda: m.backward(x, o, dp, nz, eta))
+                rec["forward/plain"] = attempt(lambda: m.forward(x, o, dp))
+                rec["backward/plain"] = attempt(lambda: m.backward(x, o, dp))
+                rec["forward/float"] = attempt(lambda: m.forward(0.7, -0.4, dp, 0.2, 1.0))
+                out["cases"][key] = rec
+    pt = RS.Scaled().ipoint(0.4)
+    for ea in MODEL_EXPRS:
+        for eb in MODEL_EXPRS:
+            cv = models.ModelConvert(eval(ea, env), eval(eb, env))
+            wrapped = cv.wrap_model_call(lambda xx, t, s, a: xx * 0.3 - 0.1 * s + 0.05 * a)
+            out["convert"][f"{ea}->{eb}"] = {
+                "output_to": attempt(lambda: cv.output_to(x, o, pt)), "output_from": attempt(lambda: cv.output_from(x, o, pt)),
+                "wrapped": attempt(lambda: wrapped(x, *pt)),
+            }  # fmt: skip
+    json.dump(out, open(os.path.join(OUT, "models_api.json"), "w"))
+
+
 def _exp(step) -> float:
     seen = {}
     orig = RN.Colored.colorize_noise
@@ -721,5 +781,6 @@ if __name__ == "__main__":
     native16()
     common_api()
     scheduling_api()
+    models_api()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
