@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void any_weights(const AnyArgs a) {
   }
 }
 
-// 4-axis units: hipFFT transforms the three inner axes (batched over batch*d0); the outermost axis (length d0 <= 64,
+// 4-axis units: hipFFT transforms the three inner axes (batched over batch*d0); the outermost axis (length d0 <= 128,
 // e.g. channels or frames) is a direct DFT per spectral column: forward, radial weights of the full 4-D frequency,
 // inverse -- one lane per column, its d0 values staged in LDS (column-private, no barriers after the twiddle table).
 constexpr int AXIS0_THREADS = 64;
@@ -232,7 +232,7 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
   int d0 = 1;
   if (rank == 4) {  // outermost axis by direct DFT (any_axis0), the inner three by hipFFT batched over batch*d0
     d0 = dims[0];
-    if (d0 > 64 || batch * d0 > 0x7fffffffll) return SKR_ERR_UNSUPPORTED;
+    if (d0 > 128 || batch * d0 > 0x7fffffffll) return SKR_ERR_UNSUPPORTED;  // (d0 + 2*d0*64) float2 of LDS: 132 KiB at 128
     dims += 1; rank = 3;
   }
   int n[3] = {1, 1, 1};
