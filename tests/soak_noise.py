@@ -55,7 +55,10 @@ def case_brownian():
             continue
         got = g.generate(st).cpu().double()
         ref = torch.stack([ON.brownian_noise(s, unit, st, ms) for s in seeds])
-        assert rel(got, ref) < 1e-5, ("brownian", unit, st, ms, rel(got, ref))
+        # unit-variance output = scale * (W(to) - W(from)) with both path values accumulated in fp32: the error floor is absolute
+        # (~1e-6), so on units of a few elements, whose largest value can be small by chance, it is measured against >= 1
+        err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1.0)
+        assert err < 1e-5, ("brownian", unit, st, ms, err)
 
 for i in range(n_cases):
     for fn in (case_offset, case_pyramid, case_colored, case_brownian):

@@ -75,6 +75,10 @@ S16 = 16 * 128 * 128
 OLD, NEW = {"one_trip": 0, "two_out": 0}, {}
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "b64":  # BASELINE config 2's own batch: 2048 workgroups, one resident wave of them
+        sw = [OLD, NEW, {"pace": 0}] + [{"xmap": x} for x in (0, 3, 5, 6, 8)] + [{"xmap": x, "pace": 0} for x in (0, 5)]
+        bench("K=4 bf16 -> bf16 + philox  B=64", 64, S4, 4, 0, False, True, switches=sw, iters=400, footprint=1.0e9)
+        bench("K=4 bf16 -> bf16           B=64", 64, S4, 4, 0, False, False, switches=sw, iters=400, footprint=1.0e9)
     if which in ("all", "k"):
         for k in (1, 2, 3, 4, 5, 6, 8):
             bench(f"K={k} bf16 -> bf16", 256, S4, k, 0, False, False, switches=[OLD, NEW, {"pace": 0}])
