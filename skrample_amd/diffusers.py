@@ -36,7 +36,7 @@ from torch import Tensor
 
 from . import scheduling
 from .common import DeltaPoint, MergeStrategy, Point, Step
-from .pytorch.noise import BatchTensorNoise, HostRandomBatch, Random, TensorNoiseCommon, TensorNoiseProps
+from .pytorch.noise import BatchTensorNoise, HostRandomBatch, Offset, Pyramid, Random, TensorNoiseCommon, TensorNoiseProps
 from . import _hip
 from .sampling import functional, interface, lazy, models, program, tableaux, traits
 from .sampling import structured as sampling
@@ -247,6 +247,9 @@ class SkrampleWrapperCore(abc.ABC):
         self._index: int = 0
         self._device: torch.device = torch.device("cpu")
         self._noise_generator: BatchTensorNoise | None = None
+        self._noise_ahead = None  # (step, tensor, event, draws before, draws after): the next step's noise, drawn on the side stream
+        self._noise_done = None  # event behind the latest generator launch, whichever stream it ran on (workspaces are shared)
+        self._noise_side = None
         self._alias_stamps: list[tuple[Tensor, int, int]] = []  # (caller tensor aliased by history, data_ptr, _version)
 
     # ---- guard of the aliased history (alias_history=True) -------------------------------------------------------
@@ -373,11 +376,87 @@ class SkrampleWrapperCore(abc.ABC):
                 return handed if lazy_ok else lazy.cast(handed, dtype or sample.dtype)
             return lazy.cast(handed.realize(torch.float32), dtype or sample.dtype)
         if self._noise_generator is None:
+            self._retire_noise_generator()
             self._noise_generator = self._make_noise_generator(step, sample, noise_type, noise_props, generator)
-        if lazy_ok:
-            return self._noise_generator.generate_lazy(step)
-        noise = self._noise_generator.generate(step)
-        return lazy.cast(noise, dtype or sample.dtype)
+        gen = self._noise_generator
+        noise = self._take_noise_ahead(step, sample, lazy_ok)
+        if noise is None:
+            if self._noise_done is not None:  # the generator's workspaces were last used on the side stream
+                torch.cuda.current_stream(sample.device).wait_event(self._noise_done)
+                self._noise_done = None
+            noise = gen.generate_lazy(step) if lazy_ok else gen.generate(step)
+        return noise if lazy_ok else lazy.cast(noise, dtype or sample.dtype)
+
+    # ---- next step's noise, drawn ahead on a side stream ----------------------------------------------------------------
+    # Pyramid / Offset noise is a chain of VALU-bound kernels that depends on nothing but (seeds, draw counter, step);
+    # the step kernel is HBM-bound.  While step i's kernel (and, in a pipeline, the network call behind it) runs on the caller's
+    # stream, the noise of step i+1 is generated on a side stream and handed over with an event.  Values and draw numbering are
+    # exactly those of generating at the moment of use: a guess that does not match the next request is dropped and the counter
+    # rewound.  Not under stream capture, not for Brownian (its cache makes queries order-dependent), not for white noise (drawn
+    # inside the step kernel anyway).
+    _AHEAD_KINDS = (Pyramid, Offset)
+    # ^ generators drawn ahead.  Measured on MI355X (tools/bench_configs.py): RKUltra-6 + Pyramid (BASELINE config 5 shard) 51.4 -> 47.9 us
+    # per stage call; Colored is left out -- its plane kernels hold 134 KiB of LDS and most of the vector registers of every CU, the
+    # step kernel cannot co-reside, and UniPC-3 + Colored (config 3) went 702 -> 736 us per call with it drawn ahead.
+
+    def _retire_noise_generator(self) -> None:
+        "drop the generator: its workspaces go back to the allocator, so whatever the side stream still runs on them must be ordered first"
+        if self._noise_done is not None and torch.cuda.is_available():
+            torch.cuda.current_stream(self._noise_side.device).wait_event(self._noise_done)
+        self._noise_generator = None
+        self._noise_ahead = self._noise_done = None
+
+    def _noise_ahead_ok(self, sample) -> bool:
+        gen = self._noise_generator
+        return (
+            getattr(self, "prefetch_noise", False)
+            and isinstance(gen, BatchTensorNoise)
+            and gen._kind in self._AHEAD_KINDS
+            and isinstance(sample, Tensor)
+            and sample.is_cuda
+            and not torch.cuda.is_current_stream_capturing()
+        )
+
+    def _take_noise_ahead(self, step: Step, sample, lazy_ok: bool):
+        ahead, self._noise_ahead = self._noise_ahead, None
+        if ahead is None:
+            return None
+        a_step, item, event, before, after = ahead
+        gen = self._noise_generator
+        if gen._draws != after:  # someone drew in between: the guess no longer sits where an in-order draw would
+            return None
+        symbolic = not isinstance(item, Tensor)  # white noise stays symbolic (drawn inside the step kernel): only the counter moved
+        if a_step != step or item.device != sample.device or torch.cuda.is_current_stream_capturing() or (symbolic and not lazy_ok):
+            gen._draws = before  # as if it had never been drawn
+            return None
+        if not symbolic:
+            main = torch.cuda.current_stream(sample.device)
+            main.wait_event(event)
+            item.record_stream(main)
+        return item
+
+    def _draw_noise_ahead(self, next_step: Step | None, sample) -> None:
+        "enqueue the generation of `next_step`'s noise on the side stream (call after this step's noise exists, before its kernel)"
+        if next_step is None or not self._noise_ahead_ok(sample):
+            return
+        gen, dev = self._noise_generator, sample.device
+        if self._noise_side is None or self._noise_side.device != dev:
+            self._noise_side = torch.cuda.Stream(device=dev)
+        side, main = self._noise_side, torch.cuda.current_stream(dev)
+        if self._noise_done is None:  # the latest generation ran on the caller's stream: order the shared workspaces behind it
+            fence = torch.cuda.Event()
+            fence.record(main)
+            side.wait_event(fence)
+        before = gen._draws
+        with torch.cuda.stream(side):
+            item = gen.generate_lazy(next_step)  # what the wrappers ask for (lazy_ok): a tensor, or symbolic white noise
+            event = None
+            if isinstance(item, Tensor):
+                event = torch.cuda.Event()
+                event.record(side)
+        self._noise_ahead = (next_step, item, event, before, gen._draws)
+        if event is not None:
+            self._noise_done = event
 
     @abc.abstractmethod
     def scale_noise(self, sample: Tensor, timestep: Tensor, noise: Tensor) -> Tensor: ...
@@ -452,6 +531,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
     allow_dynamic: bool = True
     invert_prediction: bool = False
     fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
+    prefetch_noise: bool = True
+    "(not in the reference) draw the next step's Pyramid / Offset noise ahead on a side stream (same values, same draw numbering)"
     alias_history: bool = True
     """(not in the reference) keep history entries as aliases of the caller's `sample` / `model_output` tensors.
     Set False when the caller overwrites those buffers in place between steps (e.g. a CUDA/HIP-graphed network
@@ -541,7 +622,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._raw_outputs = []
         self._raw_samples = []
         self._alias_stamps = []
-        self._noise_generator = None
+        self._retire_noise_generator()
         self._timestep_list = None
         if device is not None:
             self._device = torch.device(device)
@@ -553,6 +634,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._calls = 0
         self._previous, self._raw_outputs, self._raw_samples = [], [], []
         self._alias_stamps = []
+        self._noise_ahead = None  # (its workspace fence, _noise_done, stays)
         if self._noise_generator is not None:
             self._noise_generator._draws = 0
 
@@ -585,6 +667,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         noise = None
         if self.sampler.require_noise:
             noise = self.get_step_noise(step, sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
+            self._draw_noise_ahead(Step.from_int(idx + 1, len(table)) if idx + 1 < len(table) else None, sample)
 
         # step programs (sampling/program.py): lower each distinct step once, then replay by pointer binding
         owner = (self.sampler, self.model, self.schedule, self._steps, self.compute_scale)
@@ -645,6 +728,8 @@ class RKWrapperCore(SkrampleWrapperCore):
     allow_dynamic: bool = True
     invert_prediction: bool = False
     fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
+    prefetch_noise: bool = True
+    "(not in the reference) see SkrampleWrapperScheduler.prefetch_noise: the next step's noise is drawn on a side stream during this step's stages"
     alias_history: bool = True
     "(not in the reference) see SkrampleWrapperScheduler.alias_history; False snapshots `sample` / `model_output` per stage"
 
@@ -722,7 +807,7 @@ class RKWrapperCore(SkrampleWrapperCore):
         self._steps = steps
         if self.allow_dynamic:
             self.schedule = _apply_dynamic(self.schedule, steps, mu)
-        self._noise_generator = None
+        self._retire_noise_generator()
         if device is not None:
             self._device = torch.device(device)
 
@@ -731,8 +816,14 @@ class RKWrapperCore(SkrampleWrapperCore):
         self._index = 0
         self._derivatives, self._sample = [], None
         self._alias_stamps = []
+        self._noise_ahead = None  # (its workspace fence, _noise_done, stays)
         if self._noise_generator is not None:
             self._noise_generator._draws = 0
+
+    def _next_noise_step(self) -> Step | None:
+        "the step whose noise the next draw of this run will be for (one draw per step, at its last stage)"
+        nxt = self._index // self.order + 1
+        return Step.from_int(nxt, self._steps) if nxt < self._steps else None
 
     def scale_noise(self, sample: Tensor, timestep: Tensor, noise: Tensor) -> Tensor:
         idx = self._lookup(self.schedule_np[:, 0].tolist(), timestep, 0)
@@ -750,6 +841,7 @@ class RKWrapperCore(SkrampleWrapperCore):
             noise = None
             if abs(self.stochasticity) > 1e-8:
                 noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), self._sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
+                self._draw_noise_ahead(self._next_noise_step(), self._sample)
             self._last_noise = noise
             mix = sum((d * w for d, w in zip(self._derivatives[1:], weights[1:])), self._derivatives[0] * weights[0])
             form = space.update_form(base, mix, DeltaPoint(s0, s1), noise, self.stochasticity)
@@ -936,6 +1028,7 @@ class RKWrapperCore(SkrampleWrapperCore):
             #  the generator's stream position must not depend on which path ran)
             base = sample if self._sample is None else self._sample
             noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), base, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
+            self._draw_noise_ahead(self._next_noise_step(), base)
         plan = prog["plan"]
         seeds_ptr = None
         ok = True

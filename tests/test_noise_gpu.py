@@ -515,3 +515,63 @@ def test_component_methods(dev):
             level = iter(range(8))
             ref = ON.pyramid_component(unit, lambda shape: spec_normal(78, n * 256 + 1 + next(level), shape), lambda: next(uniforms), **kw)
             assert got.shape == unit and rel(got, ref) < 2e-5, (kw, n, rel(got, ref))
+
+
+@pytest.mark.parametrize("kind", ["colored_unipc", "pyramid_dpm", "offset_euler", "pyramid_rk", "colored_white_start"])
+def test_noise_drawn_ahead_on_the_side_stream_is_value_identical(kind, dev):
+    """The wrappers draw the next step's Pyramid / Offset noise on a side stream while this step's kernel runs
+    (prefetch_noise, default on; Colored is opted in here through _AHEAD_KINDS to cover a generator with symbolic white steps).  Same values, same draw numbering as drawing at the moment of use -- also when the caller
+    does not ask for the guessed step next (out-of-order timestep, a fresh set_timesteps in mid-run)."""
+    import skrample_amd.diffusers as PD
+    import skrample_amd.scheduling as PS
+    from skrample_amd.sampling import models as PM
+    from skrample_amd.sampling import structured as PT
+
+    def make(prefetch):
+        if kind == "colored_unipc":
+            return PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), noise_type=PN.Colored, noise_props=PN.ColoredProps(), prefetch_noise=prefetch)
+        if kind == "colored_white_start":  # exponent 0 throughout: plain white noise, which stays symbolic (drawn in the step kernel)
+            return PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), noise_type=PN.Colored, noise_props=PN.ColoredProps(color_start=0.0, color_end=0.0), prefetch_noise=prefetch)
+        if kind == "pyramid_dpm":
+            return PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=PN.Pyramid, noise_props=PN.PyramidProps(), prefetch_noise=prefetch)
+        if kind == "offset_euler":
+            return PD.SkrampleWrapperScheduler(PT.Euler(stochasticity=0.7), PS.Scaled(), noise_type=PN.Offset, noise_props=PN.OffsetProps(), prefetch_noise=prefetch)
+        return PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=3, stochasticity=1, noise_type=PN.Pyramid, noise_props=PN.PyramidProps(), prefetch_noise=prefetch)
+
+    g = torch.Generator().manual_seed(5)
+    shape, steps = (3, 4, 32, 32), 6
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+
+    def run(prefetch, order):
+        w = make(prefetch)
+        w._AHEAD_KINDS = (PN.Pyramid, PN.Offset, PN.Colored)
+        w.set_timesteps(steps)
+        ts = list(w.timesteps)
+        outs = [torch.randn(shape, generator=torch.Generator().manual_seed(100 + i)).bfloat16().to(dev) for i in range(len(ts))]
+        x, results = x0, []
+        for i in order(len(ts)):
+            x = w.step(outs[i], ts[i], x, generator=[7, 8, 9], return_dict=False)[0]
+            results.append(x.clone())
+        if order is in_order:  # a second run on the same wrapper: nothing of the first run's ahead-draw may leak into it
+            w.set_timesteps(steps)
+            x = x0
+            for i in range(2):
+                x = w.step(outs[i], ts[i], x, generator=[7, 8, 9], return_dict=False)[0]
+                results.append(x.clone())
+        torch.cuda.synchronize()
+        # draws consumed so far: a noise tensor drawn ahead and not yet asked for does not count (it is rewound if it is not wanted)
+        used = None if w._noise_generator is None else (w._noise_ahead[3] if w._noise_ahead is not None else w._noise_generator._draws)
+        return results, used, w
+
+    in_order = lambda n: range(n)  # noqa: E731
+    a, draws_a, wa = run(True, in_order)
+    b, draws_b, _ = run(False, in_order)
+    assert len(a) == len(b) and all(torch.equal(u, v) for u, v in zip(a, b)), kind
+    assert draws_a == draws_b
+    if kind != "pyramid_rk":  # (the RK wrapper walks its stages strictly in order)
+        assert wa._noise_side is not None  # the side stream was really used
+    if kind not in ("pyramid_rk", "colored_unipc"):  # (UniPC's corrector system is singular on a non-monotone step history)
+        jumps = lambda n: [0, 1, 3, 2, 4]  # noqa: E731  step 3 is asked for when 2 was drawn ahead: dropped, counter rewound
+        a, draws_a, _ = run(True, jumps)
+        b, draws_b, _ = run(False, jumps)
+        assert all(torch.equal(u, v) for u, v in zip(a, b)) and draws_a == draws_b, kind
