@@ -382,7 +382,11 @@ class SkrampleWrapperCore(abc.ABC):
         noise = self._take_noise_ahead(step, sample, lazy_ok)
         if noise is None:
             if self._noise_done is not None:  # the generator's workspaces were last used on the side stream
-                torch.cuda.current_stream(sample.device).wait_event(self._noise_done)
+                if torch.cuda.is_current_stream_capturing():
+                    # an event from outside a capture can be neither waited on nor queried inside it
+                    raise SkrampleHipError("this wrapper has drawn noise ahead on its side stream: synchronize the device and call noise_quiesced() before capturing (skrample_amd.graphs.capture_sampling_loop does)")
+                else:
+                    torch.cuda.current_stream(sample.device).wait_event(self._noise_done)
                 self._noise_done = None
             noise = gen.generate_lazy(step) if lazy_ok else gen.generate(step)
         return noise if lazy_ok else lazy.cast(noise, dtype or sample.dtype)
@@ -398,6 +402,12 @@ class SkrampleWrapperCore(abc.ABC):
     # ^ generators drawn ahead.  Measured on MI355X (tools/bench_configs.py): RKUltra-6 + Pyramid (BASELINE config 5 shard) 51.4 -> 47.9 us
     # per stage call; Colored is left out -- its plane kernels hold 134 KiB of LDS and most of the vector registers of every CU, the
     # step kernel cannot co-reside, and UniPC-3 + Colored (config 3) went 702 -> 736 us per call with it drawn ahead.
+
+    def noise_quiesced(self) -> None:
+        "(not in the reference) tell the wrapper that the device has been synchronized: nothing drawn ahead is in flight any more"
+        if self._noise_ahead is not None and self._noise_generator is not None and self._noise_generator._draws == self._noise_ahead[4]:
+            self._noise_generator._draws = self._noise_ahead[3]
+        self._noise_ahead = self._noise_done = None
 
     def _retire_noise_generator(self) -> None:
         "drop the generator: its workspaces go back to the allocator, so whatever the side stream still runs on them must be ordered first"

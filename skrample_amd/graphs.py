@@ -104,6 +104,8 @@ def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor],
             run(static_in)
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
+    if hasattr(wrapper, "noise_quiesced"):
+        wrapper.noise_quiesced()  # the warm-up may have drawn noise ahead on the wrapper's side stream; the device is idle now
 
     rows = None
     if indexed:

@@ -575,3 +575,31 @@ def test_noise_drawn_ahead_on_the_side_stream_is_value_identical(kind, dev):
         a, draws_a, _ = run(True, jumps)
         b, draws_b, _ = run(False, jumps)
         assert all(torch.equal(u, v) for u, v in zip(a, b)) and draws_a == draws_b, kind
+
+
+def test_capture_after_steps_with_noise_drawn_ahead(dev):
+    "a wrapper that has drawn noise ahead on its side stream can still be captured into a HIP graph afterwards (nothing is drawn ahead inside a capture)"
+    import skrample_amd.diffusers as PD
+    import skrample_amd.scheduling as PS
+    from skrample_amd.graphs import capture_sampling_loop
+    from skrample_amd.sampling import structured as PT
+
+    shape, steps, seeds = (3, 4, 32, 32), 5, [3, 4, 5]
+    g = torch.Generator().manual_seed(16)
+    net = lambda x, t: x * (0.5 + t / 2000)  # noqa: E731
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=PN.Pyramid)  # noqa: E731
+
+    def eager(w, x, n):
+        w.set_timesteps(steps)
+        for t in w.timesteps.tolist()[:n]:
+            x = w.step(net(x, t), t, x, generator=seeds, return_dict=False)[0]
+        return x
+
+    want = eager(mk(), x0, steps)
+    w = mk()
+    eager(w, x0, 3)  # stops mid-run: the noise of step 3 is in flight on the side stream
+    assert w._noise_ahead is not None and w._noise_done is not None
+    loop = capture_sampling_loop(w, net, x0, steps, seeds=seeds)
+    assert torch.equal(loop(x0), want)
+    assert torch.equal(eager(w, x0, steps), want)  # and eager again after the capture
