@@ -250,6 +250,7 @@ class SkrampleWrapperCore(abc.ABC):
         self._noise_ahead = None  # (step, tensor, event, draws before, draws after): the next step's noise, drawn on the side stream
         self._noise_done = None  # event behind the latest generator launch, whichever stream it ran on (workspaces are shared)
         self._noise_side = None
+        self._noise_wanted = None  # (next step, sample): drawn ahead once this call's own launch has been issued
         self._alias_stamps: list[tuple[Tensor, int, int]] = []  # (caller tensor aliased by history, data_ptr, _version)
 
     # ---- guard of the aliased history (alias_history=True) -------------------------------------------------------
@@ -444,6 +445,11 @@ class SkrampleWrapperCore(abc.ABC):
             main.wait_event(event)
             item.record_stream(main)
         return item
+
+    def _issue_noise_ahead(self) -> None:
+        wanted, self._noise_wanted = self._noise_wanted, None
+        if wanted is not None:
+            self._draw_noise_ahead(*wanted)
 
     def _draw_noise_ahead(self, next_step: Step | None, sample) -> None:
         "enqueue the generation of `next_step`'s noise on the side stream (call after this step's noise exists, before its kernel)"
@@ -677,7 +683,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         noise = None
         if self.sampler.require_noise:
             noise = self.get_step_noise(step, sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
-            self._draw_noise_ahead(Step.from_int(idx + 1, len(table)) if idx + 1 < len(table) else None, sample)
+            self._noise_wanted = (Step.from_int(idx + 1, len(table)) if idx + 1 < len(table) else None, sample)
 
         # step programs (sampling/program.py): lower each distinct step once, then replay by pointer binding
         owner = (self.sampler, self.model, self.schedule, self._steps, self.compute_scale)
@@ -719,6 +725,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._raw_samples = self._raw_samples[max(len(self._raw_samples) - keep, 0) :]
         if self.alias_history:
             self._alias_hold((sample, model_output), 2 * keep)
+        self._issue_noise_ahead()  # behind this step's launch in host order: the step kernel is never kept waiting for it
         return self._finish(record.final, record.prediction, model_output, return_dict)
 
 
@@ -851,7 +858,7 @@ class RKWrapperCore(SkrampleWrapperCore):
             noise = None
             if abs(self.stochasticity) > 1e-8:
                 noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), self._sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
-                self._draw_noise_ahead(self._next_noise_step(), self._sample)
+                self._noise_wanted = (self._next_noise_step(), self._sample)
             self._last_noise = noise
             mix = sum((d * w for d, w in zip(self._derivatives[1:], weights[1:])), self._derivatives[0] * weights[0])
             form = space.update_form(base, mix, DeltaPoint(s0, s1), noise, self.stochasticity)
@@ -885,7 +892,9 @@ class RKWrapperCore(SkrampleWrapperCore):
         elif self.alias_history:
             self._alias_check(model_output, sample)
             try:
-                return self._step_stage(model_output, sample, generator, return_dict)
+                result = self._step_stage(model_output, sample, generator, return_dict)
+                self._issue_noise_ahead()
+                return result
             finally:
                 # between stages exactly the tensors the pending state still reads are held: the step's base sample and the
                 # leaves of the stored derivative forms (the caller's own network outputs only when no rounded conversion
@@ -900,7 +909,9 @@ class RKWrapperCore(SkrampleWrapperCore):
                                 live[id(leaf)] = leaf
                 known = {id(t): (t, ptr, ver) for t, ptr, ver in self._alias_stamps}
                 self._alias_stamps = [known.get(i) or (t, t.data_ptr(), t._version) for i, t in live.items()]
-        return self._step_stage(model_output, sample, generator, return_dict)
+        result = self._step_stage(model_output, sample, generator, return_dict)
+        self._issue_noise_ahead()
+        return result
 
     def _step_stage(self, model_output: Tensor, sample: Tensor, generator, return_dict: bool):
         # stage programs: the same lower-once / replay-by-binding scheme as SkrampleWrapperScheduler.step
@@ -1038,7 +1049,7 @@ class RKWrapperCore(SkrampleWrapperCore):
             #  the generator's stream position must not depend on which path ran)
             base = sample if self._sample is None else self._sample
             noise = self.get_step_noise(Step.from_int(self._index // self.order, self._steps), base, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
-            self._draw_noise_ahead(self._next_noise_step(), base)
+            self._noise_wanted = (self._next_noise_step(), base)
         plan = prog["plan"]
         seeds_ptr = None
         ok = True
