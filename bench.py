@@ -44,10 +44,11 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="samples per GPU (default: the north-star 256)")
     ap.add_argument("--sets", type=int, default=6, help="rotating buffer sets (>= 4)")
-    ap.add_argument("--precondition", type=int, default=300, help="untimed conditioning launches before the warm-up")
+    ap.add_argument("--precondition", type=int, default=1000, help="untimed conditioning launches before the warm-up (see the comment at its use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 FETCH_SIZE / WRITE_SIZE passes (roofline.traffic falls back to the committed summary)")
+    ap.add_argument("--drift", type=int, default=0, help="diagnostic: run this many launches back to back and print the average launch time of every block of 50 (then exit)")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no wrapper-rate and graph-loop keys (used by the counter passes)")
     return ap.parse_args()
 
@@ -425,8 +426,21 @@ def main() -> None:
         e0, e1, e_first, e_warm = (torch.cuda.Event(enable_timing=True) for _ in range(4))
     for ev in (e0, e1, e_first, e_warm):  # (torch creates its HIP event at the first record: do that outside the timed region)
         ev.record()
-    # conditioning (untimed, before the contract's W warm-up steps): ~8 ms of back-to-back launches so that clocks and
-    # the page tables of all buffer sets are in their steady state however small W is
+    if args.drift:  # how the launch time moves over a long back-to-back run (clock / power management), 50 launches per reading
+        marks = [_HipEvent(stream) for _ in range(args.drift // 50 + 1)]
+        torch.cuda.synchronize(dev)
+        marks[0].record()
+        for b in range(1, len(marks)):
+            run(50, offset=50 * (b - 1))
+            marks[b].record()
+        torch.cuda.synchronize(dev)
+        print("us per launch, blocks of 50:", " ".join(f"{marks[b - 1].elapsed_time(marks[b]) * 1e3 / 50:.2f}" for b in range(1, len(marks))))
+        return
+    # conditioning (untimed, before the contract's W warm-up steps): ~26 ms of back-to-back launches so that clocks and the page
+    # tables of all buffer sets are in their steady state however small W and K are.  `--drift 4000` shows why it has to be this
+    # long: from a cold start the launch time rises to 26.3-26.4 us between launches ~100 and ~350 (power management settling),
+    # comes back by launch ~600 and then stays at 25.7-25.85 us for as long as the run lasts; a K=20 window opened after 300
+    # launches sat in that transient.  The count is reported in the JSON line (config.precondition_launches).
     run(args.precondition)
     torch.cuda.synchronize(dev)
     run(args.warmup)
@@ -522,6 +536,7 @@ def main() -> None:
                 "schedule_steps": SCHEDULE_STEPS,
                 "steady_state_steps": [STEADY[0], STEADY[-1]],
                 "buffer_sets": nsets,
+                "precondition_launches": args.precondition,
                 "parallelism": f"batch-shard x{world}, no collective",
             },
             "roofline": {
