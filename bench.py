@@ -48,6 +48,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 FETCH_SIZE / WRITE_SIZE passes (roofline.traffic falls back to the committed summary)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="diagnostic: kernel-selection switches (skr_set_tuning) applied before anything is launched")
     ap.add_argument("--drift", type=int, default=0, help="diagnostic: run this many launches back to back and print the average launch time of every block of 50 (then exit)")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no wrapper-rate and graph-loop keys (used by the counter passes)")
     return ap.parse_args()
@@ -376,6 +377,10 @@ def main() -> None:
     from skrample_amd import _hip
 
     lib = _hip.load()
+    for item in args.tune:
+        key, _, val = item.partition("=")
+        if lib.skr_set_tuning(key.encode(), int(val)) != 0:
+            raise SystemExit(f"--tune {item}: refused")
     batch = args.batch
     numel = batch * C * H * W
     plans = capture_plans(dev, shard)
@@ -434,7 +439,10 @@ def main() -> None:
             run(50, offset=50 * (b - 1))
             marks[b].record()
         torch.cuda.synchronize(dev)
-        print("us per launch, blocks of 50:", " ".join(f"{marks[b - 1].elapsed_time(marks[b]) * 1e3 / 50:.2f}" for b in range(1, len(marks))))
+        per = [marks[b - 1].elapsed_time(marks[b]) * 1e3 / 50 for b in range(1, len(marks))]
+        print("us per launch, blocks of 50:", " ".join(f"{v:.2f}" for v in per))
+        tail = per[len(per) // 2 :]
+        print(f"second half of the run: {sum(tail) / len(tail):.3f} us per launch  (--tune {args.tune})")
         return
     # conditioning (untimed, before the contract's W warm-up steps): ~26 ms of back-to-back launches so that clocks and the page
     # tables of all buffer sets are in their steady state however small W and K are.  `--drift 4000` shows why it has to be this
