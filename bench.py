@@ -319,7 +319,7 @@ def measure_traffic(batch: int) -> tuple[float | None, str]:
                    "--batch", str(batch), "--no-cpu-baseline", "--no-traffic", "--no-extras"]  # fmt: skip
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
             env["TMPDIR"] = "/tmp"
-            proc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            proc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120)
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
             if proc.returncode != 0 or not files:
                 return None, f"{name} pass failed (rc {proc.returncode}): {proc.stderr.decode(errors='replace')[-160:]}"
