@@ -200,10 +200,11 @@ int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scrat
                       int32_t d1, int32_t d2, int32_t d3, double exponent, int32_t has_energy, double energy,
                       void* stream);
 
-/* Same generator for per-sample shapes that are not powers of two (rank 1-4 after dropping size-1 dims, any
+/* Same generator for per-sample shapes that are not powers of two (rank 1-6 after dropping size-1 dims, any
  * sizes >= 2): identical pipeline with the transforms delegated to hipFFT (dlopen'ed on first use; returns
- * SKR_ERR_UNSUPPORTED when libhipfft.so is absent).  Rank 4 (e.g. channels x frames x height x width): hipFFT
- * takes the inner three axes, the outermost (<= 128 long) is a direct DFT fused with the radial weights.  Workspaces: spec_c64 = batch*prod(dims[:-1])*(dims[-1]/2+1)
+ * SKR_ERR_UNSUPPORTED when libhipfft.so is absent).  Rank 4-6 (e.g. channels x frames x height x width): hipFFT
+ * takes the inner three axes, every outer axis (<= 128 long) is a direct DFT kernel, the outermost one fused with
+ * the radial weights.  Workspaces: spec_c64 = batch*prod(dims[:-1])*(dims[-1]/2+1)
  * complex64, scratch_f32 = batch*prod(dims), partials_f64 = 4*batch*256 doubles. */
 int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
                           const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank,

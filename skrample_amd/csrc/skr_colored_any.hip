@@ -70,7 +70,8 @@ struct AnyArgs {
   const uint64_t* seeds;
   uint64_t stream;
   int64_t batch, unit;
-  int32_t d0;           // outermost axis of a 4-axis unit (1 otherwise); d1,d2,d3 are the hipFFT axes
+  int32_t n_outer;      // axes outside the three hipFFT axes (0..3), outermost first; each is a direct DFT (any_outer_axis)
+  int32_t outer[3];
   int32_t d1, d2, d3, d3h;
   float exponent_half_neg, eps_clip, inv_rmax;
 };
@@ -132,58 +133,90 @@ __global__ __launch_bounds__(256) void any_weights(const AnyArgs a) {
   }
 }
 
-// 4-axis units: hipFFT transforms the three inner axes (batched over batch*d0); the outermost axis (length d0 <= 128,
-// e.g. channels or frames) is a direct DFT per spectral column: forward, radial weights of the full 4-D frequency,
-// inverse -- one lane per column, its d0 values staged in LDS (column-private, no barriers after the twiddle table).
-constexpr int AXIS0_THREADS = 64;
-__global__ __launch_bounds__(AXIS0_THREADS) void any_axis0(const AnyArgs a) {
-  extern __shared__ float2 sh[];  // [d0] twiddles, [d0][64] values, [d0][64] weighted spectrum
+// Units with 4 to 6 transform axes: hipFFT takes the three inner axes (batched over batch * prod(outer)); every outer axis
+// (length <= 128, e.g. channels or frames) is a direct DFT per spectral line -- one lane per line, its values staged in LDS
+// (line-private, no barriers after the twiddle table).  Lines of axis j are `inner` complex elements apart, inner = everything
+// below the axis.  MODE 0 forward, 1 inverse (both in place), 2 forward + radial weights of the full N-D frequency + inverse:
+// the outermost axis, which is transformed last on the way in and first on the way out.
+constexpr int AXIS_THREADS = 64;
+template <int MODE>
+__global__ __launch_bounds__(AXIS_THREADS) void any_outer_axis(const AnyArgs a, int axis) {
+  extern __shared__ float2 sh[];  // [d] twiddles, [d][64] values, [d][64] spectrum (MODE 2)
+  const int lane = threadIdx.x, d = a.outer[axis];
   float2* tw = sh;
-  float2* v = tw + a.d0;
-  float2* x = v + a.d0 * AXIS0_THREADS;
-  const int lane = threadIdx.x, d0 = a.d0;
-  for (int j = lane; j < d0; j += AXIS0_THREADS) {
+  float2* v = tw + d;
+  float2* x = v + d * AXIS_THREADS;
+  for (int j = lane; j < d; j += AXIS_THREADS) {
     float sn, cs;
-    sincospif(-2.0f * (float)j / (float)d0, &sn, &cs);
+    sincospif(-2.0f * (float)j / (float)d, &sn, &cs);
     tw[j] = make_float2(cs, sn);
   }
   __syncthreads();
-  const int64_t cols = (int64_t)a.d1 * a.d2 * a.d3h;
-  const int64_t smp = blockIdx.y;
-  float2* base = a.spec + smp * d0 * cols;
-  for (int64_t q = (int64_t)blockIdx.x * AXIS0_THREADS + lane; q < cols; q += (int64_t)gridDim.x * AXIS0_THREADS) {
-    for (int n = 0; n < d0; ++n) v[n * AXIS0_THREADS + lane] = base[(int64_t)n * cols + q];
-    int64_t r = q;
-    const int k3 = (int)(r % a.d3h); r /= a.d3h;
-    const int k2 = (int)(r % a.d2);
-    const int k1 = (int)(r / a.d2);
-    const float f1 = a.d1 > 1 ? axis_freq(k1, a.d1) : 0.f, f2 = a.d2 > 1 ? axis_freq(k2, a.d2) : 0.f, f3 = (float)k3 / (float)a.d3;
-    const float rest = f1 * f1 + f2 * f2 + f3 * f3;
-    for (int k = 0; k < d0; ++k) {
+  const int64_t plane = (int64_t)a.d1 * a.d2 * a.d3h;
+  int64_t inner = plane, sample = plane;
+  for (int j = 0; j < a.n_outer; ++j) { sample *= a.outer[j]; if (j > axis) inner *= a.outer[j]; }
+  const int64_t lines = sample / d;
+  float2* base = a.spec + (int64_t)blockIdx.y * sample;
+  for (int64_t q = (int64_t)blockIdx.x * AXIS_THREADS + lane; q < lines; q += (int64_t)gridDim.x * AXIS_THREADS) {
+    const int64_t hi = q / inner, lo = q - hi * inner;
+    float2* line = base + hi * d * inner + lo;
+    for (int n = 0; n < d; ++n) v[n * AXIS_THREADS + lane] = line[(int64_t)n * inner];
+    if (MODE == 1) {
+      for (int n = 0; n < d; ++n) {
+        float2 acc = make_float2(0.f, 0.f);
+        int idx = 0;  // (n * k) mod d
+        for (int k = 0; k < d; ++k) {
+          const float2 t = tw[idx], u = v[k * AXIS_THREADS + lane];
+          acc.x += u.x * t.x + u.y * t.y;  // conj(t)
+          acc.y += u.y * t.x - u.x * t.y;
+          idx += n; if (idx >= d) idx -= d;
+        }
+        line[(int64_t)n * inner] = acc;
+      }
+      continue;
+    }
+    float rest = 0.f;
+    if (MODE == 2) {  // squared frequency of every other axis at this line (axis == 0: hi == 0, lo enumerates them all)
+      int64_t r = lo;
+      const int k3 = (int)(r % a.d3h); r /= a.d3h;
+      const int k2 = (int)(r % a.d2); r /= a.d2;
+      const int k1 = (int)(r % a.d1); r /= a.d1;
+      const float f1 = a.d1 > 1 ? axis_freq(k1, a.d1) : 0.f, f2 = a.d2 > 1 ? axis_freq(k2, a.d2) : 0.f, f3 = (float)k3 / (float)a.d3;
+      rest = f1 * f1 + f2 * f2 + f3 * f3;
+      for (int j = a.n_outer - 1; j >= 1; --j) {
+        const int kj = (int)(r % a.outer[j]); r /= a.outer[j];
+        const float fj = axis_freq(kj, a.outer[j]);
+        rest += fj * fj;
+      }
+    }
+    for (int k = 0; k < d; ++k) {
       float2 acc = make_float2(0.f, 0.f);
-      int idx = 0;  // (n * k) mod d0
-      for (int n = 0; n < d0; ++n) {
-        const float2 t = tw[idx], u = v[n * AXIS0_THREADS + lane];
+      int idx = 0;
+      for (int n = 0; n < d; ++n) {
+        const float2 t = tw[idx], u = v[n * AXIS_THREADS + lane];
         acc.x += u.x * t.x - u.y * t.y;
         acc.y += u.x * t.y + u.y * t.x;
-        idx += k; if (idx >= d0) idx -= d0;
+        idx += k; if (idx >= d) idx -= d;
       }
-      const float f0 = axis_freq(k, d0);
+      if (MODE == 0) { line[(int64_t)k * inner] = acc; continue; }
+      const float f0 = axis_freq(k, d);
       float radius = __builtin_amdgcn_sqrtf(f0 * f0 + rest) * a.inv_rmax;
       radius = radius < a.eps_clip ? a.eps_clip : radius;
       const float w = __builtin_amdgcn_exp2f(a.exponent_half_neg * __builtin_amdgcn_logf(radius));
-      x[k * AXIS0_THREADS + lane] = make_float2(acc.x * w, acc.y * w);
+      x[k * AXIS_THREADS + lane] = make_float2(acc.x * w, acc.y * w);
     }
-    for (int n = 0; n < d0; ++n) {
-      float2 acc = make_float2(0.f, 0.f);
-      int idx = 0;
-      for (int k = 0; k < d0; ++k) {
-        const float2 t = tw[idx], u = x[k * AXIS0_THREADS + lane];
-        acc.x += u.x * t.x + u.y * t.y;  // conj(t)
-        acc.y += u.y * t.x - u.x * t.y;
-        idx += n; if (idx >= d0) idx -= d0;
+    if (MODE == 2) {
+      for (int n = 0; n < d; ++n) {
+        float2 acc = make_float2(0.f, 0.f);
+        int idx = 0;
+        for (int k = 0; k < d; ++k) {
+          const float2 t = tw[idx], u = x[k * AXIS_THREADS + lane];
+          acc.x += u.x * t.x + u.y * t.y;  // conj(t)
+          acc.y += u.y * t.x - u.x * t.y;
+          idx += n; if (idx >= d) idx -= d;
+        }
+        line[(int64_t)n * inner] = acc;
       }
-      base[(int64_t)n * cols + q] = acc;
     }
   }
 }
@@ -220,7 +253,7 @@ __global__ __launch_bounds__(256) void any_finish(T* out, const AnyArgs a, int h
 static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
                             const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
                             double exponent, int32_t has_energy, double energy, void* stream, bool white_given) {
-  if (batch < 0 || rank < 1 || rank > 4 || !dims) return SKR_ERR_SHAPE;
+  if (batch < 0 || rank < 1 || rank > 6 || !dims) return SKR_ERR_SHAPE;
   for (int i = 0; i < rank; ++i) if (dims[i] < 2) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
   if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || (!white_given && !seeds_dev)) return SKR_ERR_NULL;
@@ -229,18 +262,23 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
   if (!f.ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
   const int full_rank = rank;
   const int32_t* full_dims = dims;
-  int d0 = 1;
-  if (rank == 4) {  // outermost axis by direct DFT (any_axis0), the inner three by hipFFT batched over batch*d0
-    d0 = dims[0];
-    if (d0 > 128 || batch * d0 > 0x7fffffffll) return SKR_ERR_UNSUPPORTED;  // (d0 + 2*d0*64) float2 of LDS: 132 KiB at 128
-    dims += 1; rank = 3;
+  AnyArgs a;
+  a.n_outer = 0; a.outer[0] = a.outer[1] = a.outer[2] = 1;
+  int64_t d0 = 1;  // product of the outer axes
+  if (rank > 3) {  // outer axes by direct DFT (any_outer_axis), the inner three by hipFFT batched over batch * prod(outer)
+    a.n_outer = rank - 3;
+    for (int j = 0; j < a.n_outer; ++j) {
+      if (dims[j] > 128) return SKR_ERR_UNSUPPORTED;  // (d + 2*d*64) float2 of LDS: 132 KiB at 128
+      a.outer[j] = dims[j];
+      d0 *= dims[j];
+    }
+    if (batch * d0 > 0x7fffffffll) return SKR_ERR_UNSUPPORTED;
+    dims += a.n_outer; rank = 3;
   }
   int n[3] = {1, 1, 1};
   for (int i = 0; i < rank; ++i) n[3 - rank + i] = dims[i];
-  AnyArgs a;
-  a.d0 = d0;
   a.real = scratch_f32; a.spec = reinterpret_cast<float2*>(spec_c64); a.partials = partials_f64; a.seeds = seeds_dev; a.stream = stream_id;
-  a.batch = batch; a.d1 = n[0]; a.d2 = n[1]; a.d3 = n[2]; a.d3h = n[2] / 2 + 1; a.unit = (int64_t)d0 * n[0] * n[1] * n[2];
+  a.batch = batch; a.d1 = n[0]; a.d2 = n[1]; a.d3 = n[2]; a.d3h = n[2] / 2 + 1; a.unit = d0 * n[0] * n[1] * n[2];
   a.exponent_half_neg = (float)(-exponent / 2.0);
   double n_eff = 0;
   for (int i = 0; i < full_rank; ++i) n_eff += full_dims[i];
@@ -287,12 +325,25 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
   if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
   if (f.r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
-  if (d0 > 1) {
-    const int64_t cols = (int64_t)a.d1 * a.d2 * a.d3h;
-    int64_t ab = (cols + AXIS0_THREADS - 1) / AXIS0_THREADS; if (ab > 4096) ab = 4096;
-    const size_t lds = sizeof(float2) * ((size_t)d0 + 2 * (size_t)d0 * AXIS0_THREADS);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(any_axis0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SKR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(any_axis0, dim3((unsigned)ab, (unsigned)batch), dim3(AXIS0_THREADS), lds, s, a);
+  if (a.n_outer > 0) {
+    const int64_t sample = d0 * a.d1 * a.d2 * a.d3h;
+    auto pass = [&](int mode, int axis) -> int {
+      const int d = a.outer[axis];
+      const int64_t lines = sample / d;
+      int64_t ab = (lines + AXIS_THREADS - 1) / AXIS_THREADS; if (ab > 4096) ab = 4096;
+      const size_t lds = sizeof(float2) * ((size_t)d + (mode == 2 ? 2 : 1) * (size_t)d * AXIS_THREADS);
+      const void* fn = mode == 0 ? reinterpret_cast<const void*>(any_outer_axis<0>) : (mode == 1 ? reinterpret_cast<const void*>(any_outer_axis<1>) : reinterpret_cast<const void*>(any_outer_axis<2>));
+      if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+      const dim3 grid((unsigned)ab, (unsigned)batch);
+      if (mode == 0) hipLaunchKernelGGL(any_outer_axis<0>, grid, dim3(AXIS_THREADS), lds, s, a, axis);
+      else if (mode == 1) hipLaunchKernelGGL(any_outer_axis<1>, grid, dim3(AXIS_THREADS), lds, s, a, axis);
+      else hipLaunchKernelGGL(any_outer_axis<2>, grid, dim3(AXIS_THREADS), lds, s, a, axis);
+      return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+    };
+    int rc;
+    for (int j = a.n_outer - 1; j >= 1; --j) if ((rc = pass(0, j)) != SKR_OK) return rc;
+    if ((rc = pass(2, 0)) != SKR_OK) return rc;  // outermost: forward, weights, inverse
+    for (int j = 1; j < a.n_outer; ++j) if ((rc = pass(1, j)) != SKR_OK) return rc;
   } else {
     int64_t wb = ((int64_t)a.d1 * a.d2 * a.d3h * batch + 255) / 256; if (wb > 256 * 32) wb = 256 * 32;
     hipLaunchKernelGGL(any_weights, dim3((unsigned)wb), dim3(256), 0, s, a);

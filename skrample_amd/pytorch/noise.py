@@ -399,8 +399,8 @@ class Colored(TensorNoiseCommon):
     def _axes(unit_shape) -> tuple[list[int], bool]:
         "(transform dims after dropping size-1 axes, whether the hand-written power-of-two path applies)"
         dims = [d for d in unit_shape if d != 1]
-        if not 1 <= len(dims) <= 4 or (len(dims) == 4 and dims[0] > 128):
-            raise SkrampleHipError(f"Colored noise needs 1 to 4 transform axes per sample (the first of four at most 128 long), got shape {tuple(unit_shape)}")
+        if not 1 <= len(dims) <= 6 or any(d > 128 for d in dims[:-3]):
+            raise SkrampleHipError(f"Colored noise needs 1 to 6 transform axes per sample (those outside the last three at most 128 long), got shape {tuple(unit_shape)}")
         pow2 = 2 <= len(dims) <= 3 and all(d & (d - 1) == 0 for d in dims) and dims[-1] >= 4 and max(dims) <= 4096
         return dims, pow2
 
@@ -408,7 +408,7 @@ class Colored(TensorNoiseCommon):
     def colorize_noise(white: torch.Tensor, exponent: float = 0.0, energy: float | None = None) -> torch.Tensor:
         """Colour an existing white-noise tensor with the power-law spectrum f^(-exponent), normalised back to the
         input's std (or to `energy`).  Size-1 dimensions are excluded from the transform; no batching -- the whole
-        tensor is one sample (reference noise.py:337-403).  Any shape with 1-4 transform axes (hipFFT)."""
+        tensor is one sample (reference noise.py:337-403).  Any shape with 1-6 transform axes (hipFFT + direct outer-axis DFTs)."""
         import ctypes
 
         _hip.require_device(white, "white noise")
@@ -418,8 +418,8 @@ class Colored(TensorNoiseCommon):
             wstd = white.float().std()
             return white if wstd.item() < 1e-8 else (white.float() * (energy / wstd)).to(white.dtype)
         dims = [d for d in white.shape if d != 1]
-        if not 1 <= len(dims) <= 4 or (len(dims) == 4 and dims[0] > 128):
-            raise SkrampleHipError(f"colorize_noise needs 1 to 4 transform axes (the first of four at most 128 long), got shape {tuple(white.shape)}")
+        if not 1 <= len(dims) <= 6 or any(d > 128 for d in dims[:-3]):
+            raise SkrampleHipError(f"colorize_noise needs 1 to 6 transform axes (those outside the last three at most 128 long), got shape {tuple(white.shape)}")
         dev, unit = white.device, math.prod(dims)
         work = white.detach().to(torch.float32).contiguous().clone().reshape(-1)  # transform workspace, overwritten
         spec = torch.empty(unit // dims[-1] * (dims[-1] // 2 + 1), dtype=torch.complex64, device=dev)

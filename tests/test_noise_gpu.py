@@ -306,7 +306,7 @@ def test_pyramid_through_wrapper(dev):
     assert torch.isfinite(x.float()).all() and x.dtype == torch.bfloat16
 
 
-@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10)])
+@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
 def test_colored(unit, dev):
     seeds = [31, 32]
     cases = [
@@ -497,7 +497,23 @@ def test_colorize_noise_equals_reference_fixtures(dev):
     assert c.shape == w.shape and c.dtype == torch.bfloat16
     assert abs(c.float().std().item() - w.bfloat16().float().std().item()) < 2e-2
     with pytest.raises(_hip.SkrampleHipError):
-        PN.Colored.colorize_noise(torch.randn(2, 2, 2, 2, 2, device=dev), exponent=1.0)
+        PN.Colored.colorize_noise(torch.randn(2, 2, 2, 2, 2, 2, 2, device=dev), exponent=1.0)  # seven transform axes
+
+
+def test_colorize_noise_with_up_to_six_axes_equals_reference_fixtures(dev):
+    """tests/golden/colorize_nd.npz: the reference's colorize_noise on tensors with 4, 5 and 6 transform axes (the whole tensor is
+    one sample: a batched video latent has five).  hipFFT takes the last three axes, every outer axis is a direct DFT kernel."""
+    from conftest import load_npz
+
+    fx = load_npz("colorize_nd.npz")
+    tags = sorted({k.split("/")[0] for k in fx})
+    assert len(tags) == 4
+    for tag in tags:
+        white = torch.from_numpy(fx[f"{tag}/white"]).to(dev)
+        exponent, energy = fx[f"{tag}/args"].tolist()
+        got = PN.Colored.colorize_noise(white, exponent=exponent, energy=None if math.isnan(energy) else energy).cpu()
+        ref = torch.from_numpy(fx[f"{tag}/out"])
+        assert got.shape == ref.shape and rel(got, ref) < 2e-5, (tag, rel(got, ref))
 
 
 def test_component_methods(dev):

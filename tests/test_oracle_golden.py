@@ -278,3 +278,12 @@ def test_native_dtype_chain_equals_the_reference_bit_for_bit(tag):
         previous.append(rec)
         keep = OA.require_previous(cfg)
         previous = previous[max(len(previous) - keep, 0) :] if keep else []
+
+
+def test_colorize_with_up_to_six_axes_fixtures():
+    "tests/golden/colorize_nd.npz (the reference's colorize_noise on 4-, 5- and 6-axis tensors): the oracle reproduces the recorded outputs"
+    fx = load_npz("colorize_nd.npz")
+    for tag in sorted({k.split("/")[0] for k in fx}):
+        exponent, energy = fx[f"{tag}/args"].tolist()
+        got = ON.colorize(torch.from_numpy(fx[f"{tag}/white"]), exponent, None if math.isnan(energy) else energy)
+        assert torch.equal(got, torch.from_numpy(fx[f"{tag}/out"])), tag

@@ -340,6 +340,18 @@ def noise() -> None:
                 blob[f"pyramid_{tag}/{u}/reference_error"] = np.asarray(type(exc).__name__)
     np.savez_compressed(os.path.join(OUT, "noise_dims.npz"), **blob)
 
+    # colorize_nd.npz: Colored.colorize_noise (noise.py:337-403) on tensors with 4, 5 and 6 transform axes -- the whole tensor
+    # is one sample there, so a batched video latent (B, C, T, H, W) has five
+    blob = {}
+    gw = torch.Generator().manual_seed(60)
+    for shape, exponent, energy in (((3, 4, 5, 6, 8), 1.0, None), ((2, 3, 2, 5, 4, 6), -0.75, None), ((5, 1, 7, 3, 9, 10), 2.0, 1.7), ((6, 3, 10, 12), 0.5, None)):
+        tag = "x".join(map(str, shape))
+        white = torch.randn(shape, generator=gw)
+        blob[f"{tag}/white"] = white.numpy()
+        blob[f"{tag}/out"] = RN.Colored.colorize_noise(white.clone(), exponent, energy).numpy()
+        blob[f"{tag}/args"] = np.asarray([exponent, float("nan") if energy is None else energy])
+    np.savez_compressed(os.path.join(OUT, "colorize_nd.npz"), **blob)
+
 
 # ---------------------------------------------------------------------------------------------------
 def _norm(v):
