@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 9
+#define SKR_ABI_VERSION 10
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 /* Devices and streams: every entry point launches on the device that owns its output buffer (queried from the pointer when
@@ -38,6 +38,7 @@ enum skr_status {
   SKR_ERR_SHAPE = 5,       /* numel / sample_numel / shape arguments inconsistent */
   SKR_ERR_LAUNCH = 6,      /* hipLaunchKernel failed (see skr_last_hip_error) */
   SKR_ERR_UNSUPPORTED = 7, /* valid request outside what the kernels cover */
+  SKR_ERR_LIBRARY = 8,     /* an external library failed its self-check: a new hipFFT plan transformed unit impulses wrongly (skr_noise_colored_any / skr_colorize) */
 };
 
 enum skr_dtype { SKR_BF16 = 0, SKR_F16 = 1, SKR_F32 = 2, SKR_F64 = 3, SKR_NONE = -1 };
@@ -247,6 +248,9 @@ const char* skr_build_info(void);
  *                   (default), 2 wherever it is instantiated, 0 never
  *   "pace"     1|0  paced load issue in the one-trip kernels (default 1)
  *   "rk_uv"    0|1|2|4  vectors per lane of the grid-stride Runge-Kutta stage kernel (0 = default)
+ *   "fft_rank" 0|1|2  skr_noise_colored_any / skr_colorize: trailing axes handed to hipFFT (0 = up to three, the default); the
+ *                   other axes run on the direct-DFT kernels, as they do by themselves when a three-axis plan fails its
+ *                   self-check (results agree to rounding, not bit for bit)
  *   "reset"    (value ignored) back to the defaults
  * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_NO_TWO_OUT, SKR_RK_UV=n. */
 int skr_set_tuning(const char* key, int32_t value);

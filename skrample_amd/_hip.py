@@ -13,7 +13,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 9
+ABI_VERSION = 10
 SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1

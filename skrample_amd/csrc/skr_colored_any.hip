@@ -8,12 +8,15 @@
 #include <stdint.h>
 
 #include <map>
+#include <set>
 #include <mutex>
 #include <tuple>
 
 #include "skr_device.h"
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
+
+namespace skr { int g_fft_rank = 0; }
 
 namespace {
 
@@ -58,6 +61,7 @@ struct Plans { hipfftHandle_t fwd, inv; uint64_t last_use; };
 typedef std::tuple<int /*device*/, hipStream_t, int, int, int, int, int64_t> PlanKey;
 std::mutex g_mutex;
 std::map<PlanKey, Plans> g_plans;
+std::set<PlanKey> g_bad_plans;  // plans whose self-check failed
 uint64_t g_plan_clock = 0;
 constexpr size_t MAX_PLANS = 32;
 
@@ -70,8 +74,8 @@ struct AnyArgs {
   const uint64_t* seeds;
   uint64_t stream;
   int64_t batch, unit;
-  int32_t n_outer;      // axes outside the three hipFFT axes (0..3), outermost first; each is a direct DFT (any_outer_axis)
-  int32_t outer[3];
+  int32_t n_outer;      // axes outside the hipFFT axes (0..5), outermost first; each is a direct DFT (any_outer_axis)
+  int32_t outer[5];
   int32_t d1, d2, d3, d3h;
   float exponent_half_neg, eps_clip, inv_rmax;
 };
@@ -248,32 +252,89 @@ __global__ __launch_bounds__(256) void any_finish(T* out, const AnyArgs a, int h
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)gridDim.x * 256) out[smp * a.unit + e] = (T)(a.real[smp * a.unit + e] * factor);
 }
 
+// ---- plan self-check -------------------------------------------------------------------------------------------------------
+// Found by the soak runs of round 2 (tools/fft_probe.py reproduces it with torch.fft alone): in a process that has created many
+// plans of other shapes, rocFFT 7.2 can hand back a real multi-dimensional plan (small power-of-two lengths, last axis 8 or 32)
+// that computes a WRONG transform -- 20-60 % off, persistently for that plan.  So every new plan pair is run once on unit
+// impulses (one per batch entry, each at its own position), whose spectrum is known in closed form, and then back; a plan that
+// fails is destroyed and the call returns SKR_ERR_LIBRARY instead of colouring noise with a broken transform.
+struct SelfTest {
+  float* real;
+  float2* spec;
+  unsigned long long* bad;
+  int64_t entries;  // batch * prod(outer)
+  int32_t n0, n1, n2, n2h;
+};
+
+__device__ __forceinline__ int64_t selftest_position(int64_t b, int64_t n) { return (int64_t)(((uint64_t)(b + 1) * 40503ull + 7ull) % (uint64_t)n); }
+
+__global__ __launch_bounds__(256) void selftest_fill(const SelfTest t) {
+  const int64_t n = (int64_t)t.n0 * t.n1 * t.n2, total = n * t.entries;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *t.bad = 0ull;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / n, e = i - b * n;
+    t.real[i] = e == selftest_position(b, n) ? 1.0f : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void selftest_check_forward(const SelfTest t) {
+  const int64_t n = (int64_t)t.n0 * t.n1 * t.n2, nh = (int64_t)t.n0 * t.n1 * t.n2h, total = nh * t.entries;
+  unsigned long long bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / nh;
+    int64_t r = i - b * nh;
+    const int k2 = (int)(r % t.n2h); r /= t.n2h;
+    const int k1 = (int)(r % t.n1);
+    const int k0 = (int)(r / t.n1);
+    int64_t p = selftest_position(b, n);
+    const int p2 = (int)(p % t.n2); p /= t.n2;
+    const int p1 = (int)(p % t.n1);
+    const int p0 = (int)(p / t.n1);
+    // exp(-2 pi i (k0 p0/n0 + k1 p1/n1 + k2 p2/n2)), the phase reduced exactly in integers before it meets floating point
+    const double turns = (double)(((int64_t)k0 * p0) % t.n0) / t.n0 + (double)(((int64_t)k1 * p1) % t.n1) / t.n1 + (double)(((int64_t)k2 * p2) % t.n2) / t.n2;
+    double sn, cs;
+    sincospi(-2.0 * turns, &sn, &cs);
+    const float2 v = t.spec[i];
+    if (!(fabs((double)v.x - cs) < 1e-3 && fabs((double)v.y - sn) < 1e-3)) ++bad;
+  }
+  if (bad) atomicAdd(t.bad, bad);
+}
+
+__global__ __launch_bounds__(256) void selftest_check_inverse(const SelfTest t) {
+  const int64_t n = (int64_t)t.n0 * t.n1 * t.n2, total = n * t.entries;
+  unsigned long long bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / n, e = i - b * n;
+    const float want = e == selftest_position(b, n) ? (float)n : 0.0f;  // unnormalised round trip
+    if (!(fabsf(t.real[i] - want) < 1e-3f * (float)n)) ++bad;
+  }
+  if (bad) atomicAdd(t.bad, bad);
+}
+
 }  // namespace
 
-static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
-                            const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
-                            double exponent, int32_t has_energy, double energy, void* stream, bool white_given) {
-  if (batch < 0 || rank < 1 || rank > 6 || !dims) return SKR_ERR_SHAPE;
-  for (int i = 0; i < rank; ++i) if (dims[i] < 2) return SKR_ERR_SHAPE;
-  if (batch == 0) return SKR_OK;
-  if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || (!white_given && !seeds_dev)) return SKR_ERR_NULL;
-  if (batch > 65535) return SKR_ERR_UNSUPPORTED;
+// one attempt with the last `fft_rank` axes given to hipFFT and every axis outside them to the direct-DFT kernels
+static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
+                               const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
+                               double exponent, int32_t has_energy, double energy, void* stream, bool white_given, int fft_rank) {
   FftApi& f = api();
   if (!f.ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
   const int full_rank = rank;
   const int32_t* full_dims = dims;
   AnyArgs a;
-  a.n_outer = 0; a.outer[0] = a.outer[1] = a.outer[2] = 1;
+  a.n_outer = 0;
+  for (int j = 0; j < 5; ++j) a.outer[j] = 1;
   int64_t d0 = 1;  // product of the outer axes
-  if (rank > 3) {  // outer axes by direct DFT (any_outer_axis), the inner three by hipFFT batched over batch * prod(outer)
-    a.n_outer = rank - 3;
+  if (rank > fft_rank) {  // outer axes by direct DFT (any_outer_axis), the inner ones by hipFFT batched over batch * prod(outer)
+    a.n_outer = rank - fft_rank;
+    if (a.n_outer > 5) return SKR_ERR_UNSUPPORTED;
     for (int j = 0; j < a.n_outer; ++j) {
       if (dims[j] > 128) return SKR_ERR_UNSUPPORTED;  // (d + 2*d*64) float2 of LDS: 132 KiB at 128
       a.outer[j] = dims[j];
       d0 *= dims[j];
     }
     if (batch * d0 > 0x7fffffffll) return SKR_ERR_UNSUPPORTED;
-    dims += a.n_outer; rank = 3;
+    dims += a.n_outer; rank = fft_rank;
   }
   int n[3] = {1, 1, 1};
   for (int i = 0; i < rank; ++i) n[3 - rank + i] = dims[i];
@@ -295,9 +356,11 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
     std::lock_guard<std::mutex> lock(g_mutex);
     const int64_t fft_batch = batch * d0;
     const PlanKey key = std::make_tuple(guard.dev, s, rank, n[0], n[1], n[2], fft_batch);
+    if (g_bad_plans.count(key)) return SKR_ERR_LIBRARY;  // failed its self-check before (the defect is persistent): do not re-plan per call
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
-      if (g_plans.size() >= MAX_PLANS) {  // evict the least recently used pair
+      static const size_t max_plans = [] { const char* e = getenv("SKR_FFT_MAX_PLANS"); return e ? (size_t)atoll(e) : MAX_PLANS; }();
+      if (g_plans.size() >= max_plans) {  // evict the least recently used pair
         auto victim = g_plans.begin();
         for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt) if (jt->second.last_use < victim->second.last_use) victim = jt;
         skr::DeviceGuard owner(nullptr);
@@ -316,6 +379,40 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
       if (f.plan_many(&p.fwd, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, (int)fft_batch) != 0) return SKR_ERR_UNSUPPORTED;
       if (f.plan_many(&p.inv, rank, nn, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, (int)fft_batch) != 0) { f.destroy(p.fwd); return SKR_ERR_UNSUPPORTED; }
       if (f.set_stream(p.fwd, s) != 0 || f.set_stream(p.inv, s) != 0) { f.destroy(p.fwd); f.destroy(p.inv); return SKR_ERR_LAUNCH; }
+      {  // self-check on unit impulses (see SelfTest above); uses this call's own workspaces before they carry anything
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+          (void)hipGetLastError();
+          f.destroy(p.fwd); f.destroy(p.inv);
+          return SKR_ERR_UNSUPPORTED;  // plans are created (and checked) outside stream capture: run the shape once eagerly first
+        }
+        SelfTest t;
+        float* test_real = a.real;
+        if (white_given) {  // a.real holds the caller's white noise: the impulses get a temporary buffer of their own
+          if (hipMalloc(reinterpret_cast<void**>(&test_real), sizeof(float) * (size_t)fft_batch * n[0] * n[1] * n[2]) != hipSuccess) {
+            (void)hipGetLastError();
+            f.destroy(p.fwd); f.destroy(p.inv);
+            return SKR_ERR_LAUNCH;
+          }
+        }
+        t.real = test_real; t.spec = a.spec; t.bad = reinterpret_cast<unsigned long long*>(a.partials); t.entries = fft_batch;
+        t.n0 = n[0]; t.n1 = n[1]; t.n2 = n[2]; t.n2h = n[2] / 2 + 1;
+        int64_t tb = ((int64_t)fft_batch * n[0] * n[1] * n[2] + 255) / 256; if (tb > 256 * 16) tb = 256 * 16;
+        unsigned long long bad = 1;
+        hipLaunchKernelGGL(selftest_fill, dim3((unsigned)tb), dim3(256), 0, s, t);
+        const bool ran = f.r2c(p.fwd, t.real, t.spec) == 0;
+        if (ran) hipLaunchKernelGGL(selftest_check_forward, dim3((unsigned)tb), dim3(256), 0, s, t);
+        const bool back = ran && f.c2r(p.inv, t.spec, t.real) == 0;
+        if (back) hipLaunchKernelGGL(selftest_check_inverse, dim3((unsigned)tb), dim3(256), 0, s, t);
+        if (!back || hipMemcpyAsync(&bad, t.bad, sizeof(bad), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) bad = 1;
+        if (white_given) (void)hipFree(test_real);
+        if (bad != 0) {
+          (void)hipGetLastError();
+          f.destroy(p.fwd); f.destroy(p.inv);
+          if (g_bad_plans.size() < 4096) g_bad_plans.insert(key);
+          return SKR_ERR_LIBRARY;
+        }
+      }
       it = g_plans.emplace(key, p).first;
     }
     it->second.last_use = ++g_plan_clock;
@@ -360,6 +457,26 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
     default: return SKR_ERR_DTYPE;
   }
   return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}
+
+static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
+                            const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
+                            double exponent, int32_t has_energy, double energy, void* stream, bool white_given) {
+  if (batch < 0 || rank < 1 || rank > 6 || !dims) return SKR_ERR_SHAPE;
+  for (int i = 0; i < rank; ++i) if (dims[i] < 2) return SKR_ERR_SHAPE;
+  if (batch == 0) return SKR_OK;
+  if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || (!white_given && !seeds_dev)) return SKR_ERR_NULL;
+  if (batch > 65535) return SKR_ERR_UNSUPPORTED;
+  // hipFFT gets the last three axes; if that plan fails its self-check (SelfTest above), only the last axis -- 1-D real plans have
+  // not shown the defect -- and the direct-DFT kernels take every other axis (each <= 128 long)
+  int first = rank < 3 ? rank : 3;
+  if (skr::g_fft_rank >= 1 && skr::g_fft_rank < first) first = skr::g_fft_rank;  // test switch (skr_set_tuning "fft_rank"): 1 exercises the fallback
+  int rc = colored_any_attempt(out, out_dtype, spec_c64, scratch_f32, partials_f64, seeds_dev, stream_id, batch, rank, dims, exponent, has_energy, energy, stream, white_given, first);
+  if (rc == SKR_ERR_LIBRARY && first > 1) {
+    const int rc1 = colored_any_attempt(out, out_dtype, spec_c64, scratch_f32, partials_f64, seeds_dev, stream_id, batch, rank, dims, exponent, has_energy, energy, stream, white_given, 1);
+    if (rc1 != SKR_ERR_UNSUPPORTED) rc = rc1;  // (an axis too long for the direct kernels: the library error stands)
+  }
+  return rc;
 }
 
 extern "C" int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,

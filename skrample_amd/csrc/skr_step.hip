@@ -587,9 +587,12 @@ extern "C" int skr_step_launch_indexed(const skr_step_plan* plan, const void* co
 
 extern "C" int skr_last_hip_error(void) { return skr::g_last_hip_error; }
 
+namespace skr { extern int g_fft_rank; }  // skr_colored_any.hip: trailing axes given to hipFFT (0 = up to three)
+
 extern "C" int skr_set_tuning(const char* key, int32_t value) {
   if (!key) return SKR_ERR_NULL;
-  if (!strcmp(key, "reset")) skr::g_tune = skr::Tuning();
+  if (!strcmp(key, "reset")) { skr::g_tune = skr::Tuning(); skr::g_fft_rank = 0; }
+  else if (!strcmp(key, "fft_rank")) skr::g_fft_rank = value;
   else if (!strcmp(key, "one_trip")) skr::g_tune.one_trip = value;
   else if (!strcmp(key, "xmap")) skr::g_tune.xmap = value;
   else if (!strcmp(key, "tile")) skr::g_tune.tile = value;

@@ -619,3 +619,21 @@ def test_capture_after_steps_with_noise_drawn_ahead(dev):
     loop = capture_sampling_loop(w, net, x0, steps, seeds=seeds)
     assert torch.equal(loop(x0), want)
     assert torch.equal(eager(w, x0, steps), want)  # and eager again after the capture
+
+
+@pytest.mark.parametrize("unit", [(4, 96, 96), (16, 19, 13), (3, 40), (3, 4, 6, 8), (16, 2, 8, 8), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6)])
+def test_colored_with_only_the_last_axis_on_hipfft(unit, dev):
+    """The route taken when a multi-dimensional hipFFT plan fails its self-check (rocFFT 7.2 can return a wrong real 2-D / 3-D
+    plan in a process that has made many others -- tools/fft_probe.py): the last axis on a 1-D hipFFT plan, every other axis on
+    the direct-DFT kernels.  Forced here through skr_set_tuning("fft_rank", 1) and held to the same oracle bar."""
+    lib = _hip.load()
+    assert lib.skr_set_tuning(b"fft_rank", 1) == 0
+    try:
+        seeds = [31, 32]
+        g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
+        for n, st in enumerate((None, Step(0.45, 0.5))):
+            got = g.generate(st).cpu()
+            ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
+            assert rel(got, ref) < 5e-5, (unit, st, rel(got, ref))
+    finally:
+        assert lib.skr_set_tuning(b"fft_rank", 0) == 0
