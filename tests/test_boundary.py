@@ -101,3 +101,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "libskrample_hip.so"))
     with pytest.raises(_hip.SkrampleHipError, match="no CPU fallback"):
         _hip.load()
+
+
+def test_header_is_plain_c(tmp_path):
+    "the drop-in boundary is a C ABI: include/skrample_hip.h must compile as C99 (and as C++) with nothing but the standard headers"
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    src = tmp_path / "h.c"
+    src.write_text(f'#include "{os.path.join(ROOT, "include", "skrample_hip.h")}"\nint main(void) {{ skr_step_plan p; (void)p; return SKR_ABI_VERSION == {_hip.ABI_VERSION} ? 0 : 1; }}\n')
+    assert subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "h.o")], capture_output=True).returncode == 0
+    if shutil.which("g++") is not None:
+        assert subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-x", "c++", str(src)], capture_output=True).returncode == 0
