@@ -115,3 +115,23 @@ def test_header_is_plain_c(tmp_path):
     assert subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "h.o")], capture_output=True).returncode == 0
     if shutil.which("g++") is not None:
         assert subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-x", "c++", str(src)], capture_output=True).returncode == 0
+
+
+@pytest.mark.gpu
+def test_plain_c_client(tmp_path):
+    """tests/abi_client.c -- a C99 program that knows only include/skrample_hip.h, the HIP runtime and libskrample_hip.so (no Python,
+    no torch) -- builds with gcc and runs a one-output step, a two-output step and an in-kernel Philox draw through the ABI"""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs gcc and the ROCm headers")
+    exe = tmp_path / "abi_client"
+    lib_dir = os.path.dirname(_hip.LIB_PATH)
+    build = subprocess.run(
+        ["gcc", "-std=c99", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_client.c"),
+         "-L", lib_dir, "-lskrample_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+        capture_output=True, text=True)  # fmt: skip
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "abi client ok" in run.stdout, (run.stdout, run.stderr)
