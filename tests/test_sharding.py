@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two gloo ranks run the SAME shard arithmetic bench.py runs (skrample_amd.sharding: rank / world
+"""N > 1 path on CPU: two and four gloo ranks run the SAME shard arithmetic bench.py runs (skrample_amd.sharding: rank / world
 from the launcher's environment, contiguous batch slices, seeds by GLOBAL sample index, MAX-over-ranks timing, whole-job
 rate) -- the only things ranks share; there is no data-path collective to test."""
 
@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -34,19 +35,20 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     dist.destroy_process_group()
 
 
-def test_two_rank_shards_equal_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_rank_shards_equal_single_process(world, tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    single = BatchShard(0, 1, 2 * B_PER_RANK)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    single = BatchShard(0, 1, world * B_PER_RANK)
     whole = np.stack([ON.philox_normal(s, 3 * 256, UNIT) for s in single.seeds()])
-    parts = np.concatenate([np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")])
-    assert np.array_equal(whole, parts)  # 1 process over the full batch == concatenation of the 2 shards
-    assert np.concatenate([np.load(tmp_path / "ids0.npy"), np.load(tmp_path / "ids1.npy")]).tolist() == list(single.sample_ids)
+    parts = np.concatenate([np.load(tmp_path / f"shard{r}.npy") for r in range(world)])
+    assert np.array_equal(whole, parts)  # 1 process over the full batch == concatenation of the shards
+    assert np.concatenate([np.load(tmp_path / f"ids{r}.npy") for r in range(world)]).tolist() == list(single.sample_ids)
     wall, kernel, rate, global_batch = np.load(tmp_path / "summary.npy")
-    assert wall == 0.020 and kernel == 0.004  # rank 0 reports the slowest rank's times
-    assert rate == 2 * 20 / 0.020 and global_batch == 2 * B_PER_RANK
+    assert wall == pytest.approx(0.010 * world) and kernel == pytest.approx(0.002 * world)  # rank 0 reports the slowest rank's times
+    assert rate == pytest.approx(world * 20 / (0.010 * world)) and global_batch == world * B_PER_RANK
 
 
 def test_shard_rules():
