@@ -3,6 +3,8 @@ config 1 is "on CPU torch").  They are evaluated by skrample_amd's own host exec
 the same collapsed linear forms the HIP kernel runs, in plain torch.  These tests need no GPU: they replay the
 reference-recorded fixtures and the oracle on the CPU, and check that device work can never end up here."""
 
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -58,7 +60,7 @@ def test_samplers_vs_oracle_on_cpu(sampler):
     mk_o, mk_p = SAMPLERS[sampler]
     steps, shape = 7, (2, 3, 10, 6)
     for sname, mname in (("karras_scaled", "eps"), ("linear", "flow")):
-        g = torch.Generator().manual_seed(hash((sampler, sname)) % 2**31)
+        g = torch.Generator().manual_seed(zlib.crc32(f"{sampler}/{sname}".encode()))  # (str hashes change from process to process)
         w = PD.SkrampleWrapperScheduler(mk_p(), SCHEDULES[sname][1](), MODELS[mname][1])
         o = OW.StepDriver(mk_o(), oracle_schedule(sname, steps), MODELS[mname][0])
         w.set_timesteps(steps)

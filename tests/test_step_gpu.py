@@ -8,6 +8,8 @@ result.  All launches go through the C-ABI (skr_step_launch) -- there is no othe
 import ctypes
 import itertools
 
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -162,7 +164,7 @@ def test_samplers_vs_oracle(sampler, dev):
     mk_o, mk_p = SAMPLERS[sampler]
     steps, shape = 9, (3, 4, 24, 20)
     for sname, mname in (("karras_scaled", "eps"), ("linear", "flow"), ("zsnr", "v"), ("scaled", "data")):
-        g = torch.Generator().manual_seed(hash((sampler, sname)) % 2**31)
+        g = torch.Generator().manual_seed(zlib.crc32(f"{sampler}/{sname}".encode()))  # (str hashes change from process to process)
         w = PD.SkrampleWrapperScheduler(mk_p(), SCHEDULES[sname][1](), MODELS[mname][1])
         o = OW.StepDriver(mk_o(), oracle_schedule(sname, steps), MODELS[mname][0])
         w.set_timesteps(steps)
@@ -626,7 +628,7 @@ def test_rounded_conversion_equals_torch_op_by_op(dtype, kinds, dev):
     reference evaluates to_x / from_x one tensor op at a time in the input dtype (fp32 op result, then the tensor
     dtype: in fp16 a fused multiply-convert would round once and miss the reference on fp32 ties)"""
     n = 8 * 4096
-    g = torch.Generator().manual_seed(hash(kinds) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(repr(kinds).encode()) % 1000)
     s_, o_ = (torch.randn(n, generator=g) * 1.5).to(dtype), torch.randn(n, generator=g).to(dtype)
     k = (0.9, 0.09999999999999998, 0.7310585786300049, 0.35)
     to_kind, from_kind = kinds
