@@ -414,7 +414,7 @@ def evaluate(forms: Sequence[Lin], dtypes: Sequence[torch.dtype | None], acc_f64
         if t.shape != shape and t.numel() != numel:
             raise SkrampleHipError(f"operand shape {tuple(t.shape)} does not match {shape}")
     narrow_types = [t.dtype for t in prepared.values() if t.dtype != wide]
-    group_a = max(set(narrow_types), key=narrow_types.count) if narrow_types else wide
+    group_a = max(dict.fromkeys(narrow_types), key=narrow_types.count) if narrow_types else wide  # (first seen wins a tie: no dependence on hash order)
     # outputs must be group_a or wide
     for k, od in enumerate(out_dtypes):
         if od not in (group_a, wide):
