@@ -1491,3 +1491,41 @@ def test_noise_seeding_rules(dev):
     x1 = x3[:1].contiguous()
     f, w1 = run(x1.shape, torch.Generator().manual_seed(1), x1)
     assert torch.equal(f, d[:1]) and len(w1._noise_generator.generators) == 1  # same seed, same item => same result
+
+
+def test_two_streams_do_not_interfere(dev):
+    """Every entry point launches on the caller's stream and keeps no per-call state: two sampling loops interleaved on two HIP
+    streams (one with in-kernel Philox noise, one with Pyramid noise drawn ahead on its own side stream) give the bits of the
+    same loops run one after the other."""
+    from skrample_amd.pytorch import noise as PN
+
+    shape, steps = (4, 4, 32, 32), 6
+    g = torch.Generator().manual_seed(77)
+    xa, xb = (torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(2))
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps)]
+    mk_a = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))  # noqa: E731
+    mk_b = lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Scaled(), noise_type=PN.Pyramid)  # noqa: E731
+
+    def alone(mk, x, seeds):
+        w = mk()
+        w.set_timesteps(steps)
+        for i, t in enumerate(w.timesteps.tolist()):
+            x = w.step(outs[i], t, x, generator=seeds, return_dict=False)[0]
+        torch.cuda.synchronize()
+        return x.clone()
+
+    want_a, want_b = alone(mk_a, xa, [1, 2, 3, 4]), alone(mk_b, xb, [5, 6, 7, 8])
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    wa, wb = mk_a(), mk_b()
+    wa.set_timesteps(steps)
+    wb.set_timesteps(steps)
+    ta, tb = wa.timesteps.tolist(), wb.timesteps.tolist()
+    torch.cuda.synchronize()
+    ya, yb = xa, xb
+    for i in range(steps):
+        with torch.cuda.stream(sa):
+            ya = wa.step(outs[i], ta[i], ya, generator=[1, 2, 3, 4], return_dict=False)[0]
+        with torch.cuda.stream(sb):
+            yb = wb.step(outs[i], tb[i], yb, generator=[5, 6, 7, 8], return_dict=False)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(ya, want_a) and torch.equal(yb, want_b)
