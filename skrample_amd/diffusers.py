@@ -283,7 +283,7 @@ class SkrampleWrapperCore(abc.ABC):
     def _alias_hold(self, tensors, keep: int) -> None:
         "stamp this call's caller-owned tensors; `keep` = how many of the most recent stamps stay live"
         for t in tensors:
-            if isinstance(t, Tensor):
+            if isinstance(t, Tensor) and t.numel() > 0:  # (empty tensors own no buffer: their data_ptr says nothing)
                 self._alias_stamps.append((t, t.data_ptr(), t._version))
         self._alias_stamps = self._alias_stamps[max(len(self._alias_stamps) - keep, 0):] if keep > 0 else []
 
@@ -358,8 +358,9 @@ class SkrampleWrapperCore(abc.ABC):
             seeds = [generator]
         else:
             # fallback: seed from each item's middle element (one small gather + sync, first step only)
-            flat = sample.reshape(sample.shape[0], -1)
-            mids = flat[:, flat.shape[1] // 2].to(torch.float64).cpu().tolist()
+            per_item = math.prod(sample.shape[1:])
+            flat = sample.reshape(sample.shape[0], per_item)
+            mids = flat[:, per_item // 2].to(torch.float64).cpu().tolist() if per_item else [0.0] * sample.shape[0]
             seeds = [int(v * 1e4 * (step.position() + 1)) for v in mids]
         if not sample.is_cuda:  # host-resident latents (the reference's CPU path): torch's own generators, as the reference
             if noise_type is not Random:
@@ -376,6 +377,8 @@ class SkrampleWrapperCore(abc.ABC):
             if lazy_ok or not isinstance(handed, lazy.PhiloxNoise):
                 return handed if lazy_ok else lazy.cast(handed, dtype or sample.dtype)
             return lazy.cast(handed.realize(torch.float32), dtype or sample.dtype)
+        if isinstance(sample, Tensor) and sample.numel() == 0:  # an empty batch draws nothing (and has no items to seed generators from)
+            return torch.empty(sample.shape, dtype=dtype or sample.dtype, device=sample.device)
         if self._noise_generator is None:
             self._retire_noise_generator()
             self._noise_generator = self._make_noise_generator(step, sample, noise_type, noise_props, generator)
@@ -908,7 +911,7 @@ class RKWrapperCore(SkrampleWrapperCore):
                             if isinstance(leaf, Tensor):
                                 live[id(leaf)] = leaf
                 known = {id(t): (t, ptr, ver) for t, ptr, ver in self._alias_stamps}
-                self._alias_stamps = [known.get(i) or (t, t.data_ptr(), t._version) for i, t in live.items()]
+                self._alias_stamps = [known.get(i) or (t, t.data_ptr(), t._version) for i, t in live.items() if t.numel() > 0]
         result = self._step_stage(model_output, sample, generator, return_dict)
         self._issue_noise_ahead()
         return result

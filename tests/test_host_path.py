@@ -172,3 +172,21 @@ def test_mixed_residency_is_refused():
     mixed = lazy.Lin({**a.terms, id(fake): (fake, 1.0)}, a.shape, a.device)
     with pytest.raises(_hip.SkrampleHipError, match="all live on the HIP device or all on the host"):
         lazy.evaluate([mixed], [torch.float32])
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_empty_batch_through_the_wrappers(device):
+    "B = 0: every wrapper steps an empty batch to an empty batch (no generator to seed, no buffer for the alias guard to compare)"
+    makers = [
+        lambda: PD.SkrampleWrapperScheduler(PT.Euler(), PS.Scaled()),
+        lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled())),
+        lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Scaled()),
+        lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=3, stochasticity=1),
+    ]
+    for mk in makers:
+        w = mk()
+        w.set_timesteps(3)
+        x = torch.zeros(0, 4, 8, 8, dtype=torch.bfloat16, device=device)
+        for t in w.timesteps:
+            x = torch.as_tensor(w.step(torch.zeros_like(x), t, x, return_dict=False)[0])
+            assert tuple(x.shape) == (0, 4, 8, 8) and x.dtype == torch.bfloat16 and x.device.type == device
