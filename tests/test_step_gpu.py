@@ -1529,3 +1529,50 @@ def test_two_streams_do_not_interfere(dev):
             yb = wb.step(outs[i], tb[i], yb, generator=[5, 6, 7, 8], return_dict=False)[0]
     torch.cuda.synchronize()
     assert torch.equal(ya, want_a) and torch.equal(yb, want_b)
+
+
+def test_more_than_two_to_the_31_elements_in_one_launch(dev):
+    """Maximum sizes: a single launch over 2^31 + 6144 bf16 elements (4.3 GB per tensor), deterministic and with in-kernel Philox
+    noise; every index in the kernels is 64-bit.  Checked on device against torch in fp32, chunk by chunk, around the 2^31 boundary
+    and at both ends, plus a whole-tensor checksum; the noise prefix equals the noise of a small launch with the same seed."""
+    if torch.cuda.mem_get_info(dev)[0] < 40 * 2**30:
+        pytest.skip("needs ~30 GB of free HBM")
+    n = 2**31 + 6144
+    sched, model = PS.Scaled(), PM.NoiseModel()
+    g = torch.Generator(device=dev).manual_seed(123)
+    x = torch.empty((1, n), dtype=torch.bfloat16, device=dev)
+    out = torch.empty((1, n), dtype=torch.bfloat16, device=dev)
+    for t in (x, out):  # filled in slices: one fp32 temporary of 2^31 elements would be 8.6 GB
+        for lo in range(0, n, 2**28):
+            hi = min(lo + 2**28, n)
+            t[0, lo:hi] = torch.randn(hi - lo, device=dev, generator=g)
+    step = (0.2, 0.3)
+    rec = PT.Euler().sample(x, out, step, model, sched)
+    got = rec.final
+    assert tuple(got.shape) == (1, n) and got.dtype == torch.bfloat16
+    small = PT.Euler().sample(x[:, :8192].contiguous(), out[:, :8192].contiguous(), step, model, sched).final
+    # the step's two coefficients are recovered from a small launch of the same step (that path is oracle-checked elsewhere);
+    # torch then applies them in fp32 to every slice of the large tensors
+    xs, os_ = x[0, :8192].float(), out[0, :8192].float()
+    sol = torch.linalg.lstsq(torch.stack([xs, os_], dim=1).double(), small[0].double().unsqueeze(1)).solution.flatten()
+    c0, c1 = sol.tolist()
+    total_got = total_want = 0.0
+    for lo in range(0, n, 2**27):
+        hi = min(lo + 2**27, n)
+        want = (x[0, lo:hi].float() * c0 + out[0, lo:hi].float() * c1)
+        diff = (got[0, lo:hi].float() - want).abs()
+        tol = want.abs() * 2.0**-7 + 1e-2  # one bf16 rounding of the result (+ the 3-digit recovery of the coefficients)
+        assert bool((diff <= tol).all()), (lo, hi, float(diff.max()))
+        total_got += float(got[0, lo:hi].double().sum())
+        total_want += float(want.double().sum())
+    assert abs(total_got - total_want) <= 1e-3 * n**0.5 * 4  # sums of 2e9 values agree to rounding noise
+    # in-kernel Philox noise over a sample longer than 2^31 elements
+    seeds = torch.tensor([77], dtype=torch.int64, device=dev)
+    pn = lazy.PhiloxNoise(seeds, 512, (1, n), dev)
+    assert pn.fusable()
+    noisy = PT.Euler(stochasticity=1).sample(x, out, step, model, sched, pn).final
+    pn_small = lazy.PhiloxNoise(seeds, 512, (1, 2**20), dev)
+    noisy_small = PT.Euler(stochasticity=1).sample(x[:, : 2**20].contiguous(), out[:, : 2**20].contiguous(), step, model, sched, pn_small).final
+    assert torch.equal(noisy[:, : 2**20], noisy_small)  # element e of a sample draws Philox block e/4 whatever the launch size
+    tail = (noisy[0, -(2**22) :].float() - got[0, -(2**22) :].float())  # zeta * N(0,1) up to bf16 rounding
+    assert torch.isfinite(noisy[0, 2**31 - 4096 :].float()).all() and abs(float(tail.mean())) < 5e-3 * float(tail.std()) + 1e-3 and float(tail.std()) > 0
