@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import contextvars
 import math
+import os
 from typing import Any, Sequence
 
 import torch
@@ -290,8 +291,8 @@ def _default_dtype(form: Lin) -> torch.dtype:
 # at 2 MiB multiples, so all streams then start on the same HBM channel/bank phase and collide; shifting the
 # tensors this engine allocates (every step result, i.e. the next step's `sample` and history `sample`) by odd
 # multiples of 4 KiB takes ~3.5 % off the fused DPM-2 step (tools/tune/tune_step.hip, "mask=21" runs).
-_STAGGER_SLOTS = 8
-_STAGGER_BYTES = 8192
+_STAGGER_SLOTS = int(os.environ.get("SKR_STAGGER_SLOTS", "8"))  # (environment overrides: tuning experiments only)
+_STAGGER_BYTES = int(os.environ.get("SKR_STAGGER_BYTES", "8192"))
 _stagger_next = 0
 
 
