@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import threading
 
 import torch
@@ -168,14 +169,41 @@ class IndexedRows:
         return lib.skr_step_launch_indexed(ctypes.byref(plan), arr, out0_ptr, out1_ptr, seeds_ptr, numel, self.rows_dev.data_ptr(), self.index_dev.data_ptr(), k, stream_ptr)
 
 
-indexed: IndexedRows | None = None  # installed by skrample_amd.graphs while it records / captures / re-targets a loop
+# Launch hooks, PER THREAD (a scheduler instance is single-threaded by contract, but several may run in different threads of one
+# process, and a hook installed by one of them must not record or redirect the launches of another):
+#   _hip.indexed  IndexedRows | None   installed by skrample_amd.graphs while it records / captures / re-targets a loop
+#   _hip.trace    list | None          launches are appended while a wrapper lowers a step program (sampling/program.py)
+# Both read and assign like plain module attributes (`_hip.trace = []`); the module's class routes them to thread-local storage.
+_hooks = threading.local()
+
+
+class _HipModule(type(sys)):
+    @property
+    def indexed(self) -> "IndexedRows | None":
+        return getattr(_hooks, "indexed", None)
+
+    @indexed.setter
+    def indexed(self, value) -> None:
+        _hooks.indexed = value
+
+    @property
+    def trace(self) -> "list | None":
+        return getattr(_hooks, "trace", None)
+
+    @trace.setter
+    def trace(self, value) -> None:
+        _hooks.trace = value
+
+
+sys.modules[__name__].__class__ = _HipModule
 
 
 def step_launch_raw(plan: StepPlanC, arr, out0_ptr, out1_ptr, seeds_ptr, numel: int, stream_ptr: int) -> int:
     "every skr_step_launch of the package goes through here (status returned, not checked)"
     lib = load()
-    if indexed is not None:
-        return indexed.launch(lib, plan, arr, out0_ptr, out1_ptr, seeds_ptr, numel, stream_ptr)
+    rows = getattr(_hooks, "indexed", None)
+    if rows is not None:
+        return rows.launch(lib, plan, arr, out0_ptr, out1_ptr, seeds_ptr, numel, stream_ptr)
     return lib.skr_step_launch(ctypes.byref(plan), arr, out0_ptr, out1_ptr, seeds_ptr, numel, stream_ptr)
 
 
@@ -263,14 +291,15 @@ def current_stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-# When a list is installed here every launch appends (plan, inputs, out0, out1, seeds, numel): used by
-# bench.py to lift the exact plans the samplers emit and replay them through the C ABI.
-trace: list | None = None
+# When a list is installed as `_hip.trace` (per thread, see _HipModule) every launch appends
+# (plan, inputs, out0, out1, seeds, numel): used by the step programs and by bench.py to lift the exact plans the
+# samplers emit and replay them through the C ABI.
 
 
 def launch_step(plan: StepPlanC, inputs: list[torch.Tensor], out0, out1, seeds, numel: int, device: torch.device) -> None:
     "one fused kernel launch on torch's current stream of `device`"
-    lib = load()
+    load()
+    trace = getattr(_hooks, "trace", None)
     if trace is not None:
         trace.append((plan, list(inputs), out0, out1, seeds, numel))
     n = len(inputs)

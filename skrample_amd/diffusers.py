@@ -252,6 +252,7 @@ class SkrampleWrapperCore(abc.ABC):
         self._noise_side = None
         self._noise_wanted = None  # (next step, sample): drawn ahead once this call's own launch has been issued
         self._alias_stamps: list[tuple[Tensor, int, int]] = []  # (caller tensor aliased by history, data_ptr, _version)
+        self._alias_auto = None  # alias_history="auto": None before a run's first call, (model_output, sample) of that call, then "alias" / "snapshot"
 
     # ---- guard of the aliased history (alias_history=True) -------------------------------------------------------
     # The reference deep-copies every record (structured.py:113-125); this engine keeps the caller's own tensors as
@@ -279,6 +280,25 @@ class SkrampleWrapperCore(abc.ABC):
                 raise SkrampleHipError(self._ALIAS_HELP.format(what="its buffer now holds this step's model_output"))
             if ptr == sample.data_ptr() and t is not sample:
                 raise SkrampleHipError(self._ALIAS_HELP.format(what="its buffer now holds this step's sample"))
+
+    def _alias_now(self, model_output: Tensor, sample: Tensor) -> bool:
+        """True: this call keeps the caller's tensors as history operands; False: it snapshots them.
+        alias_history="auto" (the default) finds out which kind of caller it has: the run's first call snapshots and HOLDS the
+        caller's two tensors, which pins their addresses -- a network that allocates its output afresh (eager PyTorch) cannot
+        hand the next output back at the same address, a network with static output memory (HIP-graphed, torch.compile
+        mode="reduce-overhead", an in-place `buf.copy_()` loop) does exactly that.  The second call compares and settles the
+        mode for the rest of the run: aliasing (0 bytes written, guarded as before) or snapshots (+8 B/element/step)."""
+        setting = self.alias_history
+        if setting is True or setting is False:
+            return setting
+        state = self._alias_auto
+        if state is None:
+            self._alias_auto = (model_output, sample)
+            return False
+        if isinstance(state, tuple):
+            static = model_output.data_ptr() == state[0].data_ptr() or sample.data_ptr() == state[1].data_ptr()
+            self._alias_auto = state = "snapshot" if static else "alias"
+        return state == "alias"
 
     def _alias_hold(self, tensors, keep: int) -> None:
         "stamp this call's caller-owned tensors; `keep` = how many of the most recent stamps stay live"
@@ -393,6 +413,8 @@ class SkrampleWrapperCore(abc.ABC):
                     torch.cuda.current_stream(sample.device).wait_event(self._noise_done)
                 self._noise_done = None
             noise = gen.generate_lazy(step) if lazy_ok else gen.generate(step)
+            if self._noise_side is not None and isinstance(gen, BatchTensorNoise) and isinstance(sample, Tensor) and sample.is_cuda:
+                gen.used_on(torch.cuda.current_stream(sample.device))  # (workspaces may have been allocated under the side stream)
         return noise if lazy_ok else lazy.cast(noise, dtype or sample.dtype)
 
     # ---- next step's noise, drawn ahead on a side stream ----------------------------------------------------------------
@@ -407,11 +429,24 @@ class SkrampleWrapperCore(abc.ABC):
     # per stage call; Colored is left out -- its plane kernels hold 134 KiB of LDS and most of the vector registers of every CU, the
     # step kernel cannot co-reside, and UniPC-3 + Colored (config 3) went 702 -> 736 us per call with it drawn ahead.
 
+    def _drain_noise_ahead(self) -> None:
+        """run boundary (reset_run): wait on the host for whatever the side stream still draws, so that the new run -- which may be
+        recorded into a HIP graph, where an event from outside the capture can be neither waited on nor queried -- starts
+        with no cross-stream fence pending.  One event wait per run, at most one noise generation long."""
+        if self._noise_done is not None and not torch.cuda.is_current_stream_capturing():
+            self._noise_done.synchronize()
+            self._noise_done = None
+
     def noise_quiesced(self) -> None:
         "(not in the reference) tell the wrapper that the device has been synchronized: nothing drawn ahead is in flight any more"
         if self._noise_ahead is not None and self._noise_generator is not None and self._noise_generator._draws == self._noise_ahead[4]:
             self._noise_generator._draws = self._noise_ahead[3]
         self._noise_ahead = self._noise_done = None
+
+    def _forget_issued_timesteps(self) -> None:
+        "a new schedule: elements of `timesteps` tensors handed out for the previous one no longer name a step (the reference's list.index raises there)"
+        self._issued_timesteps = []
+        self._foreign_timesteps = {}
 
     def _retire_noise_generator(self) -> None:
         "drop the generator: its workspaces go back to the allocator, so whatever the side stream still runs on them must be ordered first"
@@ -473,6 +508,7 @@ class SkrampleWrapperCore(abc.ABC):
             if isinstance(item, Tensor):
                 event = torch.cuda.Event()
                 event.record(side)
+        gen.used_on(side)  # (workspaces allocated under the caller's stream: a later re-allocation must not recycle them under the side stream's feet)
         self._noise_ahead = (next_step, item, event, before, gen._draws)
         if event is not None:
             self._noise_done = event
@@ -525,7 +561,19 @@ class SkrampleWrapperCore(abc.ABC):
                 if not 0 <= expected < len(table):
                     raise ValueError(f"step {expected} is outside the {len(table)}-step schedule")
                 return expected
-            value = timestep.item()
+            # a foreign device scalar: one read-back per tensor OBJECT (remembered by identity + version, never by address: a
+            # recycled allocation would otherwise be mistaken for an earlier timestep)
+            known = getattr(self, "_foreign_timesteps", None)
+            if known is None:
+                known = self._foreign_timesteps = {}
+            hit = known.get(id(timestep))
+            if hit is not None and hit[0]() is timestep and hit[1] == timestep._version:
+                return hit[2]
+            idx = table.index(timestep.item())
+            if len(known) > 4096:
+                known.clear()
+            known[id(timestep)] = (weakref.ref(timestep), timestep._version, idx)
+            return idx
         return table.index(value)
 
     @staticmethod
@@ -552,10 +600,12 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
     fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
     prefetch_noise: bool = True
     "(not in the reference) draw the next step's Pyramid / Offset noise ahead on a side stream (same values, same draw numbering)"
-    alias_history: bool = True
-    """(not in the reference) keep history entries as aliases of the caller's `sample` / `model_output` tensors.
-    Set False when the caller overwrites those buffers in place between steps (e.g. a CUDA/HIP-graphed network
-    with static output memory): the wrapper then snapshots both tensors, at 4 B/element of extra traffic."""
+    alias_history: bool | str = "auto"
+    """(not in the reference) True: keep history entries as aliases of the caller's `sample` / `model_output` tensors (0 bytes
+    written; guarded: reusing a held buffer raises).  False: snapshot both tensors every step (+8 B/element/step), safe for callers
+    that overwrite those buffers between steps (a HIP-graphed network with static output memory).  "auto" (default): the first
+    call of a run snapshots and pins the caller's tensors, the second call sees whether the caller hands back the same memory and
+    the run continues with snapshots (static buffers) or aliases (fresh tensors) -- see `_alias_now`."""
 
     def __post_init__(self) -> None:
         super().__post_init__()
@@ -641,7 +691,9 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._raw_outputs = []
         self._raw_samples = []
         self._alias_stamps = []
+        self._alias_auto = None
         self._retire_noise_generator()
+        self._forget_issued_timesteps()
         self._timestep_list = None
         if device is not None:
             self._device = torch.device(device)
@@ -653,7 +705,9 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._calls = 0
         self._previous, self._raw_outputs, self._raw_samples = [], [], []
         self._alias_stamps = []
-        self._noise_ahead = None  # (its workspace fence, _noise_done, stays)
+        self._alias_auto = None
+        self._noise_ahead = None
+        self._drain_noise_ahead()
         if self._noise_generator is not None:
             self._noise_generator._draws = 0
 
@@ -677,9 +731,10 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         idx = self._lookup(table, timestep, self._index + self._calls)
         self._calls += 1
         step = Step.from_int(idx, len(table))
-        if not self.alias_history and self.sampler.require_previous > 0:
+        aliasing = self.sampler.require_previous > 0 and self._alias_now(model_output, sample)
+        if self.sampler.require_previous > 0 and not aliasing:
             sample, model_output = sample.clone(), model_output.clone()
-        elif self.alias_history:
+        elif aliasing:
             self._alias_check(model_output, sample)
 
         prediction = LazyTensor(-Lin.leaf(model_output), model_output.dtype) if self.invert_prediction else model_output
@@ -726,7 +781,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._previous = self._previous[max(len(self._previous) - keep, 0) :]
         self._raw_outputs = self._raw_outputs[max(len(self._raw_outputs) - keep, 0) :]
         self._raw_samples = self._raw_samples[max(len(self._raw_samples) - keep, 0) :]
-        if self.alias_history:
+        if aliasing:
             self._alias_hold((sample, model_output), 2 * keep)
         self._issue_noise_ahead()  # behind this step's launch in host order: the step kernel is never kept waiting for it
         return self._finish(record.final, record.prediction, model_output, return_dict)
@@ -750,8 +805,8 @@ class RKWrapperCore(SkrampleWrapperCore):
     fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
     prefetch_noise: bool = True
     "(not in the reference) see SkrampleWrapperScheduler.prefetch_noise: the next step's noise is drawn on a side stream during this step's stages"
-    alias_history: bool = True
-    "(not in the reference) see SkrampleWrapperScheduler.alias_history; False snapshots `sample` / `model_output` per stage"
+    alias_history: bool | str = "auto"
+    "(not in the reference) see SkrampleWrapperScheduler.alias_history; snapshots are per stage call"
 
     def __post_init__(self) -> None:
         super().__post_init__()
@@ -784,11 +839,16 @@ class RKWrapperCore(SkrampleWrapperCore):
         return self._schedule_full(self._steps)
 
     @functools.cached_property
-    def schedule_np_trim(self) -> np.ndarray:
-        "all_points without the stages that sit on the clean end (the network is never called there)"
+    def trim_indices(self) -> tuple[int, ...]:
+        "positions in all_points of the rows of schedule_np_trim (stages on the clean end are dropped: the network is never called there)"
         clean = self.schedule.point_0
-        kept = [p for p in self.all_points if abs(p.timestep - clean.timestep) > 1e-8 and abs(p.sigma - clean.sigma) > 1e-8]
-        return np.asarray(kept if kept else self.all_points, dtype=np.float64)
+        kept = tuple(i for i, p in enumerate(self.all_points) if abs(p.timestep - clean.timestep) > 1e-8 and abs(p.sigma - clean.sigma) > 1e-8)
+        return kept if kept else tuple(range(len(self.all_points)))
+
+    @functools.cached_property
+    def schedule_np_trim(self) -> np.ndarray:
+        "all_points without the stages that sit on the clean end"
+        return np.asarray([self.all_points[i] for i in self.trim_indices], dtype=np.float64)
 
     @property
     def sigma_space(self) -> scheduling.SigmaSpace:
@@ -816,10 +876,13 @@ class RKWrapperCore(SkrampleWrapperCore):
         self._derivatives.clear()
         self._sample = None
         self._alias_stamps = []
+        self._alias_auto = None
         with contextlib.suppress(AttributeError):
             del self.all_points
         with contextlib.suppress(AttributeError):
             del self.schedule_np_trim
+        with contextlib.suppress(AttributeError):
+            del self.trim_indices
         self.schedule = self._schedule
         steps = self._resolve_steps(num_inference_steps, timesteps, sigmas)
         if steps is None:
@@ -828,6 +891,7 @@ class RKWrapperCore(SkrampleWrapperCore):
         if self.allow_dynamic:
             self.schedule = _apply_dynamic(self.schedule, steps, mu)
         self._retire_noise_generator()
+        self._forget_issued_timesteps()
         if device is not None:
             self._device = torch.device(device)
 
@@ -836,7 +900,9 @@ class RKWrapperCore(SkrampleWrapperCore):
         self._index = 0
         self._derivatives, self._sample = [], None
         self._alias_stamps = []
-        self._noise_ahead = None  # (its workspace fence, _noise_done, stays)
+        self._alias_auto = None
+        self._noise_ahead = None
+        self._drain_noise_ahead()
         if self._noise_generator is not None:
             self._noise_generator._draws = 0
 
@@ -887,12 +953,16 @@ class RKWrapperCore(SkrampleWrapperCore):
         if value is None:  # device timestep: checked through its position in the `timesteps` tensor we handed out (no sync)
             idx = self._device_timestep_index(timestep)
             if idx is not None:
-                assert idx == self._index, f"Expected timestep {expected} for step {self._index}, got element {idx} of the schedule!"
+                # `timesteps` is the TRIMMED table: element idx is stage trim_indices[idx] of all_points (a tableau with a
+                # c = 1 stage before its last one -- Cash-Karp, Fehlberg, SSPRK3 ... -- drops rows ahead of the final stages)
+                at = self.trim_indices[idx] if idx < len(self.trim_indices) else -1
+                assert at == self._index, f"Expected timestep {expected} for step {self._index}, got element {idx} of the schedule!"
         if value is not None:
             assert value == expected, f"Expected timestep {expected} for step {self._index}, got {timestep=}!"
-        if not self.alias_history and self.order > 1:
+        aliasing = self.order > 1 and self._alias_now(model_output, sample)
+        if self.order > 1 and not aliasing:
             sample, model_output = sample.clone(), model_output.clone()
-        elif self.alias_history:
+        elif aliasing:
             self._alias_check(model_output, sample)
             try:
                 result = self._step_stage(model_output, sample, generator, return_dict)

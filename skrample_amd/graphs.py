@@ -28,6 +28,7 @@ class CapturedLoop:
     def __init__(self, graph: torch.cuda.CUDAGraph, static_in: torch.Tensor, static_out: torch.Tensor, seeds_dev: torch.Tensor | None, rows=None, runner=None):
         self.graph, self.static_in, self.static_out, self.seeds_dev = graph, static_in, static_out, seeds_dev
         self.rows, self._runner = rows, runner  # _hip.IndexedRows of an indexed capture; runner(wrapper, x) = the captured loop body
+        self._filled = {0}  # table slots that hold a schedule (the capture itself fills slot 0; the others start as zero rows)
 
     @property
     def slots(self) -> int:
@@ -52,12 +53,15 @@ class CapturedLoop:
         if self.rows.cursor != self.rows.length:
             raise _hip.SkrampleHipError(f"the new schedule issued {self.rows.cursor} launches, the captured loop has {self.rows.length}: re-capture")
         self.rows.upload(slot)
+        self._filled.add(slot)
 
     def __call__(self, latents: torch.Tensor, seeds: Sequence[int] | None = None, slot: int | None = None) -> torch.Tensor:
         self.static_in.copy_(latents)
         if slot is not None:
             if self.rows is None or not 0 <= slot < self.rows.slots:
                 raise ValueError("no such schedule slot")
+            if slot not in self._filled:
+                raise ValueError(f"schedule slot {slot} has never been loaded: call retarget(wrapper, slot={slot}) first (its rows are all zero)")
             self.rows.index_dev.fill_(slot * self.rows.length)  # the device-resident step index: row = index + position in the loop
         if seeds is not None:
             if self.seeds_dev is None:

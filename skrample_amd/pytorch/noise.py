@@ -626,6 +626,29 @@ class BatchTensorNoise(SkrampleTensorNoise):
         g = self.generators[0]
         return self._kind._batch_lazy(tuple(g.shape), self._seeds, self._stream(), step, g.props, g.dtype, self._state)
 
+    def workspace_tensors(self) -> list[torch.Tensor]:
+        "every device buffer the generator keeps between draws (scratch, partial sums, level tables, caches) and its seed vector"
+        found = [self._seeds]
+
+        def walk(v) -> None:
+            if isinstance(v, torch.Tensor):
+                found.append(v)
+            elif isinstance(v, (tuple, list)):
+                for w in v:
+                    walk(w)
+
+        for v in self._state.values():
+            walk(v)
+        return found
+
+    def used_on(self, stream: "torch.cuda.Stream") -> None:
+        """The buffers above were just used by launches on `stream`.  They belong to whichever stream was current when they were
+        allocated; telling the allocator about the other one keeps a buffer that is dropped later (a shape change re-allocates
+        the workspaces) from being handed out again while that stream may still be writing it."""
+        for t in self.workspace_tensors():
+            if t.is_cuda:
+                t.record_stream(stream)
+
     @classmethod
     def from_batch_inputs(cls, subclass, unit_shape, seeds: list, props=None, dtype: torch.dtype = torch.float32) -> "BatchTensorNoise":
         unit_shape = tuple(unit_shape)

@@ -498,3 +498,39 @@ def test_tableau_constructors():
                 assert distance(a, b) > 1e-2
     for provider in PF.STABLE_PROVIDERS.values():  # reference test_tableau_preset_nondefault
         assert provider not in PF.DEFAULT_PROVIDERS.values()
+
+
+def test_rk_wrapper_trim_indices_name_the_stage_of_each_timestep():
+    """`timesteps` of the Runge-Kutta wrappers is all_points WITHOUT the stages on the clean end; element k of it
+    is stage trim_indices[k] of the walk.  Cash-Karp (RKUltra order 6) and SSPRK3 have a c = 1 stage ahead of their last one, so
+    the last elements sit one position earlier than their stage (reference diffusers.py:652-666 builds the same trimmed table)."""
+    import skrample_amd.diffusers as PD
+    import skrample_amd.scheduling as PS
+    from skrample_amd.sampling import tableaux as TB
+
+    seen_shift = 0
+    for mk in (
+        lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=6),
+        lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=3, providers={3: TB.SSP.RK3_3}),
+        lambda: PD.RKUltraWrapperScheduler(PS.Linear(), sampler_order=4),
+        lambda: PD.DynasauRKWrapperScheduler(PS.Scaled(), sampler_order=6),
+    ):
+        for steps in (1, 3, 7):
+            w = mk()
+            w.set_timesteps(steps)
+            kept = w.trim_indices
+            assert len(kept) == len(w.schedule_np_trim) == len(w.timesteps)
+            for k, at in enumerate(kept):
+                assert w.schedule_np_trim[k, 0] == w.all_points[at].timestep
+            assert list(kept) == sorted(set(kept))
+            seen_shift += list(kept) != list(range(len(kept)))
+            # the walk visits exactly the kept stages, in order, when fed the table (host floats)
+            import torch
+
+            x = torch.zeros(1, 2, 4, 4)
+            visited = []
+            for t in w.timesteps.tolist():
+                visited.append(w._index)
+                x = w.step(torch.ones_like(x), t, x, return_dict=False)[0]
+            assert visited == list(kept)
+    assert seen_shift >= 2  # the case the check used to get wrong does occur

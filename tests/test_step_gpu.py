@@ -1064,9 +1064,10 @@ def test_stage_replay_fallback_keeps_the_noise_stream(dev):
 
 
 def test_aliased_history_is_guarded(dev):
-    """the default wrapper keeps the caller's tensors as history operands (the reference deep-copies, structured.py:113-125):
+    """alias_history=True keeps the caller's tensors as history operands (the reference deep-copies, structured.py:113-125):
     a caller that reuses its buffers must get an error, never a silently wrong step; alias_history=False snapshots and must
-    then reproduce the result of a run on fresh tensors bit for bit."""
+    then reproduce the result of a run on fresh tensors bit for bit; the default ("auto") finds out which caller it has and
+    never raises for the two static-buffer patterns (test_alias_auto_* below)."""
     shape, steps = (2, 4, 16, 16), 6
     g = torch.Generator().manual_seed(77)
     x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
@@ -1087,13 +1088,20 @@ def test_aliased_history_is_guarded(dev):
             x = w.step(out, t, x, generator=[1, 2], return_dict=False)[0]
         return x
 
-    fresh = run(mk(), None)
+    fresh = run(mk(alias_history=True), None)
+    assert torch.equal(run(mk(), None), fresh)  # default ("auto") on fresh tensors: same bits
     for reuse in ("copy_", "static"):
         with pytest.raises(_hip.SkrampleHipError, match="alias_history=False"):
-            run(mk(), reuse)
+            run(mk(alias_history=True), reuse)
         assert torch.equal(run(mk(alias_history=False), reuse), fresh)
-    # in-place edit of the latents between steps
+        w = mk()
+        assert torch.equal(run(w, reuse), fresh)  # the default no longer throws where the reference works
+        assert w._alias_auto == "snapshot"
     w = mk()
+    run(w, None)
+    assert w._alias_auto == "alias"  # fresh tensors every step: history entries are the caller's own tensors (0 bytes written)
+    # in-place edit of the latents between steps
+    w = mk(alias_history=True)
     w.set_timesteps(steps)
     ts = w.timesteps.tolist()
     x = w.step(outs[0], ts[0], x0.clone(), generator=[1, 2], return_dict=False)[0]
@@ -1107,7 +1115,7 @@ def test_aliased_history_is_guarded(dev):
     for t in w.timesteps.tolist():
         x = w.step(buf, t, x, return_dict=False)[0]
     # Runge-Kutta stages: the step's base sample is held until the last stage
-    rk = PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=4)
+    rk = PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=4, alias_history=True)
     rk.set_timesteps(3)
     ts = rk.timesteps.tolist()
     base = x0.clone()
@@ -1115,6 +1123,42 @@ def test_aliased_history_is_guarded(dev):
     base.add_(1.0)
     with pytest.raises(_hip.SkrampleHipError, match="modified in place"):
         rk.step(outs[1], ts[1], nxt, return_dict=False)
+
+
+def test_alias_auto_static_output_network_loops(dev):
+    """The default wrappers run a loop whose network writes every output into ONE static buffer (a HIP-graphed network, an
+    in-place copy_) without raising, for multistep and Runge-Kutta samplers alike, and reproduce the fresh-tensor run bit for
+    bit; a second run of the same wrapper (set_timesteps) decides afresh."""
+    shape, steps = (2, 4, 16, 16), 5
+    g = torch.Generator().manual_seed(78)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps * 6)]
+    makers = [
+        lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel()),
+        lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=4), PS.ZSNR(), PM.VelocityModel()),
+        lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=6, stochasticity=1),
+        lambda: PD.DynasauRKWrapperScheduler(PS.Scaled(), sampler_order=3),
+    ]
+    for mk in makers:
+        def run(w, static, latents_static=False):
+            w.set_timesteps(steps)
+            x, buf, lat = x0, torch.empty_like(outs[0]), x0.clone()
+            for i, t in enumerate(w.timesteps.tolist()):
+                out = outs[i]
+                if static:
+                    buf.copy_(out)
+                    out = buf
+                if latents_static:  # the pipeline keeps ONE latents buffer too
+                    lat.copy_(x)
+                    x = lat
+                x = w.step(out, t, x, generator=[1, 2], return_dict=False)[0]
+            return x.clone()
+
+        fresh = run(mk(), False)
+        w = mk()
+        assert torch.equal(run(w, True), fresh) and w._alias_auto == "snapshot"
+        assert torch.equal(run(w, False), fresh) and w._alias_auto == "alias"  # next run, other caller behaviour
+        assert torch.equal(run(mk(), False, latents_static=True), fresh)
 
 
 def test_whole_loop_graph_capture(dev):

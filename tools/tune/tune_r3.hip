@@ -1,0 +1,680 @@
+// Round-3 experiment harness: the launch shapes that sat below the headline in round 2.
+//   scenario "rk"   Runge-Kutta stage: K bf16 reads, TWO bf16 writes           (64x4x256x256)
+//   scenario "two"  UniPC step: NA bf16 + one fp32 read, fp32 + bf16 writes    (256x16x128x128)
+//   scenario "b64"  BASELINE config 2's own batch: 4 bf16 reads + Philox, one bf16 write (64x4x128x128)
+//   scenario "bigk" Adams 5-9 / UniPC >= 4: 10..18 bf16 reads, one bf16 write  (256x4x128x128)
+//   scenario "mix"  machine ceilings: r reads + w writes of 16 B per lane, no arithmetic
+// Every variant is its own template instantiation (rocprofv3 --kernel-trace separates them) and every variant of a
+// scenario must produce the same bytes as the scenario's first one (word sums of the outputs are compared).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tune_r3 tune_r3.hip
+//   ./tune_r3 [only=substring] [reps=3] [iters=200]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+#include <dlfcn.h>
+#include "../../include/skrample_hip.h"
+#include "../../skrample_amd/csrc/skr_philox.h"
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  f32x2_t f = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+
+constexpr int MAXIN = 20;
+struct Args {
+  const void* in[MAXIN];
+  void* out0;   // fp32 state (two) / derivative (rk) / the result (one output)
+  void* out1;
+  const uint64_t* seeds;
+  float c0[MAXIN];
+  float c1[MAXIN];
+  float chain, zeta0, zeta1;
+  uint64_t stream0, stream1;
+  int lr;          // log2 run length of the XCD chunk map
+  int bps_shift;   // log2(chunks per sample)
+};
+
+// store policies: 0 plain write-back, 1 nt, 2 sc0 sc1, 3 sc1
+template <int SP> __device__ __forceinline__ void st16(void* p, u32x4_t v) {
+  if constexpr (SP == 0) *reinterpret_cast<u32x4_t*>(p) = v;
+  else if constexpr (SP == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+  else if constexpr (SP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+template <int SP> __device__ __forceinline__ void st8(void* p, u32x2_t v) {
+  if constexpr (SP == 0) *reinterpret_cast<u32x2_t*>(p) = v;
+  else if constexpr (SP == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x2_t*>(p));
+  else if constexpr (SP == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4_t ld16(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
+__device__ __forceinline__ u32x2_t ld8(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p)); }
+
+__device__ __forceinline__ uint32_t chunk_of(uint32_t b, int lr) {
+  const uint32_t g = 3 + lr;
+  return ((b >> g) << g) + ((b & 7u) << lr) + ((b >> 3) & ((1u << lr) - 1u));
+}
+
+__device__ __forceinline__ void widen(u32x4_t q, float w[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { w[2 * i] = __uint_as_float(q[i] << 16); w[2 * i + 1] = __uint_as_float(q[i] & 0xFFFF0000u); }
+}
+__device__ __forceinline__ u32x4_t pack8(const float s[8]) {
+  u32x4_t q;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = pack_bf16(s[2 * i], s[2 * i + 1]);
+  return q;
+}
+
+// ---- uniform bf16 kernels: K reads, NO (1 | 2) writes; natural layout (lane owns 8 consecutive elements) ----------
+// NO == 2 is the RK stage shape: out0 = f(in0, in1) (a stand-in for the rounded conversion: two rounded ops), out1 = chain*out0 + sum
+// PACE: 0 burst, 1 s_sleep 16 between loads, 2 sleep between the two stores, 3 loads in two halves around the scalar fetch
+// NOISE: 0 | 1 (one draw added to the last output)
+// UV: vectors per lane (spaced BLK apart)
+template <int K, int NO, int BLK, int UV, int SP0, int SP1, int PACE, int NOISE, int ORDER>
+__global__ __launch_bounds__(BLK) void ku(const Args a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.lr);
+  const int64_t v0 = (int64_t)c * (BLK * UV) + threadIdx.x;
+  u32x4_t r[UV][K];
+  int64_t vj = v0;
+#pragma unroll
+  for (int u = 0; u < UV; ++u)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      r[u][j] = ld16(reinterpret_cast<const u32x4_t*>(a.in[j]) + vj + u * BLK);
+      if constexpr (PACE == 1) {
+        if (j < K - 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_sleep 16" : "+v"(vj)); __builtin_amdgcn_sched_barrier(0); }
+      }
+    }
+  __builtin_amdgcn_sched_barrier(0);
+  float z[UV][8];
+  if constexpr (NOISE) {
+    const uint32_t smp = c >> a.bps_shift;
+    const uint64_t seed = a.seeds[smp];
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const uint64_t blk = (uint64_t)(v0 + u * BLK - ((int64_t)smp << a.bps_shift) * (BLK * UV)) * 2;
+      skr::normal4(seed, a.stream0, blk, z[u]);
+      skr::normal4(seed, a.stream0, blk + 1, z[u] + 4);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UV; ++u) {
+    float s[8], d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      float w[8];
+      widen(r[u][j], w);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.c1[j], w[i], s[i]);
+      if (NO == 2 && j == 1) {
+        float w0[8];
+        widen(r[u][0], w0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {  // two individually rounded ops + an IEEE divide, as the pair conversion does
+          float t = __uint_as_float(pack_bf16(a.c0[0] * w[i], 0.f) << 16);
+          t = __uint_as_float(pack_bf16(w0[i] - t, 0.f) << 16);
+          d[i] = __uint_as_float(pack_bf16(__fdiv_rn(t, a.c0[1]), 0.f) << 16);
+        }
+      }
+    }
+    if constexpr (NO == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.chain, d[i], s[i]);
+    }
+    if constexpr (NOISE) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.zeta1, z[u][i], s[i]);
+    }
+    const int64_t v = v0 + u * BLK;
+    if constexpr (NO == 2) {
+      if constexpr (ORDER == 0) {
+        st16<SP1>(reinterpret_cast<u32x4_t*>(a.out1) + v, pack8(s));
+        if constexpr (PACE == 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_sleep 16"); __builtin_amdgcn_sched_barrier(0); }
+        st16<SP0>(reinterpret_cast<u32x4_t*>(a.out0) + v, pack8(d));
+      } else {
+        st16<SP0>(reinterpret_cast<u32x4_t*>(a.out0) + v, pack8(d));
+        if constexpr (PACE == 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_sleep 16"); __builtin_amdgcn_sched_barrier(0); }
+        st16<SP1>(reinterpret_cast<u32x4_t*>(a.out1) + v, pack8(s));
+      }
+    } else {
+      st16<SP0>(reinterpret_cast<u32x4_t*>(a.out0) + v, pack8(s));
+    }
+  }
+}
+
+// RK stage, derivative written EARLY: the first two operands are loaded, converted and stored while the other K-2 are in flight
+template <int K, int BLK, int SP0, int SP1>
+__global__ __launch_bounds__(BLK) void krk_early(const Args a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.lr);
+  const int64_t v = (int64_t)c * BLK + threadIdx.x;
+  u32x4_t r[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) r[j] = ld16(reinterpret_cast<const u32x4_t*>(a.in[j]) + v);
+  __builtin_amdgcn_sched_barrier(0);
+  float w0[8], w1[8], d[8], s[8];
+  widen(r[0], w0);
+  widen(r[1], w1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float t = __uint_as_float(pack_bf16(a.c0[0] * w1[i], 0.f) << 16);
+    t = __uint_as_float(pack_bf16(w0[i] - t, 0.f) << 16);
+    d[i] = __uint_as_float(pack_bf16(__fdiv_rn(t, a.c0[1]), 0.f) << 16);
+  }
+  st16<SP0>(reinterpret_cast<u32x4_t*>(a.out0) + v, pack8(d));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.c1[1], w1[i], __builtin_fmaf(a.c1[0], w0[i], 0.f));
+#pragma unroll
+  for (int j = 2; j < K; ++j) {
+    float w[8];
+    widen(r[j], w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.c1[j], w[i], s[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.chain, d[i], s[i]);
+  st16<SP1>(reinterpret_cast<u32x4_t*>(a.out1) + v, pack8(s));
+}
+
+// ---- two outputs, mixed widths: NA bf16 + NB (0|1) fp32 reads; out0 fp32, out1 bf16 ----------------------------------
+// LAYOUT 0  tile layout for everything (round 2): lane l of a wave owns elements 4l..4l+3 and 256+4l..+3 of the wave's
+//           512-element tile; bf16 as two 8-byte accesses, fp32 as two whole-line 16-byte accesses
+// LAYOUT 1  as 0, but the bf16 RESULT is exchanged through LDS to 8 consecutive elements per lane: one 16-byte store
+// LAYOUT 2  natural layout for the arithmetic (bf16: one 16-byte access per lane); the fp32 operand is loaded in whole
+//           lines (tile) and exchanged through LDS, the fp32 result is exchanged back and stored in whole lines
+// SPB / SPF: store policy of the bf16 / fp32 output
+template <int NA, int NB, int LAYOUT, int SPB, int SPF, int NOISE>
+__global__ __launch_bounds__(256) void km(const Args a) {
+  __shared__ float lds[LAYOUT == 0 ? 1 : 4 * 512];
+  const uint32_t c = chunk_of(blockIdx.x, a.lr);
+  const int64_t v = (int64_t)c * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = (v >> 6) << 7;         // group (4 elements) index of the wave's tile
+  const int64_t g0 = tile + lane, g1 = g0 + 64;
+  float* wl = lds + (LAYOUT == 0 ? 0 : (threadIdx.x >> 6) * 512);
+  u32x4_t ra[NA];
+  f32x4_t rb0[NB > 0 ? NB : 1], rb1[NB > 0 ? NB : 1];
+  if constexpr (LAYOUT == 2) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ra[j] = ld16(reinterpret_cast<const u32x4_t*>(a.in[j]) + v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const u32x2_t lo = ld8(reinterpret_cast<const u32x2_t*>(a.in[j]) + g0), hi = ld8(reinterpret_cast<const u32x2_t*>(a.in[j]) + g1);
+      ra[j] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    rb0[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(a.in[NA + j]) + g0);
+    rb1[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(a.in[NA + j]) + g1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float z0[8], z1[8];
+  if constexpr (NOISE) {
+    const uint32_t smp = c >> a.bps_shift;
+    const uint64_t seed = a.seeds[smp];
+    const int64_t vs = v - ((int64_t)smp << a.bps_shift) * 256;
+    uint64_t b0, b1;
+    if constexpr (LAYOUT == 2) { b0 = 2 * vs; b1 = 2 * vs + 1; }
+    else { b0 = ((vs >> 6) << 7) + lane; b1 = b0 + 64; }
+    skr::normal4(seed, a.stream0, b0, z0); skr::normal4(seed, a.stream0, b1, z0 + 4);
+    skr::normal4(seed, a.stream1, b0, z1); skr::normal4(seed, a.stream1, b1, z1 + 4);
+  }
+  float s0[8], s1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    float w[8];
+    widen(ra[j], w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0[i] = __builtin_fmaf(a.c0[j], w[i], s0[i]); s1[i] = __builtin_fmaf(a.c1[j], w[i], s1[i]); }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    float w[8];
+    if constexpr (LAYOUT == 2) {  // tile -> natural through the wave's own LDS slab (no barrier: one wave, in-order LDS)
+      *reinterpret_cast<f32x4_t*>(wl + 4 * lane) = rb0[j];
+      *reinterpret_cast<f32x4_t*>(wl + 256 + 4 * lane) = rb1[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wl + 8 * lane), hi = *reinterpret_cast<const f32x4_t*>(wl + 8 * lane + 4);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { w[i] = lo[i]; w[4 + i] = hi[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { w[i] = rb0[j][i]; w[4 + i] = rb1[j][i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0[i] = __builtin_fmaf(a.c0[NA + j], w[i], s0[i]); s1[i] = __builtin_fmaf(a.c1[NA + j], w[i], s1[i]); }
+  }
+  if constexpr (NOISE) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s0[i] = __builtin_fmaf(a.zeta0, z0[i], s0[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s1[i] = __builtin_fmaf(a.chain, s0[i], s1[i]);
+  if constexpr (NOISE) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = __builtin_fmaf(a.zeta1, z1[i], s1[i]);
+  }
+  const u32x4_t q = pack8(s1);
+  if constexpr (LAYOUT == 0) {
+    st8<SPB>(reinterpret_cast<u32x2_t*>(a.out1) + g0, u32x2_t{q[0], q[1]});
+    st8<SPB>(reinterpret_cast<u32x2_t*>(a.out1) + g1, u32x2_t{q[2], q[3]});
+    st16<SPF>(reinterpret_cast<u32x4_t*>(a.out0) + g0, __builtin_bit_cast(u32x4_t, f32x4_t{s0[0], s0[1], s0[2], s0[3]}));
+    st16<SPF>(reinterpret_cast<u32x4_t*>(a.out0) + g1, __builtin_bit_cast(u32x4_t, f32x4_t{s0[4], s0[5], s0[6], s0[7]}));
+  } else if constexpr (LAYOUT == 1) {
+    uint32_t* wu = reinterpret_cast<uint32_t*>(wl);   // 256 dwords of packed bf16 per wave tile
+    *reinterpret_cast<u32x2_t*>(wu + 2 * lane) = u32x2_t{q[0], q[1]};
+    *reinterpret_cast<u32x2_t*>(wu + 128 + 2 * lane) = u32x2_t{q[2], q[3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const u32x4_t o = *reinterpret_cast<const u32x4_t*>(wu + 4 * lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    st16<SPB>(reinterpret_cast<u32x4_t*>(a.out1) + v, o);
+    st16<SPF>(reinterpret_cast<u32x4_t*>(a.out0) + g0, __builtin_bit_cast(u32x4_t, f32x4_t{s0[0], s0[1], s0[2], s0[3]}));
+    st16<SPF>(reinterpret_cast<u32x4_t*>(a.out0) + g1, __builtin_bit_cast(u32x4_t, f32x4_t{s0[4], s0[5], s0[6], s0[7]}));
+  } else {
+    st16<SPB>(reinterpret_cast<u32x4_t*>(a.out1) + v, q);
+    *reinterpret_cast<f32x4_t*>(wl + 8 * lane) = f32x4_t{s0[0], s0[1], s0[2], s0[3]};
+    *reinterpret_cast<f32x4_t*>(wl + 8 * lane + 4) = f32x4_t{s0[4], s0[5], s0[6], s0[7]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(wl + 4 * lane), hi = *reinterpret_cast<const u32x4_t*>(wl + 256 + 4 * lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    st16<SPF>(reinterpret_cast<u32x4_t*>(a.out0) + g0, lo);
+    st16<SPF>(reinterpret_cast<u32x4_t*>(a.out0) + g1, hi);
+  }
+}
+
+// ---- time-phased RK stage: loads only in even windows of the chip-wide real-time counter, stores only in odd ones -------
+// (s_memrealtime: 100 MHz, the same value on every CU -- a phase signal that needs no communication)
+template <int K, int BLK, int P>   // P = window length in 10 ns ticks
+__global__ __launch_bounds__(BLK) void kphase(const Args a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.lr);
+  const int64_t v = (int64_t)c * BLK + threadIdx.x;
+  while (((__builtin_amdgcn_s_memrealtime() / P) & 1) != 0) __builtin_amdgcn_s_sleep(2);
+  u32x4_t r[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) r[j] = ld16(reinterpret_cast<const u32x4_t*>(a.in[j]) + v);
+  __builtin_amdgcn_sched_barrier(0);
+  float w0[8], w1[8], d[8], s[8];
+  widen(r[0], w0);
+  widen(r[1], w1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float t = __uint_as_float(pack_bf16(a.c0[0] * w1[i], 0.f) << 16);
+    t = __uint_as_float(pack_bf16(w0[i] - t, 0.f) << 16);
+    d[i] = __uint_as_float(pack_bf16(__fdiv_rn(t, a.c0[1]), 0.f) << 16);
+    s[i] = __builtin_fmaf(a.c1[1], w1[i], __builtin_fmaf(a.c1[0], w0[i], 0.f));
+  }
+#pragma unroll
+  for (int j = 2; j < K; ++j) {
+    float w[8];
+    widen(r[j], w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.c1[j], w[i], s[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = __builtin_fmaf(a.chain, d[i], s[i]);
+  u32x4_t q1 = pack8(s), q0 = pack8(d);
+  asm volatile("" : "+v"(q1), "+v"(q0));
+  __builtin_amdgcn_sched_barrier(0);
+  while (((__builtin_amdgcn_s_memrealtime() / P) & 1) == 0) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_sched_barrier(0);
+  st16<2>(reinterpret_cast<u32x4_t*>(a.out1) + v, q1);
+  st16<2>(reinterpret_cast<u32x4_t*>(a.out0) + v, q0);
+}
+
+// ---- machine ceilings: R 16-byte reads + W 16-byte writes per lane, xor only ------------------------------------------
+template <int R, int W, int BLK, int SP>
+__global__ __launch_bounds__(BLK) void kmix(const Args a) {
+  const uint32_t c = chunk_of(blockIdx.x, a.lr);
+  const int64_t v = (int64_t)c * BLK + threadIdx.x;
+  u32x4_t acc = {1u, 2u, 3u, 4u};
+  u32x4_t r[R > 0 ? R : 1];
+#pragma unroll
+  for (int j = 0; j < R; ++j) r[j] = ld16(reinterpret_cast<const u32x4_t*>(a.in[j]) + v);
+#pragma unroll
+  for (int j = 0; j < R; ++j) acc ^= r[j];
+  if constexpr (W == 0) {
+    if (acc[0] == 0x12345678u && acc[1] == 0x9abcdef0u) st16<0>(reinterpret_cast<u32x4_t*>(a.out0) + v, acc);
+  }
+  if constexpr (W >= 1) st16<SP>(reinterpret_cast<u32x4_t*>(a.out0) + v, acc);
+  if constexpr (W >= 2) st16<SP>(reinterpret_cast<u32x4_t*>(a.out1) + v, acc + 1u);
+}
+
+// ---- helpers -----------------------------------------------------------------------------------------------------------
+__global__ void fill_bf16(uint32_t* p, int64_t nwords, uint32_t salt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u + salt;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    // two bf16 values in (-2, 2): sign + exponent 0x3f/0x3e.. keep them finite and ordinary
+    const uint32_t lo = 0x3f00u | (h & 0x80ffu), hi = 0x3f00u | ((h >> 16) & 0x80ffu);
+    p[i] = lo | (hi << 16);
+  }
+}
+__global__ void fill_f32(float* p, int64_t n, uint32_t salt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u + salt;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (float)(int32_t)h * (1.0f / 2147483648.0f);
+  }
+}
+__global__ void wordsum(const uint32_t* p, int64_t nwords, unsigned long long* out) {
+  unsigned long long s = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x) s += (unsigned long long)p[i] * (unsigned long long)((i & 1023) + 1);
+  atomicAdd(out, s);
+}
+
+struct Scenario {
+  std::string name;
+  int64_t numel;       // elements per tensor
+  int64_t sample;      // elements per sample
+  int n16, n32;        // input tensors
+  int out0_bytes;      // bytes per element of out0 (0 = none)
+  int out1_bytes;
+  int nsets;
+  std::vector<std::vector<void*>> in;
+  std::vector<void*> o0, o1;
+  uint64_t* seeds = nullptr;
+  bool out0_unwritten = false;   // (read-only ceilings: the buffer exists, nothing is stored)
+  double bytes_per_launch() const { return (double)numel * (2.0 * n16 + 4.0 * n32 + (out0_unwritten ? 0 : out0_bytes) + out1_bytes); }
+  void alloc() {
+    for (int s = 0; s < nsets; ++s) {
+      std::vector<void*> v;
+      for (int j = 0; j < n16; ++j) { void* p; CK(hipMalloc(&p, numel * 2)); hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, 0, (uint32_t*)p, numel / 2, (uint32_t)(s * 131 + j * 7 + 1)); v.push_back(p); }
+      for (int j = 0; j < n32; ++j) { void* p; CK(hipMalloc(&p, numel * 4)); hipLaunchKernelGGL(fill_f32, dim3(2048), dim3(256), 0, 0, (float*)p, numel, (uint32_t)(s * 977 + j * 13 + 5)); v.push_back(p); }
+      in.push_back(v);
+      void *a = nullptr, *b = nullptr;
+      if (out0_bytes) CK(hipMalloc(&a, numel * out0_bytes + (4 << 20)));
+      if (out1_bytes) CK(hipMalloc(&b, numel * out1_bytes + (4 << 20)));
+      o0.push_back(a); o1.push_back(b);
+    }
+    const int64_t batch = numel / sample;
+    std::vector<uint64_t> h(batch);
+    for (int64_t i = 0; i < batch; ++i) h[i] = 42 + i;
+    CK(hipMalloc(&seeds, batch * 8));
+    CK(hipMemcpy(seeds, h.data(), batch * 8, hipMemcpyHostToDevice));
+    CK(hipDeviceSynchronize());
+  }
+  void release() {
+    for (auto& v : in) for (void* p : v) CK(hipFree(p));
+    for (void* p : o0) if (p) CK(hipFree(p));
+    for (void* p : o1) if (p) CK(hipFree(p));
+    CK(hipFree(seeds));
+    in.clear(); o0.clear(); o1.clear();
+  }
+};
+
+struct Variant { std::string name; int elems_per_wg; std::function<void(const Args&, unsigned)> launch; };
+
+static std::string g_only;
+static int g_reps = 3, g_iters = 200;
+static int64_t g_off1 = 0;   // byte offset of out1 inside its allocation (stream placement experiments)
+static int64_t g_off0 = 0;
+static unsigned long long* g_sum;
+
+static int lr_for(int64_t chunks, int want) {
+  int lr = want;
+  while (lr > 0 && chunks % (8ll << lr) != 0) --lr;
+  return lr;
+}
+
+static void run_scenario(Scenario& sc, std::vector<Variant>& vars, int want_lr = 7) {
+  bool any = false;
+  for (auto& v : vars) if (g_only.empty() || (sc.name + "/" + v.name).find(g_only) != std::string::npos) any = true;
+  if (!any) return;
+  sc.alloc();
+  printf("# %s: numel %lld, %d bf16 + %d fp32 in, out0 %d B, out1 %d B, %.1f MB per launch, %d sets (floor %.2f us at 8 TB/s)\n", sc.name.c_str(),
+         (long long)sc.numel, sc.n16, sc.n32, sc.out0_bytes, sc.out1_bytes, sc.bytes_per_launch() / 1e6, sc.nsets, sc.bytes_per_launch() / 8e6);
+  unsigned long long ref0 = 0, ref1 = 0;
+  bool have_ref = false;
+  for (auto& v : vars) {
+    if (!g_only.empty() && (sc.name + "/" + v.name).find(g_only) == std::string::npos) continue;
+    const int64_t chunks = sc.numel / v.elems_per_wg;
+    Args a;
+    memset(&a, 0, sizeof a);
+    for (int j = 0; j < MAXIN; ++j) { a.c0[j] = 0.11f * (j + 1); a.c1[j] = -0.05f * (j + 1); }
+    a.c0[1] = 0.9f;
+    a.chain = 0.5f; a.zeta0 = 0.3f; a.zeta1 = 0.2f; a.stream0 = 1; a.stream1 = 2; a.seeds = sc.seeds;
+    a.lr = lr_for(chunks, want_lr);
+    const int64_t cps = sc.sample / v.elems_per_wg;
+    a.bps_shift = 0;
+    while ((1ll << a.bps_shift) < cps) ++a.bps_shift;
+    auto go = [&](int s) {
+      for (size_t j = 0; j < sc.in[s].size(); ++j) a.in[j] = sc.in[s][j];
+      a.out0 = sc.o0[s] ? (char*)sc.o0[s] + g_off0 : nullptr; a.out1 = sc.o1[s] ? (char*)sc.o1[s] + g_off1 : nullptr;
+      v.launch(a, (unsigned)chunks);
+    };
+    // correctness: set 0
+    go(0);
+    CK(hipDeviceSynchronize());
+    unsigned long long s0 = 0, s1 = 0;
+    if (sc.out0_bytes) { CK(hipMemset(g_sum, 0, 8)); hipLaunchKernelGGL(wordsum, dim3(1024), dim3(256), 0, 0, (const uint32_t*)((char*)sc.o0[0] + g_off0), sc.numel * sc.out0_bytes / 4, g_sum); CK(hipMemcpy(&s0, g_sum, 8, hipMemcpyDeviceToHost)); }
+    if (sc.out1_bytes) { CK(hipMemset(g_sum, 0, 8)); hipLaunchKernelGGL(wordsum, dim3(1024), dim3(256), 0, 0, (const uint32_t*)((char*)sc.o1[0] + g_off1), sc.numel * sc.out1_bytes / 4, g_sum); CK(hipMemcpy(&s1, g_sum, 8, hipMemcpyDeviceToHost)); }
+    const char* ok = "ref";
+    if (!have_ref) { ref0 = s0; ref1 = s1; have_ref = true; }
+    else ok = (s0 == ref0 && s1 == ref1) ? "same" : "DIFF";
+    if (sc.name.rfind("mix", 0) == 0 || v.name.rfind("LIB", 0) == 0 || v.name.rfind("kmix", 0) == 0) ok = "-";
+    // conditioning (~30 ms), then best of reps
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0)); for (int i = 0; i < 20; ++i) go(i % sc.nsets); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const int cond = (int)(30.0 / (ms / 20 > 1e-3 ? ms / 20 : 1e-3)) + 1;
+    for (int i = 0; i < cond; ++i) go(i % sc.nsets);
+    double best = 1e30, sum = 0;
+    for (int rep = 0; rep < g_reps; ++rep) {
+      for (int i = 0; i < 20; ++i) go(i % sc.nsets);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0)); for (int i = 0; i < g_iters; ++i) go(i % sc.nsets); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / g_iters;
+      best = us < best ? us : best; sum += us;
+    }
+    const double tbs = sc.bytes_per_launch() / best / 1e6;
+    printf("%-16s %-44s off %lld/%lld lr %d  best %8.2f us  avg %8.2f us  %6.3f TB/s  %.3f  %s\n", sc.name.c_str(), v.name.c_str(), (long long)g_off0, (long long)g_off1, a.lr, best, sum / g_reps, tbs, tbs / 8, ok);
+    fflush(stdout);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  }
+  sc.release();
+}
+
+// the shipped library on the same buffers (kind: 0 one output, 1 RK stage, 2 two outputs fp32 + bf16)
+typedef int (*launch_fn)(const skr_step_plan*, const void* const*, void*, void*, const uint64_t*, int64_t, void*);
+typedef int (*tuning_fn)(const char*, int);
+static launch_fn g_lib_launch = nullptr;
+static tuning_fn g_lib_tuning = nullptr;
+static void load_lib() {
+  if (g_lib_launch) return;
+  const char* path = getenv("SKR_LIB") ? getenv("SKR_LIB") : "skrample_amd/csrc/libskrample_hip.so";
+  void* h = dlopen(path, RTLD_NOW);
+  if (!h) { printf("cannot load %s: %s\n", path, dlerror()); exit(1); }
+  g_lib_launch = (launch_fn)dlsym(h, "skr_step_launch");
+  g_lib_tuning = (tuning_fn)dlsym(h, "skr_set_tuning");
+}
+static Variant lib_variant(const std::string& name, int kind, int n16, int n32, bool noise, int64_t numel, int64_t sample, const char* tune_key = nullptr, int tune_val = 0) {
+  load_lib();
+  auto plan = std::make_shared<skr_step_plan>();
+  memset(plan.get(), 0, sizeof(skr_step_plan));
+  plan->n_terms = n16 + n32; plan->n_group_a = n16; plan->dtype_a = SKR_BF16; plan->dtype_b = n32 ? SKR_F32 : SKR_BF16;
+  plan->out0_dtype = kind == 2 ? SKR_F32 : SKR_BF16;
+  plan->out1_dtype = kind == 0 ? SKR_NONE : SKR_BF16;
+  plan->sample_numel = sample; plan->chain = 0.5;
+  for (int k = 0; k < n16 + n32; ++k) { plan->coef0[k] = 0.11 * (k + 1); plan->coef1[k] = -0.05 * (k + 1); }
+  if (noise) { plan->noise_mode = 1; plan->zeta0 = kind == 1 ? 0.0 : 0.3; plan->zeta1 = kind == 0 ? 0.0 : 0.2; plan->stream0 = 1; plan->stream1 = 2; }
+  if (kind == 1) { plan->convert_to = 1; plan->convert_from = 1; plan->convert_k[0] = 0.7; plan->convert_k[1] = 0.9; plan->convert_k[2] = 0.4; plan->convert_k[3] = 1.3; }
+  std::string key = tune_key ? tune_key : "";
+  return Variant{name, 2048, [plan, numel, key, tune_val, n16, n32](const Args& a, unsigned) {
+    if (!key.empty()) g_lib_tuning(key.c_str(), tune_val);
+    const int st = g_lib_launch(plan.get(), a.in, a.out0, a.out1, a.seeds, numel, nullptr);
+    if (st) { printf("skr_step_launch failed: %d\n", st); exit(1); }
+  }};
+}
+
+#define KU(K, NO, BLK, UV, SP0, SP1, PACE, NOISE, ORDER) \
+  Variant{"ku<K" #K ",NO" #NO ",B" #BLK ",UV" #UV ",sp" #SP0 #SP1 ",pace" #PACE ",n" #NOISE ",ord" #ORDER ">", BLK * UV * 8, \
+          [](const Args& a, unsigned chunks) { hipLaunchKernelGGL((ku<K, NO, BLK, UV, SP0, SP1, PACE, NOISE, ORDER>), dim3(chunks), dim3(BLK), 0, 0, a); }}
+#define KRKE(K, BLK, SP0, SP1) \
+  Variant{"krk_early<K" #K ",B" #BLK ",sp" #SP0 #SP1 ">", BLK * 8, \
+          [](const Args& a, unsigned chunks) { hipLaunchKernelGGL((krk_early<K, BLK, SP0, SP1>), dim3(chunks), dim3(BLK), 0, 0, a); }}
+#define KPH(K, BLK, P) \
+  Variant{"kphase<K" #K ",B" #BLK ",P" #P ">", BLK * 8, \
+          [](const Args& a, unsigned chunks) { hipLaunchKernelGGL((kphase<K, BLK, P>), dim3(chunks), dim3(BLK), 0, 0, a); }}
+#define KM(NA, NB, LAYOUT, SPB, SPF, NOISE) \
+  Variant{"km<NA" #NA ",NB" #NB ",L" #LAYOUT ",spb" #SPB ",spf" #SPF ",n" #NOISE ">", 2048, \
+          [](const Args& a, unsigned chunks) { hipLaunchKernelGGL((km<NA, NB, LAYOUT, SPB, SPF, NOISE>), dim3(chunks), dim3(256), 0, 0, a); }}
+#define KMIX(R, W, BLK, SP) \
+  Variant{"kmix<R" #R ",W" #W ",B" #BLK ",sp" #SP ">", BLK * 8, \
+          [](const Args& a, unsigned chunks) { hipLaunchKernelGGL((kmix<R, W, BLK, SP>), dim3(chunks), dim3(BLK), 0, 0, a); }}
+
+int main(int argc, char** argv) {
+  for (int i = 1; i < argc; ++i) {
+    if (!strncmp(argv[i], "only=", 5)) g_only = argv[i] + 5;
+    else if (!strncmp(argv[i], "reps=", 5)) g_reps = atoi(argv[i] + 5);
+    else if (!strncmp(argv[i], "iters=", 6)) g_iters = atoi(argv[i] + 6);
+  }
+  CK(hipMalloc(&g_sum, 8));
+  const int64_t S4 = 4 * 128 * 128, S16 = 16 * 128 * 128, S4B = 4 * 256 * 256;
+
+  if (g_only.rfind("place", 0) == 0) {  // second write stream shifted inside its allocation
+    const int64_t offs[] = {0, 256, 512, 1024, 2048, 4096, 8192, 12288, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 1048576 + 4096, 2097152 + 20480};
+    g_only = "";
+    for (int64_t o : offs) {
+      g_off1 = o;
+      { Scenario sc{"mix_r2w2", 64 * S4B, S4B, 2, 0, 2, 2, 6}; std::vector<Variant> v = {KMIX(2, 2, 256, 2)}; run_scenario(sc, v); }
+      { Scenario sc{"rk3", 64 * S4B, S4B, 3, 0, 2, 2, 6}; std::vector<Variant> v = {KU(3, 2, 256, 1, 2, 2, 0, 0, 0)}; run_scenario(sc, v); }
+    }
+    const int64_t offs2[] = {0, 4096, 12288, 65536 + 4096, 1048576 + 4096};
+    for (int64_t o : offs2) {
+      g_off1 = o;
+      { Scenario sc{"two8n", 256 * S16, S16, 8, 1, 4, 2, 2}; std::vector<Variant> v = {KM(8, 1, 0, 2, 2, 1)}; run_scenario(sc, v); }
+    }
+    return 0;
+  }
+  if (g_only.rfind("lib", 0) == 0) {  // the shipped library against the harness kernels, same buffers, same run
+    g_only = "";
+    { Scenario sc{"rk2", 64 * S4B, S4B, 2, 0, 2, 2, 6}; std::vector<Variant> v = {KU(2, 2, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB rk K=2", 1, 2, 0, false, sc.numel, sc.sample), KU(2, 2, 128, 1, 2, 2, 0, 0, 0), KMIX(2, 2, 256, 2)}; run_scenario(sc, v); }
+    { Scenario sc{"rk3", 64 * S4B, S4B, 3, 0, 2, 2, 6}; std::vector<Variant> v = {KU(3, 2, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB rk K=3", 1, 3, 0, false, sc.numel, sc.sample), KU(3, 2, 128, 1, 2, 2, 0, 0, 0), KMIX(3, 2, 256, 2)}; run_scenario(sc, v); }
+    { Scenario sc{"rk5", 64 * S4B, S4B, 5, 0, 2, 2, 5}; std::vector<Variant> v = {KU(5, 2, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB rk K=5", 1, 5, 0, false, sc.numel, sc.sample), KU(5, 2, 128, 1, 2, 2, 0, 0, 0)}; run_scenario(sc, v); }
+    { Scenario sc{"rk7", 64 * S4B, S4B, 7, 0, 2, 2, 4}; std::vector<Variant> v = {KU(7, 2, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB rk K=7", 1, 7, 0, false, sc.numel, sc.sample), KU(7, 2, 128, 1, 2, 2, 0, 0, 0)}; run_scenario(sc, v); }
+    { Scenario sc{"two8n", 256 * S16, S16, 8, 1, 4, 2, 2}; std::vector<Variant> v = {KM(8, 1, 0, 2, 2, 1), lib_variant("LIB two 8+1 philox", 2, 8, 1, true, sc.numel, sc.sample), KM(8, 1, 2, 1, 1, 1), KM(8, 1, 0, 1, 1, 1)}; run_scenario(sc, v); }
+    { Scenario sc{"two10", 256 * S16, S16, 10, 1, 4, 2, 2}; std::vector<Variant> v = {KM(10, 1, 0, 2, 2, 0), lib_variant("LIB two 10+1", 2, 10, 1, false, sc.numel, sc.sample), KM(10, 1, 0, 1, 1, 0)}; run_scenario(sc, v); }
+    { Scenario sc{"b64", 64 * S4, S4, 4, 0, 2, 0, 16}; std::vector<Variant> v = {KU(4, 1, 256, 1, 2, 2, 0, 1, 0), lib_variant("LIB K=4 philox B=64", 0, 4, 0, true, sc.numel, sc.sample), KMIX(4, 1, 256, 2)}; run_scenario(sc, v); }
+    { Scenario sc{"head", 256 * S4, S4, 4, 0, 2, 0, 6}; std::vector<Variant> v = {KU(4, 1, 256, 1, 2, 2, 0, 1, 0), lib_variant("LIB K=4 philox B=256", 0, 4, 0, true, sc.numel, sc.sample), KMIX(4, 1, 256, 2)}; run_scenario(sc, v); }
+    { Scenario sc{"bigk10", 256 * S4, S4, 10, 0, 2, 0, 3}; std::vector<Variant> v = {KU(10, 1, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB K=10", 0, 10, 0, false, sc.numel, sc.sample)}; run_scenario(sc, v); }
+    { Scenario sc{"bigk14", 256 * S4, S4, 14, 0, 2, 0, 3}; std::vector<Variant> v = {KU(14, 1, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB K=14", 0, 14, 0, false, sc.numel, sc.sample)}; run_scenario(sc, v); }
+    { Scenario sc{"bigk18", 256 * S4, S4, 18, 0, 2, 0, 2}; std::vector<Variant> v = {KU(18, 1, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB K=18", 0, 18, 0, false, sc.numel, sc.sample)}; run_scenario(sc, v); }
+    { Scenario sc{"k1", 256 * S4, S4, 1, 0, 2, 0, 8}; std::vector<Variant> v = {KU(1, 1, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB K=1", 0, 1, 0, false, sc.numel, sc.sample), KMIX(1, 1, 256, 2), KU(1, 1, 128, 1, 2, 2, 0, 0, 0), KU(1, 1, 512, 1, 2, 2, 0, 0, 0)}; run_scenario(sc, v); }
+    { Scenario sc{"k2", 256 * S4, S4, 2, 0, 2, 0, 8}; std::vector<Variant> v = {KU(2, 1, 256, 1, 2, 2, 0, 0, 0), lib_variant("LIB K=2", 0, 2, 0, false, sc.numel, sc.sample), KMIX(2, 1, 256, 2), KU(2, 1, 128, 1, 2, 2, 0, 0, 0), KU(2, 1, 512, 1, 2, 2, 0, 0, 0)}; run_scenario(sc, v); }
+    return 0;
+  }
+  if (g_only.rfind("phase", 0) == 0) {
+    g_only = "";
+    Scenario sc{"rk2", 64 * S4B, S4B, 2, 0, 2, 2, 6};
+    std::vector<Variant> v = {KU(2, 2, 256, 1, 2, 2, 0, 0, 0), KPH(2, 256, 100), KPH(2, 256, 200), KPH(2, 256, 300), KPH(2, 256, 400), KPH(2, 256, 50), KPH(2, 512, 250), KPH(2, 1024, 250), KPH(2, 128, 250)};
+    run_scenario(sc, v);
+    Scenario sc3{"rk3", 64 * S4B, S4B, 3, 0, 2, 2, 6};
+    std::vector<Variant> v3 = {KU(3, 2, 256, 1, 2, 2, 0, 0, 0), KPH(3, 256, 100), KPH(3, 256, 200), KPH(3, 256, 300), KPH(3, 256, 400)};
+    run_scenario(sc3, v3);
+    return 0;
+  }
+  if (g_only.rfind("ceil64", 0) == 0) {
+    g_only = "";
+    { Scenario sc{"mix64_r4w1", 64 * S4, S4, 4, 0, 2, 0, 16}; std::vector<Variant> v = {KMIX(4, 1, 256, 2), KMIX(4, 1, 512, 2), KMIX(4, 1, 1024, 2), KMIX(4, 1, 256, 0)}; run_scenario(sc, v); }
+    { Scenario sc{"mix64_r4w0", 64 * S4, S4, 4, 0, 2, 0, 16}; sc.out0_unwritten = true; std::vector<Variant> v = {KMIX(4, 0, 256, 2), KMIX(4, 0, 512, 2)}; run_scenario(sc, v); }
+    { Scenario sc{"mix128_r4w1", 128 * S4, S4, 4, 0, 2, 0, 12}; std::vector<Variant> v = {KMIX(4, 1, 256, 2), KMIX(4, 1, 512, 2)}; run_scenario(sc, v); }
+    { Scenario sc{"mix32_r4w1", 32 * S4, S4, 4, 0, 2, 0, 32}; std::vector<Variant> v = {KMIX(4, 1, 256, 2), KMIX(4, 1, 128, 2)}; run_scenario(sc, v); }
+    { Scenario sc{"mix16_r4w1", 16 * S4, S4, 4, 0, 2, 0, 64}; std::vector<Variant> v = {KMIX(4, 1, 256, 2), KMIX(4, 1, 128, 2), KMIX(4, 1, 64, 2)}; run_scenario(sc, v); }
+    return 0;
+  }
+  {  // machine ceilings at the RK-stage size
+    for (int r = 0; r <= 4; ++r)
+      for (int w = 0; w <= 2; ++w) {
+        if (r + w == 0) continue;
+        Scenario sc{"mix_r" + std::to_string(r) + "w" + std::to_string(w), 64 * S4B, S4B, r, 0, w >= 1 ? 2 : 0, w >= 2 ? 2 : 0, 6};
+        if (w == 0) { sc.out0_bytes = 2; sc.out0_unwritten = true; }
+        std::vector<Variant> vars;
+#define MIXROW(R, W) if (r == R && w == W) { vars = {KMIX(R, W, 256, 2), KMIX(R, W, 256, 0), KMIX(R, W, 256, 1), KMIX(R, W, 512, 2), KMIX(R, W, 1024, 2)}; }
+        MIXROW(1, 0) MIXROW(2, 0) MIXROW(4, 0) MIXROW(0, 1) MIXROW(0, 2) MIXROW(1, 1) MIXROW(2, 1) MIXROW(4, 1) MIXROW(1, 2) MIXROW(2, 2) MIXROW(3, 2) MIXROW(4, 2)
+#undef MIXROW
+        if (vars.empty()) continue;
+        run_scenario(sc, vars);
+      }
+  }
+  {  // RK stage, K = 2, 3, 5
+    Scenario sc{"rk2", 64 * S4B, S4B, 2, 0, 2, 2, 6};
+    std::vector<Variant> vars = {
+      KU(2, 2, 256, 1, 2, 2, 0, 0, 0), KU(2, 2, 256, 1, 2, 2, 0, 0, 1), KU(2, 2, 256, 1, 0, 0, 0, 0, 0), KU(2, 2, 256, 1, 1, 1, 0, 0, 0), KU(2, 2, 256, 1, 3, 3, 0, 0, 0),
+      KU(2, 2, 256, 1, 2, 0, 0, 0, 0), KU(2, 2, 256, 1, 0, 2, 0, 0, 0), KU(2, 2, 256, 1, 2, 2, 1, 0, 0), KU(2, 2, 256, 1, 2, 2, 2, 0, 0),
+      KU(2, 2, 128, 1, 2, 2, 0, 0, 0), KU(2, 2, 512, 1, 2, 2, 0, 0, 0), KU(2, 2, 1024, 1, 2, 2, 0, 0, 0), KU(2, 2, 256, 2, 2, 2, 0, 0, 0), KU(2, 2, 256, 4, 2, 2, 0, 0, 0), KU(2, 2, 128, 2, 2, 2, 0, 0, 0),
+      KRKE(2, 256, 2, 2)};
+    run_scenario(sc, vars);
+  }
+  {
+    Scenario sc{"rk3", 64 * S4B, S4B, 3, 0, 2, 2, 6};
+    std::vector<Variant> vars = {
+      KU(3, 2, 256, 1, 2, 2, 0, 0, 0), KU(3, 2, 256, 1, 2, 2, 0, 0, 1), KU(3, 2, 256, 1, 0, 0, 0, 0, 0), KU(3, 2, 256, 1, 2, 0, 0, 0, 0), KU(3, 2, 256, 1, 2, 2, 1, 0, 0), KU(3, 2, 256, 1, 2, 2, 2, 0, 0),
+      KU(3, 2, 128, 1, 2, 2, 0, 0, 0), KU(3, 2, 512, 1, 2, 2, 0, 0, 0), KU(3, 2, 256, 2, 2, 2, 0, 0, 0), KRKE(3, 256, 2, 2), KRKE(3, 512, 2, 2)};
+    run_scenario(sc, vars);
+  }
+  {
+    Scenario sc{"rk5", 64 * S4B, S4B, 5, 0, 2, 2, 5};
+    std::vector<Variant> vars = {
+      KU(5, 2, 256, 1, 2, 2, 0, 0, 0), KU(5, 2, 256, 1, 2, 2, 0, 0, 1), KU(5, 2, 256, 1, 0, 0, 0, 0, 0), KU(5, 2, 256, 1, 2, 0, 0, 0, 0), KU(5, 2, 256, 1, 2, 2, 1, 0, 0), KU(5, 2, 256, 1, 2, 2, 2, 0, 0),
+      KU(5, 2, 128, 1, 2, 2, 0, 0, 0), KU(5, 2, 512, 1, 2, 2, 0, 0, 0), KU(5, 2, 256, 2, 2, 2, 0, 0, 0), KRKE(5, 256, 2, 2), KRKE(5, 512, 2, 2)};
+    run_scenario(sc, vars);
+  }
+  {  // UniPC-3 step, Philox: 8 bf16 + fp32 state in, fp32 state + bf16 result out
+    Scenario sc{"two8n", 256 * S16, S16, 8, 1, 4, 2, 2};
+    std::vector<Variant> vars = {KM(8, 1, 0, 2, 2, 1), KM(8, 1, 1, 2, 2, 1), KM(8, 1, 2, 2, 2, 1), KM(8, 1, 0, 0, 2, 1), KM(8, 1, 0, 2, 0, 1), KM(8, 1, 0, 0, 0, 1), KM(8, 1, 2, 2, 0, 1), KM(8, 1, 2, 0, 0, 1), KM(8, 1, 2, 3, 3, 1), KM(8, 1, 2, 1, 1, 1)};
+    run_scenario(sc, vars);
+  }
+  {  // UniPC-3 with noise tensors
+    Scenario sc{"two10", 256 * S16, S16, 10, 1, 4, 2, 2};
+    std::vector<Variant> vars = {KM(10, 1, 0, 2, 2, 0), KM(10, 1, 1, 2, 2, 0), KM(10, 1, 2, 2, 2, 0), KM(10, 1, 0, 0, 2, 0), KM(10, 1, 2, 2, 0, 0), KM(10, 1, 2, 0, 0, 0)};
+    run_scenario(sc, vars);
+  }
+  {  // BASELINE config 2's own batch
+    Scenario sc{"b64", 64 * S4, S4, 4, 0, 2, 0, 16};
+    std::vector<Variant> vars = {
+      KU(4, 1, 256, 1, 2, 2, 0, 1, 0), KU(4, 1, 128, 1, 2, 2, 0, 1, 0), KU(4, 1, 64, 1, 2, 2, 0, 1, 0), KU(4, 1, 512, 1, 2, 2, 0, 1, 0), KU(4, 1, 1024, 1, 2, 2, 0, 1, 0),
+      KU(4, 1, 256, 1, 2, 2, 0, 0, 0), KU(4, 1, 128, 1, 2, 2, 0, 0, 0), KU(4, 1, 64, 1, 2, 2, 0, 0, 0), KU(4, 1, 512, 1, 2, 2, 0, 0, 0), KU(4, 1, 256, 1, 0, 0, 0, 1, 0), KU(4, 1, 128, 1, 0, 0, 0, 1, 0)};
+    run_scenario(sc, vars, 7);
+    Scenario sc3{"b64_lr3", 64 * S4, S4, 4, 0, 2, 0, 16};
+    std::vector<Variant> v3 = {KU(4, 1, 256, 1, 2, 2, 0, 1, 0), KU(4, 1, 128, 1, 2, 2, 0, 1, 0)};
+    run_scenario(sc3, v3, 3);
+    Scenario sc0{"b64_lr0", 64 * S4, S4, 4, 0, 2, 0, 16};
+    run_scenario(sc0, v3, 0);
+    Scenario sc5{"b64_lr5", 64 * S4, S4, 4, 0, 2, 0, 16};
+    run_scenario(sc5, v3, 5);
+  }
+  {  // many operands, one output
+    Scenario s10{"bigk10", 256 * S4, S4, 10, 0, 2, 0, 3};
+    std::vector<Variant> v10 = {KU(10, 1, 256, 1, 2, 2, 0, 0, 0), KU(10, 1, 128, 1, 2, 2, 0, 0, 0), KU(10, 1, 512, 1, 2, 2, 0, 0, 0), KU(10, 1, 256, 1, 2, 2, 1, 0, 0)};
+    run_scenario(s10, v10);
+    Scenario s14{"bigk14", 256 * S4, S4, 14, 0, 2, 0, 3};
+    std::vector<Variant> v14 = {KU(14, 1, 256, 1, 2, 2, 0, 0, 0), KU(14, 1, 128, 1, 2, 2, 0, 0, 0), KU(14, 1, 512, 1, 2, 2, 0, 0, 0)};
+    run_scenario(s14, v14);
+    Scenario s18{"bigk18", 256 * S4, S4, 18, 0, 2, 0, 2};
+    std::vector<Variant> v18 = {KU(18, 1, 256, 1, 2, 2, 0, 0, 0), KU(18, 1, 128, 1, 2, 2, 0, 0, 0), KU(18, 1, 512, 1, 2, 2, 0, 0, 0)};
+    run_scenario(s18, v18);
+  }
+  return 0;
+}
