@@ -358,12 +358,13 @@ static int launch_k_uv(StepArgs<float>& args, hipStream_t stream, bool& taken) {
 template <typename T, bool NOISE>
 static int launch_k(StepArgs<float>& args, hipStream_t stream, bool& taken) {
   taken = false;
-  if (args.n_terms < 1 || args.n_terms > 8 || args.numel % VEC != 0) return SKR_OK;
+  if (args.n_terms < 1 || args.n_terms > 20 || args.numel % VEC != 0) return SKR_OK;
   {
-    const int rc = launch_one_trip_k<T>(args, NOISE, stream, taken);  // whole chunks: one-trip kernel (skr_step_fast.hip)
+    const int rc = launch_one_trip_k<T>(args, NOISE, stream, taken);  // whole chunks: one-trip kernel (skr_step_fast.hip), <= 20 operands
     if (taken) return rc;
   }
   if (args.rows != nullptr) { taken = true; return SKR_ERR_UNSUPPORTED; }  // indexed launches: one-trip kernels only
+  if (args.n_terms > 8) return SKR_OK;  // (the grid-stride compile-time kernels stop at 8: ragged launches of more operands take the general kernel)
   if constexpr (NOISE) {
     return launch_k_uv<T, true, 1>(args, stream, taken);
   } else {
@@ -599,6 +600,7 @@ extern "C" int skr_set_tuning(const char* key, int32_t value) {
   else if (!strcmp(key, "rk_uv")) skr::g_tune.rk_uv = value;
   else if (!strcmp(key, "two_out")) skr::g_tune.two_out = value;
   else if (!strcmp(key, "pace")) skr::g_tune.pace = value;
+  else if (!strcmp(key, "rk_blk")) skr::g_tune.rk_blk = (value == 128 || value == 256) ? value : 0;
   else return SKR_ERR_UNSUPPORTED;
   return SKR_OK;
 }

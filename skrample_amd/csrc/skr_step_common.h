@@ -13,7 +13,7 @@ namespace skr {
 
 // tuning switches (defaults = the measured best; initialised from the environment, changed with skr_set_tuning)
 struct Tuning {
-  int one_trip, xmap, tile, rk_uv, two_out, pace;
+  int one_trip, xmap, tile, rk_uv, two_out, pace, rk_blk;
   Tuning() {
     const char* e;
     one_trip = !((e = getenv("SKR_ONE_TRIP")) && e[0] == '0');
@@ -22,6 +22,7 @@ struct Tuning {
     rk_uv = (e = getenv("SKR_RK_UV")) ? atoi(e) : 0;
     two_out = getenv("SKR_NO_TWO_OUT") == nullptr;
     pace = getenv("SKR_NO_PACE") == nullptr;
+    rk_blk = (e = getenv("SKR_RK_BLK")) ? atoi(e) : 0;  // threads per workgroup of the one-trip Runge-Kutta stage kernel: 0 = by operand count, 128, 256
   }
 };
 extern Tuning g_tune;  // defined in skr_step.hip

@@ -43,8 +43,12 @@ __device__ __forceinline__ uint32_t chunk_of(uint32_t b, int lr) {  // lr = log2
   return ((b >> g) << g) + ((b & 7u) << lr) + ((b >> 3) & ((1u << lr) - 1u));
 }
 
+// kernarg sizes: 4 / 8 / 12 / 16 / 20 operand slots (Adams-Bashforth 5-9 and UniP >= 5 give 10-18 operands: round 3)
+constexpr int one_trip_kmax(int k) { return k <= 4 ? 4 : (k <= 8 ? 8 : (k <= 12 ? 12 : (k <= 16 ? 16 : 20))); }
+constexpr int ONE_TRIP_MAX_K = 20;
+
 template <typename T, int K, bool NOISE, bool TILE, bool PACE, bool TAB>
-__global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 4 ? 4 : 8)> a) {
+__global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<one_trip_kmax(K)> a) {
   const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
   const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
   Raw<T> raw[K];
@@ -142,14 +146,37 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k1(const OneTripArgs<(K <= 
   store8<T, float, TILE>(a.out0, v, s);
 }
 
+// Kernarg of the one-trip Runge-Kutta stage kernel: as for step_kernel_k1, everything the first instructions need -- the
+// operand pointers, the chunk map, both output pointers -- leads, and stages of <= 4 operands have all of it in the first
+// 64-byte line (round 2's RkArgs kept xmap_lr in the third line, behind the coefficients: the first load of every wave
+// waited for two scalar lines instead of one; tools/tune/tune_r3.hip "lib": K=2 24.05 -> 23.1 us, K=5 38.97 -> 37.8 us).
+template <int KMAX>
+struct RkOneTripArgs {
+  const void* in[KMAX];
+  void* out0;
+  void* out1;
+  const uint64_t* seeds;
+  int32_t xmap_lr;
+  int32_t bps_shift;
+  float c1[KMAX];
+  float chain;
+  float ck[4];
+  int32_t conv_to, conv_from;
+  float zeta1;
+  uint64_t stream1;
+  RowRef tab;
+};
+
 // NOISE: the step's last stage of a stochastic tableau step adds zeta1 * N(stream1) to out1 (the derivative out0 is never noisy)
-template <typename T, int K, bool TILE, bool NOISE, bool TAB>
-__global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
+// BLK: threads per workgroup (256, or 128 = 1024-element chunks: tools/tune/tune_r3.hip measured the 5-operand stage 1-4 % faster so)
+template <typename T, int K, bool TILE, bool NOISE, bool TAB, int BLK>
+__global__ __launch_bounds__(BLK) void step_kernel_rk1(const RkOneTripArgs<(K <= 4 ? 4 : 8)> a) {
   const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
-  const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
+  const int64_t v = (int64_t)c * BLK + threadIdx.x;
   Raw<T> raw[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) raw[j] = load_raw<T, TILE>(a.in[j], v);
+  __builtin_amdgcn_sched_barrier(0);  // every load is out before the first scalar of the arithmetic is fetched
   float k[4] = {a.ck[0], a.ck[1], a.ck[2], a.ck[3]}, cf[K], chain = a.chain, zeta1 = a.zeta1;
   uint64_t stream1 = a.stream1;
 #pragma unroll
@@ -172,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_rk1(const RkArgs a) {
       uint32_t smp, within;
       sample_of(c, a.bps_shift, smp, within);
       const uint64_t seed = a.seeds[smp];
-      const uint32_t vs = within * BLOCK + threadIdx.x;
+      const uint32_t vs = within * BLK + threadIdx.x;
       normal4(seed, stream1, (uint64_t)group0<TILE>((int64_t)vs), z1);
       normal4(seed, stream1, (uint64_t)group1<TILE>((int64_t)vs), z1 + 4);
     }
@@ -236,9 +263,16 @@ static int launch_k1(const StepArgs<float>& args, int bps_shift, hipStream_t str
 #define SKR_K(N) case N: if (args.rows != nullptr) hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, true, true>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); \
                         else if (g_tune.pace) hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, true, false>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); \
                         else hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, false, false>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); break
+  // more than 8 operands: one unpaced instantiation each (plus the table form while the operands fit a device-resident row)
+#define SKR_KB(N) case N: if (args.rows != nullptr) { if constexpr (N <= SKR_ROW_TERMS) hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, false, true>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); else return SKR_ERR_UNSUPPORTED; } \
+                         else hipLaunchKernelGGL((step_kernel_k1<T, N, NOISE, TILE, false, false>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, fa); break
   if constexpr (KMAX == 4) { switch (args.n_terms) { SKR_K(1); SKR_K(2); SKR_K(3); SKR_K(4); } }
-  else { switch (args.n_terms) { SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); } }
+  else if constexpr (KMAX == 8) { switch (args.n_terms) { SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); } }
+  else if constexpr (KMAX == 12) { switch (args.n_terms) { SKR_KB(9); SKR_KB(10); SKR_KB(11); SKR_KB(12); } }
+  else if constexpr (KMAX == 16) { switch (args.n_terms) { SKR_KB(13); SKR_KB(14); SKR_KB(15); SKR_KB(16); } }
+  else { switch (args.n_terms) { SKR_KB(17); SKR_KB(18); SKR_KB(19); SKR_KB(20); } }
 #undef SKR_K
+#undef SKR_KB
   return finish_launch();
 }
 
@@ -248,26 +282,41 @@ int launch_one_trip_k(const StepArgs<float>& args, bool noise, hipStream_t strea
   taken = false;
   int bps_shift = 0;
   if (!one_trip_ok(args.numel, args.sample_numel, noise, &bps_shift, args.rows != nullptr) || (sizeof(T) == 4 && !g_tune.tile && args.rows == nullptr)) return SKR_OK;
+  if (args.n_terms > ONE_TRIP_MAX_K) return SKR_OK;
   taken = true;
-  if (noise) return args.n_terms <= 4 ? launch_k1<T, true, 4>(args, bps_shift, stream) : launch_k1<T, true, 8>(args, bps_shift, stream);
-  return args.n_terms <= 4 ? launch_k1<T, false, 4>(args, bps_shift, stream) : launch_k1<T, false, 8>(args, bps_shift, stream);
+#define SKR_GO(NOISE)                                                              \
+  switch (one_trip_kmax(args.n_terms)) {                                           \
+    case 4: return launch_k1<T, NOISE, 4>(args, bps_shift, stream);                \
+    case 8: return launch_k1<T, NOISE, 8>(args, bps_shift, stream);                \
+    case 12: return launch_k1<T, NOISE, 12>(args, bps_shift, stream);              \
+    case 16: return launch_k1<T, NOISE, 16>(args, bps_shift, stream);              \
+    default: return launch_k1<T, NOISE, 20>(args, bps_shift, stream);              \
+  }
+  if (noise) { SKR_GO(true) }
+  SKR_GO(false)
+#undef SKR_GO
 }
 template int launch_one_trip_k<bf16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
 template int launch_one_trip_k<f16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
 template int launch_one_trip_k<float>(const StepArgs<float>&, bool, hipStream_t, bool&);
 
-template <typename T, bool NOISE>
+template <typename T, bool NOISE, int KMAX, int BLK>
 static int launch_rk1(const StepArgs<float>& args, unsigned chunks, int bps_shift, hipStream_t stream) {
   constexpr bool TILE = sizeof(T) == 4;
-  RkArgs ra;
+  if constexpr (BLK == 128) {  // half-size chunks: twice as many of them, per sample too
+    chunks *= 2;
+    bps_shift = bps_shift >= 0 ? bps_shift + 1 : 2 * bps_shift;
+  }
+  RkOneTripArgs<KMAX> ra;
   ra.seeds = args.seeds; ra.zeta1 = args.zeta1; ra.stream1 = args.stream1; ra.bps_shift = bps_shift;
-  for (int k = 0; k < 8; ++k) { ra.in[k] = k < args.n_terms ? args.in[k] : nullptr; ra.c1[k] = k < args.n_terms ? args.c1[k] : 0.f; }
+  for (int k = 0; k < KMAX; ++k) { ra.in[k] = k < args.n_terms ? args.in[k] : nullptr; ra.c1[k] = k < args.n_terms ? args.c1[k] : 0.f; }
   ra.out0 = args.out0; ra.out1 = args.out1; ra.chain = args.chain;
   for (int i = 0; i < 4; ++i) ra.ck[i] = (float)args.ck[i];
-  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.numel = args.numel; ra.xmap_lr = xmap_lr_for(chunks); ra.tab = RowRef{args.rows, args.index, args.row_offset};
-#define SKR_K(N) case N: if (args.rows != nullptr) hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE, NOISE, true>), dim3(chunks), dim3(BLOCK), 0, stream, ra); \
-                        else hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE, NOISE, false>), dim3(chunks), dim3(BLOCK), 0, stream, ra); break
-  switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); }
+  ra.conv_to = args.conv_to; ra.conv_from = args.conv_from; ra.xmap_lr = xmap_lr_for(chunks); ra.tab = RowRef{args.rows, args.index, args.row_offset};
+#define SKR_K(N) case N: if (args.rows != nullptr) hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE, NOISE, true, BLK>), dim3(chunks), dim3(BLK), 0, stream, ra); \
+                        else hipLaunchKernelGGL((step_kernel_rk1<T, N, TILE, NOISE, false, BLK>), dim3(chunks), dim3(BLK), 0, stream, ra); break
+  if constexpr (KMAX == 4) { switch (args.n_terms) { SKR_K(2); SKR_K(3); SKR_K(4); } }
+  else { switch (args.n_terms) { SKR_K(5); SKR_K(6); SKR_K(7); SKR_K(8); } }
 #undef SKR_K
   return finish_launch();
 }
@@ -281,7 +330,15 @@ int launch_one_trip_rk(const StepArgs<float>& args, bool noise, hipStream_t stre
   if (noise && args.rows == nullptr && args.zeta0 != 0.f) return SKR_OK;  // (a noisy derivative does not occur; left to the general kernel)
   taken = true;
   const unsigned chunks = (unsigned)(args.numel / ((int64_t)BLOCK * VEC));
-  return noise ? launch_rk1<T, true>(args, chunks, bps_shift, stream) : launch_rk1<T, false>(args, chunks, bps_shift, stream);
+  // 128-thread workgroups for the 4-6 operand stages (tools/bench_plan.py rk, same box: K=4 33.5 vs 34.0 us, K=5 38.7 vs 39.8, K=6 43.7 vs
+  // 45.2; K=2 / 3 lose 1-2 % with them and K >= 7 is unchanged); rk_blk = 128 / 256 forces one size
+  const bool small_blocks = g_tune.rk_blk == 128 || (g_tune.rk_blk == 0 && args.n_terms >= 4 && args.n_terms <= 6);
+  if (small_blocks && chunks < 0x40000000u && bps_shift > -0x20000000) {
+    if (args.n_terms <= 4) return noise ? launch_rk1<T, true, 4, 128>(args, chunks, bps_shift, stream) : launch_rk1<T, false, 4, 128>(args, chunks, bps_shift, stream);
+    return noise ? launch_rk1<T, true, 8, 128>(args, chunks, bps_shift, stream) : launch_rk1<T, false, 8, 128>(args, chunks, bps_shift, stream);
+  }
+  if (args.n_terms <= 4) return noise ? launch_rk1<T, true, 4, 256>(args, chunks, bps_shift, stream) : launch_rk1<T, false, 4, 256>(args, chunks, bps_shift, stream);
+  return noise ? launch_rk1<T, true, 8, 256>(args, chunks, bps_shift, stream) : launch_rk1<T, false, 8, 256>(args, chunks, bps_shift, stream);
 }
 template int launch_one_trip_rk<bf16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
 template int launch_one_trip_rk<f16_t>(const StepArgs<float>&, bool, hipStream_t, bool&);
@@ -306,7 +363,7 @@ struct TwoOutArgs {
   float c1[NMAX];
   RowRef tab;
 };
-constexpr int two_out_nmax(int n) { return n <= 4 ? 4 : (n <= 8 ? 8 : 12); }
+constexpr int two_out_nmax(int n) { return n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 12 ? 12 : (n <= 16 ? 16 : (n <= 20 ? 20 : 24)))); }
 
 template <typename TA, int NA, int NB, bool NOISE, bool PACE, bool TAB>
 __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out_nmax(NA + NB)> a) {
@@ -454,6 +511,19 @@ int launch_one_trip_two(const StepArgs<float>& args, bool noise, bool group_b_f3
     return g_tune.pace ? launch_k2<TA, A, B, true, true, false>(args, bps_shift, stream) : launch_k2<TA, A, B, true, false, false>(args, bps_shift, stream); \
   }
   SKR_GO(2, 0) SKR_GO(3, 0) SKR_GO(4, 0) SKR_GO(4, 1) SKR_GO(6, 1) SKR_GO(7, 1) SKR_GO(8, 1) SKR_GO(10, 1)
+#undef SKR_GO
+  // UniPC / SPC of order 5-9 (2n+2 operands, +2 with noise tensors) and the previous state: unpaced, and the table form
+  // while the operands fit a device-resident row (tools/trace_plans.py)
+#define SKR_GO(A, B)                                                                             \
+  if (na == A && nb == B) {                                                                      \
+    if (args.rows != nullptr) {                                                                  \
+      if constexpr (A + B <= SKR_ROW_TERMS) { taken = true; return noise ? launch_k2<TA, A, B, true, false, true>(args, bps_shift, stream) : launch_k2<TA, A, B, false, false, true>(args, bps_shift, stream); } \
+      else return SKR_OK;                                                                        \
+    }                                                                                            \
+    taken = true;                                                                                \
+    return noise ? launch_k2<TA, A, B, true, false, false>(args, bps_shift, stream) : launch_k2<TA, A, B, false, false, false>(args, bps_shift, stream); \
+  }
+  SKR_GO(12, 1) SKR_GO(14, 1) SKR_GO(16, 1) SKR_GO(18, 1) SKR_GO(20, 1) SKR_GO(22, 1)
 #undef SKR_GO
   return SKR_OK;
 }

@@ -64,7 +64,7 @@ def test_cfg5_rkultra6_pyramid_vs_oracle_small(dev):
 
     def noise_fn(step=None):  # the draw the wrapper's own generator makes for this step (draw n <-> step n)
         drawn.append(1)
-        return shadow.generate(step).cpu()
+        return shadow.generate(step).float().cpu()  # the wrapper widens the drawn tensor to compute_scale (diffusers.py:343-346)
 
     g = torch.Generator().manual_seed(17)
     x = torch.randn(shape, generator=g).bfloat16()
@@ -122,7 +122,7 @@ def test_full_size_configs_with_their_noise(name, dev):
     for i in range(calls):
         xin, oin = ins[i]
         if isinstance(o, OW.RKDriver):
-            ref = o.step(oin, o.timesteps[i], xin, noise_fn=lambda step=None: shadow.generate(step).cpu())
+            ref = o.step(oin, o.timesteps[i], xin, noise_fn=lambda step=None: shadow.generate(step).float().cpu())
         else:
             ref = o.step(oin, o.timesteps[i], xin, noise=shadow.generate(Step.from_int(i, steps)).cpu())[0]
         assert_close(full[i], ref, torch.bfloat16, f"{name} call {i}", flips=0.10)
@@ -299,3 +299,95 @@ def test_two_process_shards_equal_the_single_process_run(name, dev, tmp_path):
     assert [(d["lo"], d["hi"]) for d in parts] == [(0, B // 2), (B // 2, B)]
     assert torch.equal(torch.cat([d["x"] for d in parts]), whole["x"])
     assert BatchShard(0, 2, B // 2).seeds(42) + BatchShard(1, 2, B // 2).seeds(42) == BatchShard(0, 1, B).seeds(42)
+
+
+# ---- SPC's signed-power blend: a condition-aware bound instead of pinned seeds ------------------------
+# blend(a, c) = spowf(wp * spowf(a, P) + wc * spowf(c, P), 1 / P)        reference structured.py:568-572, common.py:187-190
+# Where the two powered terms cancel, the inner sum u carries the rounding of BOTH terms, |du| <= k * eps32 * (|t1| + |t2|), and
+# the outer power turns it into |d blend| ~ (1/P) |u|^(1/P - 1) |du|: an absolute error that does not scale with the result.  A
+# float32 evaluation -- the oracle's torch.pow as much as the kernel's exp2 / log2 -- cannot do better, so the parity bar for this
+# one non-linear op is stated elementwise:
+#     |hip - exact| <= 1e-5 * max|exact| + K * eps32 * (|wp| |a|^P + |wc| |c|^P)^(1/P)
+# (for P < 1 the bracket majorises (1/P) |u|^(1/P-1) (|t1|+|t2|); for P > 1 the cancelled region is where the reference itself
+# loses its digits and the bound is checked against the float64 value).
+def _spow(v, f):
+    return v.abs().pow(f) * torch.where(v < 0, -1.0, 1.0).to(v.dtype)
+
+
+@pytest.mark.parametrize("power", [0.5, 2.0, 3.0, 1.0 / 3.0, 0.75])
+def test_power_blend_error_model(power, dev):
+    from skrample_amd.sampling import lazy
+
+    eps32, K = 2.0**-23, 64.0
+    worst = 0.0
+    for seed in range(24):
+        g = torch.Generator().manual_seed(7000 + seed)
+        n = 4096
+        a = torch.randn(n, generator=g)
+        c = torch.randn(n, generator=g)
+        wp, wc = (0.35, 0.65) if seed % 3 else (1.7, -0.7)  # (a negative weight: cancellation between same-signed operands)
+        if seed % 2:  # constructed cancellation: the two powered terms nearly annihilate in a quarter of the elements
+            t = (abs(wp) * a[: n // 4].abs().pow(power) / abs(wc)).pow(1.0 / power) * (1 + 1e-4 * torch.randn(n // 4, generator=g))
+            c[: n // 4] = t * torch.where((a[: n // 4] < 0) ^ (wp * wc > 0), 1.0, -1.0)
+        got = lazy.power_blend(a.to(dev), c.to(dev), wp, wc, power, torch.float32).cpu().double()
+        a64, c64 = a.double(), c.double()
+        exact = _spow(wp * _spow(a64, power) + wc * _spow(c64, power), 1.0 / power)
+        scale = (abs(wp) * a64.abs().pow(power) + abs(wc) * c64.abs().pow(power)).pow(1.0 / power)
+        bound = 1e-5 * exact.abs().max() + K * eps32 * scale
+        if power > 1:  # sqrt-like outer power: |d blend| = |du| / (P |u|^(1 - 1/P)) is unbounded at u = 0; bound it through u
+            u = wp * _spow(a64, power) + wc * _spow(c64, power)
+            du = K * eps32 * (abs(wp) * a64.abs().pow(power) + abs(wc) * c64.abs().pow(power))
+            bound = 1e-5 * exact.abs().max() + torch.maximum(_spow(u.abs() + du, 1.0 / power) - _spow((u.abs() - du).clamp_min(0), 1.0 / power), K * eps32 * scale)
+        err = (got - exact).abs()
+        assert (err <= bound).all(), (power, seed, (err / bound).max().item())
+        worst = max(worst, (err / bound).max().item())
+        # the oracle's own float32 evaluation sits under the same bound
+        ref32 = _spow(wp * _spow(a, power) + wc * _spow(c, power), 1.0 / power).double()
+        assert ((ref32 - exact).abs() <= bound).all()
+    assert worst < 1.0
+
+
+SPC_POWER = {
+    "spc_power_half_dpm": (lambda: OA.make("spc", power=0.5, predictor=OA.make("dpm", 2, eta=0.5), corrector=OA.make("adams", 2)), lambda: PT.SPC(power=0.5, predictor=PT.DPM(order=2, stochasticity=0.5), corrector=PT.Adams(order=2))),
+    "spc_power2": (lambda: OA.make("spc", power=2), lambda: PT.SPC(power=2)),
+    "spc_power3_bias": (lambda: OA.make("spc", power=3, bias=0.2), lambda: PT.SPC(power=3, bias=0.2)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SPC_POWER))
+def test_spc_power_seed_sweep_vs_oracle(name, dev):
+    """The seed sweep the round-2 suite stopped drawing (a process-dependent `hash()` seed once produced 1.14e-5 against the 1e-5
+    bar for `spc_power_half_dpm/scaled/data step 7`; that input is not recoverable, so 40 seeds x 4 schedule/model pairs x 9
+    steps are drawn here instead).  Yardstick: the reference's arithmetic itself, evaluated in float64 -- the engine must be
+    within the float32 bar of it, widened only by what the reference's OWN float32 evaluation loses to the blend's cancellation
+    on the same input (its distance from its float64 self)."""
+    from cases import MODELS, SCHEDULES, oracle_schedule
+    from test_step_gpu import Injected
+
+    mk_o, mk_p = SPC_POWER[name]
+    steps, shape = 9, (3, 4, 24, 20)
+    over_plain_bar = 0
+    for seed in range(40):
+        for sname, mname in (("karras_scaled", "eps"), ("linear", "flow"), ("zsnr", "v"), ("scaled", "data")):
+            g = torch.Generator().manual_seed(100003 * seed + len(sname) * 31 + len(mname))
+            w = PD.SkrampleWrapperScheduler(mk_p(), SCHEDULES[sname][1](), MODELS[mname][1])
+            o32 = OW.StepDriver(mk_o(), oracle_schedule(sname, steps), MODELS[mname][0])
+            o64 = OW.StepDriver(mk_o(), oracle_schedule(sname, steps), MODELS[mname][0], compute=torch.float64)
+            for d in (w, o32, o64):
+                d.set_timesteps(steps)
+            noises = [torch.randn(shape, generator=g) for _ in range(steps)]
+            w._noise_generator = Injected(noises, dev)
+            x = torch.randn(shape, generator=g)
+            for i, t in enumerate(w.timesteps):
+                out = torch.randn(shape, generator=g)
+                got = w.step(out.to(dev), t, x.to(dev), return_dict=False)[0].cpu().double()
+                r32 = o32.step(out, t, x, noise=noises[i])[0]
+                r64 = o64.step(out.double(), t, x.double(), noise=noises[i].double())[0]
+                top = r64.abs().max().item()
+                own = (r32.double() - r64).abs().max().item()  # what float32 costs the reference on this input
+                err = (got - r64).abs().max().item()
+                assert err <= 1e-5 * top + 4.0 * own, (name, seed, sname, mname, i, err / top, own / top)
+                over_plain_bar += (got - r32.double()).abs().max().item() > 1e-5 * top
+                x = r32
+    # informational guard: excursions over the plain 1e-5 bar stay rare (they are the cancellation cases the model explains)
+    assert over_plain_bar <= 8, over_plain_bar

@@ -532,7 +532,12 @@ def test_tile_layout_agrees_bitwise(dtypes, n_terms, two_outputs, dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
-@pytest.mark.parametrize(("n_terms", "noise", "rk"), [(1, False, False), (4, True, False), (4, False, False), (8, True, False), (2, False, True), (5, False, True), (8, False, True), (3, True, True), (6, True, True)])
+@pytest.mark.parametrize(
+    ("n_terms", "noise", "rk"),
+    [(1, False, False), (4, True, False), (4, False, False), (8, True, False), (2, False, True), (5, False, True), (8, False, True), (3, True, True), (6, True, True)]
+    # round 3: compile-time kernels up to 20 operands (Adams-Bashforth 5-9: 10-18 operands; the `one_trip` switch sends these to the general kernel)
+    + [(9, False, False), (10, False, False), (12, True, False), (13, False, False), (14, False, False), (16, True, False), (17, False, False), (18, False, False), (20, True, False)],
+)
 @pytest.mark.parametrize("chunks_per_sample", [64, 18])
 def test_one_trip_kernels_agree_bitwise(dtype, n_terms, noise, rk, chunks_per_sample, dev):
     """launches made of whole 2048-element chunks take the one-trip loads-first kernels (XCD-aware chunk map, 1-D grid);
@@ -581,7 +586,11 @@ def test_one_trip_kernels_agree_bitwise(dtype, n_terms, noise, rk, chunks_per_sa
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize(("n_a", "n_b", "noise"), [(2, 0, True), (3, 0, False), (4, 0, True), (4, 1, True), (6, 1, False), (7, 1, False), (8, 1, True), (10, 1, False), (8, 1, False)])
+@pytest.mark.parametrize(
+    ("n_a", "n_b", "noise"),
+    [(2, 0, True), (3, 0, False), (4, 0, True), (4, 1, True), (6, 1, False), (7, 1, False), (8, 1, True), (10, 1, False), (8, 1, False)]
+    + [(12, 1, True), (14, 1, False), (16, 1, True), (18, 1, False), (20, 1, True), (22, 1, False)],  # round 3: UniPC / SPC of order 5-9
+)
 def test_two_output_kernels_agree_bitwise(dtype, n_a, n_b, noise, dev):
     """UniPC / SPC steps (fp32 state out0 + 16-bit out1, 16-bit operands + at most one fp32 state) take a compile-time
     one-trip kernel when the launch is made of whole chunks; it must give the bits of the general runtime-term-list kernel,

@@ -88,11 +88,18 @@ if __name__ == "__main__":
             bench(f"K={k} bf16 -> bf16", 256, S4, k, 0, False, False, switches=[OLD, NEW, {"pace": 0}])
         for k in (2, 4, 6):
             bench(f"K={k} bf16 -> bf16 + philox", 256, S4, k, 0, False, True, switches=[OLD, NEW, {"pace": 0}])
+    if which in ("all", "bigk"):  # round 3: Adams-Bashforth 5-9 / UniP >= 5 (10-18 operands), UniPC / SPC of order 5-9
+        for k in (10, 14, 18, 20):
+            bench(f"K={k} bf16 -> bf16", 256, S4, k, 0, False, False, switches=[OLD, NEW])
+        bench("K=12 bf16 -> bf16 + philox", 256, S4, 12, 0, False, True, switches=[OLD, NEW])
+        for na in (12, 16, 20):
+            bench(f"two-out NA={na} NB=1", 256, S4, na, 1, True, False, switches=[OLD, NEW])
+        bench("two-out NA=14 NB=1 philox", 256, S4, 14, 1, True, True, switches=[OLD, NEW])
     if which in ("all", "two"):
         for na, nb, noise in ((8, 1, True), (8, 1, False), (10, 1, False), (6, 1, True), (4, 1, True), (4, 0, False)):
             bench(f"two-out NA={na} NB={nb} {'philox' if noise else ''}", 256, S16, na, nb, True, noise, switches=[OLD, NEW, {"pace": 0}])
     if which in ("all", "rk"):
-        for k in (2, 3, 5, 7):
+        for k in (2, 3, 4, 5, 6, 7, 8):
             bench(f"rk stage K={k}", 64, 4 * 256 * 256, k, 0, False, False, rk=True, switches=[OLD, NEW])
     if which in ("all", "f32"):
         for k in (2, 4):
