@@ -60,7 +60,9 @@ def make_wrapper():
     import skrample_amd.scheduling as PS
     from skrample_amd.sampling import structured as PT
 
-    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))
+    # alias_history=True: the synthetic "network" hands over fresh tensors, which the default ("auto") would find out by its second
+    # call -- stated here so that the traced plans name the caller's own tensors from the first step on (capture_plans maps pointers)
+    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), alias_history=True)
     w.set_timesteps(SCHEDULE_STEPS)
     return w
 
@@ -237,7 +239,9 @@ def graph_loop_rate(dev: torch.device) -> dict | None:
             return outs[calls[0] % len(outs)]
 
         seeds = list(range(42, 42 + batch))
-        mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))  # noqa: E731
+        # (alias_history=True: `net` rotates distinct buffers, so no snapshot kernels are recorded into the loop; the default "auto"
+        #  would snapshot the first call of every run -- two copy kernels per replay)
+        mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), alias_history=True)  # noqa: E731
         w = mk()
 
         def eager():

@@ -46,7 +46,25 @@ struct ColoredArgs {
   float exponent_half_neg;   // -exponent / 2
   float eps_clip;
   float inv_rmax;
+#ifdef SKR_COLORED_TRACE
+  uint64_t* trace;           // tools/tune/tune_colored.hip only: [block][16] phase stamps of the plane kernels (s_memrealtime, 10 ns)
+#endif
 };
+
+// Phase stamps for the timeline harness (tools/tune/tune_colored.hip); compiled out of the library.
+#ifdef SKR_COLORED_TRACE
+uint64_t* g_colored_trace = nullptr;
+#define SKR_STAMP(i)                                                                                          \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && a.trace) {                                                                        \
+      uint64_t* t_ = a.trace + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;                           \
+      t_[(MODE == 1 ? 6 : 0) + (i)] = __builtin_amdgcn_s_memrealtime();                                       \
+      if ((i) == 0) { t_[MODE == 1 ? 14 : 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t_[MODE == 1 ? 15 : 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } \
+    }                                                                                                         \
+  } while (0)
+#else
+#define SKR_STAMP(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
@@ -286,10 +304,18 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
   const int64_t smp = blockIdx.y;
   const int i1 = blockIdx.x;
   const uint32_t magic_wh = (uint32_t)((0x100000000ull + (uint32_t)WH - 1) / (uint32_t)WH);  // q / WH == umulhi(q, magic) for q < 2^16
+  SKR_STAMP(0);
   make_twiddles(tw_w, W);
   make_twiddles(tw_h, H);
   float2* plane = a.spec + ((smp * a.d1 + i1) * (int64_t)H) * WH;
   double s1 = 0.0, s2 = 0.0;
+  double fa[4] = {0.0, 0.0, 0.0, 0.0};  // MODE 1, first wave: this lane's share of the sample's partial sums (white s1 s2, coloured s1 s2)
+  if (MODE == 1 && threadIdx.x < 64) {
+    const double* pw = a.partials + (0 * a.batch + smp) * a.n_slots * 2;
+    for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += pw[2 * sl]; fa[1] += pw[2 * sl + 1]; }
+    const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
+    for (int sl = threadIdx.x; sl < a.n_slots_c; sl += 64) { fa[2] += pc[2 * sl]; fa[3] += pc[2 * sl + 1]; }
+  }
 
   if (MODE != 1) {
     const uint64_t seed = a.seeds[smp];
@@ -308,7 +334,9 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       }
       s1 += (double)p1; s2 += (double)p2;
     }
+    SKR_STAMP(1);
     fft_tile<false>(t1, tw_w, W, logW, pairs);
+    SKR_STAMP(2);
     {
       // untangle the row pairs into the column tile (bit-reversed along H for the column transform)
       float2 ra[PLANE_ITEMS], rb[PLANE_ITEMS];
@@ -335,12 +363,14 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       }
     }
     fft_tile<false>(t2, tw_h, H, logH, WH);
+    SKR_STAMP(3);
     if (MODE == 0) block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
     if (MODE == 0) {
       for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
         const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
         plane[q] = t2[k * ldh + row];
       }
+      SKR_STAMP(4);
       return;
     }
     // MODE 2: weights in place (+ the Parseval sums of the weighted spectrum), then bit-reverse the columns for the inverse
@@ -389,9 +419,11 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
         }
       }
     }
+    SKR_STAMP(1);
   }
 
   fft_tile<true>(t2, tw_h, H, logH, WH);
+  SKR_STAMP(2);
   {
     // pack row pairs (Hermitian expansion along W), bit-reversed along W
     float2 rz[PLANE_ITEMS];
@@ -418,17 +450,30 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
     }
   }
   fft_tile<true>(t1, tw_w, W, logW, pairs);
+  SKR_STAMP(3);
   const float scale = 1.0f / ((float)a.d1 * (float)H * (float)W);
   float factor;
   if (MODE == 2) factor = (float)s1;
   else {
-    double w1 = 0, w2 = 0, c1 = 0, c2 = 0;  // every block sums the sample's partials itself (a few dozen doubles, fixed order)
-    for (int sl = 0; sl < a.n_slots; ++sl) { const double* pw = a.partials + ((0 * a.batch + smp) * a.n_slots + sl) * 2; w1 += pw[0]; w2 += pw[1]; }
-    const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
-    for (int sl = 0; sl < a.n_slots_c; ++sl) { c1 += pc[2 * sl]; c2 += pc[2 * sl + 1]; }
-    const double n = (double)a.d1 * (double)H * (double)W;
-    factor = rescale_factor(w1, w2, c1, c2 / n, n, a.has_energy, a.energy);
+    // the sample's rescale factor from the partial sums (white: one slot per plane, coloured: one per block of the outer-axis
+    // kernel).  Their loads were issued by the first wave when the block started (fa[]: lane l holds slots l, l + 64, ... summed in
+    // that order), so they arrived long ago; here a fixed-order shuffle tree finishes the four sums and one LDS word hands the
+    // factor to the block.  (Round 2 had EVERY thread walk all slots in a rolled loop of dependent loads at this point: 5.5 us of
+    // each block's 24 us -- tools/tune/tune_colored.hip.)
+    __shared__ float factor_sh;
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
+      if (threadIdx.x == 0) {
+        const double n = (double)a.d1 * (double)H * (double)W;
+        factor_sh = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
+      }
+    }
+    __syncthreads();
+    factor = factor_sh;
   }
+  SKR_STAMP(4);
   T* dst = reinterpret_cast<T*>(a.out) + ((smp * a.d1 + i1) * (int64_t)H) * W;
   // 4 consecutive values of one row per item: one 8-byte (16-bit T) or 16-byte (fp32) store
   for (int q = threadIdx.x; q < pairs * (W / 4); q += PLANE_THREADS) {
@@ -444,6 +489,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       db[0] = (T)(z0.y * scale * factor); db[1] = (T)(z1.y * scale * factor); db[2] = (T)(z2.y * scale * factor); db[3] = (T)(z3.y * scale * factor);
     }
   }
+  SKR_STAMP(5);
 }
 
 // ---- pass B / C / D: a strided axis of length N; lines start at consecutive complex positions --------------------
@@ -643,6 +689,9 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   a.stream = stream_id; a.batch = batch; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
   a.exponent_half_neg = (float)(-exponent / 2.0);
   a.out = out; a.has_energy = has_energy; a.energy = energy; a.n_slots_c = 0;
+#ifdef SKR_COLORED_TRACE
+  a.trace = g_colored_trace;
+#endif
   const int nd = d1 > 1 ? 3 : 2;
   const double n_eff = nd == 3 ? ((double)d1 + d2 + d3) / 3.0 : ((double)d2 + d3) / 2.0;
   a.eps_clip = (float)(0.5 / (n_eff > 4.0 ? n_eff : 4.0));

@@ -152,6 +152,34 @@ def test_step_fixtures(name):
         x = prev
 
 
+HIGH_ORDER_CASES = {  # tests/golden/steps_extra3.npz (round 3): Adams-Bashforth up to 9, UniP / UniPC beyond 3
+    "unipc6_sde_eps": (lambda n: OW.StepDriver(OA.make("unipc", 6, eta=1), OS.scaled(), "eps"), torch.bfloat16),
+    "adams9_eps_karras": (lambda n: OW.StepDriver(OA.make("adams", 9), OS.karras(OS.scaled(), steps=n), "eps"), torch.bfloat16),
+    "adams6_v_zsnr": (lambda n: OW.StepDriver(OA.make("adams", 6), OS.zsnr(), "v"), torch.bfloat16),
+    "unip7_flow": (lambda n: OW.StepDriver(OA.make("unip", 7), OS.linear(), "flow"), torch.float32),
+    "unipc9_flow": (lambda n: OW.StepDriver(OA.make("unipc", 9), OS.linear(), "flow"), torch.bfloat16),
+}
+
+
+@pytest.mark.parametrize("name", HIGH_ORDER_CASES)
+def test_high_order_step_fixtures(name):
+    "oracle == reference SkrampleWrapperScheduler.step, bit for bit, for the high orders north_star names (12-step runs)"
+    blob = load_npz("steps_extra3.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
+    mk, dt = HIGH_ORDER_CASES[name]
+    n = len(fx["timesteps"])
+    drv = mk(n)
+    drv.set_timesteps(n)
+    assert np.array_equal(drv.timesteps.numpy(), fx["timesteps"])
+    x = from_bits(fx["x0"], dt)
+    for i in range(n):
+        noise = torch.from_numpy(fx["noises"][i]) if fx["noises"].size else None
+        prev, pred = drv.step(from_bits(fx["outs"][i], dt), drv.timesteps[i], x, noise=noise)
+        assert torch.equal(prev, from_bits(fx["prev"][i], dt)), (name, i)
+        assert torch.equal(pred, from_bits(fx["pred"][i], dt)), (name, i)
+        x = prev
+
+
 def test_pyramid_dims_fixtures():
     """Pyramid over other `dims` subsets (reference noise.py:146-193): the oracle reproduces what the reference returned for the
     axis pairs it accepts; the single non-trailing axes it rejects (RuntimeError inside its own permute) are recorded as such"""

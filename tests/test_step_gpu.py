@@ -117,6 +117,16 @@ EXTRA2_WRAPPERS = {
 }
 
 
+# round 3 (tests/golden/steps_extra3.npz): the high orders, on one 2048-element sample -> the compile-time kernels of 10-22 operands
+EXTRA3_WRAPPERS = {
+    "unipc6_sde_eps": (lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=6, stochasticity=1), PS.Scaled()), torch.bfloat16),
+    "adams9_eps_karras": (lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=9), PS.Karras(PS.Scaled())), torch.bfloat16),
+    "adams6_v_zsnr": (lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=6), PS.ZSNR(), PM.VelocityModel()), torch.bfloat16),
+    "unip7_flow": (lambda: PD.SkrampleWrapperScheduler(PT.UniP(order=7), PS.Linear(), PM.FlowModel()), torch.float32),
+    "unipc9_flow": (lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=9), PS.Linear(), PM.FlowModel()), torch.bfloat16),
+}
+
+
 def replay_fixture(w, fx, dtype, dev, name):
     "teacher-forced replay: every step sees exactly the inputs the reference saw"
     n_calls = len(fx["timesteps"])
@@ -156,6 +166,26 @@ def test_extra2_fixtures(name, dev):
     fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
     mk, dt = EXTRA2_WRAPPERS[name]
     replay_fixture(mk(), fx, dt, dev, name)
+
+
+@pytest.mark.parametrize("name", EXTRA3_WRAPPERS)
+def test_high_order_fixtures(name, dev):
+    """Adams-Bashforth 6 / 9, UniP 7, UniPC 6 / 9 (north_star: "Adams-IPNDM 1-9"): outputs of the reference's own step() replayed
+    through the wrapper; the launches are traced to make sure the late steps really take the compile-time one-trip kernels'
+    operand counts (> 8 operands in one launch)."""
+    blob = load_npz("steps_extra3.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
+    mk, dt = EXTRA3_WRAPPERS[name]
+    w = mk()
+    w.set_timesteps(len(fx["timesteps"]))
+    _hip.trace = []
+    try:
+        # (tracing here only records; the wrapper's own program tracing is skipped while a trace list is installed)
+        replay_fixture(w, fx, dt, dev, name)
+        widest = max(plan.n_terms for plan, *_ in _hip.trace)
+    finally:
+        _hip.trace = None
+    assert widest > 8, widest
 
 
 # ---- every sampler x model on the GPU vs the oracle (fp32 in/out, injected noise) ---------------------------

@@ -7,6 +7,14 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from skrample_amd import _hip
+from skrample_amd.sampling.lazy import empty_output
+
+# Where the buffers sit.  "engine" (default): tensors the ENGINE allocates in a real run -- every output, and the inputs that are
+# earlier engine results (samples, stored derivatives, the fp32 state: even operand slots here) -- come from its output allocator
+# (lazy.empty_output: start shifted by 4 KiB + k * 8 KiB inside the allocation); network outputs (odd slots) come straight from
+# torch.  "torch": everything straight from torch's allocator -- same-sized tensors then sit exact multiples of their size apart
+# (32 MiB for the RK shard), the worst case for the HBM channel map (round 2's numbers were taken this way).
+PLACEMENT = os.environ.get("SKR_BENCH_PLACEMENT", "engine")
 
 dev = torch.device("cuda:0")
 lib = _hip.load()
@@ -20,10 +28,16 @@ def bench(name, batch, sample, n_a, n_b, two_out, noise, rk=False, dtype=torch.b
     nsets = max(2, min(8, int(footprint // per_set) + 1))
     g = torch.Generator(device=dev).manual_seed(1)
     sets = []
+    def alloc(dt, engine_owned, fill=True):
+        t = empty_output((n,), dt, dev) if (engine_owned and PLACEMENT == "engine") else torch.empty(n, device=dev, dtype=dt)
+        if fill:
+            t.copy_(torch.randn(n, device=dev, generator=g))
+        return t
+
     for _ in range(nsets):
-        ins = [torch.randn(n, device=dev, generator=g).to(dtype) for _ in range(n_a)] + [torch.randn(n, device=dev, generator=g) for _ in range(n_b)]
-        o0 = torch.empty(n, device=dev, dtype=torch.float32 if two_out else dtype)
-        o1 = torch.empty(n, device=dev, dtype=dtype) if (two_out or rk) else None
+        ins = [alloc(dtype, k % 2 == 0) for k in range(n_a)] + [alloc(torch.float32, True) for _ in range(n_b)]
+        o0 = alloc(torch.float32 if two_out else dtype, True, fill=False)
+        o1 = alloc(dtype, True, fill=False) if (two_out or rk) else None
         sets.append((ins, o0, o1))
     seeds = torch.arange(batch, dtype=torch.int64, device=dev) + 42
     code = _hip.DTYPE_CODE[dtype]

@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("SKR_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")
 sys.path.insert(0, HERE)
 
 import ref_loader  # noqa: E402
@@ -261,6 +261,22 @@ def steps() -> None:
         for k, v in rec.items():
             blob[f"{name}/{k}"] = v
     np.savez_compressed(os.path.join(OUT, "steps_extra2.npz"), **blob)
+
+    # round 3: the high orders north_star names (Adams-Bashforth up to 9, UniPC / UniP beyond 3), on ONE 2048-element sample so
+    # that the replay takes the compile-time one-trip kernels (whole 2048-element chunks) -- 10 to 22 operands per launch
+    extra3 = {
+        "unipc6_sde_eps": (lambda: RD.SkrampleWrapperScheduler(structured.UniPC(order=6, stochasticity=1), RS.Scaled()), bf16),
+        "adams9_eps_karras": (lambda: RD.SkrampleWrapperScheduler(structured.Adams(order=9), RS.Karras(RS.Scaled())), bf16),
+        "adams6_v_zsnr": (lambda: RD.SkrampleWrapperScheduler(structured.Adams(order=6), RS.ZSNR(), models.VelocityModel()), bf16),
+        "unip7_flow": (lambda: RD.SkrampleWrapperScheduler(structured.UniP(order=7), RS.Linear(), models.FlowModel()), f32),
+        "unipc9_flow": (lambda: RD.SkrampleWrapperScheduler(structured.UniPC(order=9), RS.Linear(), models.FlowModel()), bf16),
+    }
+    blob = {}
+    for i, (name, (mk, dt)) in enumerate(extra3.items()):
+        rec = run_wrapper(mk(), 1, (4, 16, 32), 12, dt, seed=4000 + i)
+        for k, v in rec.items():
+            blob[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "steps_extra3.npz"), **blob)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ for d in dirs:
             if needle in r["Kernel_Name"]:
                 counters[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-        if "pmc" in d or "fetch" in d or "write" in d or "sq" in d or "tcc" in d:
+        if not os.path.basename(os.path.normpath(d)).endswith("_trace"):
             continue  # durations only from the plain trace pass (counter passes serialise and slow the kernels)
         for r in csv.DictReader(open(path)):
             if needle in r["Kernel_Name"]:

@@ -13,6 +13,10 @@ import json
 import statistics
 import sys
 
+import os
+
+RAW = os.environ.get("SKR_PROF_RAW", "gpurun_out")   # where the rocprofv3 pass directories (prof_trace, prof_fetch, ...) are
+OUT = os.environ.get("SKR_PROF_OUT", "profiles")     # where the summaries go
 round_tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 needle = sys.argv[2] if len(sys.argv) > 2 else "step_kernel_k1<skr::bf16_t, 4, true, false, true, false>"  # headline: K=4 bf16 + Philox, one-trip paced kernel, kernarg scalars
 HEADLINE_GRID = 256 * 4 * 128 * 128 // 8  # threads of a B=256 launch: bench.py's extra graph-loop key runs the same kernel at B=64
@@ -27,19 +31,19 @@ def counter(path: str, name: str) -> list[float]:
 import collections
 
 groups: dict = collections.defaultdict(list)
-for r in csv.DictReader(open("gpurun_out/prof_trace/prof_kernel_trace.csv")):
+for r in csv.DictReader(open(f"{RAW}/prof_trace/prof_kernel_trace.csv")):
     wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
     grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
     groups[(r["Kernel_Name"], grid // wg, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 total = sum(sum(v) for v in groups.values())
-with open(f"profiles/{round_tag}_kernel_stats.csv", "w", newline="") as fh:
+with open(f"{OUT}/{round_tag}_kernel_stats.csv", "w", newline="") as fh:
     wr = csv.writer(fh)
     wr.writerow(["Name", "Workgroups", "WorkgroupSize", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for (name, wgs, wg), d in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         wr.writerow([name[:160], wgs, wg, len(d), sum(d), f"{statistics.mean(d):.3f}", f"{100 * sum(d) / total:.2f}", min(d), max(d), f"{statistics.pstdev(d):.3f}"])
 
-fetch = counter("gpurun_out/prof_fetch/prof_counter_collection.csv", "FETCH_SIZE")
-write = counter("gpurun_out/prof_write/prof_counter_collection.csv", "WRITE_SIZE")
+fetch = counter(f"{RAW}/prof_fetch/prof_counter_collection.csv", "FETCH_SIZE")
+write = counter(f"{RAW}/prof_write/prof_counter_collection.csv", "WRITE_SIZE")
 # steady-state launches only (the first, order-1 step of every schedule reads no history)
 fetch = [v for v in fetch if v > 0.75 * max(fetch)]
 out = {
@@ -54,7 +58,7 @@ out = {
     "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B on wide coalesced streams), WRITE_SIZE x1, KiB -> bytes",
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline (one counter per pass; B=256 launches only)",
 }
-json.dump(out, open(f"profiles/{round_tag}_pmc_traffic.json", "w"), indent=1)
+json.dump(out, open(f"{OUT}/{round_tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 
 
@@ -63,7 +67,7 @@ import glob
 import os
 
 sq = {}
-for path in sorted(glob.glob("gpurun_out/prof_sq*/prof_counter_collection.csv")) + sorted(glob.glob("gpurun_out/prof_misc/prof_counter_collection.csv")):
+for path in sorted(glob.glob(f"{RAW}/prof_sq*/prof_counter_collection.csv")) + sorted(glob.glob(f"{RAW}/prof_misc/prof_counter_collection.csv")):
     acc: dict[str, list[float]] = {}
     for r in csv.DictReader(open(path)):
         if needle in r["Kernel_Name"] and int(r["Grid_Size"]) == HEADLINE_GRID:
@@ -90,5 +94,5 @@ if sq:
         derived["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     json.dump({"kernel": needle, "counters": sq, "derived": derived,
                "note": "SQ_* cycle counters are in quad-cycles summed over waves (guides/MI355X_MICROARCH.md); WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES"},
-              open(f"profiles/{round_tag}_sq_counters.json", "w"), indent=1)
+              open(f"{OUT}/{round_tag}_sq_counters.json", "w"), indent=1)
     print(json.dumps(derived, indent=1))
