@@ -70,6 +70,46 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 
 __device__ __forceinline__ unsigned brev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
 
+// ---- small transforms in registers (natural order in and out): the short outer axis, and the first LDS pass of fft_tile ----
+template <bool INV> __device__ __forceinline__ float2 mul_i(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <bool INV> __device__ __forceinline__ void dft4(float2& v0, float2& v1, float2& v2, float2& v3) {
+  const float2 a = cadd(v0, v2), b = csub(v0, v2), c = cadd(v1, v3), d = mul_i<INV>(csub(v1, v3));
+  v0 = cadd(a, c); v2 = csub(a, c); v1 = cadd(b, d); v3 = csub(b, d);
+}
+template <bool INV> __device__ __forceinline__ float2 rot8(float2 a) {  // a * exp(-+ i pi/4)
+  constexpr float r = 0.70710678118654752440f;
+  return INV ? make_float2(r * (a.x - a.y), r * (a.x + a.y)) : make_float2(r * (a.x + a.y), r * (a.y - a.x));
+}
+template <bool INV> __device__ __forceinline__ void dft8(float2 v[8]) {
+  float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  dft4<INV>(e0, e1, e2, e3);
+  dft4<INV>(o0, o1, o2, o3);
+  o1 = rot8<INV>(o1); o2 = mul_i<INV>(o2); o3 = mul_i<INV>(rot8<INV>(o3));
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0); v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2); v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+template <bool INV> __device__ __forceinline__ void dft16(float2 v[16]) {
+  float2 e[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+  dft8<INV>(e);
+  dft8<INV>(o);
+  constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+  const float sg = INV ? 1.f : -1.f;
+  const float2 w[8] = {{1.f, 0.f}, {c1, sg * s1}, {h, sg * h}, {s1, sg * c1}, {0.f, sg}, {-s1, sg * c1}, {-h, sg * h}, {-c1, sg * s1}};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const float2 t = cmul(o[k], w[k]); v[k] = cadd(e[k], t); v[k + 8] = csub(e[k], t); }
+}
+template <int N, bool INV> __device__ __forceinline__ void dft_n(float2 v[N]) {
+  if constexpr (N == 16) dft16<INV>(v);
+  else if constexpr (N == 8) dft8<INV>(v);
+  else if constexpr (N == 4) dft4<INV>(v[0], v[1], v[2], v[3]);
+  else { const float2 t = v[0]; v[0] = cadd(t, v[1]); v[1] = csub(t, v[1]); }
+}
+
 // In-place DIT over L lines of N points held in `buf` (line-major, stride N+1), input already in bit-reversed
 // order.  `tw` holds exp(-2 pi i k / N), k < N/2; INVERSE conjugates it.  Two radix-2 stages are fused per LDS
 // round trip (each work item carries 4 points through stages s and s+1 in registers), with one plain radix-2
@@ -81,8 +121,13 @@ __device__ __forceinline__ float2 twid(const float2* tw, int idx) {
   return w;
 }
 
-template <bool INVERSE>
-__device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, int logN, int L) {
+// SKIP8: the caller has already applied stages 0-2 (it produced the tile through 8-point transforms in registers: the plane
+// kernels fuse the transposing steps between row and column tiles with the first pass of the transform that follows)
+// TO_GLOBAL: the LAST pass sends its (natural-order) results to global memory instead of back to the tile -- element n of
+// line l goes to gout[n * gpitch + l] (the forward plane kernel's half spectrum: lines are frequency columns, so with
+// consecutive lanes on consecutive lines every store instruction covers a run of a spectrum row); the tile is dead afterwards.
+template <bool INVERSE, bool SKIP8 = false, bool TO_GLOBAL = false>
+__device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, int logN, int L, float2* gout = nullptr, int gpitch = 0) {
   const int half_n = N >> 1, ld = N + 1;
   // Work-item -> (line, k) mapping.  Early stages (butterfly span h < 32) touch points 4h apart, which lands
   // consecutive k on the same LDS banks; there consecutive lanes take consecutive LINES instead (line stride
@@ -91,7 +136,29 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
   const bool by_line = L >= 32;
   const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
   int s = 0;
-  if (logN & 1) {  // leftover radix-2 stage first (half = 1, twiddle = 1)
+  if constexpr (SKIP8) {
+    s = 3;
+  } else if ((logN & 1) && logN >= 3) {
+    // odd log2 N (128-point lines: every BASELINE shape): stages 0-2 in ONE LDS round trip -- each item takes 8 consecutive
+    // points (they hold an 8-point subsequence in 3-bit-reversed order), transforms them in registers and puts them back.
+    // Round 2 spent two round trips on these stages (a bare radix-2 pass, 23 instructions per butterfly, then a radix-2^2 pass):
+    // 432 instructions per thread and transform against ~150 here, and one barrier + one full LDS write of the tile fewer.
+    // Consecutive lanes take consecutive LINES (pitch N+1 complex = 2 banks mod 64: 8-byte accesses of 32 lanes tile all banks).
+    __syncthreads();
+    const int groups = N >> 3, total = L * groups;
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+      int line, g;
+      if (by_line) { g = (int)__umulhi((uint32_t)t, magic); line = t - g * L; }
+      else { line = t >> (logN - 3); g = t & (groups - 1); }
+      float2* p = buf + line * ld + 8 * g;
+      float2 v[8];
+      v[0] = p[0]; v[4] = p[1]; v[2] = p[2]; v[6] = p[3]; v[1] = p[4]; v[5] = p[5]; v[3] = p[6]; v[7] = p[7];
+      dft8<INVERSE>(v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = v[k];
+    }
+    s = 3;
+  } else if (logN & 1) {  // 2-point lines: the single radix-2 stage (half = 1, twiddle = 1)
     __syncthreads();
     const int total = L * half_n;
     for (int t = threadIdx.x; t < total; t += blockDim.x) {
@@ -111,7 +178,8 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
     const int step1 = half_n >> s, step2 = half_n >> (s + 1);
     __syncthreads();
     const int total = L * quarter;
-    const bool line_major = by_line && h < 32;
+    const bool last_out = TO_GLOBAL && s + 2 == logN;
+    const bool line_major = by_line && (h < 32 || last_out);
     for (int t = threadIdx.x; t < total; t += blockDim.x) {
       int line, k;
       if (line_major) { k = (int)__umulhi((uint32_t)t, magic); line = t - k * L; }
@@ -127,10 +195,18 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
       // stage s+1: (f0,f2) at position pos, (f1,f3) at position pos + h
       const float2 w2 = twid<INVERSE>(tw, pos * step2), w3 = twid<INVERSE>(tw, (pos + h) * step2);
       const float2 c2 = cmul(f2, w2), c3 = cmul(f3, w3);
-      p[0] = make_float2(f0.x + c2.x, f0.y + c2.y);
-      p[2 * h] = make_float2(f0.x - c2.x, f0.y - c2.y);
-      p[h] = make_float2(f1.x + c3.x, f1.y + c3.y);
-      p[3 * h] = make_float2(f1.x - c3.x, f1.y - c3.y);
+      if (TO_GLOBAL && last_out) {
+        float2* g = gout + (int64_t)pos * gpitch + line;  // (the last pass has one block of 4h = N points per line: position = pos + i h)
+        g[0] = make_float2(f0.x + c2.x, f0.y + c2.y);
+        g[(int64_t)2 * h * gpitch] = make_float2(f0.x - c2.x, f0.y - c2.y);
+        g[(int64_t)h * gpitch] = make_float2(f1.x + c3.x, f1.y + c3.y);
+        g[(int64_t)3 * h * gpitch] = make_float2(f1.x - c3.x, f1.y - c3.y);
+      } else {
+        p[0] = make_float2(f0.x + c2.x, f0.y + c2.y);
+        p[2 * h] = make_float2(f0.x - c2.x, f0.y - c2.y);
+        p[h] = make_float2(f1.x + c3.x, f1.y + c3.y);
+        p[3 * h] = make_float2(f1.x - c3.x, f1.y - c3.y);
+      }
     }
   }
   __syncthreads();
@@ -337,6 +413,48 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
     SKR_STAMP(1);
     fft_tile<false>(t1, tw_w, W, logW, pairs);
     SKR_STAMP(2);
+    constexpr bool FUSE_COL = CH >= 5 && (CH & 1) && CW >= 3;  // 128-row planes: the column transform opens with an 8-point pass
+    if constexpr (FUSE_COL) {
+      // Untangling FUSED with stages 0-2 of the column transform.  Positions 8g..8g+7 of a column hold rows r0 + (H/8) n in
+      // 3-bit-reversed order, r0 = bitrev(g); rows 2 p0 and 2 p0 + 1 come out of the same row pair, so one item -- (kw, p0) --
+      // untangles the eight pairs p0 + (H/16) n, owns both 8-row subsequences, transforms them in registers and, behind the
+      // barrier (the column tile overwrites the row tile), puts each into its group of 8 consecutive column positions.  One
+      // LDS round trip of the whole tile and one barrier less than untangle-then-transform; W/2 x H/16 items with kw >= 1 fill
+      // the block exactly at 128 x 128, the DC column's H/16 items ride on the first lanes.
+      constexpr int P0 = H / 16, MAIN = (W / 2) * P0, ROUNDS = (MAIN + PLANE_THREADS - 1) / PLANE_THREADS;
+      float2 va[ROUNDS + 1][8], vb[ROUNDS + 1][8];
+      auto untangle8 = [&](int k, int p0, float2* xa, float2* xb) {
+        const int kn = (W - k) & (W - 1);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const float2 zk = t1[(p0 + P0 * n) * ldw + k], zn = t1[(p0 + P0 * n) * ldw + kn];
+          xa[n] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+          xb[n] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        }
+        dft8<false>(xa);
+        dft8<false>(xb);
+      };
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int q = threadIdx.x + r * PLANE_THREADS;
+        if (q < MAIN) untangle8(1 + (q & (W / 2 - 1)), q >> (CW - 1), va[r], vb[r]);
+      }
+      if (threadIdx.x < P0) untangle8(0, threadIdx.x, va[ROUNDS], vb[ROUNDS]);
+      __syncthreads();
+      auto put8 = [&](int k, int p0, const float2* xa, const float2* xb) {
+        float2* ca = t2 + k * ldh + 8 * (int)brev(2 * p0, CH - 3);
+        float2* cb = t2 + k * ldh + 8 * (int)brev(2 * p0 + 1, CH - 3);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { ca[m] = xa[m]; cb[m] = xb[m]; }
+      };
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int q = threadIdx.x + r * PLANE_THREADS;
+        if (q < MAIN) put8(1 + (q & (W / 2 - 1)), q >> (CW - 1), va[r], vb[r]);
+      }
+      if (threadIdx.x < P0) put8(0, threadIdx.x, va[ROUNDS], vb[ROUNDS]);
+      fft_tile<false, true, MODE == 0>(t2, tw_h, H, logH, WH, plane, WH);
+    } else {
     {
       // untangle the row pairs into the column tile (bit-reversed along H for the column transform)
       float2 ra[PLANE_ITEMS], rb[PLANE_ITEMS];
@@ -362,16 +480,19 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
         }
       }
     }
-    fft_tile<false>(t2, tw_h, H, logH, WH);
+    fft_tile<false, false, MODE == 0 && (CH >= 2)>(t2, tw_h, H, logH, WH, plane, WH);
+    }
     SKR_STAMP(3);
     if (MODE == 0) block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
     if (MODE == 0) {
-      for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
-        const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
-        plane[q] = t2[k * ldh + row];
+      if constexpr (CH < 2) {  // (runtime-size instantiation: the transform's last pass may be the 2-point one, which writes the tile)
+        for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
+          const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
+          plane[q] = t2[k * ldh + row];
+        }
       }
       SKR_STAMP(4);
-      return;
+      return;  // (compile-time sizes: the column transform's last pass stored the half spectrum itself)
     }
     // MODE 2: weights in place (+ the Parseval sums of the weighted spectrum), then bit-reverse the columns for the inverse
     double p1 = 0.0, p2 = 0.0;
@@ -398,6 +519,42 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       if (row < r) { float2 t = t2[k * ldh + row]; t2[k * ldh + row] = t2[k * ldh + r]; t2[k * ldh + r] = t; }
     }
   } else {
+    if constexpr (CH >= 5 && (CH & 1) && CW >= 3) {
+      // The spectrum load FUSED with stages 0-2 of the column transform: an item -- (kw, g) -- loads the eight rows
+      // r0 + (H/8) n, r0 = bitrev(g), of one frequency column straight into registers (consecutive lanes = consecutive kw:
+      // 8-byte loads in runs of a spectrum row), transforms them and writes positions 8g..8g+7 of the column once.  All loads
+      // of the block go out before the first butterfly (W/2 x H/8 items fill two rounds exactly at 128 x 128; the Nyquist
+      // column's H/8 items ride on the first lanes).
+      constexpr int G = H / 8, MAIN = (W / 2) * G, ROUNDS = (MAIN + PLANE_THREADS - 1) / PLANE_THREADS;
+      float2 lv[ROUNDS + 1][8];
+      auto load8 = [&](int k, int g, float2* v) {
+        const float2* src = plane + (int64_t)brev(g, CH - 3) * WH + k;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) v[n] = src[(int64_t)n * G * WH];
+      };
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int q = threadIdx.x + r * PLANE_THREADS;
+        if (q < MAIN) load8(q & (W / 2 - 1), q >> (CW - 1), lv[r]);
+      }
+      if (threadIdx.x < G) load8(W / 2, threadIdx.x, lv[ROUNDS]);
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int q = threadIdx.x + r * PLANE_THREADS;
+        if (q < MAIN) {
+          dft8<true>(lv[r]);
+          float2* col = t2 + (q & (W / 2 - 1)) * ldh + 8 * (q >> (CW - 1));
+#pragma unroll
+          for (int m = 0; m < 8; ++m) col[m] = lv[r][m];
+        }
+      }
+      if (threadIdx.x < G) {
+        dft8<true>(lv[ROUNDS]);
+        float2* col = t2 + (W / 2) * ldh + 8 * threadIdx.x;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) col[m] = lv[ROUNDS][m];
+      }
+    } else {
     // all of the plane's loads are issued before the first LDS write (a rolled loop would pay one HBM latency per trip)
     const int total = H * WH;  // <= 2 * PLANE_THREADS * PLANE_ITEMS (host check)
 #pragma unroll
@@ -419,11 +576,48 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
         }
       }
     }
+    }
     SKR_STAMP(1);
   }
 
-  fft_tile<true>(t2, tw_h, H, logH, WH);
+  fft_tile<true, MODE == 1 && CH >= 5 && (CH & 1) && CW >= 3>(t2, tw_h, H, logH, WH);
   SKR_STAMP(2);
+  constexpr bool FUSE_ROW = CW >= 5 && (CW & 1) && CH >= 2;  // 128-point rows: the row transform opens with an 8-point pass
+  if constexpr (FUSE_ROW) {
+    // Hermitian packing FUSED with stages 0-2 of the row transform (the mirror image of the fused untangling above): positions
+    // 8g..8g+7 of a row-pair line hold frequencies k0 + (W/8) n in 3-bit-reversed order, k0 = bitrev(g); an item -- (pair, g) --
+    // builds those eight packed values from the column tile, transforms them in registers and writes the group behind the
+    // barrier.  Consecutive lanes take consecutive pairs: 16-byte reads of (row 2p, row 2p+1) side by side, writes one line apart.
+    constexpr int G = W / 8, ROUNDS = ((H / 2) * G + PLANE_THREADS - 1) / PLANE_THREADS;
+    float2 rv[ROUNDS][8];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int q = threadIdx.x + r * PLANE_THREADS;
+      if (q < pairs * G) {
+        const int pr = q & (pairs - 1), k0 = (int)brev(q >> (CH - 1), CW - 3);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const int k = k0 + G * n;
+          const int m = k < WH ? k : W - k;
+          float2 xa = t2[m * ldh + 2 * pr], xb = t2[m * ldh + 2 * pr + 1];
+          if (m == 0 || 2 * m == W) { xa.y = 0.f; xb.y = 0.f; }
+          if (k >= WH) { xa.y = -xa.y; xb.y = -xb.y; }
+          rv[r][n] = make_float2(xa.x - xb.y, xa.y + xb.x);
+        }
+        dft8<true>(rv[r]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int q = threadIdx.x + r * PLANE_THREADS;
+      if (q < pairs * G) {
+        float2* dst8 = t1 + (q & (pairs - 1)) * ldw + 8 * (q >> (CH - 1));
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dst8[m] = rv[r][m];
+      }
+    }
+  } else
   {
     // pack row pairs (Hermitian expansion along W), bit-reversed along W
     float2 rz[PLANE_ITEMS];
@@ -449,30 +643,25 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       if (q < total) t1[(q & (pairs - 1)) * ldw + brev(q >> (logH - 1), logW)] = rz[i];
     }
   }
-  fft_tile<true>(t1, tw_w, W, logW, pairs);
+  // The sample's rescale factor from the partial sums (white: one slot per plane, coloured: one per block of the outer-axis
+  // kernel).  Their loads were issued by the first wave when the block started (fa[]: lane l holds slots l, l + 64, ... summed in
+  // that order); the first wave finishes the four sums with a fixed-order shuffle tree BEFORE the row transform -- whose barriers
+  // publish the one LDS word -- so nothing of it is left on the block's critical path.  (Round 2 had EVERY thread walk all
+  // slots in a rolled loop of dependent loads after the last transform: 5.5 us of each block's 24 us, tools/tune/tune_colored.hip.)
+  __shared__ float factor_sh;
+  if (MODE == 1 && threadIdx.x < 64) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
+    if (threadIdx.x == 0) {
+      const double n = (double)a.d1 * (double)H * (double)W;
+      factor_sh = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
+    }
+  }
+  fft_tile<true, FUSE_ROW>(t1, tw_w, W, logW, pairs);
   SKR_STAMP(3);
   const float scale = 1.0f / ((float)a.d1 * (float)H * (float)W);
-  float factor;
-  if (MODE == 2) factor = (float)s1;
-  else {
-    // the sample's rescale factor from the partial sums (white: one slot per plane, coloured: one per block of the outer-axis
-    // kernel).  Their loads were issued by the first wave when the block started (fa[]: lane l holds slots l, l + 64, ... summed in
-    // that order), so they arrived long ago; here a fixed-order shuffle tree finishes the four sums and one LDS word hands the
-    // factor to the block.  (Round 2 had EVERY thread walk all slots in a rolled loop of dependent loads at this point: 5.5 us of
-    // each block's 24 us -- tools/tune/tune_colored.hip.)
-    __shared__ float factor_sh;
-    if (threadIdx.x < 64) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
-      if (threadIdx.x == 0) {
-        const double n = (double)a.d1 * (double)H * (double)W;
-        factor_sh = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
-      }
-    }
-    __syncthreads();
-    factor = factor_sh;
-  }
+  const float factor = MODE == 2 ? (float)s1 : factor_sh;
   SKR_STAMP(4);
   T* dst = reinterpret_cast<T*>(a.out) + ((smp * a.d1 + i1) * (int64_t)H) * W;
   // 4 consecutive values of one row per item: one 8-byte (16-bit T) or 16-byte (fp32) store
@@ -553,45 +742,6 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const Colore
 // ---- pass C for short outer axes (d1 <= 16, i.e. the channel axis of every latent): one LINE PER LANE --------
 // The whole column lives in registers: 2..16-point forward DFT, radial weights, inverse DFT, with no LDS and
 // no barrier.  Adjacent lanes own adjacent columns, so every load/store instruction is fully coalesced.
-template <bool INV> __device__ __forceinline__ float2 mul_i(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-
-template <bool INV> __device__ __forceinline__ void dft4(float2& v0, float2& v1, float2& v2, float2& v3) {
-  const float2 a = cadd(v0, v2), b = csub(v0, v2), c = cadd(v1, v3), d = mul_i<INV>(csub(v1, v3));
-  v0 = cadd(a, c); v2 = csub(a, c); v1 = cadd(b, d); v3 = csub(b, d);
-}
-template <bool INV> __device__ __forceinline__ float2 rot8(float2 a) {  // a * exp(-+ i pi/4)
-  constexpr float r = 0.70710678118654752440f;
-  return INV ? make_float2(r * (a.x - a.y), r * (a.x + a.y)) : make_float2(r * (a.x + a.y), r * (a.y - a.x));
-}
-template <bool INV> __device__ __forceinline__ void dft8(float2 v[8]) {
-  float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
-  dft4<INV>(e0, e1, e2, e3);
-  dft4<INV>(o0, o1, o2, o3);
-  o1 = rot8<INV>(o1); o2 = mul_i<INV>(o2); o3 = mul_i<INV>(rot8<INV>(o3));
-  v[0] = cadd(e0, o0); v[4] = csub(e0, o0); v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
-  v[2] = cadd(e2, o2); v[6] = csub(e2, o2); v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
-}
-template <bool INV> __device__ __forceinline__ void dft16(float2 v[16]) {
-  float2 e[8], o[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
-  dft8<INV>(e);
-  dft8<INV>(o);
-  constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
-  const float sg = INV ? 1.f : -1.f;
-  const float2 w[8] = {{1.f, 0.f}, {c1, sg * s1}, {h, sg * h}, {s1, sg * c1}, {0.f, sg}, {-s1, sg * c1}, {-h, sg * h}, {-c1, sg * s1}};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { const float2 t = cmul(o[k], w[k]); v[k] = cadd(e[k], t); v[k + 8] = csub(e[k], t); }
-}
-template <int N, bool INV> __device__ __forceinline__ void dft_n(float2 v[N]) {
-  if constexpr (N == 16) dft16<INV>(v);
-  else if constexpr (N == 8) dft8<INV>(v);
-  else if constexpr (N == 4) dft4<INV>(v[0], v[1], v[2], v[3]);
-  else { const float2 t = v[0]; v[0] = cadd(t, v[1]); v[1] = csub(t, v[1]); }
-}
-
 template <int N>
 __global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs a) {
   const int64_t cols = (int64_t)a.d2 * a.d3h;  // columns per sample; element n of column q sits at q + n*cols

@@ -1,7 +1,7 @@
 # Round-3 evidence, one gpurun call from the repo root:  bash tools/collect_r03.sh [part ...]
 #   parts: bench  (headline bench lines + rocprofv3 kernel trace + PMC / SQ passes of bench.py)
 #          plans  (cold-buffer plan launches: kernel trace + FETCH / WRITE / SQ / TCC passes -> k2 / rk1 / k1 counters)
-#          configs (per-config kernel stats and wrapper rates), micro (bench_plan / bench_graph), noise
+#          configs (per-config kernel stats and wrapper rates), micro (bench_plan / bench_graph), noise, colored (SQ counters of the Colored kernels)
 # The raw rocprofv3 output stays in /tmp on the box (hundreds of MB); only the condensed files come back, under
 # gpurun_out/r3c/profiles/ -- copy what is to be judged from there into profiles/.
 set -e
@@ -58,5 +58,13 @@ if has noise; then
   f=$(stats_csv $RAW/prof_noise); [ -n "$f" ] && cp $f $O/profiles/r03_noise_kernel_stats.csv
   $T 300 python3 $R/tools/bench_noise.py 2>&1 | grep -v amdgpu.ids > $O/profiles/r03_bench_noise.txt
   echo "noise part done"
+fi
+if has colored; then
+  C="python3 $R/tools/prof_colored.py"
+  $T 300 rocprofv3 --kernel-trace --stats -d $RAW/col_trace -o n --output-format csv -- $C > $O/col_trace.log 2>&1
+  $T 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace -d $RAW/col_sq -o n --output-format csv -- $C > $O/col_sq.log 2>&1
+  $T 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU --kernel-trace -d $RAW/col_sq2 -o n --output-format csv -- $C > $O/col_sq2.log 2>&1 || echo "second colored SQ pass failed"
+  python3 $R/tools/summarize_counters.py $O/profiles/r03_colored_sq_counters.json colored_ $RAW/col_trace $RAW/col_sq $RAW/col_sq2 > $O/summarize_colored.log 2>&1 || echo "summarize colored failed"
+  echo "colored part done"
 fi
 du -sh $R/gpurun_out || true

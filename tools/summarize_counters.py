@@ -50,6 +50,8 @@ for key in sorted(set(counters) | set(durations)):
                 dv[k.lower() + "_frac_of_wave_cycles"] = c[k] / wc
     if c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c:
         dv["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    if c.get("SQ_WAVES") and "SQ_INSTS_LDS" in c:
+        dv["lds_instructions_per_wave"] = c["SQ_INSTS_LDS"] / c["SQ_WAVES"]
     if c.get("SQ_WAVES") and wc:
         dv["wave_lifetime_quad_cycles"] = wc / c["SQ_WAVES"]
     if "TCC_HIT_sum" in c and c.get("TCC_MISS_sum"):
