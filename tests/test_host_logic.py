@@ -534,3 +534,28 @@ def test_rk_wrapper_trim_indices_name_the_stage_of_each_timestep():
                 x = w.step(torch.ones_like(x), t, x, return_dict=False)[0]
             assert visited == list(kept)
     assert seen_shift >= 2  # the case the check used to get wrong does occur
+
+
+def test_launch_hooks_are_per_thread():
+    "ADVICE r2 (low): `_hip.trace` / `_hip.indexed` installed by one thread must not record or redirect another thread's launches"
+    import threading
+
+    from skrample_amd import _hip
+
+    seen = {}
+    _hip.trace = []
+    _hip.indexed = "rows-of-this-thread"
+    try:
+        def other():
+            seen["trace"], seen["indexed"] = _hip.trace, _hip.indexed
+            _hip.trace = ["theirs"]
+
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen == {"trace": None, "indexed": None}
+        assert _hip.trace == [] and _hip.indexed == "rows-of-this-thread"
+    finally:
+        _hip.trace = None
+        _hip.indexed = None
+    assert _hip.trace is None and _hip.indexed is None

@@ -240,6 +240,24 @@ def test_user_capture_after_a_run_that_drew_noise_ahead(dev):
     assert torch.equal(static_out, eager)
 
 
+def test_captured_loop_refuses_a_slot_that_was_never_loaded(dev):
+    "ADVICE r2 (low): replaying a table slot that no schedule was loaded into ran every step with all-zero scalars"
+    from skrample_amd.graphs import capture_sampling_loop
+
+    shape, steps, seeds = (2, 4, 32, 32), 4, [3, 4]
+    mk = lambda **kw: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), **kw)  # noqa: E731
+    net = lambda x, t: x * 0.5  # noqa: E731
+    x0 = torch.randn(shape, device=dev).bfloat16()
+    loop = capture_sampling_loop(mk(), net, x0, steps, seeds=seeds, indexed=True, slots=3)
+    ref = loop(x0)
+    assert torch.isfinite(ref.float()).all() and ref.float().abs().max() > 0
+    with pytest.raises(ValueError, match="never been loaded"):
+        loop(x0, slot=2)
+    loop.retarget(mk(), slot=2)
+    assert torch.equal(loop(x0, slot=2), ref)
+    assert torch.equal(loop(x0, slot=0), ref)
+
+
 WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, {root!r})
