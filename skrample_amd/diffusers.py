@@ -24,6 +24,7 @@ import ctypes
 import dataclasses
 import functools
 import math
+import os
 import weakref
 from collections import OrderedDict
 from collections.abc import Hashable, Mapping, Sequence
@@ -425,8 +426,9 @@ class SkrampleWrapperCore(abc.ABC):
     # rewound.  Not under stream capture, not for Brownian (its cache makes queries order-dependent), not for white noise (drawn
     # inside the step kernel anyway).
     _AHEAD_KINDS = (Pyramid, Offset)
-    # ^ generators drawn ahead.  Measured on MI355X (tools/bench_configs.py): RKUltra-6 + Pyramid (BASELINE config 5 shard) 51.4 -> 47.9 us
-    # per stage call; Colored is left out -- its plane kernels hold 134 KiB of LDS and most of the vector registers of every CU, the
+    # ^ generators drawn ahead when prefetch_noise=True.  Round 2 measured RKUltra-6 + Pyramid (BASELINE config 5 shard) 51.4 -> 47.9 us per
+    # stage call with it; round 3's alternating A/B (tools/ab_prefetch.py) finds it 5 % slower there and only DPM-2 + Pyramid faster, so it is
+    # off by default.  Colored is left out -- its plane kernels hold 134 KiB of LDS and most of the vector registers of every CU, the
     # step kernel cannot co-reside, and UniPC-3 + Colored (config 3) went 702 -> 736 us per call with it drawn ahead.
 
     def _drain_noise_ahead(self) -> None:
@@ -495,7 +497,7 @@ class SkrampleWrapperCore(abc.ABC):
             return
         gen, dev = self._noise_generator, sample.device
         if self._noise_side is None or self._noise_side.device != dev:
-            self._noise_side = torch.cuda.Stream(device=dev)
+            self._noise_side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SKR_NOISE_SIDE_PRIORITY", "0")))
         side, main = self._noise_side, torch.cuda.current_stream(dev)
         if self._noise_done is None:  # the latest generation ran on the caller's stream: order the shared workspaces behind it
             fence = torch.cuda.Event()
@@ -598,8 +600,12 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
     allow_dynamic: bool = True
     invert_prediction: bool = False
     fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
-    prefetch_noise: bool = True
-    "(not in the reference) draw the next step's Pyramid / Offset noise ahead on a side stream (same values, same draw numbering)"
+    prefetch_noise: bool = False
+    """(not in the reference) draw the next step's Pyramid / Offset noise ahead on a side HIP stream while this step's kernels run (same
+    values, same draw numbering).  Opt-in since round 3: measured A/B/A/B in one process (tools/ab_prefetch.py) it gains 8 % for
+    DPM-2 + Pyramid at 256x4x128x128 (108 vs 118 us per call) but LOSES 5 % on BASELINE config 5's shard (RKUltra-6 + Pyramid, 55.2 vs
+    52.6 us per stage call: the generator's blocks take CU slots from the stage kernels on the critical path) and 37 % with Offset
+    (77 vs 56 us: the cross-stream event hand-over costs more than the 19 us kernel it hides)."""
     alias_history: bool | str = "auto"
     """(not in the reference) True: keep history entries as aliases of the caller's `sample` / `model_output` tensors (0 bytes
     written; guarded: reusing a held buffer raises).  False: snapshot both tensors every step (+8 B/element/step), safe for callers
@@ -803,8 +809,8 @@ class RKWrapperCore(SkrampleWrapperCore):
     allow_dynamic: bool = True
     invert_prediction: bool = False
     fake_config: dict[str, Any] = dataclasses.field(default_factory=DEFAULT_FAKE_CONFIG.copy)
-    prefetch_noise: bool = True
-    "(not in the reference) see SkrampleWrapperScheduler.prefetch_noise: the next step's noise is drawn on a side stream during this step's stages"
+    prefetch_noise: bool = False
+    "(not in the reference) see SkrampleWrapperScheduler.prefetch_noise: the next step's noise is drawn on a side stream during this step's stages (opt-in)"
     alias_history: bool | str = "auto"
     "(not in the reference) see SkrampleWrapperScheduler.alias_history; snapshots are per stage call"
 

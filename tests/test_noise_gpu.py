@@ -536,7 +536,7 @@ def test_component_methods(dev):
 @pytest.mark.parametrize("kind", ["colored_unipc", "pyramid_dpm", "offset_euler", "pyramid_rk", "colored_white_start"])
 def test_noise_drawn_ahead_on_the_side_stream_is_value_identical(kind, dev):
     """The wrappers draw the next step's Pyramid / Offset noise on a side stream while this step's kernel runs
-    (prefetch_noise, default on; Colored is opted in here through _AHEAD_KINDS to cover a generator with symbolic white steps).  Same values, same draw numbering as drawing at the moment of use -- also when the caller
+    (prefetch_noise=True; Colored is opted in here through _AHEAD_KINDS to cover a generator with symbolic white steps).  Same values, same draw numbering as drawing at the moment of use -- also when the caller
     does not ask for the guessed step next (out-of-order timestep, a fresh set_timesteps in mid-run)."""
     import skrample_amd.diffusers as PD
     import skrample_amd.scheduling as PS
@@ -604,7 +604,7 @@ def test_capture_after_steps_with_noise_drawn_ahead(dev):
     g = torch.Generator().manual_seed(16)
     net = lambda x, t: x * (0.5 + t / 2000)  # noqa: E731
     x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
-    mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=PN.Pyramid)  # noqa: E731
+    mk = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=PN.Pyramid, prefetch_noise=True)  # noqa: E731
 
     def eager(w, x, n):
         w.set_timesteps(steps)

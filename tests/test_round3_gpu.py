@@ -210,7 +210,7 @@ def test_user_capture_after_a_run_that_drew_noise_ahead(dev):
     capture of the next run (after reset_run / set_timesteps, no skrample_amd.graphs helper) must work and replay the eager
     result."""
     shape, steps, seeds = (2, 4, 32, 32), 4, [3, 4]
-    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), noise_type=PN.Pyramid, noise_props=PN.PyramidProps())
+    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), noise_type=PN.Pyramid, noise_props=PN.PyramidProps(), prefetch_noise=True)
     w.set_timesteps(steps)
     ts = w.timesteps.tolist()
     g = torch.Generator().manual_seed(2)
