@@ -591,8 +591,9 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()  # rank 0's informational extras (wrapper rate, graph loop) are done: every rank leaves together
         dist.destroy_process_group()
 
 
