@@ -800,6 +800,18 @@ def test_full_size_properties(dev):
 
 FULL_SIZE = {
     # name: (wrapper factory, oracle factory, shape per GPU, calls)
+    "cfg2_dpm2_sde_karras": (  # BASELINE config 2 as written: B = 64 on one GPU
+        lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled())),
+        lambda n: OW.StepDriver(OA.make("dpm", 2, eta=1), OS.karras(OS.scaled(), steps=n), "eps"),
+        (64, 4, 128, 128),
+        6,
+    ),
+    "headline_dpm2_sde_karras_b256": (  # the north-star shape of the same config
+        lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled())),
+        lambda n: OW.StepDriver(OA.make("dpm", 2, eta=1), OS.karras(OS.scaled(), steps=n), "eps"),
+        (256, 4, 128, 128),
+        5,
+    ),
     "cfg3_unipc3_sde_flow": (
         lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel()),
         lambda n: OW.StepDriver(OA.make("unipc", 3, eta=1), OS.linear(), "flow"),
