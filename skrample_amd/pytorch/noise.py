@@ -595,7 +595,6 @@ class HostRandomBatch:
     generate_lazy = generate
 
 
-@dataclass
 class _LazyGenerators(Sequence):
     """The per-item generators of a batch, built on first access.  The reference builds one generator object per batch item
     (noise.py:438-446) and so does `BatchTensorNoise.generators`; here the batch runs on its seed vector as ONE launch, and 256
@@ -632,6 +631,7 @@ class _LazyGenerators(Sequence):
         return f"<{len(self)} x {self._subclass.__name__} generators, built on access>"
 
 
+@dataclass
 class BatchTensorNoise(SkrampleTensorNoise):
     """One logical generator per batch item, executed as a single launch.  `generators` is kept for
     API compatibility (len == batch); the batch shares one draw counter."""

@@ -559,3 +559,19 @@ def test_launch_hooks_are_per_thread():
         _hip.trace = None
         _hip.indexed = None
     assert _hip.trace is None and _hip.indexed is None
+
+
+def test_lazy_generator_list_behaves_like_the_list_it_replaces():
+    "BatchTensorNoise.generators: one object per batch item as in the reference (noise.py:438-446), built on access"
+    import dataclasses
+
+    from skrample_amd.pytorch import noise as PN
+
+    lazy = PN._LazyGenerators(PN.Random, (4, 8, 8), [5, 6, 7], None, torch.float32)
+    assert len(lazy) == 3 and not lazy._made
+    assert isinstance(lazy[1], PN.Random) and lazy[1].seed == 6 and lazy[-1].seed == 7 and lazy[1] is lazy[1]
+    assert [g.seed for g in lazy] == [5, 6, 7] and [g.seed for g in lazy[1:]] == [6, 7]
+    assert lazy == [PN.Random.from_inputs((4, 8, 8), s, dtype=torch.float32) for s in (5, 6, 7)]
+    with pytest.raises(IndexError):
+        lazy[3]
+    assert dataclasses.is_dataclass(PN.BatchTensorNoise) and [f.name for f in dataclasses.fields(PN.BatchTensorNoise)][0] == "generators"
