@@ -107,7 +107,7 @@ int skr_step_launch(const skr_step_plan* plan, const void* const* inputs, void* 
  * the row's kinds.  One captured loop therefore serves any schedule of its length (rewrite the rows: new sigmas, shift,
  * begin index, stochasticity) and several resident schedules (move index_dev), with no re-capture and no host sync.
  * Rows with zeta = 0 skip the draw exactly as a launch without noise does.  Covered: launches the one-trip kernels take
- * (whole 2048-element chunks, <= 16 operands, fp32 accumulation); anything else returns SKR_ERR_UNSUPPORTED.
+ * (whole 2048-element chunks, <= 16 operands -- the size of a row --, fp32 accumulation); anything else returns SKR_ERR_UNSUPPORTED.
  */
 #define SKR_ROW_TERMS 16
 typedef struct skr_step_row {
@@ -248,11 +248,13 @@ const char* skr_build_info(void);
  *                   (default), 2 wherever it is instantiated, 0 never
  *   "pace"     1|0  paced load issue in the one-trip kernels (default 1)
  *   "rk_uv"    0|1|2|4  vectors per lane of the grid-stride Runge-Kutta stage kernel (0 = default)
+ *   "rk_blk"   0|128|256  threads per workgroup of the one-trip Runge-Kutta stage kernel (0 = by operand count, the default:
+ *                   128 for 4-6 operands, 256 otherwise)
  *   "fft_rank" 0|1|2  skr_noise_colored_any / skr_colorize: trailing axes handed to hipFFT (0 = up to three, the default); the
  *                   other axes run on the direct-DFT kernels, as they do by themselves when a three-axis plan fails its
  *                   self-check (results agree to rounding, not bit for bit)
  *   "reset"    (value ignored) back to the defaults
- * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_NO_TWO_OUT, SKR_RK_UV=n. */
+ * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_NO_TWO_OUT, SKR_RK_UV=n, SKR_RK_BLK=n. */
 int skr_set_tuning(const char* key, int32_t value);
 
 #ifdef __cplusplus
