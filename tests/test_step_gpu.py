@@ -1271,14 +1271,14 @@ def test_whole_loop_graph_capture_vs_oracle(indexed, dev):
     assert rel_err(got, ref) < 5e-5, rel_err(got, ref)  # 9 chained steps of <= 1e-5 each (Philox normals within 2e-6)
 
 
-@pytest.mark.parametrize("kind", ["dpm2_sde", "unipc3_sde", "adams4", "rk4_sde"])
+@pytest.mark.parametrize("kind", ["dpm2_sde", "unipc3_sde", "adams4", "rk4_sde", "adams7", "unipc5_sde"])
 def test_indexed_graph_serves_other_schedules(kind, dev):
     """skr_step_launch_indexed: one captured loop, step scalars resident on the device.  Re-targeting it to other schedules of
     the same length (other sigmas, other base schedule, other stochasticity) only rewrites rows -- no re-capture -- and must
     reproduce the eager run of that scheduler bit for bit; several schedules stay resident and are picked by the device index."""
     from skrample_amd.graphs import capture_sampling_loop
 
-    shape, steps, seeds = (4, 4, 32, 32), 6, [11, 12, 13, 14]
+    shape, steps, seeds = (4, 4, 32, 32), (10 if kind in ("adams7", "unipc5_sde") else 6), [11, 12, 13, 14]
     g = torch.Generator().manual_seed(31)
     # (the toy network ignores t: a host float t would be frozen into the graph; real pipelines feed the device-resident
     #  `scheduler.timesteps`, which is data like the rows)
@@ -1289,6 +1289,9 @@ def test_indexed_graph_serves_other_schedules(kind, dev):
         "unipc3_sde": lambda sch, eta=1.0: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=eta), sch),
         "adams4": lambda sch, eta=0.0: PD.SkrampleWrapperScheduler(PT.Adams(order=4), sch),
         "rk4_sde": lambda sch, eta=1.0: PD.RKUltraWrapperScheduler(sch, sampler_order=4, stochasticity=eta),
+        # round 3: the table forms of the 9-16-operand compile-time kernels (a device-resident row holds 16 operands)
+        "adams7": lambda sch, eta=0.0: PD.SkrampleWrapperScheduler(PT.Adams(order=7), sch),
+        "unipc5_sde": lambda sch, eta=1.0: PD.SkrampleWrapperScheduler(PT.UniPC(order=5, stochasticity=eta), sch),
     }
     mk = makers[kind]
     variants = [PS.Karras(PS.Scaled()), PS.Scaled(), PS.Karras(PS.Scaled(), rho=3.0), PS.Exponential(PS.Scaled())]
@@ -1307,7 +1310,7 @@ def test_indexed_graph_serves_other_schedules(kind, dev):
     for k, sch in enumerate(variants):
         assert torch.equal(outs[k], eager(mk(sch), x0)), (kind, k)
     assert not torch.equal(outs[0], outs[1])
-    if kind != "adams4":  # another stochasticity is just other zeta / gamma values in the rows
+    if kind not in ("adams4", "adams7"):  # another stochasticity is just other zeta / gamma values in the rows
         loop.retarget(mk(variants[1], 0.5), slot=0)
         assert torch.equal(loop(x0, slot=0), eager(mk(variants[1], 0.5), x0))
     x1 = torch.randn(shape, generator=g).bfloat16().to(dev)
