@@ -681,6 +681,278 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
   SKR_STAMP(5);
 }
 
+// ---- planes whose sides are 2^a * 3 or 2^a * 5 (96, 160, 192, 320 ... : latents of 768 / 1280 / 1536-pixel images) ------------
+// Round 3.  Cooley-Tukey with ONE odd factor per axis: n = r * m (r in {1, 3, 5}, m = 2^a).  A line is kept as r sub-lines of m
+// points (+1 pad each): sub-line q holds x[r j + q] in bit-reversed order, the power-of-two transform above runs over all
+// sub-lines at once (they are just r * L lines of m points), and one more pass combines them,
+//     X[k2 + m j] = sum_q  w_n^(q k2) * w_r^(q j) * Y_q[k2],
+// in place at the sub-line positions -- so natural index k lives at k + k / m (`mixed_nat`), and an input element n goes to
+// (n % r) * (m + 1) + bitrev(n / r) (`mixed_pos`).  Everything around the transforms is the plane kernel's scheme (drawn in
+// place, two real rows per complex row transform, transposes staged through registers into the same LDS region, Parseval
+// rescale), with runtime sizes; the outer (channel) axis is the same register kernel.  hipFFT was the only route for these
+// shapes before: 13.9 Gelem/s at 64 x (4, 96, 96) against 95 Gelem/s at 64 x (4, 128, 128).
+struct MixedAxis {
+  int32_t n, r, a, m, pitch;  // n = r << a, m = 1 << a, pitch = r * (m + 1)
+  uint32_t magic_r;           // v / r == umulhi(v, magic_r) for v < 2^16
+};
+__device__ __forceinline__ int mixed_pos(const MixedAxis& x, int n) {
+  const int hi = x.r == 1 ? n : (int)__umulhi((uint32_t)n, x.magic_r);
+  return (n - hi * x.r) * (x.m + 1) + (int)brev((unsigned)hi, x.a);
+}
+__device__ __forceinline__ int mixed_nat(const MixedAxis& x, int k) { return k + (k >> x.a); }
+
+__device__ __forceinline__ void make_twiddles_full(float2* tw, int n) {  // exp(-2 pi i k / n), k < n
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    float s, c;
+    sincospif(-2.0f * (float)k / (float)n, &s, &c);
+    tw[k] = make_float2(c, s);
+  }
+}
+
+// the combining pass of the odd factor, over `lines` lines of the tile (in place; r = 1: nothing to do)
+template <bool INVERSE>
+__device__ __forceinline__ void mixed_combine(float2* tile, const float2* tw_full, const MixedAxis& x, int lines) {
+  if (x.r == 1) return;
+  const int total = lines << x.a;
+  for (int t = threadIdx.x; t < total; t += blockDim.x) {
+    const int line = t >> x.a, k2 = t & (x.m - 1);
+    float2* p = tile + line * x.pitch + k2;
+    float2 y[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (q < x.r) y[q] = q == 0 ? p[0] : cmul(p[q * (x.m + 1)], twid<INVERSE>(tw_full, q * k2));
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j < x.r) {
+        float2 acc = y[0];
+#pragma unroll
+        for (int q = 1; q < 5; ++q) {
+          if (q < x.r) {
+            int e = q * j;
+            e -= (e >= 3 * x.r) ? 3 * x.r : ((e >= 2 * x.r) ? 2 * x.r : ((e >= x.r) ? x.r : 0));  // (q j) mod r, q j <= 16 < 4 r
+            const float2 w = twid<INVERSE>(tw_full, e * x.m);
+            const float2 t2 = cmul(y[q], w);
+            acc = make_float2(acc.x + t2.x, acc.y + t2.y);
+          }
+        }
+        p[j * (x.m + 1)] = acc;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+struct MixedGeom {
+  MixedAxis h, w;
+  uint32_t magic_wh;  // v / (w.n / 2 + 1)
+};
+
+// MODE as colored_plane: 0 white -> half spectrum, 1 half spectrum -> real plane (result dtype), 2 both (2-D units)
+template <int MODE, typename T>
+__global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const ColoredArgs a, const MixedGeom g) {
+  extern __shared__ float2 smem[];
+  const MixedAxis ax_h = g.h, ax_w = g.w;
+  const int H = ax_h.n, W = ax_w.n, WH = W / 2 + 1, ldw = ax_w.pitch, ldh = ax_h.pitch, pairs = H >> 1;
+  float2* tw_w = smem;                 // full circle, W entries
+  float2* tw_h = tw_w + W;             // full circle, H entries
+  float2* tw_ws = tw_h + H;            // sub-transform tables: m / 2 entries each
+  float2* tw_hs = tw_ws + (ax_w.m >> 1);
+  float2* t1 = tw_hs + (ax_h.m >> 1);  // row-pair tile: pairs lines of pitch ldw
+  float2* t2 = t1;                     // column tile: WH lines of pitch ldh (aliases t1)
+  const int64_t smp = blockIdx.y;
+  const int i1 = blockIdx.x;
+  double fa[4] = {0.0, 0.0, 0.0, 0.0};
+  if (MODE == 1 && threadIdx.x < 64) {  // the sample's partial sums: loaded now, reduced before the last transform (see colored_plane)
+    const double* pw = a.partials + (0 * a.batch + smp) * a.n_slots * 2;
+    for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += pw[2 * sl]; fa[1] += pw[2 * sl + 1]; }
+    const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
+    for (int sl = threadIdx.x; sl < a.n_slots_c; sl += 64) { fa[2] += pc[2 * sl]; fa[3] += pc[2 * sl + 1]; }
+  }
+  make_twiddles_full(tw_w, W);
+  make_twiddles_full(tw_h, H);
+  make_twiddles(tw_ws, ax_w.m);
+  make_twiddles(tw_hs, ax_h.m);
+  float2* plane = a.spec + ((smp * a.d1 + i1) * (int64_t)H) * WH;
+  double s1 = 0.0, s2 = 0.0;
+
+  if (MODE != 1) {
+    const uint64_t seed = a.seeds[smp];
+    const int quads = W >> 2;
+    const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint32_t)quads - 1) / (uint32_t)quads);
+    for (int q = threadIdx.x; q < pairs * quads; q += PLANE_THREADS) {
+      const int pr = (int)__umulhi((uint32_t)q, magic_q), n4 = (q - pr * quads) * 4;
+      const int64_t ea = ((int64_t)i1 * H + 2 * pr) * W + n4;
+      float za[4], zb[4];
+      normal4(seed, a.stream, (uint64_t)ea >> 2, za);
+      normal4(seed, a.stream, (uint64_t)(ea + W) >> 2, zb);
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t1[pr * ldw + mixed_pos(ax_w, n4 + j)] = make_float2(za[j], zb[j]);
+        p1 += za[j] + zb[j];
+        p2 = __builtin_fmaf(za[j], za[j], __builtin_fmaf(zb[j], zb[j], p2));
+      }
+      s1 += (double)p1; s2 += (double)p2;
+    }
+    fft_tile<false>(t1, tw_ws, ax_w.m, ax_w.a, pairs * ax_w.r);
+    mixed_combine<false>(t1, tw_w, ax_w, pairs);
+    {
+      // untangle the row pairs into the column tile (digit-reversed along H)
+      float2 ra[PLANE_ITEMS], rb[PLANE_ITEMS];
+      const int total = pairs * WH;
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = threadIdx.x + i * PLANE_THREADS;
+        if (q < total) {
+          const int pr = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - pr * WH;
+          const int kn = k == 0 ? 0 : W - k;
+          const float2 zk = t1[pr * ldw + mixed_nat(ax_w, k)], zn = t1[pr * ldw + mixed_nat(ax_w, kn)];
+          ra[i] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+          rb[i] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = threadIdx.x + i * PLANE_THREADS;
+        if (q < total) {
+          const int pr = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - pr * WH;
+          t2[k * ldh + mixed_pos(ax_h, 2 * pr)] = ra[i];
+          t2[k * ldh + mixed_pos(ax_h, 2 * pr + 1)] = rb[i];
+        }
+      }
+    }
+    fft_tile<false>(t2, tw_hs, ax_h.m, ax_h.a, WH * ax_h.r);
+    mixed_combine<false>(t2, tw_h, ax_h, WH);
+    if (MODE == 0) {
+      block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
+      for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
+        const int row = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - row * WH;
+        plane[q] = t2[k * ldh + mixed_nat(ax_h, row)];
+      }
+      return;
+    }
+    // MODE 2: weights in place (+ Parseval sums), then the columns go back to digit-reversed order for the inverse transform
+    double p1 = 0.0, p2 = 0.0;
+    const uint32_t magic_h = (uint32_t)((0x100000000ull + (uint32_t)H - 1) / (uint32_t)H);
+    {
+      float2 rz[PLANE_ITEMS];
+      const int total = H * WH;
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = threadIdx.x + i * PLANE_THREADS;
+        if (q < total) {
+          const int k = (int)__umulhi((uint32_t)q, magic_h), row = q - k * H;
+          const float f2 = axis_freq(row, H), f3 = (float)k / (float)W;
+          const float wgt = radial_weight(f2 * f2 + f3 * f3, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
+          float2 v = t2[k * ldh + mixed_nat(ax_h, row)];
+          v = make_float2(v.x * wgt, v.y * wgt);
+          rz[i] = v;
+          const float e = __builtin_fmaf(v.x, v.x, v.y * v.y);
+          p2 += (double)((k == 0 || 2 * k == W) ? e : 2.f * e);
+          if (q == 0) p1 = (double)v.x;
+        }
+      }
+      {
+        double tot[4] = {s1, s2, p1, p2};
+        block_sums4_bcast(tot);  // (also the barrier between the reads above and the writes below)
+        const double n = (double)H * (double)W;
+        s1 = (double)rescale_factor(tot[0], tot[1], tot[2], tot[3] / n, n, a.has_energy, a.energy);  // s1 now carries the factor
+      }
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = threadIdx.x + i * PLANE_THREADS;
+        if (q < total) {
+          const int k = (int)__umulhi((uint32_t)q, magic_h), row = q - k * H;
+          t2[k * ldh + mixed_pos(ax_h, row)] = rz[i];
+        }
+      }
+    }
+  } else {
+    const int total = H * WH;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float2 rz[PLANE_ITEMS];
+      const int base = half * PLANE_THREADS * PLANE_ITEMS;
+      if (base >= total) break;
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = base + threadIdx.x + i * PLANE_THREADS;
+        if (q < total) rz[i] = plane[q];
+      }
+#pragma unroll
+      for (int i = 0; i < PLANE_ITEMS; ++i) {
+        const int q = base + threadIdx.x + i * PLANE_THREADS;
+        if (q < total) {
+          const int row = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - row * WH;
+          t2[k * ldh + mixed_pos(ax_h, row)] = rz[i];
+        }
+      }
+    }
+  }
+
+  fft_tile<true>(t2, tw_hs, ax_h.m, ax_h.a, WH * ax_h.r);
+  mixed_combine<true>(t2, tw_h, ax_h, WH);
+  {
+    // pack row pairs (Hermitian expansion along W), digit-reversed along W; consecutive lanes = consecutive pairs of one frequency
+    float2 rz[PLANE_ITEMS];
+    const int total = pairs * W;
+    const uint32_t magic_p = (uint32_t)((0x100000000ull + (uint32_t)pairs - 1) / (uint32_t)pairs);
+#pragma unroll
+    for (int i = 0; i < PLANE_ITEMS; ++i) {
+      const int q = threadIdx.x + i * PLANE_THREADS;
+      if (q < total) {
+        const int k = (int)__umulhi((uint32_t)q, magic_p), pr = q - k * pairs;
+        const int m = k < WH ? k : W - k;
+        float2 xa = t2[m * ldh + mixed_nat(ax_h, 2 * pr)], xb = t2[m * ldh + mixed_nat(ax_h, 2 * pr + 1)];
+        if (m == 0 || 2 * m == W) { xa.y = 0.f; xb.y = 0.f; }
+        if (k >= WH) { xa.y = -xa.y; xb.y = -xb.y; }
+        rz[i] = make_float2(xa.x - xb.y, xa.y + xb.x);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PLANE_ITEMS; ++i) {
+      const int q = threadIdx.x + i * PLANE_THREADS;
+      if (q < total) {
+        const int k = (int)__umulhi((uint32_t)q, magic_p), pr = q - k * pairs;
+        t1[pr * ldw + mixed_pos(ax_w, k)] = rz[i];
+      }
+    }
+  }
+  __shared__ float factor_sh;
+  if (MODE == 1 && threadIdx.x < 64) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
+    if (threadIdx.x == 0) {
+      const double n = (double)a.d1 * (double)H * (double)W;
+      factor_sh = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
+    }
+  }
+  fft_tile<true>(t1, tw_ws, ax_w.m, ax_w.a, pairs * ax_w.r);
+  mixed_combine<true>(t1, tw_w, ax_w, pairs);
+  const float scale = 1.0f / ((float)a.d1 * (float)H * (float)W);
+  const float factor = MODE == 2 ? (float)s1 : factor_sh;
+  T* dst = reinterpret_cast<T*>(a.out) + ((smp * a.d1 + i1) * (int64_t)H) * W;
+  const int quads = W >> 2;
+  const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint32_t)quads - 1) / (uint32_t)quads);
+  for (int q = threadIdx.x; q < pairs * quads; q += PLANE_THREADS) {
+    const int pr = (int)__umulhi((uint32_t)q, magic_q), n4 = (q - pr * quads) * 4;
+    const float2* line = t1 + pr * ldw;
+    const float2 z0 = line[mixed_nat(ax_w, n4)], z1 = line[mixed_nat(ax_w, n4 + 1)], z2 = line[mixed_nat(ax_w, n4 + 2)], z3 = line[mixed_nat(ax_w, n4 + 3)];
+    if constexpr (sizeof(T) <= 4) {
+      store4_from_f32<T>(dst + (int64_t)(2 * pr) * W + n4, z0.x * scale * factor, z1.x * scale * factor, z2.x * scale * factor, z3.x * scale * factor);
+      store4_from_f32<T>(dst + (int64_t)(2 * pr + 1) * W + n4, z0.y * scale * factor, z1.y * scale * factor, z2.y * scale * factor, z3.y * scale * factor);
+    } else {
+      T* da = dst + (int64_t)(2 * pr) * W + n4;
+      T* db = dst + (int64_t)(2 * pr + 1) * W + n4;
+      da[0] = (T)(z0.x * scale * factor); da[1] = (T)(z1.x * scale * factor); da[2] = (T)(z2.x * scale * factor); da[3] = (T)(z3.x * scale * factor);
+      db[0] = (T)(z0.y * scale * factor); db[1] = (T)(z1.y * scale * factor); db[2] = (T)(z2.y * scale * factor); db[3] = (T)(z3.y * scale * factor);
+    }
+  }
+}
+
 // ---- pass B / C / D: a strided axis of length N; lines start at consecutive complex positions --------------------
 //   element n of line q (within a sample):  (q / inner) * outer + (q % inner) + n * stride
 // MODE 0 forward, 1 inverse, 2 forward + radial weights + inverse (outermost axis)
@@ -832,7 +1104,29 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   if (batch == 0) return SKR_OK;
   if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || !seeds_dev) return SKR_ERR_NULL;
   const int l3 = ilog2_exact(d3), l2 = ilog2_exact(d2), l1 = d1 == 1 ? 0 : ilog2_exact(d1);
-  if (l3 < 2 || l2 < 1 || l1 < 0 || d3 > FFT_MAX_TILE || d2 > FFT_MAX_TILE || d1 > FFT_MAX_TILE) return SKR_ERR_UNSUPPORTED;  // power-of-two axes only
+  const bool pow2 = l3 >= 2 && l2 >= 1 && l1 >= 0 && d3 <= FFT_MAX_TILE && d2 <= FFT_MAX_TILE && d1 <= FFT_MAX_TILE;
+  // planes with one factor 3 or 5 per side (96, 160, 192 ...) under a power-of-two channel axis: colored_plane_mixed
+  MixedGeom mg;
+  auto factor_axis = [](int d, MixedAxis& x) -> bool {
+    int r = 1, v = d;
+    if (v % 3 == 0) { r = 3; v /= 3; } else if (v % 5 == 0) { r = 5; v /= 5; }
+    if (v < 4 || (v & (v - 1)) != 0 || d > 4096) return false;
+    int lg = 0;
+    while ((1 << lg) < v) ++lg;
+    x.n = d; x.r = r; x.a = lg; x.m = v; x.pitch = r * (v + 1);
+    x.magic_r = (uint32_t)((0x100000000ull + (uint32_t)r - 1) / (uint32_t)r);
+    return true;
+  };
+  bool mixed = false;
+  size_t lds_mixed = 0;
+  if (!pow2 && l1 >= 0 && d1 <= 16 && d2 % 2 == 0 && d3 % 4 == 0 && factor_axis(d2, mg.h) && factor_axis(d3, mg.w) && getenv("SKR_FFT_NO_MIXED") == nullptr) {
+    const int64_t pairs = d2 / 2, wh = d3 / 2 + 1;
+    const size_t tile = (size_t)(pairs * mg.w.pitch > wh * mg.h.pitch ? pairs * mg.w.pitch : wh * mg.h.pitch);
+    lds_mixed = sizeof(float2) * ((size_t)d3 + d2 + mg.w.m / 2 + mg.h.m / 2 + tile);
+    mg.magic_wh = (uint32_t)((0x100000000ull + (uint32_t)wh - 1) / (uint32_t)wh);
+    mixed = lds_mixed <= 150 * 1024 && pairs * d3 <= PLANE_THREADS * PLANE_ITEMS && (int64_t)d2 * wh <= PLANE_THREADS * PLANE_ITEMS && d1 <= partial_slots;
+  }
+  if (!pow2 && !mixed) return SKR_ERR_UNSUPPORTED;  // (the caller takes skr_noise_colored_any: hipFFT)
   if (batch > 65535) return SKR_ERR_UNSUPPORTED;
   ColoredArgs a;
   a.spec = reinterpret_cast<float2*>(spec_c64); a.real_out = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
@@ -876,6 +1170,33 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     return -1;  // caller uses the LDS tile kernel
   };
 
+  if (mixed) {
+    a.n_slots = d1;
+    dim3 grid((unsigned)d1, (unsigned)batch);
+#define SKR_MIXED_T(MODE, T) do { SKR_ALLOW_LDS((colored_plane_mixed<MODE, T>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, T>), grid, dim3(PLANE_THREADS), lds_mixed, s, a, mg); } while (0)
+#define SKR_MIXED(MODE)                                             \
+    switch (out_dtype) {                                            \
+      case SKR_BF16: SKR_MIXED_T(MODE, __bf16); break;              \
+      case SKR_F16: SKR_MIXED_T(MODE, _Float16); break;             \
+      case SKR_F32: SKR_MIXED_T(MODE, float); break;                \
+      case SKR_F64: SKR_MIXED_T(MODE, double); break;               \
+      default: return SKR_ERR_DTYPE;                                \
+    }                                                               \
+    SKR_CHECK_LAUNCH()
+    if (nd == 2) {
+      SKR_MIXED(2);
+    } else {
+      SKR_MIXED_T(0, float);
+      SKR_CHECK_LAUNCH();
+      a.n_slots_c = (int32_t)(2 * partial_slots - d1 < 4096 ? 2 * partial_slots - d1 : 4096);
+      const int rc = outer_axis();
+      if (rc != SKR_OK) return rc;
+      SKR_MIXED(1);
+    }
+#undef SKR_MIXED
+#undef SKR_MIXED_T
+    return SKR_OK;
+  }
   if (fused) {
     if (d1 > partial_slots) return SKR_ERR_SHAPE;
     a.n_slots = d1;

@@ -405,6 +405,13 @@ class Colored(TensorNoiseCommon):
         return dims, pow2
 
     @staticmethod
+    def _mixed_radix_candidate(dims: list[int]) -> bool:
+        "2-D / 3-D units the mixed-radix plane kernel may take (it decides itself: sides 2^a * {1, 3, 5}, plane fits LDS)"
+        if not 2 <= len(dims) <= 3 or dims[-1] % 4 or dims[-2] % 2 or max(dims) > 4096:
+            return False
+        return len(dims) == 2 or (dims[0] <= 16 and dims[0] & (dims[0] - 1) == 0)
+
+    @staticmethod
     def colorize_noise(white: torch.Tensor, exponent: float = 0.0, energy: float | None = None) -> torch.Tensor:
         """Colour an existing white-noise tensor with the power-law spectrum f^(-exponent), normalised back to the
         input's std (or to `energy`).  Size-1 dimensions are excluded from the transform; no batching -- the whole
@@ -465,14 +472,18 @@ class Colored(TensorNoiseCommon):
         out = torch.empty((batch, *unit_shape), dtype=dtype, device=dev)
         lib, hstream = _launch_ctx(seeds)
         has_energy, energy = (0, 0.0) if props.energy is None else (1, float(props.energy))
-        if pow2:
+        status = _hip.SKR_ERR_UNSUPPORTED
+        if pow2 or cls._mixed_radix_candidate(dims):
+            # hand-written LDS transforms: powers of two, and planes with one factor 3 or 5 per side (96, 160 ... under a
+            # power-of-two channel axis); the library answers SKR_ERR_UNSUPPORTED for what its kernels do not cover
             d1, d2, d3 = ([1] + dims)[-3:]
             status = lib.skr_noise_colored(
                 out.data_ptr(), _hip.DTYPE_CODE[dtype], spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), slots, seeds.data_ptr(), stream,
                 batch, d1, d2, d3, float(exponent), has_energy, energy, hstream,
             )
-            _hip.check(status, "skr_noise_colored")
-        else:
+            if pow2 or status != _hip.SKR_ERR_UNSUPPORTED:
+                _hip.check(status, "skr_noise_colored")
+        if status == _hip.SKR_ERR_UNSUPPORTED:
             status = lib.skr_noise_colored_any(
                 out.data_ptr(), _hip.DTYPE_CODE[dtype], spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), seeds.data_ptr(), stream,
                 batch, len(dims), (ctypes.c_int32 * len(dims))(*dims), float(exponent), has_energy, energy, hstream,

@@ -306,7 +306,8 @@ def test_pyramid_through_wrapper(dev):
     assert torch.isfinite(x.float()).all() and x.dtype == torch.bfloat16
 
 
-@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (4, 64, 64), (16, 64, 64), (8, 32, 32), (2, 128, 64), (4, 32, 128), (128, 128), (1, 128, 128), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
+@pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (4, 64, 64), (16, 64, 64), (8, 32, 32), (2, 128, 64), (4, 32, 128), (128, 128), (1, 128, 128),
+                                  (16, 96, 96), (4, 96, 128), (4, 128, 96), (4, 160, 96), (4, 80, 80), (96, 96), (2, 48, 96), (8, 24, 12), (4, 96, 160), (1, 192, 96), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
 def test_colored(unit, dev):
     seeds = [31, 32]
     cases = [
@@ -619,6 +620,41 @@ def test_capture_after_steps_with_noise_drawn_ahead(dev):
     loop = capture_sampling_loop(w, net, x0, steps, seeds=seeds)
     assert torch.equal(loop(x0), want)
     assert torch.equal(eager(w, x0, steps), want)  # and eager again after the capture
+
+
+@pytest.mark.parametrize("unit", [(4, 96, 96), (16, 96, 96), (96, 96), (4, 96, 128), (4, 160, 96), (2, 80, 80), (8, 24, 12)])
+def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, dev):
+    """Planes with one factor 3 or 5 per side (latents of 768 / 1280-pixel images ...) take the hand-written mixed-radix plane kernel
+    (round 3) -- `skr_noise_colored` itself answers OK for them, where it used to refuse everything but powers of two -- and the
+    result agrees with the hipFFT route (`skr_noise_colored_any`) on the same seeds, which the oracle tests above pin."""
+    import ctypes
+
+    lib = _hip.load()
+    seeds, batch = [51, 52, 53], 3
+    dims = [d for d in unit if d != 1]
+    n = int(np.prod(dims))
+    half = n // dims[-1] * (dims[-1] // 2 + 1)
+    sd = PN.seeds_tensor(seeds, dev)
+    outs = []
+    for route in ("lds", "hipfft"):
+        spec = torch.empty(batch * half, dtype=torch.complex64, device=dev)
+        scratch = torch.empty(batch * n, dtype=torch.float32, device=dev)
+        partials = torch.empty(4 * batch * 256, dtype=torch.float64, device=dev)
+        out = torch.empty((batch, *unit), dtype=torch.float32, device=dev)
+        st = _hip.current_stream_ptr(dev)
+        if route == "lds":
+            d1, d2, d3 = ([1] + dims)[-3:]
+            status = lib.skr_noise_colored(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), 256, sd.data_ptr(), 512, batch, d1, d2, d3, 1.0, 0, 0.0, st)
+        else:
+            status = lib.skr_noise_colored_any(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), sd.data_ptr(), 512, batch, len(dims), (ctypes.c_int32 * len(dims))(*dims), 1.0, 0, 0.0, st)
+        assert status == 0, (route, status)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert rel(outs[0], outs[1]) < 2e-5, rel(outs[0], outs[1])
+    assert abs(outs[0].std().item() - 1.0) < 0.05
+    # a side with a factor the kernel does not handle is still refused (and served by hipFFT through the Python layer)
+    spec = torch.empty(batch * 4 * 56 * 29, dtype=torch.complex64, device=dev)
+    assert lib.skr_noise_colored(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), 256, sd.data_ptr(), 512, 1, 1, 28, 56, 1.0, 0, 0.0, _hip.current_stream_ptr(dev)) == 7
 
 
 @pytest.mark.parametrize("unit", [(4, 96, 96), (16, 19, 13), (3, 40), (3, 4, 6, 8), (16, 2, 8, 8), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6)])
