@@ -748,8 +748,9 @@ struct MixedGeom {
 };
 
 // MODE as colored_plane: 0 white -> half spectrum, 1 half spectrum -> real plane (result dtype), 2 both (2-D units)
-template <int MODE, typename T>
-__global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const ColoredArgs a, const MixedGeom g) {
+// THREADS: 512 (two blocks per CU for planes up to ~128 x 128) or 1024 (one block: 160- and 192-point sides)
+template <int MODE, typename T, int THREADS>
+__global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs a, const MixedGeom g) {
   extern __shared__ float2 smem[];
   const MixedAxis ax_h = g.h, ax_w = g.w;
   const int H = ax_h.n, W = ax_w.n, WH = W / 2 + 1, ldw = ax_w.pitch, ldh = ax_h.pitch, pairs = H >> 1;
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
     const uint64_t seed = a.seeds[smp];
     const int quads = W >> 2;
     const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint32_t)quads - 1) / (uint32_t)quads);
-    for (int q = threadIdx.x; q < pairs * quads; q += PLANE_THREADS) {
+    for (int q = threadIdx.x; q < pairs * quads; q += THREADS) {
       const int pr = (int)__umulhi((uint32_t)q, magic_q), n4 = (q - pr * quads) * 4;
       const int64_t ea = ((int64_t)i1 * H + 2 * pr) * W + n4;
       float za[4], zb[4];
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
       const int total = pairs * WH;
 #pragma unroll
       for (int i = 0; i < PLANE_ITEMS; ++i) {
-        const int q = threadIdx.x + i * PLANE_THREADS;
+        const int q = threadIdx.x + i * THREADS;
         if (q < total) {
           const int pr = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - pr * WH;
           const int kn = k == 0 ? 0 : W - k;
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < PLANE_ITEMS; ++i) {
-        const int q = threadIdx.x + i * PLANE_THREADS;
+        const int q = threadIdx.x + i * THREADS;
         if (q < total) {
           const int pr = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - pr * WH;
           t2[k * ldh + mixed_pos(ax_h, 2 * pr)] = ra[i];
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
     mixed_combine<false>(t2, tw_h, ax_h, WH);
     if (MODE == 0) {
       block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
-      for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
+      for (int q = threadIdx.x; q < H * WH; q += THREADS) {
         const int row = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - row * WH;
         plane[q] = t2[k * ldh + mixed_nat(ax_h, row)];
       }
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
       const int total = H * WH;
 #pragma unroll
       for (int i = 0; i < PLANE_ITEMS; ++i) {
-        const int q = threadIdx.x + i * PLANE_THREADS;
+        const int q = threadIdx.x + i * THREADS;
         if (q < total) {
           const int k = (int)__umulhi((uint32_t)q, magic_h), row = q - k * H;
           const float f2 = axis_freq(row, H), f3 = (float)k / (float)W;
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
       }
 #pragma unroll
       for (int i = 0; i < PLANE_ITEMS; ++i) {
-        const int q = threadIdx.x + i * PLANE_THREADS;
+        const int q = threadIdx.x + i * THREADS;
         if (q < total) {
           const int k = (int)__umulhi((uint32_t)q, magic_h), row = q - k * H;
           t2[k * ldh + mixed_pos(ax_h, row)] = rz[i];
@@ -873,16 +874,16 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float2 rz[PLANE_ITEMS];
-      const int base = half * PLANE_THREADS * PLANE_ITEMS;
+      const int base = half * THREADS * PLANE_ITEMS;
       if (base >= total) break;
 #pragma unroll
       for (int i = 0; i < PLANE_ITEMS; ++i) {
-        const int q = base + threadIdx.x + i * PLANE_THREADS;
+        const int q = base + threadIdx.x + i * THREADS;
         if (q < total) rz[i] = plane[q];
       }
 #pragma unroll
       for (int i = 0; i < PLANE_ITEMS; ++i) {
-        const int q = base + threadIdx.x + i * PLANE_THREADS;
+        const int q = base + threadIdx.x + i * THREADS;
         if (q < total) {
           const int row = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - row * WH;
           t2[k * ldh + mixed_pos(ax_h, row)] = rz[i];
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
     const uint32_t magic_p = (uint32_t)((0x100000000ull + (uint32_t)pairs - 1) / (uint32_t)pairs);
 #pragma unroll
     for (int i = 0; i < PLANE_ITEMS; ++i) {
-      const int q = threadIdx.x + i * PLANE_THREADS;
+      const int q = threadIdx.x + i * THREADS;
       if (q < total) {
         const int k = (int)__umulhi((uint32_t)q, magic_p), pr = q - k * pairs;
         const int m = k < WH ? k : W - k;
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PLANE_ITEMS; ++i) {
-      const int q = threadIdx.x + i * PLANE_THREADS;
+      const int q = threadIdx.x + i * THREADS;
       if (q < total) {
         const int k = (int)__umulhi((uint32_t)q, magic_p), pr = q - k * pairs;
         t1[pr * ldw + mixed_pos(ax_w, k)] = rz[i];
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane_mixed(const Color
   T* dst = reinterpret_cast<T*>(a.out) + ((smp * a.d1 + i1) * (int64_t)H) * W;
   const int quads = W >> 2;
   const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint32_t)quads - 1) / (uint32_t)quads);
-  for (int q = threadIdx.x; q < pairs * quads; q += PLANE_THREADS) {
+  for (int q = threadIdx.x; q < pairs * quads; q += THREADS) {
     const int pr = (int)__umulhi((uint32_t)q, magic_q), n4 = (q - pr * quads) * 4;
     const float2* line = t1 + pr * ldw;
     const float2 z0 = line[mixed_nat(ax_w, n4)], z1 = line[mixed_nat(ax_w, n4 + 1)], z2 = line[mixed_nat(ax_w, n4 + 2)], z3 = line[mixed_nat(ax_w, n4 + 3)];
@@ -1119,12 +1120,20 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   };
   bool mixed = false;
   size_t lds_mixed = 0;
+  int mixed_threads = 0;
   if (!pow2 && l1 >= 0 && d1 <= 16 && d2 % 2 == 0 && d3 % 4 == 0 && factor_axis(d2, mg.h) && factor_axis(d3, mg.w) && getenv("SKR_FFT_NO_MIXED") == nullptr) {
     const int64_t pairs = d2 / 2, wh = d3 / 2 + 1;
     const size_t tile = (size_t)(pairs * mg.w.pitch > wh * mg.h.pitch ? pairs * mg.w.pitch : wh * mg.h.pitch);
     lds_mixed = sizeof(float2) * ((size_t)d3 + d2 + mg.w.m / 2 + mg.h.m / 2 + tile);
     mg.magic_wh = (uint32_t)((0x100000000ull + (uint32_t)wh - 1) / (uint32_t)wh);
-    mixed = lds_mixed <= 150 * 1024 && pairs * d3 <= PLANE_THREADS * PLANE_ITEMS && (int64_t)d2 * wh <= PLANE_THREADS * PLANE_ITEMS && d1 <= partial_slots;
+    // 512-thread blocks while every register-staged transpose fits 18 items per thread, else 1024 (3-D units only need the
+    // row-pair transposes to fit; 2-D units also the full half plane)
+    auto fits = [&](int threads) {
+      return pairs * d3 <= (int64_t)threads * PLANE_ITEMS && pairs * wh <= (int64_t)threads * PLANE_ITEMS && (int64_t)d2 * wh <= 2ll * threads * PLANE_ITEMS &&
+             (d1 > 1 || (int64_t)d2 * wh <= (int64_t)threads * PLANE_ITEMS);
+    };
+    mixed_threads = fits(512) ? 512 : (fits(1024) ? 1024 : 0);
+    mixed = lds_mixed <= 156 * 1024 && mixed_threads != 0 && d1 <= partial_slots;
   }
   if (!pow2 && !mixed) return SKR_ERR_UNSUPPORTED;  // (the caller takes skr_noise_colored_any: hipFFT)
   if (batch > 65535) return SKR_ERR_UNSUPPORTED;
@@ -1173,7 +1182,10 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   if (mixed) {
     a.n_slots = d1;
     dim3 grid((unsigned)d1, (unsigned)batch);
-#define SKR_MIXED_T(MODE, T) do { SKR_ALLOW_LDS((colored_plane_mixed<MODE, T>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, T>), grid, dim3(PLANE_THREADS), lds_mixed, s, a, mg); } while (0)
+#define SKR_MIXED_T(MODE, T) do {                                                                                                              \
+      if (mixed_threads == 512) { SKR_ALLOW_LDS((colored_plane_mixed<MODE, T, 512>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, T, 512>), grid, dim3(512), lds_mixed, s, a, mg); } \
+      else { SKR_ALLOW_LDS((colored_plane_mixed<MODE, T, 1024>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, T, 1024>), grid, dim3(1024), lds_mixed, s, a, mg); }              \
+    } while (0)
 #define SKR_MIXED(MODE)                                             \
     switch (out_dtype) {                                            \
       case SKR_BF16: SKR_MIXED_T(MODE, __bf16); break;              \
