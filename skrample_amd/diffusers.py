@@ -24,7 +24,6 @@ import ctypes
 import dataclasses
 import functools
 import math
-import os
 import weakref
 from collections import OrderedDict
 from collections.abc import Hashable, Mapping, Sequence
@@ -497,7 +496,7 @@ class SkrampleWrapperCore(abc.ABC):
             return
         gen, dev = self._noise_generator, sample.device
         if self._noise_side is None or self._noise_side.device != dev:
-            self._noise_side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SKR_NOISE_SIDE_PRIORITY", "0")))
+            self._noise_side = torch.cuda.Stream(device=dev)  # (a high-priority side stream measured 4 us per stage call WORSE on BASELINE config 5)
         side, main = self._noise_side, torch.cuda.current_stream(dev)
         if self._noise_done is None:  # the latest generation ran on the caller's stream: order the shared workspaces behind it
             fence = torch.cuda.Event()
