@@ -287,7 +287,13 @@ def require_device(t: torch.Tensor, what: str) -> None:
         )
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the handle without building a torch.cuda.Stream object (1.5 -> 0.3 us per step)
+
+
 def current_stream_ptr(device: torch.device) -> int:
+    "hipStream_t of torch's current stream on `device`"
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 

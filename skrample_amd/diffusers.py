@@ -736,8 +736,9 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         idx = self._lookup(table, timestep, self._index + self._calls)
         self._calls += 1
         step = Step.from_int(idx, len(table))
-        aliasing = self.sampler.require_previous > 0 and self._alias_now(model_output, sample)
-        if self.sampler.require_previous > 0 and not aliasing:
+        keep = self.sampler.require_previous  # (a computed property: read once per step)
+        aliasing = keep > 0 and self._alias_now(model_output, sample)
+        if keep > 0 and not aliasing:
             sample, model_output = sample.clone(), model_output.clone()
         elif aliasing:
             self._alias_check(model_output, sample)
@@ -782,7 +783,6 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._previous.append(record)
         self._raw_outputs.append(model_output)
         self._raw_samples.append(sample)
-        keep = self.sampler.require_previous
         self._previous = self._previous[max(len(self._previous) - keep, 0) :]
         self._raw_outputs = self._raw_outputs[max(len(self._raw_outputs) - keep, 0) :]
         self._raw_samples = self._raw_samples[max(len(self._raw_samples) - keep, 0) :]

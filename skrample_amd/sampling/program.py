@@ -161,7 +161,7 @@ class StepProgram:
         lib = _hip.load()
         if _hip.trace is not None:
             _hip.trace.append((plan, ops, out0, out1, None, self.numel))
-        status = _hip.step_launch_raw(plan, arr, out0.data_ptr(), out1.data_ptr() if out1 is not None else None, seeds_ptr, self.numel, torch.cuda.current_stream(device).cuda_stream)
+        status = _hip.step_launch_raw(plan, arr, out0.data_ptr(), out1.data_ptr() if out1 is not None else None, seeds_ptr, self.numel, _hip.current_stream_ptr(device))
         _hip.check(status, "skr_step_launch")
         outs = (out0, out1)
         final = outs[self.final_out]
