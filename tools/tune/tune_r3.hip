@@ -655,7 +655,8 @@ int main(int argc, char** argv) {
     Scenario sc{"b64", 64 * S4, S4, 4, 0, 2, 0, 16};
     std::vector<Variant> vars = {
       KU(4, 1, 256, 1, 2, 2, 0, 1, 0), KU(4, 1, 128, 1, 2, 2, 0, 1, 0), KU(4, 1, 64, 1, 2, 2, 0, 1, 0), KU(4, 1, 512, 1, 2, 2, 0, 1, 0), KU(4, 1, 1024, 1, 2, 2, 0, 1, 0),
-      KU(4, 1, 256, 1, 2, 2, 0, 0, 0), KU(4, 1, 128, 1, 2, 2, 0, 0, 0), KU(4, 1, 64, 1, 2, 2, 0, 0, 0), KU(4, 1, 512, 1, 2, 2, 0, 0, 0), KU(4, 1, 256, 1, 0, 0, 0, 1, 0), KU(4, 1, 128, 1, 0, 0, 0, 1, 0)};
+      KU(4, 1, 256, 1, 2, 2, 0, 0, 0), KU(4, 1, 128, 1, 2, 2, 0, 0, 0), KU(4, 1, 64, 1, 2, 2, 0, 0, 0), KU(4, 1, 512, 1, 2, 2, 0, 0, 0), KU(4, 1, 256, 1, 0, 0, 0, 1, 0), KU(4, 1, 128, 1, 0, 0, 0, 1, 0),
+      KU(4, 1, 256, 2, 2, 2, 0, 1, 0), KU(4, 1, 256, 4, 2, 2, 0, 1, 0), KU(4, 1, 128, 2, 2, 2, 0, 1, 0), KU(4, 1, 64, 2, 2, 2, 0, 1, 0)};
     run_scenario(sc, vars, 7);
     Scenario sc3{"b64_lr3", 64 * S4, S4, 4, 0, 2, 0, 16};
     std::vector<Variant> v3 = {KU(4, 1, 256, 1, 2, 2, 0, 1, 0), KU(4, 1, 128, 1, 2, 2, 0, 1, 0)};
