@@ -351,6 +351,66 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis(const ColoredAr
   }
 }
 
+// Pass E writing the RESULT dtype itself (round 3; planes too large for the plane kernels, 3-D units with a short outer axis):
+// the coloured std is known by Parseval from the weighted spectrum -- the outer-axis kernel reduced it into the partials, as it does
+// for the plane path -- so the rescale factor is available before the first real value exists, and the fp32 scratch (a write and a
+// read of the whole sample) and the finishing pass disappear.
+template <typename T>
+__global__ __launch_bounds__(FFT_THREADS) void colored_last_axis_out(const ColoredArgs a, int logN, int L) {
+  extern __shared__ float2 smem[];
+  const int N = a.d3, ld = N + 1;
+  float2* tw = smem;
+  float2* buf = smem + N / 2;
+  const int64_t smp = blockIdx.y;
+  const int64_t n_lines = (int64_t)a.d1 * a.d2;
+  const int64_t line0 = (int64_t)blockIdx.x * L;
+  const int lines = (int)((n_lines - line0) < L ? (n_lines - line0) : L);
+  const int pairs = lines >> 1;
+  double fa[4] = {0.0, 0.0, 0.0, 0.0};
+  if (threadIdx.x < 64) {  // the sample's partial sums (white from pass A, Parseval from the outer-axis pass): loaded now, reduced below
+    const double* pw = a.partials + (0 * a.batch + smp) * a.n_slots * 2;
+    for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += pw[2 * sl]; fa[1] += pw[2 * sl + 1]; }
+    const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
+    for (int sl = threadIdx.x; sl < a.n_slots_c; sl += 64) { fa[2] += pc[2 * sl]; fa[3] += pc[2 * sl + 1]; }
+  }
+  make_twiddles(tw, N);
+  const float2* src = a.spec + (smp * n_lines + line0) * a.d3h;
+  for (int q = threadIdx.x; q < pairs * N; q += FFT_THREADS) {
+    const int pr = q >> logN, k = q & (N - 1);
+    const int m = k < a.d3h ? k : N - k;
+    float2 xa = src[(int64_t)(2 * pr) * a.d3h + m], xb = src[(int64_t)(2 * pr + 1) * a.d3h + m];
+    if (m == 0 || 2 * m == N) { xa.y = 0.f; xb.y = 0.f; }
+    if (k >= a.d3h) { xa.y = -xa.y; xb.y = -xb.y; }
+    buf[pr * ld + brev(k, logN)] = make_float2(xa.x - xb.y, xa.y + xb.x);
+  }
+  __shared__ float factor_sh;
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
+    if (threadIdx.x == 0) {
+      const double n = (double)a.d1 * (double)a.d2 * (double)a.d3;
+      factor_sh = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
+    }
+  }
+  fft_tile<true>(buf, tw, N, logN, pairs);
+  const float gain = factor_sh / ((float)a.d1 * (float)a.d2 * (float)a.d3);
+  T* dst = reinterpret_cast<T*>(a.out) + (smp * n_lines + line0) * N;
+  for (int q = threadIdx.x; q < pairs * (N >> 2); q += FFT_THREADS) {
+    const int pr = q >> (logN - 2), n4 = (q & ((N >> 2) - 1)) * 4;
+    const float2 z0 = buf[pr * ld + n4], z1 = buf[pr * ld + n4 + 1], z2 = buf[pr * ld + n4 + 2], z3 = buf[pr * ld + n4 + 3];
+    if constexpr (sizeof(T) <= 4) {
+      store4_from_f32<T>(dst + (int64_t)(2 * pr) * N + n4, z0.x * gain, z1.x * gain, z2.x * gain, z3.x * gain);
+      store4_from_f32<T>(dst + (int64_t)(2 * pr + 1) * N + n4, z0.y * gain, z1.y * gain, z2.y * gain, z3.y * gain);
+    } else {
+      T* da = dst + (int64_t)(2 * pr) * N + n4;
+      T* db = dst + (int64_t)(2 * pr + 1) * N + n4;
+      da[0] = (T)(z0.x * gain); da[1] = (T)(z1.x * gain); da[2] = (T)(z2.x * gain); da[3] = (T)(z3.x * gain);
+      db[0] = (T)(z0.y * gain); db[1] = (T)(z1.y * gain); db[2] = (T)(z2.y * gain); db[3] = (T)(z3.y * gain);
+    }
+  }
+}
+
 // ---- fused passes over the two inner axes: one (sample, i1) plane of d2 x d3 per block, entirely in LDS ---------
 // MODE 0: white noise -> rows (two-for-one) -> columns -> half spectrum to HBM          (replaces passes A + B)
 // MODE 1: half spectrum -> columns^-1 -> rows^-1 -> real plane + statistics            (replaces passes D + E)
@@ -1273,9 +1333,12 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
   };
   int rc;
+  // 3-D units with a short outer axis: Parseval partials from the outer-axis kernel, so that pass E can write the result itself
+  const bool direct_out = nd == 3 && d1 <= 16 && d3 % 4 == 0 && 2 * partial_slots - blocks_a >= 1;
   if (nd == 3) {
     // axis 2 (length d2, stride d3h): lines = (i1, k3)
     if ((rc = strided(0, d2, l2, (int64_t)d1 * d3h, d3h, (int64_t)d2 * d3h, d3h, 2)) != SKR_OK) return rc;
+    if (direct_out) a.n_slots_c = (int32_t)(2 * partial_slots - blocks_a < 4096 ? 2 * partial_slots - blocks_a : 4096);
     rc = outer_axis();
     if (rc == -1) rc = strided(2, d1, l1, (int64_t)d2 * d3h, (int64_t)d2 * d3h, 0, (int64_t)d2 * d3h, 1);
     if (rc != SKR_OK) return rc;
@@ -1284,6 +1347,20 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     if ((rc = strided(2, d2, l2, d3h, d3h, 0, d3h, 2)) != SKR_OK) return rc;
   }
 
+  if (direct_out) {  // pass E writes the result dtype; no scratch, no pass F
+    dim3 grid_e((unsigned)blocks_a, (unsigned)batch);
+    switch (out_dtype) {
+#define SKR_E(T) SKR_ALLOW_LDS(colored_last_axis_out<T>, lds_a); hipLaunchKernelGGL(colored_last_axis_out<T>, grid_e, dim3(FFT_THREADS), lds_a, s, a, l3, La)
+      case SKR_BF16: SKR_E(__bf16); break;
+      case SKR_F16: SKR_E(_Float16); break;
+      case SKR_F32: SKR_E(float); break;
+      case SKR_F64: SKR_E(double); break;
+#undef SKR_E
+      default: return SKR_ERR_DTYPE;
+    }
+    SKR_CHECK_LAUNCH();
+    return SKR_OK;
+  }
   // pass E: last axis inverse -> real scratch
   hipLaunchKernelGGL(colored_last_axis<false>, dim3((unsigned)blocks_a, (unsigned)batch), dim3(FFT_THREADS), lds_a, s, a, l3, La);
   SKR_CHECK_LAUNCH();

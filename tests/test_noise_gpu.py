@@ -307,7 +307,7 @@ def test_pyramid_through_wrapper(dev):
 
 
 @pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (4, 64, 64), (16, 64, 64), (8, 32, 32), (2, 128, 64), (4, 32, 128), (128, 128), (1, 128, 128),
-                                  (16, 96, 96), (4, 96, 128), (4, 128, 96), (4, 160, 96), (4, 80, 80), (96, 96), (2, 48, 96), (8, 24, 12), (4, 96, 160), (1, 192, 96), (4, 160, 160), (2, 192, 192), (160, 160), (192, 192), (2, 320, 64), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
+                                  (16, 96, 96), (4, 96, 128), (4, 128, 96), (4, 160, 96), (4, 80, 80), (96, 96), (2, 48, 96), (8, 24, 12), (4, 96, 160), (1, 192, 96), (4, 160, 160), (2, 192, 192), (160, 160), (192, 192), (2, 320, 64), (2, 256, 256), (16, 256, 128), (4, 128, 512), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
 def test_colored(unit, dev):
     seeds = [31, 32]
     cases = [
