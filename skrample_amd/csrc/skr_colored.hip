@@ -375,13 +375,31 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_last_axis_out(const Color
   }
   make_twiddles(tw, N);
   const float2* src = a.spec + (smp * n_lines + line0) * a.d3h;
-  for (int q = threadIdx.x; q < pairs * N; q += FFT_THREADS) {
-    const int pr = q >> logN, k = q & (N - 1);
-    const int m = k < a.d3h ? k : N - k;
-    float2 xa = src[(int64_t)(2 * pr) * a.d3h + m], xb = src[(int64_t)(2 * pr + 1) * a.d3h + m];
-    if (m == 0 || 2 * m == N) { xa.y = 0.f; xb.y = 0.f; }
-    if (k >= a.d3h) { xa.y = -xa.y; xb.y = -xb.y; }
-    buf[pr * ld + brev(k, logN)] = make_float2(xa.x - xb.y, xa.y + xb.x);
+  // four items = eight loads in flight per lane (a rolled loop pays one HBM latency per item)
+  for (int q0 = threadIdx.x; q0 < pairs * N; q0 += 4 * FFT_THREADS) {
+    float2 xa[4], xb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * FFT_THREADS;
+      if (q < pairs * N) {
+        const int pr = q >> logN, k = q & (N - 1);
+        const int m = k < a.d3h ? k : N - k;
+        xa[u] = src[(int64_t)(2 * pr) * a.d3h + m];
+        xb[u] = src[(int64_t)(2 * pr + 1) * a.d3h + m];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * FFT_THREADS;
+      if (q < pairs * N) {
+        const int pr = q >> logN, k = q & (N - 1);
+        const int m = k < a.d3h ? k : N - k;
+        float2 va = xa[u], vb = xb[u];
+        if (m == 0 || 2 * m == N) { va.y = 0.f; vb.y = 0.f; }
+        if (k >= a.d3h) { va.y = -va.y; vb.y = -vb.y; }
+        buf[pr * ld + brev(k, logN)] = make_float2(va.x - vb.y, va.y + vb.x);
+      }
+    }
   }
   __shared__ float factor_sh;
   if (threadIdx.x < 64) {
@@ -1036,7 +1054,20 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const Colore
   const int64_t off_t = (qt / inner) * outer + (qt % inner);
   const bool live = jt < lines;
   if (live) {
-    for (int n = nt0; n < N; n += dn) buf[jt * ld + brev(n, logN)] = base[off_t + (int64_t)n * stride];
+    // eight loads in flight per lane (a rolled loop pays one HBM latency per element: 62 -> see DESIGN, 64 x (4,256,256))
+    for (int n0 = nt0; n0 < N; n0 += 8 * dn) {
+      float2 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = n0 + u * dn;
+        if (n < N) r[u] = base[off_t + (int64_t)n * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = n0 + u * dn;
+        if (n < N) buf[jt * ld + brev(n, logN)] = r[u];
+      }
+    }
   }
   fft_tile<MODE == 1>(buf, tw, N, logN, lines);
   if (MODE == 2) {
