@@ -759,8 +759,9 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
   SKR_STAMP(5);
 }
 
-// ---- planes whose sides are 2^a * 3 or 2^a * 5 (96, 160, 192, 320 ... : latents of 768 / 1280 / 1536-pixel images) ------------
-// Round 3.  Cooley-Tukey with ONE odd factor per axis: n = r * m (r in {1, 3, 5}, m = 2^a).  A line is kept as r sub-lines of m
+// ---- planes whose sides are 2^a * r, r odd <= 63 (96, 112, 144, 152, 160, 168, 192 ... : latents of 768 / 896 / 1152 / 1216 / 1280 /
+// 1344 / 1536-pixel images) ----
+// Round 3.  Cooley-Tukey with ONE odd factor per axis: n = r * m (r odd, 1 ... 63, m = 2^a >= 4).  A line is kept as r sub-lines of m
 // points (+1 pad each): sub-line q holds x[r j + q] in bit-reversed order, the power-of-two transform above runs over all
 // sub-lines at once (they are just r * L lines of m points), and one more pass combines them,
 //     X[k2 + m j] = sum_q  w_n^(q k2) * w_r^(q j) * Y_q[k2],
@@ -787,34 +788,63 @@ __device__ __forceinline__ void make_twiddles_full(float2* tw, int n) {  // exp(
   }
 }
 
-// the combining pass of the odd factor, over `lines` lines of the tile (in place; r = 1: nothing to do)
+// the combining pass of the odd factor, over `lines` lines of the tile (in place; r = 1: nothing to do).
+// r = 3, 5: one thread per output group, the r twiddled inputs in registers.
+// other r (7 ... 63): one LANE per output, the r outputs of a group on adjacent lanes of ONE wave in the same iteration,
+//     X[k] = sum_q  w_n^(q k mod n) * Y_q[k mod m],
+// read from LDS by all r lanes (same address: a broadcast) and written back over the inputs.  A wave's LDS instructions
+// execute in order and every lane's store depends on all of its loads, so no lane's store can pass another lane's load of
+// the same group: in place without a block barrier, for any r at run time, and no register array indexed by r.
 template <bool INVERSE>
 __device__ __forceinline__ void mixed_combine(float2* tile, const float2* tw_full, const MixedAxis& x, int lines) {
   if (x.r == 1) return;
-  const int total = lines << x.a;
-  for (int t = threadIdx.x; t < total; t += blockDim.x) {
-    const int line = t >> x.a, k2 = t & (x.m - 1);
-    float2* p = tile + line * x.pitch + k2;
-    float2 y[5];
+  if (x.r <= 5) {
+    const int total = lines << x.a;
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+      const int line = t >> x.a, k2 = t & (x.m - 1);
+      float2* p = tile + line * x.pitch + k2;
+      float2 y[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
-      if (q < x.r) y[q] = q == 0 ? p[0] : cmul(p[q * (x.m + 1)], twid<INVERSE>(tw_full, q * k2));
+      for (int q = 0; q < 5; ++q)
+        if (q < x.r) y[q] = q == 0 ? p[0] : cmul(p[q * (x.m + 1)], twid<INVERSE>(tw_full, q * k2));
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      if (j < x.r) {
-        float2 acc = y[0];
+      for (int j = 0; j < 5; ++j) {
+        if (j < x.r) {
+          float2 acc = y[0];
 #pragma unroll
-        for (int q = 1; q < 5; ++q) {
-          if (q < x.r) {
-            int e = q * j;
-            e -= (e >= 3 * x.r) ? 3 * x.r : ((e >= 2 * x.r) ? 2 * x.r : ((e >= x.r) ? x.r : 0));  // (q j) mod r, q j <= 16 < 4 r
-            const float2 w = twid<INVERSE>(tw_full, e * x.m);
-            const float2 t2 = cmul(y[q], w);
-            acc = make_float2(acc.x + t2.x, acc.y + t2.y);
+          for (int q = 1; q < 5; ++q) {
+            if (q < x.r) {
+              int e = q * j;
+              e -= (e >= 3 * x.r) ? 3 * x.r : ((e >= 2 * x.r) ? 2 * x.r : ((e >= x.r) ? x.r : 0));  // (q j) mod r, q j <= 16 < 4 r
+              const float2 w = twid<INVERSE>(tw_full, e * x.m);
+              const float2 t2 = cmul(y[q], w);
+              acc = make_float2(acc.x + t2.x, acc.y + t2.y);
+            }
           }
+          p[j * (x.m + 1)] = acc;
         }
-        p[j * (x.m + 1)] = acc;
       }
+    }
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int gl = (int)__umulhi((uint32_t)lane, x.magic_r), j = lane - gl * x.r;  // group within the wave's batch, output within the group
+    const int per_wave = 64 / x.r, groups = lines << x.a;
+    for (int base = wave * per_wave; base < groups; base += waves * per_wave) {
+      const int grp = base + gl;
+      const bool on = gl < per_wave && grp < groups;
+      const int line = grp >> x.a, k2 = grp & (x.m - 1), k = k2 + (j << x.a);
+      float2* p = tile + (on ? line * x.pitch + k2 : 0);
+      float2 acc = p[0];
+      int e = 0;  // (q k) mod n
+#pragma unroll 2
+      for (int q = 1; q < x.r; ++q) {
+        e += k;
+        e -= e >= x.n ? x.n : 0;
+        const float2 t2 = cmul(p[q * (x.m + 1)], twid<INVERSE>(tw_full, on ? e : 0));
+        acc = make_float2(acc.x + t2.x, acc.y + t2.y);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (on) p[j * (x.m + 1)] = acc;
     }
   }
   __syncthreads();
@@ -1197,12 +1227,14 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || !seeds_dev) return SKR_ERR_NULL;
   const int l3 = ilog2_exact(d3), l2 = ilog2_exact(d2), l1 = d1 == 1 ? 0 : ilog2_exact(d1);
   const bool pow2 = l3 >= 2 && l2 >= 1 && l1 >= 0 && d3 <= FFT_MAX_TILE && d2 <= FFT_MAX_TILE && d1 <= FFT_MAX_TILE;
-  // planes with one factor 3 or 5 per side (96, 160, 192 ...) under a power-of-two channel axis: colored_plane_mixed
+  // planes whose sides are a power of two times an odd factor up to 63 (96, 112, 144, 160, 192 ...) under a power-of-two channel axis: colored_plane_mixed
   MixedGeom mg;
   auto factor_axis = [](int d, MixedAxis& x) -> bool {
-    int r = 1, v = d;
-    if (v % 3 == 0) { r = 3; v /= 3; } else if (v % 5 == 0) { r = 5; v /= 5; }
-    if (v < 4 || (v & (v - 1)) != 0 || d > 4096) return false;
+    int v = d;
+    while (v % 2 == 0) v /= 2;
+    const int r = v;  // the odd part: one direct r-point combining pass
+    v = d / r;
+    if (r > 63 || v < 4 || d > 4096) return false;
     int lg = 0;
     while ((1 << lg) < v) ++lg;
     x.n = d; x.r = r; x.a = lg; x.m = v; x.pitch = r * (v + 1);

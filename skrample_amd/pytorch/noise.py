@@ -406,7 +406,7 @@ class Colored(TensorNoiseCommon):
 
     @staticmethod
     def _mixed_radix_candidate(dims: list[int]) -> bool:
-        "2-D / 3-D units the mixed-radix plane kernel may take (it decides itself: sides 2^a * {1, 3, 5}, plane fits LDS)"
+        "2-D / 3-D units the mixed-radix plane kernel may take (it decides itself: sides 2^a * odd factor <= 63, plane fits LDS)"
         if not 2 <= len(dims) <= 3 or dims[-1] % 4 or dims[-2] % 2 or max(dims) > 4096:
             return False
         return len(dims) == 2 or (dims[0] <= 16 and dims[0] & (dims[0] - 1) == 0)
