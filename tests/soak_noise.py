@@ -43,6 +43,16 @@ def case_colored():
         unit = (rng.choice((2, 3, 4, 16)), rng.choice((2, 5, 8))) + tuple(min(d, 24) for d in unit[2:])
     T.test_colored.__wrapped__(unit, dev) if hasattr(T.test_colored, "__wrapped__") else T.test_colored(unit, dev)
 
+def case_colored_mixed():
+    "sides 4 * k: the mixed-radix plane kernel where the odd part is <= 63 and the plane fits LDS, hipFFT otherwise"
+    while True:
+        h, w = 4 * rng.randint(3, 50), 4 * rng.randint(3, 50)
+        if h * w <= 36000:
+            break
+    lead = rng.choice((None, 1, 2, 4, 8))
+    unit = (h, w) if lead is None else (lead, h, w)
+    T.test_colored.__wrapped__(unit, dev) if hasattr(T.test_colored, "__wrapped__") else T.test_colored(unit, dev)
+
 def diag_colored(unit):
     "which side moved?  device result vs the oracle (torch CPU FFT) vs an independent float64 numpy evaluation of the same pipeline"
     if unit is None:
@@ -96,7 +106,7 @@ def case_brownian():
         assert err < 1e-5, ("brownian", unit, st, ms, err)
 
 for i in range(n_cases):
-    for fn in ((case_offset, case_pyramid, case_colored, case_brownian) if not os.environ.get("SOAK_ONLY") else (globals()["case_" + os.environ["SOAK_ONLY"]],)):
+    for fn in ((case_offset, case_pyramid, case_colored, case_colored_mixed, case_brownian) if not os.environ.get("SOAK_ONLY") else (globals()["case_" + os.environ["SOAK_ONLY"]],)):
         state = rng.getstate()
         try:
             fn()
@@ -111,6 +121,6 @@ for i in range(n_cases):
             except Exception as e2:
                 print("   the same case again: fails again --", str(e2)[:200])
             rng.setstate(after)
-            if fn is case_colored:
+            if fn in (case_colored, case_colored_mixed):
                 diag_colored(e.args[0][0] if e.args and isinstance(e.args[0], tuple) else None)
 print("done, failures:", bad)
