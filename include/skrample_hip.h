@@ -194,8 +194,8 @@ int skr_noise_pyramid_nd(void* out, int32_t out_dtype, float* scratch_f32, float
 /* Colored.generate / colorize_noise (noise.py:337-425): white Philox noise shaped in the Fourier domain by
  * clamp(radial_frequency, eps)^(-exponent/2) and rescaled per sample to the white noise's std (or `energy`).
  * The per-sample transform is over (d1, d2, d3) (d1 = 1 for a 2-D unit).  Covered by the hand-written LDS transforms: every axis a
- * power of two <= 4096; or d1 a power of two <= 16 (or 1) over planes whose sides are 2^a * r, r odd <= 63 (a >= 2: every
- * multiple of 4 up to 252, then 96 * 2^k, 160 * 2^k ...: 96, 104, 112, 144, 152, 160, 168, 192 ...) as long as one plane fits a CU's LDS (up to 192 x 192).  Other shapes:
+ * power of two <= 4096; or d1 a power of two <= 16 (or 1) over planes whose sides are 2^a * r, r odd <= 63, with d2 even and
+ * d3 a multiple of 4 (every such side up to 126 / 252, then 96 * 2^k, 160 * 2^k ...: 90, 96, 104, 112, 144, 152, 160, 168, 192 ...) as long as one plane fits a CU's LDS (up to 192 x 192).  Other shapes:
  * SKR_ERR_UNSUPPORTED -- use skr_noise_colored_any.
  * Workspaces (caller-provided): spec_c64 = batch*d1*d2*(d3/2+1) complex64, scratch_f32 = batch*d1*d2*d3,
  * partials_f64 = 4*batch*partial_slots doubles with partial_slots >= ceil(d1*d2 / max(1, 4096/d3)). */

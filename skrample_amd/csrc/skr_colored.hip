@@ -761,7 +761,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
 
 // ---- planes whose sides are 2^a * r, r odd <= 63 (96, 112, 144, 152, 160, 168, 192 ... : latents of 768 / 896 / 1152 / 1216 / 1280 /
 // 1344 / 1536-pixel images) ----
-// Round 3.  Cooley-Tukey with ONE odd factor per axis: n = r * m (r odd, 1 ... 63, m = 2^a >= 4).  A line is kept as r sub-lines of m
+// Round 3.  Cooley-Tukey with ONE odd factor per axis: n = r * m (r odd, 1 ... 63, m = 2^a >= 2).  A line is kept as r sub-lines of m
 // points (+1 pad each): sub-line q holds x[r j + q] in bit-reversed order, the power-of-two transform above runs over all
 // sub-lines at once (they are just r * L lines of m points), and one more pass combines them,
 //     X[k2 + m j] = sum_q  w_n^(q k2) * w_r^(q j) * Y_q[k2],
@@ -779,6 +779,8 @@ __device__ __forceinline__ int mixed_pos(const MixedAxis& x, int n) {
   return (n - hi * x.r) * (x.m + 1) + (int)brev((unsigned)hi, x.a);
 }
 __device__ __forceinline__ int mixed_nat(const MixedAxis& x, int k) { return k + (k >> x.a); }
+// q / d by multiply-high with magic = ceil(2^32 / d) (exact for q < 2^16); d = 1 has no 32-bit magic (it wraps to 0): q itself
+__device__ __forceinline__ int div_magic(int q, uint32_t magic) { return magic == 0u ? q : (int)__umulhi((uint32_t)q, magic); }
 
 __device__ __forceinline__ void make_twiddles_full(float2* tw, int n) {  // exp(-2 pi i k / n), k < n
   for (int k = threadIdx.x; k < n; k += blockDim.x) {
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
     const int quads = W >> 2;
     const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint32_t)quads - 1) / (uint32_t)quads);
     for (int q = threadIdx.x; q < pairs * quads; q += THREADS) {
-      const int pr = (int)__umulhi((uint32_t)q, magic_q), n4 = (q - pr * quads) * 4;
+      const int pr = div_magic(q, magic_q), n4 = (q - pr * quads) * 4;
       const int64_t ea = ((int64_t)i1 * H + 2 * pr) * W + n4;
       float za[4], zb[4];
       normal4(seed, a.stream, (uint64_t)ea >> 2, za);
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = threadIdx.x + i * THREADS;
         if (q < total) {
-          const int pr = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - pr * WH;
+          const int pr = div_magic(q, g.magic_wh), k = q - pr * WH;
           const int kn = k == 0 ? 0 : W - k;
           const float2 zk = t1[pr * ldw + mixed_nat(ax_w, k)], zn = t1[pr * ldw + mixed_nat(ax_w, kn)];
           ra[i] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
@@ -925,7 +927,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = threadIdx.x + i * THREADS;
         if (q < total) {
-          const int pr = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - pr * WH;
+          const int pr = div_magic(q, g.magic_wh), k = q - pr * WH;
           t2[k * ldh + mixed_pos(ax_h, 2 * pr)] = ra[i];
           t2[k * ldh + mixed_pos(ax_h, 2 * pr + 1)] = rb[i];
         }
@@ -936,7 +938,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
     if (MODE == 0) {
       block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
       for (int q = threadIdx.x; q < H * WH; q += THREADS) {
-        const int row = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - row * WH;
+        const int row = div_magic(q, g.magic_wh), k = q - row * WH;
         plane[q] = t2[k * ldh + mixed_nat(ax_h, row)];
       }
       return;
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = threadIdx.x + i * THREADS;
         if (q < total) {
-          const int k = (int)__umulhi((uint32_t)q, magic_h), row = q - k * H;
+          const int k = div_magic(q, magic_h), row = q - k * H;
           const float f2 = axis_freq(row, H), f3 = (float)k / (float)W;
           const float wgt = radial_weight(f2 * f2 + f3 * f3, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
           float2 v = t2[k * ldh + mixed_nat(ax_h, row)];
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = threadIdx.x + i * THREADS;
         if (q < total) {
-          const int k = (int)__umulhi((uint32_t)q, magic_h), row = q - k * H;
+          const int k = div_magic(q, magic_h), row = q - k * H;
           t2[k * ldh + mixed_pos(ax_h, row)] = rz[i];
         }
       }
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = base + threadIdx.x + i * THREADS;
         if (q < total) {
-          const int row = (int)__umulhi((uint32_t)q, g.magic_wh), k = q - row * WH;
+          const int row = div_magic(q, g.magic_wh), k = q - row * WH;
           t2[k * ldh + mixed_pos(ax_h, row)] = rz[i];
         }
       }
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
     for (int i = 0; i < PLANE_ITEMS; ++i) {
       const int q = threadIdx.x + i * THREADS;
       if (q < total) {
-        const int k = (int)__umulhi((uint32_t)q, magic_p), pr = q - k * pairs;
+        const int k = div_magic(q, magic_p), pr = q - k * pairs;
         const int m = k < WH ? k : W - k;
         float2 xa = t2[m * ldh + mixed_nat(ax_h, 2 * pr)], xb = t2[m * ldh + mixed_nat(ax_h, 2 * pr + 1)];
         if (m == 0 || 2 * m == W) { xa.y = 0.f; xb.y = 0.f; }
@@ -1024,7 +1026,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
     for (int i = 0; i < PLANE_ITEMS; ++i) {
       const int q = threadIdx.x + i * THREADS;
       if (q < total) {
-        const int k = (int)__umulhi((uint32_t)q, magic_p), pr = q - k * pairs;
+        const int k = div_magic(q, magic_p), pr = q - k * pairs;
         t1[pr * ldw + mixed_pos(ax_w, k)] = rz[i];
       }
     }
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
   const int quads = W >> 2;
   const uint32_t magic_q = (uint32_t)((0x100000000ull + (uint32_t)quads - 1) / (uint32_t)quads);
   for (int q = threadIdx.x; q < pairs * quads; q += THREADS) {
-    const int pr = (int)__umulhi((uint32_t)q, magic_q), n4 = (q - pr * quads) * 4;
+    const int pr = div_magic(q, magic_q), n4 = (q - pr * quads) * 4;
     const float2* line = t1 + pr * ldw;
     const float2 z0 = line[mixed_nat(ax_w, n4)], z1 = line[mixed_nat(ax_w, n4 + 1)], z2 = line[mixed_nat(ax_w, n4 + 2)], z3 = line[mixed_nat(ax_w, n4 + 3)];
     if constexpr (sizeof(T) <= 4) {
@@ -1234,7 +1236,7 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     while (v % 2 == 0) v /= 2;
     const int r = v;  // the odd part: one direct r-point combining pass
     v = d / r;
-    if (r > 63 || v < 4 || d > 4096) return false;
+    if (r > 63 || v < 2 || d > 4096) return false;  // (d2 even and d3 % 4 == 0 are the plane kernel's own conditions)
     int lg = 0;
     while ((1 << lg) < v) ++lg;
     x.n = d; x.r = r; x.a = lg; x.m = v; x.pitch = r * (v + 1);

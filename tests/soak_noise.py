@@ -44,9 +44,9 @@ def case_colored():
     T.test_colored.__wrapped__(unit, dev) if hasattr(T.test_colored, "__wrapped__") else T.test_colored(unit, dev)
 
 def case_colored_mixed():
-    "sides 4 * k: the mixed-radix plane kernel where the odd part is <= 63 and the plane fits LDS, hipFFT otherwise"
+    "even heights, widths 4 * k: the mixed-radix plane kernel where the odd part is <= 63 and the plane fits LDS, hipFFT otherwise"
     while True:
-        h, w = 4 * rng.randint(3, 50), 4 * rng.randint(3, 50)
+        h, w = 2 * rng.randint(3, 100), 4 * rng.randint(1, 50)
         if h * w <= 36000:
             break
     lead = rng.choice((None, 1, 2, 4, 8))

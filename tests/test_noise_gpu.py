@@ -307,7 +307,7 @@ def test_pyramid_through_wrapper(dev):
 
 
 @pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (4, 64, 64), (16, 64, 64), (8, 32, 32), (2, 128, 64), (4, 32, 128), (128, 128), (1, 128, 128),
-                                  (16, 96, 96), (4, 96, 128), (4, 128, 96), (4, 160, 96), (4, 80, 80), (96, 96), (4, 112, 144), (4, 104, 152), (2, 168, 96), (56, 88), (4, 28, 44), (8, 136, 120), (1, 124, 116), (2, 244, 68), (2, 48, 96), (8, 24, 12), (4, 96, 160), (1, 192, 96), (4, 160, 160), (2, 192, 192), (160, 160), (192, 192), (2, 320, 64), (2, 256, 256), (16, 256, 128), (4, 128, 512), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
+                                  (16, 96, 96), (4, 96, 128), (4, 128, 96), (4, 160, 96), (4, 80, 80), (96, 96), (4, 112, 144), (4, 104, 152), (2, 168, 96), (56, 88), (4, 28, 44), (8, 136, 120), (1, 124, 116), (2, 244, 68), (4, 90, 160), (2, 30, 40), (2, 6, 4), (4, 120, 4), (2, 2, 12), (2, 12), (102, 4), (2, 48, 96), (8, 24, 12), (4, 96, 160), (1, 192, 96), (4, 160, 160), (2, 192, 192), (160, 160), (192, 192), (2, 320, 64), (2, 256, 256), (16, 256, 128), (4, 128, 512), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
 def test_colored(unit, dev):
     seeds = [31, 32]
     cases = [
@@ -623,7 +623,7 @@ def test_capture_after_steps_with_noise_drawn_ahead(dev):
 
 
 @pytest.mark.parametrize("unit", [(4, 96, 96), (16, 96, 96), (96, 96), (4, 96, 128), (4, 160, 96), (2, 80, 80), (8, 24, 12), (4, 160, 160), (2, 192, 192), (160, 160),
-                                  (4, 112, 144), (4, 104, 152), (2, 168, 96), (56, 88), (4, 28, 44), (1, 124, 116), (8, 136, 120), (2, 184, 100), (2, 108, 104), (16, 36, 52), (2, 244, 68), (4, 132, 140), (252, 68)])
+                                  (4, 112, 144), (4, 104, 152), (2, 168, 96), (56, 88), (4, 28, 44), (1, 124, 116), (8, 136, 120), (2, 184, 100), (2, 108, 104), (16, 36, 52), (2, 244, 68), (4, 132, 140), (252, 68), (4, 90, 160), (2, 30, 40), (1, 126, 100), (8, 18, 12), (2, 6, 4), (4, 120, 4), (2, 2, 12), (2, 12), (102, 4)])
 def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, dev):
     """Planes whose sides are a power of two (>= 4) times an odd factor up to 63 (latents of 768 / 896 / 1152 / 1216 / 1280 / 1344-pixel images ...) take the hand-written mixed-radix plane kernel
     (round 3) -- `skr_noise_colored` itself answers OK for them, where it used to refuse everything but powers of two -- and the
@@ -657,7 +657,7 @@ def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, d
     spec = torch.empty(260 * 131, dtype=torch.complex64, device=dev)
     scratch = torch.empty(260 * 260, dtype=torch.float32, device=dev)
     out = torch.empty(260 * 260, dtype=torch.float32, device=dev)
-    for d2, d3 in ((96, 260), (74, 96), (260, 64)):  # odd part 65 > 63; power-of-two part below 4
+    for d2, d3 in ((96, 260), (45, 96), (260, 64), (134, 64)):  # odd part 65 / 67 > 63; odd height
         assert lib.skr_noise_colored(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), 256, sd.data_ptr(), 512, 1, 1, d2, d3, 1.0, 0, 0.0, _hip.current_stream_ptr(dev)) == 7
 
 
