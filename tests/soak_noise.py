@@ -43,6 +43,37 @@ def case_colored():
         unit = (rng.choice((2, 3, 4, 16)), rng.choice((2, 5, 8))) + tuple(min(d, 24) for d in unit[2:])
     T.test_colored.__wrapped__(unit, dev) if hasattr(T.test_colored, "__wrapped__") else T.test_colored(unit, dev)
 
+def case_colored_extreme():
+    "power-of-two units of extreme aspect (one-quad rows, one row pair, long lines, deep outer axes): every route of skr_noise_colored"
+    nd = rng.choice((2, 3, 3))
+    total = 1
+    unit = []
+    for ax in range(nd):
+        hi = 12 if ax == nd - 1 else (7 if nd == 3 and ax == 0 else 12)
+        lo = 2 if ax == nd - 1 else (1 if ax == nd - 2 else 0)
+        e = rng.choice((lo, lo, lo + 1, rng.randint(lo, hi), hi if rng.random() < 0.15 else rng.randint(lo, min(hi, 8))))
+        unit.append(1 << e)
+    while np.prod(unit) > (1 << 21):
+        i = int(np.argmax(unit))
+        unit[i] //= 2
+    T.test_colored.__wrapped__(tuple(unit), dev) if hasattr(T.test_colored, "__wrapped__") else T.test_colored(tuple(unit), dev)
+
+def case_pyramid_extreme():
+    "narrow, short and near-limit planes for the LDS kernels and the any-shape kernels"
+    lead = rng.choice((1, 2, 3))
+    h = rng.choice((1, 2, 3, 4, 5, 7, 8, 16, 31, 64, 200, 380))
+    w = rng.choice((4, 8, 12, 20, 28, 36, 252, 380, 2, 3, 5, 6, 7, 9, 13, 250))
+    if h * w > 380 * 380 or h * w < 2:
+        h = 8
+    unit = (lead, h, w)
+    kw = dict(strength=rng.choice((0.3, 0.6, 0.9)), depth=rng.choice((99, 1, 2, 5)))
+    seeds = [rng.randrange(2**63) for _ in range(2)]
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=PN.PyramidProps(**kw), dtype=torch.float32)
+    for n in range(2):
+        ref = torch.stack([T.pyramid_reference(unit, s, n * 256, **kw) for s in seeds])
+        got = g.generate(None).cpu()
+        assert rel(got, ref) < 2e-5, ("pyramid", unit, kw, n, rel(got, ref))
+
 def case_colored_mixed():
     "even heights, widths 4 * k: the mixed-radix plane kernel where the odd part is <= 63 and the plane fits LDS, hipFFT otherwise"
     while True:
@@ -106,7 +137,7 @@ def case_brownian():
         assert err < 1e-5, ("brownian", unit, st, ms, err)
 
 for i in range(n_cases):
-    for fn in ((case_offset, case_pyramid, case_colored, case_colored_mixed, case_brownian) if not os.environ.get("SOAK_ONLY") else (globals()["case_" + os.environ["SOAK_ONLY"]],)):
+    for fn in ((case_offset, case_pyramid, case_pyramid_extreme, case_colored, case_colored_mixed, case_colored_extreme, case_brownian) if not os.environ.get("SOAK_ONLY") else (globals()["case_" + os.environ["SOAK_ONLY"]],)):
         state = rng.getstate()
         try:
             fn()
@@ -121,6 +152,6 @@ for i in range(n_cases):
             except Exception as e2:
                 print("   the same case again: fails again --", str(e2)[:200])
             rng.setstate(after)
-            if fn in (case_colored, case_colored_mixed):
+            if fn in (case_colored, case_colored_mixed, case_colored_extreme):
                 diag_colored(e.args[0][0] if e.args and isinstance(e.args[0], tuple) else None)
 print("done, failures:", bad)
