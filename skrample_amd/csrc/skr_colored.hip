@@ -46,6 +46,8 @@ struct ColoredArgs {
   float exponent_half_neg;   // -exponent / 2
   float eps_clip;
   float inv_rmax;
+  uint32_t* ctl;             // colored_sample only: [0] ticket counter, [1 + 2 s], [2 + 2 s] the two arrival counters of sample s (zeroed before the launch)
+  int32_t* failed;           // colored_sample only: host-visible flag, set if an arrival counter never filled (see sample_barrier)
 #ifdef SKR_COLORED_TRACE
   uint64_t* trace;           // tools/tune/tune_colored.hip only: [block][16] phase stamps of the plane kernels (s_memrealtime, 10 ns)
 #endif
@@ -69,6 +71,31 @@ uint64_t* g_colored_trace = nullptr;
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 __device__ __forceinline__ unsigned brev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
+
+// Spectrum / partial-sum accesses of colored_sample, whose blocks exchange data INSIDE a launch: relaxed agent-scope atomics,
+// i.e. plain 8-byte loads and stores that go to the coherence point (`sc1`) instead of this XCD's write-back L2 -- what lets
+// sample_barrier get by without the agent-scope fences (a full L2 write-back + invalidate each: 4.3 ms instead of 0.35 ms per draw
+// when every wave fenced).  COH = false: the ordinary accesses of the three-launch path.
+template <bool COH>
+__device__ __forceinline__ void gstore(float2* p, float2 v) {
+  if constexpr (COH) __hip_atomic_store(reinterpret_cast<uint64_t*>(p), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ float2 gload(const float2* p) {
+  if constexpr (COH) return __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void gstore(double* p, double v) {
+  if constexpr (COH) __hip_atomic_store(reinterpret_cast<uint64_t*>(p), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ double gload(const double* p) {
+  if constexpr (COH) return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+}
 
 // ---- small transforms in registers (natural order in and out): the short outer axis, and the first LDS pass of fft_tile ----
 template <bool INV> __device__ __forceinline__ float2 mul_i(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
@@ -126,7 +153,7 @@ __device__ __forceinline__ float2 twid(const float2* tw, int idx) {
 // TO_GLOBAL: the LAST pass sends its (natural-order) results to global memory instead of back to the tile -- element n of
 // line l goes to gout[n * gpitch + l] (the forward plane kernel's half spectrum: lines are frequency columns, so with
 // consecutive lanes on consecutive lines every store instruction covers a run of a spectrum row); the tile is dead afterwards.
-template <bool INVERSE, bool SKIP8 = false, bool TO_GLOBAL = false>
+template <bool INVERSE, bool SKIP8 = false, bool TO_GLOBAL = false, bool COH = false>
 __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, int logN, int L, float2* gout = nullptr, int gpitch = 0) {
   const int half_n = N >> 1, ld = N + 1;
   // Work-item -> (line, k) mapping.  Early stages (butterfly span h < 32) touch points 4h apart, which lands
@@ -197,10 +224,10 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
       const float2 c2 = cmul(f2, w2), c3 = cmul(f3, w3);
       if (TO_GLOBAL && last_out) {
         float2* g = gout + (int64_t)pos * gpitch + line;  // (the last pass has one block of 4h = N points per line: position = pos + i h)
-        g[0] = make_float2(f0.x + c2.x, f0.y + c2.y);
-        g[(int64_t)2 * h * gpitch] = make_float2(f0.x - c2.x, f0.y - c2.y);
-        g[(int64_t)h * gpitch] = make_float2(f1.x + c3.x, f1.y + c3.y);
-        g[(int64_t)3 * h * gpitch] = make_float2(f1.x - c3.x, f1.y - c3.y);
+        gstore<COH>(g, make_float2(f0.x + c2.x, f0.y + c2.y));
+        gstore<COH>(g + (int64_t)2 * h * gpitch, make_float2(f0.x - c2.x, f0.y - c2.y));
+        gstore<COH>(g + (int64_t)h * gpitch, make_float2(f1.x + c3.x, f1.y + c3.y));
+        gstore<COH>(g + (int64_t)3 * h * gpitch, make_float2(f1.x - c3.x, f1.y - c3.y));
       } else {
         p[0] = make_float2(f0.x + c2.x, f0.y + c2.y);
         p[2 * h] = make_float2(f0.x - c2.x, f0.y - c2.y);
@@ -232,6 +259,7 @@ __device__ __forceinline__ float radial_weight(float sum_sq, float inv_rmax, flo
 }
 
 // block-wide sum of two doubles into partial slot (fixed order)
+template <bool COH = false>
 __device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
   __shared__ double red[2][16];  // up to 1024 threads
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
@@ -241,7 +269,7 @@ __device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
   if (threadIdx.x == 0) {
     double a = 0.0, b = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[0][w]; b += red[1][w]; }
-    slot[0] = a; slot[1] = b;
+    gstore<COH>(slot, a); gstore<COH>(slot + 1, b);
   }
 }
 
@@ -446,17 +474,14 @@ constexpr int PLANE_ITEMS = 18;  // staged items per thread: the host keeps (d2/
 // CH / CW: log2 of the plane's height / width as compile-time constants (0 = runtime).  With them every LDS row pitch
 // (W + 1, H + 1) multiply becomes a shift-add and the loop trip counts are known: the runtime-size kernel spends a quarter
 // of its VALU issue on quarter-rate v_mul_lo_u32 index arithmetic.
-template <int MODE, typename T, int CH, int CW>
-__global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs a, int logH_rt, int logW_rt) {
-  extern __shared__ float2 smem[];
+template <int MODE, typename T, int CH, int CW, bool COH = false>
+__device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, int logW_rt, const int64_t smp, const int i1, float2* smem) {
   const int logH = CH ? CH : logH_rt, logW = CW ? CW : logW_rt;
   const int H = CH ? (1 << CH) : a.d2, W = CW ? (1 << CW) : a.d3, WH = CW ? (1 << CW) / 2 + 1 : a.d3h, ldw = W + 1, ldh = H + 1, pairs = H >> 1;
   float2* tw_w = smem;
   float2* tw_h = tw_w + W / 2;
   float2* t1 = tw_h + H / 2;  // row-pair tile
   float2* t2 = t1;            // column tile (aliases t1)
-  const int64_t smp = blockIdx.y;
-  const int i1 = blockIdx.x;
   const uint32_t magic_wh = (uint32_t)((0x100000000ull + (uint32_t)WH - 1) / (uint32_t)WH);  // q / WH == umulhi(q, magic) for q < 2^16
   SKR_STAMP(0);
   make_twiddles(tw_w, W);
@@ -466,9 +491,9 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
   double fa[4] = {0.0, 0.0, 0.0, 0.0};  // MODE 1, first wave: this lane's share of the sample's partial sums (white s1 s2, coloured s1 s2)
   if (MODE == 1 && threadIdx.x < 64) {
     const double* pw = a.partials + (0 * a.batch + smp) * a.n_slots * 2;
-    for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += pw[2 * sl]; fa[1] += pw[2 * sl + 1]; }
+    for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += gload<COH>(pw + 2 * sl); fa[1] += gload<COH>(pw + 2 * sl + 1); }
     const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
-    for (int sl = threadIdx.x; sl < a.n_slots_c; sl += 64) { fa[2] += pc[2 * sl]; fa[3] += pc[2 * sl + 1]; }
+    for (int sl = threadIdx.x; sl < a.n_slots_c; sl += 64) { fa[2] += gload<COH>(pc + 2 * sl); fa[3] += gload<COH>(pc + 2 * sl + 1); }
   }
 
   if (MODE != 1) {
@@ -531,7 +556,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
         if (q < MAIN) put8(1 + (q & (W / 2 - 1)), q >> (CW - 1), va[r], vb[r]);
       }
       if (threadIdx.x < P0) put8(0, threadIdx.x, va[ROUNDS], vb[ROUNDS]);
-      fft_tile<false, true, MODE == 0>(t2, tw_h, H, logH, WH, plane, WH);
+      fft_tile<false, true, MODE == 0, COH>(t2, tw_h, H, logH, WH, plane, WH);
     } else {
     {
       // untangle the row pairs into the column tile (bit-reversed along H for the column transform)
@@ -558,15 +583,15 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
         }
       }
     }
-    fft_tile<false, false, MODE == 0 && (CH >= 2)>(t2, tw_h, H, logH, WH, plane, WH);
+    fft_tile<false, false, MODE == 0 && (CH >= 2), COH>(t2, tw_h, H, logH, WH, plane, WH);
     }
     SKR_STAMP(3);
-    if (MODE == 0) block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
+    if (MODE == 0) block_sums<COH>(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
     if (MODE == 0) {
       if constexpr (CH < 2) {  // (runtime-size instantiation: the transform's last pass may be the 2-point one, which writes the tile)
         for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
           const int row = (int)__umulhi((uint32_t)q, magic_wh), k = q - row * WH;
-          plane[q] = t2[k * ldh + row];
+          gstore<COH>(plane + q, t2[k * ldh + row]);
         }
       }
       SKR_STAMP(4);
@@ -608,7 +633,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
       auto load8 = [&](int k, int g, float2* v) {
         const float2* src = plane + (int64_t)brev(g, CH - 3) * WH + k;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) v[n] = src[(int64_t)n * G * WH];
+        for (int n = 0; n < 8; ++n) v[n] = gload<COH>(src + (int64_t)n * G * WH);
       };
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) {
@@ -643,7 +668,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
 #pragma unroll
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = base + threadIdx.x + i * PLANE_THREADS;
-        if (q < total) rz[i] = plane[q];
+        if (q < total) rz[i] = gload<COH>(plane + q);
       }
 #pragma unroll
       for (int i = 0; i < PLANE_ITEMS; ++i) {
@@ -757,6 +782,12 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
     }
   }
   SKR_STAMP(5);
+}
+
+template <int MODE, typename T, int CH, int CW>
+__global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs a, int logH_rt, int logW_rt) {
+  extern __shared__ float2 smem[];
+  plane_body<MODE, T, CH, CW>(a, logH_rt, logW_rt, (int64_t)blockIdx.y, (int)blockIdx.x, smem);
 }
 
 // ---- planes whose sides are 2^a * r, r odd <= 63 (96, 112, 144, 152, 160, 168, 192 ... : latents of 768 / 896 / 1152 / 1216 / 1280 /
@@ -1138,6 +1169,30 @@ __global__ __launch_bounds__(FFT_THREADS) void colored_strided_axis(const Colore
 // ---- pass C for short outer axes (d1 <= 16, i.e. the channel axis of every latent): one LINE PER LANE --------
 // The whole column lives in registers: 2..16-point forward DFT, radial weights, inverse DFT, with no LDS and
 // no barrier.  Adjacent lanes own adjacent columns, so every load/store instruction is fully coalesced.
+// one column of the outer axis (element n at base[q + n * cols]): forward, radial weights, Parseval terms, inverse -- in registers
+template <int N, bool PACE = false>
+__device__ __forceinline__ void outer_column(const ColoredArgs& a, float2 (&v)[N], int64_t q, double& p1, double& p2) {
+  dft_n<N, false>(v);
+  const int k2 = (int)(q / a.d3h), k3 = (int)(q - (int64_t)k2 * a.d3h);
+  const float f2 = axis_freq(k2, a.d2), f3 = (float)k3 / (float)a.d3;
+  const float rest = f2 * f2 + f3 * f3;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float f1 = axis_freq(k, N);
+    const float wgt = radial_weight(f1 * f1 + rest, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
+    v[k] = make_float2(v[k].x * wgt, v[k].y * wgt);
+    if constexpr (PACE) __builtin_amdgcn_sched_barrier(0);  // (sixteen weights in flight at once cost 50 registers)
+  }
+  {
+    float e = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) e = __builtin_fmaf(v[k].x, v[k].x, __builtin_fmaf(v[k].y, v[k].y, e));
+    p2 += (double)((k3 == 0 || 2 * k3 == a.d3) ? e : 2.f * e);
+    if (q == 0) p1 = (double)v[0].x;
+  }
+  dft_n<N, true>(v);
+}
+
 template <int N>
 __global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs a) {
   const int64_t cols = (int64_t)a.d2 * a.d3h;  // columns per sample; element n of column q sits at q + n*cols
@@ -1148,29 +1203,119 @@ __global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs
     float2 v[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) v[n] = base[q + (int64_t)n * cols];
-    dft_n<N, false>(v);
-    const int k2 = (int)(q / a.d3h), k3 = (int)(q - (int64_t)k2 * a.d3h);
-    const float f2 = axis_freq(k2, a.d2), f3 = (float)k3 / (float)a.d3;
-    const float rest = f2 * f2 + f3 * f3;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const float f1 = axis_freq(k, N);
-      const float wgt = radial_weight(f1 * f1 + rest, a.inv_rmax, a.eps_clip, a.exponent_half_neg);
-      v[k] = make_float2(v[k].x * wgt, v[k].y * wgt);
-    }
-    {
-      float e = 0.f;
-#pragma unroll
-      for (int k = 0; k < N; ++k) e = __builtin_fmaf(v[k].x, v[k].x, __builtin_fmaf(v[k].y, v[k].y, e));
-      p2 += (double)((k3 == 0 || 2 * k3 == a.d3) ? e : 2.f * e);
-      if (q == 0) p1 = (double)v[0].x;
-    }
-    dft_n<N, true>(v);
+    outer_column<N>(a, v, q, p1, p2);
 #pragma unroll
     for (int n = 0; n < N; ++n) base[q + (int64_t)n * cols] = v[n];
   }
   if (a.n_slots_c > 0) block_sums(p1, p2, a.partials + (int64_t)a.batch * a.n_slots * 2 + (smp * a.n_slots_c + blockIdx.x) * 2);
 }
+
+#ifdef SKR_COLORED_SAMPLE
+// ---- one launch per draw for 3-D units: the planes of a sample meet twice inside the kernel ------------------------------
+// Round 3 EXPERIMENT, not compiled into the library (-DSKR_COLORED_SAMPLE: tools/tune/tune_colored.hip, tools/ab_colored_sample.py).
+// Measured SLOWER than the three launches: 622 vs 339 us at 256 x (16, 128, 128), 367 vs 332 us at 1024 x (4, 128, 128)
+// (profiles/r03_colored_one_launch_experiment.txt).  A block spends 27 us between its last spectrum store and the end of
+// its outer-axis share and 12 us more at the second arrival -- its sample's planes start up to 30 us apart once the first
+// dispatch round is over -- and holds its 67 KB of LDS all the while, so a CU has no block in a transform 63-82 % of the
+// time; and the exchange has to bypass the XCD's write-back L2 (`sc1` accesses: +3 us per forward plane), because the
+// agent-scope fences that would make ordinary accesses visible across XCDs write back and invalidate the whole L2 each time
+// (4.3 ms per draw with them).  A task queue that never waits (A / B / C tasks of different samples interleaved by ticket) would
+// still pay the `sc1` stores: 19 + 15 + ~5 us per plane against 15.5 + 15.5 + the hidden share of 83 us now -- a few per
+// cent at best.  Kept for the record of what the exchange costs on this memory system.
+// The three launches above (plane kernel -> outer axis -> plane kernel) move the half spectrum through HBM four
+// times, and the outer-axis launch in the middle is nothing but that traffic (83 of 341 us at 256 x (16, 128, 128), at
+// 6.5 TB/s).  Here ONE block owns plane i1 of a sample from the draw to the result: it transforms its plane and stores the
+// half spectrum, waits for the sample's other planes, runs the outer axis over its 1 / d1 share of the columns (forward,
+// weights, Parseval sums, inverse: in registers, as above), waits again and takes its plane back through the inverse
+// transforms.  The exchange is 66 KB per block and step, most of it still in L2 / the Infinity Cache, while the CU's other
+// block computes: no phase of the draw is bound by HBM any more.
+// Waiting for sibling blocks is safe only if they are guaranteed to be running or to start without this block's help.  Blocks
+// therefore take their (sample, plane) from a TICKET drawn when they start: tickets below the oldest unfinished one all belong to
+// finished blocks, every ticket holder is resident, and a sample's d1 tickets are consecutive -- so whenever the chip has no room
+// for a new block, the resident ones (>= d1 of them) include every sibling of the oldest sample, which can finish.  No
+// assumption about the order in which the hardware starts blocks.  A wait is bounded all the same (2 s of the real-time
+// counter): on expiry the block raises `failed` (host-visible, checked by the next call) and leaves.
+// Every global access the planes of a sample exchange goes to the coherence point (gstore / gload<true>), so the arrival needs no
+// cache maintenance: each wave waits for its own stores to be acknowledged, the block meets, one lane signs in and polls.
+__device__ __forceinline__ bool sample_barrier(uint32_t* counter, uint32_t expected, int32_t* failed) {
+  __shared__ int arrived_sh;
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt / lgkmcnt / expcnt 0: this wave's stores of the phase before have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    int ok = 1;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { ok = 0; break; }  // 100 MHz: 2 s
+    }
+    if (!ok) __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    arrived_sh = ok;
+  }
+  __syncthreads();
+  return arrived_sh != 0;
+}
+
+template <typename T, int CH, int CW, int N>
+__global__ __launch_bounds__(PLANE_THREADS, 4) void colored_sample(const ColoredArgs a, int logH_rt, int logW_rt) {
+  extern __shared__ float2 smem[];
+  __shared__ uint32_t ticket_sh;
+  if (threadIdx.x == 0) ticket_sh = __hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const uint32_t ticket = ticket_sh;
+  const int64_t smp = ticket / (uint32_t)N;
+  const int i1 = (int)(ticket % (uint32_t)N);
+  if (smp >= a.batch) return;  // (cannot happen: the grid is batch * N blocks)
+  plane_body<0, float, CH, CW, true>(a, logH_rt, logW_rt, smp, i1, smem);
+  if (!sample_barrier(a.ctl + 1 + 2 * smp, (uint32_t)N, a.failed)) return;
+  {
+    // this block's share of the sample's columns: [c0, c1), two columns per thread in flight
+    const int64_t cols = (int64_t)a.d2 * a.d3h;
+    const int64_t per = (cols + N - 1) / N, c0 = per * i1, c1 = c0 + per < cols ? c0 + per : cols;
+    float2* base = a.spec + smp * (int64_t)N * cols;
+    double p1 = 0.0, p2 = 0.0;
+    // (32-bit column indices on uniform per-plane pointers: one offset register serves the N loads and stores of a column)
+    const uint32_t cols32 = (uint32_t)cols, e1 = (uint32_t)c1;
+    if constexpr (N >= 16) {  // one column per thread and trip (two would not fit the 128 registers of four waves per SIMD)
+      for (uint32_t q = (uint32_t)c0 + threadIdx.x; q < e1; q += PLANE_THREADS) {
+        float2 v[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) v[n] = gload<true>(base + (size_t)n * cols32 + q);
+        outer_column<N, true>(a, v, q, p1, p2);
+#pragma unroll
+        for (int n = 0; n < N; ++n) gstore<true>(base + (size_t)n * cols32 + q, v[n]);
+      }
+    } else {
+      for (uint32_t q = (uint32_t)c0 + threadIdx.x; q < e1; q += 2 * PLANE_THREADS) {
+        const uint32_t q2 = q + PLANE_THREADS;
+        const bool two = q2 < e1;
+        float2 v[N], w[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) v[n] = gload<true>(base + (size_t)n * cols32 + q);
+        if (two) {
+#pragma unroll
+          for (int n = 0; n < N; ++n) w[n] = gload<true>(base + (size_t)n * cols32 + q2);
+        }
+        outer_column<N>(a, v, q, p1, p2);
+#pragma unroll
+        for (int n = 0; n < N; ++n) gstore<true>(base + (size_t)n * cols32 + q, v[n]);
+        if (two) {
+          outer_column<N>(a, w, q2, p1, p2);
+#pragma unroll
+          for (int n = 0; n < N; ++n) gstore<true>(base + (size_t)n * cols32 + q2, w[n]);
+        }
+      }
+    }
+    block_sums<true>(p1, p2, a.partials + (int64_t)a.batch * a.n_slots * 2 + (smp * a.n_slots_c + i1) * 2);
+  }
+#ifdef SKR_COLORED_TRACE
+  if (threadIdx.x == 0 && a.trace) a.trace[(int64_t)blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (!sample_barrier(a.ctl + 2 + 2 * smp, (uint32_t)N, a.failed)) return;
+  plane_body<1, T, CH, CW, true>(a, logH_rt, logW_rt, smp, i1, smem);
+}
+
+#endif  // SKR_COLORED_SAMPLE
 
 // ---- pass F: rescale per sample ---------------------------------------------------------------------------------
 template <typename T>
@@ -1215,6 +1360,7 @@ static int ilog2_exact(int64_t v) {
   return l;
 }
 
+[[maybe_unused]] static int32_t* g_sample_failed = nullptr;  // (SKR_COLORED_SAMPLE experiment) pinned, host-visible: raised by a colored_sample block whose wait for its sample's other planes expired
 #define SKR_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH; } while (0)
 // kernels that need more than the default 48 KiB of dynamic LDS must opt in
 #define SKR_ALLOW_LDS(kernel, bytes) do { if ((bytes) > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) return SKR_ERR_UNSUPPORTED; } while (0)
@@ -1337,6 +1483,16 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   if (fused) {
     if (d1 > partial_slots) return SKR_ERR_SHAPE;
     a.n_slots = d1;
+#ifdef SKR_COLORED_SAMPLE
+    // 3-D units of 128 x 128 / 64 x 64 planes (16-bit and fp32 results): the whole draw in one launch (colored_sample)
+    bool sample_fused = nd == 3 && l2 == l3 && (l2 == 7 || l2 == 6) && (out_dtype == SKR_BF16 || out_dtype == SKR_F16 || out_dtype == SKR_F32) &&
+                        4 * batch * (int64_t)d1 + batch + 1 <= 4 * batch * partial_slots && getenv("SKR_FFT_NO_SAMPLE") == nullptr;
+    if (sample_fused) {
+      if (!g_sample_failed && hipHostMalloc(reinterpret_cast<void**>(&g_sample_failed), sizeof(int32_t), hipHostMallocMapped) == hipSuccess) *g_sample_failed = 0;
+      if (!g_sample_failed) sample_fused = false;
+      else if (*g_sample_failed) return SKR_ERR_LAUNCH;  // an earlier colored_sample launch gave up waiting: its result was not valid
+    }
+#endif
     dim3 grid((unsigned)d1, (unsigned)batch);
 #define SKR_PLANE_T(MODE, T, CH, CW) do { SKR_ALLOW_LDS((colored_plane<MODE, T, CH, CW>), lds_plane); hipLaunchKernelGGL((colored_plane<MODE, T, CH, CW>), grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3); } while (0)
 #define SKR_PLANE_SZ(MODE, T)                                                    \
@@ -1354,6 +1510,33 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     SKR_CHECK_LAUNCH()
     if (nd == 2) {
       SKR_PLANE(2);
+#ifdef SKR_COLORED_SAMPLE
+    } else if (sample_fused) {
+      // one launch: tickets + two arrival counters per sample at the tail of the partials buffer, zeroed on the stream
+      a.n_slots_c = d1;
+      a.ctl = reinterpret_cast<uint32_t*>(partials_f64 + 4 * batch * (int64_t)d1);
+      a.failed = g_sample_failed;
+      if (hipMemsetAsync(a.ctl, 0, sizeof(uint32_t) * (size_t)(2 * batch + 1), s) != hipSuccess) return SKR_ERR_LAUNCH;
+      dim3 grid1((unsigned)(batch * d1));
+#define SKR_SAMPLE_N(T, CH, CW, N) do { SKR_ALLOW_LDS((colored_sample<T, CH, CW, N>), lds_plane); hipLaunchKernelGGL((colored_sample<T, CH, CW, N>), grid1, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3); } while (0)
+#define SKR_SAMPLE_SZ(T, CH, CW)                                     \
+      switch (d1) {                                                  \
+        case 2: SKR_SAMPLE_N(T, CH, CW, 2); break;                   \
+        case 4: SKR_SAMPLE_N(T, CH, CW, 4); break;                   \
+        case 8: SKR_SAMPLE_N(T, CH, CW, 8); break;                   \
+        default: SKR_SAMPLE_N(T, CH, CW, 16); break;                 \
+      }
+#define SKR_SAMPLE(T) do { if (l2 == 7) { SKR_SAMPLE_SZ(T, 7, 7) } else { SKR_SAMPLE_SZ(T, 6, 6) } } while (0)
+      switch (out_dtype) {
+        case SKR_BF16: SKR_SAMPLE(__bf16); break;
+        case SKR_F16: SKR_SAMPLE(_Float16); break;
+        default: SKR_SAMPLE(float); break;
+      }
+      SKR_CHECK_LAUNCH();
+#undef SKR_SAMPLE
+#undef SKR_SAMPLE_SZ
+#undef SKR_SAMPLE_N
+#endif
     } else {
       SKR_PLANE_SZ(0, float);
       SKR_CHECK_LAUNCH();

@@ -88,5 +88,26 @@ int main(int argc, char** argv) {
     }
     printf("# mean fraction of the kernel span in which a CU has NO block in a compute phase: %.3f\n", idle_sum / cus);
   }
+  if (getenv("SKR_FFT_NO_SAMPLE") == nullptr) {
+    // one-launch kernel (colored_sample): the twelve stamps of a block are one timeline --
+    // start | drawn | rows | columns | stored || arrival 1 + outer axis done || arrival 2 = inverse start | landed | columns | rows | factor | stored
+    uint64_t t0 = ~0ull;
+    for (int64_t b = 0; b < blocks; ++b) t0 = std::min(t0, h[b * 16]);
+    std::vector<double> sum(12, 0.0);
+    for (int64_t b = 0; b < blocks; ++b)
+      for (int i = 1; i < 12; ++i) sum[i] += (double)(h[b * 16 + i] - h[b * 16 + i - 1]) * 0.01;
+    printf("# one launch, mean interval durations (us):");
+    for (int i = 1; i < 12; ++i) printf(" %.2f", sum[i] / blocks);
+    printf("\n");
+    std::vector<std::pair<uint64_t, int64_t>> order;
+    for (int64_t b = 0; b < blocks; ++b) order.push_back({h[b * 16], b});
+    std::sort(order.begin(), order.end());
+    for (int64_t k = 0; k < (int64_t)order.size(); k += order.size() / 48) {
+      const int64_t b = order[k].second;
+      printf("  start rank %5lld block %5lld:", (long long)k, (long long)b);
+      for (int i = 0; i < 12; ++i) printf(" %8.2f", (double)(h[b * 16 + i] - t0) * 0.01);
+      printf("\n");
+    }
+  }
   return 0;
 }
