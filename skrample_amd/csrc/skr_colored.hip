@@ -46,6 +46,7 @@ struct ColoredArgs {
   float exponent_half_neg;   // -exponent / 2
   float eps_clip;
   float inv_rmax;
+  int32_t raw;               // MODE 1 of the plane kernels: plain inverse transform (no 1/N, no rescale factor) -- colored_planes
   uint32_t* ctl;             // colored_sample only: [0] ticket counter, [1 + 2 s], [2 + 2 s] the two arrival counters of sample s (zeroed before the launch)
   int32_t* failed;           // colored_sample only: host-visible flag, set if an arrival counter never filled (see sample_barrier)
 #ifdef SKR_COLORED_TRACE
@@ -489,7 +490,7 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
   float2* plane = a.spec + ((smp * a.d1 + i1) * (int64_t)H) * WH;
   double s1 = 0.0, s2 = 0.0;
   double fa[4] = {0.0, 0.0, 0.0, 0.0};  // MODE 1, first wave: this lane's share of the sample's partial sums (white s1 s2, coloured s1 s2)
-  if (MODE == 1 && threadIdx.x < 64) {
+  if (MODE == 1 && !a.raw && threadIdx.x < 64) {
     const double* pw = a.partials + (0 * a.batch + smp) * a.n_slots * 2;
     for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += gload<COH>(pw + 2 * sl); fa[1] += gload<COH>(pw + 2 * sl + 1); }
     const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
@@ -758,12 +759,12 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
       for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
     if (threadIdx.x == 0) {
       const double n = (double)a.d1 * (double)H * (double)W;
-      factor_sh = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
+      factor_sh = a.raw ? 1.0f : rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
     }
   }
   fft_tile<true, FUSE_ROW>(t1, tw_w, W, logW, pairs);
   SKR_STAMP(3);
-  const float scale = 1.0f / ((float)a.d1 * (float)H * (float)W);
+  const float scale = a.raw ? 1.0f : 1.0f / ((float)a.d1 * (float)H * (float)W);
   const float factor = MODE == 2 ? (float)s1 : factor_sh;
   SKR_STAMP(4);
   T* dst = reinterpret_cast<T*>(a.out) + ((smp * a.d1 + i1) * (int64_t)H) * W;
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
   const int64_t smp = blockIdx.y;
   const int i1 = blockIdx.x;
   double fa[4] = {0.0, 0.0, 0.0, 0.0};
-  if (MODE == 1 && threadIdx.x < 64) {  // the sample's partial sums: loaded now, reduced before the last transform (see colored_plane)
+  if (MODE == 1 && !a.raw && threadIdx.x < 64) {  // the sample's partial sums: loaded now, reduced before the last transform (see colored_plane)
     const double* pw = a.partials + (0 * a.batch + smp) * a.n_slots * 2;
     for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += pw[2 * sl]; fa[1] += pw[2 * sl + 1]; }
     const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
@@ -1069,12 +1070,12 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
     if (threadIdx.x == 0) {
       const double n = (double)a.d1 * (double)H * (double)W;
-      factor_sh = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
+      factor_sh = a.raw ? 1.0f : rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
     }
   }
   fft_tile<true>(t1, tw_ws, ax_w.m, ax_w.a, pairs * ax_w.r);
   mixed_combine<true>(t1, tw_w, ax_w, pairs);
-  const float scale = 1.0f / ((float)a.d1 * (float)H * (float)W);
+  const float scale = a.raw ? 1.0f : 1.0f / ((float)a.d1 * (float)H * (float)W);
   const float factor = MODE == 2 ? (float)s1 : factor_sh;
   T* dst = reinterpret_cast<T*>(a.out) + ((smp * a.d1 + i1) * (int64_t)H) * W;
   const int quads = W >> 2;
@@ -1365,6 +1366,90 @@ static int ilog2_exact(int64_t v) {
 // kernels that need more than the default 48 KiB of dynamic LDS must opt in
 #define SKR_ALLOW_LDS(kernel, bytes) do { if ((bytes) > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) return SKR_ERR_UNSUPPORTED; } while (0)
 
+namespace skr {
+
+static bool mixed_factor_axis(int d, MixedAxis& x) {
+  int v = d;
+  while (v % 2 == 0) v /= 2;
+  const int r = v;  // the odd part: one direct r-point combining pass
+  v = d / r;
+  if (r > 63 || v < 2 || d > 4096) return false;  // (d2 even and d3 % 4 == 0 are the plane kernel's own conditions)
+  int lg = 0;
+  while ((1 << lg) < v) ++lg;
+  x.n = d; x.r = r; x.a = lg; x.m = v; x.pitch = r * (v + 1);
+  x.magic_r = (uint32_t)((0x100000000ull + (uint32_t)r - 1) / (uint32_t)r);
+  return true;
+}
+
+// geometry, LDS bytes and block size of colored_plane_mixed for a d2 x d3 plane (two_d: the plane is a whole 2-D unit, whose
+// half plane is staged in registers once more); false if the plane is not covered
+static bool mixed_plane_geometry(int d2, int d3, bool two_d, MixedGeom& mg, size_t& lds, int& threads) {
+  if (d2 % 2 != 0 || d3 % 4 != 0 || !mixed_factor_axis(d2, mg.h) || !mixed_factor_axis(d3, mg.w)) return false;
+  const int64_t pairs = d2 / 2, wh = d3 / 2 + 1;
+  const size_t tile = (size_t)(pairs * mg.w.pitch > wh * mg.h.pitch ? pairs * mg.w.pitch : wh * mg.h.pitch);
+  lds = sizeof(float2) * ((size_t)d3 + d2 + mg.w.m / 2 + mg.h.m / 2 + tile);
+  mg.magic_wh = (uint32_t)((0x100000000ull + (uint32_t)wh - 1) / (uint32_t)wh);
+  // 512-thread blocks while every register-staged transpose fits 18 items per thread, else 1024 (3-D units only need the
+  // row-pair transposes to fit; 2-D units also the full half plane)
+  auto fits = [&](int t) {
+    return pairs * d3 <= (int64_t)t * PLANE_ITEMS && pairs * wh <= (int64_t)t * PLANE_ITEMS && (int64_t)d2 * wh <= 2ll * t * PLANE_ITEMS &&
+           (!two_d || (int64_t)d2 * wh <= (int64_t)t * PLANE_ITEMS);
+  };
+  threads = fits(512) ? 512 : (fits(1024) ? 1024 : 0);
+  return lds <= 156 * 1024 && threads != 0;
+}
+
+// Independent d2 x d3 planes on the LDS plane kernels, for skr_colored_any.hip (3-D units whose leading axis is a direct DFT there:
+// not a power of two <= 16).  mode 0: plane p of sample b is drawn
+// (elements p * d2 * d3 ... of the sample's Philox stream) and transformed, half spectrum to spec[b][p][d2][d3/2+1], its (sum,
+// sum of squares) to plane_partials[b][p][2].  mode 1: the plain inverse of every plane (no 1/N: hipFFT's C2R convention), fp32,
+// to real_out[b][p][d2][d3].  SKR_ERR_UNSUPPORTED for a plane shape the kernels do not cover.
+int colored_planes(int mode, float2* spec, double* plane_partials, float* real_out, const uint64_t* seeds, uint64_t stream_id,
+                   int64_t batch, int64_t planes, int32_t d2, int32_t d3, hipStream_t s) {
+  if (batch <= 0 || planes <= 0 || batch > 65535 || planes > 0x7fffffffll || d2 < 2 || d3 < 4 || getenv("SKR_FFT_NO_PLANES") != nullptr) return SKR_ERR_UNSUPPORTED;
+  ColoredArgs a;
+  a.spec = spec; a.real_out = nullptr; a.partials = plane_partials; a.seeds = seeds; a.stream = stream_id;
+  a.batch = batch; a.d1 = (int32_t)planes; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
+  a.n_slots = (int32_t)planes; a.n_slots_c = 0; a.has_energy = 0; a.energy = 0.0; a.out = real_out;
+  a.exponent_half_neg = 0.f; a.eps_clip = 1.f; a.inv_rmax = 1.f; a.raw = 1; a.ctl = nullptr; a.failed = nullptr;
+#ifdef SKR_COLORED_TRACE
+  a.trace = nullptr;
+#endif
+  const dim3 grid((unsigned)planes, (unsigned)batch);
+  const int l3 = ilog2_exact(d3), l2 = ilog2_exact(d2);
+  const int64_t d3h = a.d3h;
+  const size_t tile_points = (size_t)(d2 / 2) * (d3 + 1) > (size_t)d3h * (d2 + 1) ? (size_t)(d2 / 2) * (d3 + 1) : (size_t)d3h * (d2 + 1);
+  const size_t lds_plane = sizeof(float2) * ((size_t)d3 / 2 + d2 / 2 + tile_points);
+  const bool pow2_plane = l3 >= 2 && l2 >= 1 && lds_plane <= 150 * 1024 && (int64_t)(d2 / 2) * d3 <= PLANE_THREADS * PLANE_ITEMS &&
+                          (int64_t)(d2 / 2) * d3h <= PLANE_THREADS * PLANE_ITEMS && (int64_t)d2 * d3h <= 2ll * PLANE_THREADS * PLANE_ITEMS;
+  if (pow2_plane) {
+#define SKR_PLANES_T(MODE, CH, CW) do { SKR_ALLOW_LDS((colored_plane<MODE, float, CH, CW>), lds_plane); hipLaunchKernelGGL((colored_plane<MODE, float, CH, CW>), grid, dim3(PLANE_THREADS), lds_plane, s, a, l2, l3); } while (0)
+#define SKR_PLANES(MODE)                                \
+    if (l2 == 7 && l3 == 7) SKR_PLANES_T(MODE, 7, 7);   \
+    else if (l2 == 6 && l3 == 6) SKR_PLANES_T(MODE, 6, 6); \
+    else SKR_PLANES_T(MODE, 0, 0)
+    if (mode == 0) { SKR_PLANES(0); } else { SKR_PLANES(1); }
+#undef SKR_PLANES
+#undef SKR_PLANES_T
+    SKR_CHECK_LAUNCH();
+    return SKR_OK;
+  }
+  MixedGeom mg;
+  size_t lds_mixed = 0;
+  int threads = 0;
+  if (!mixed_plane_geometry(d2, d3, false, mg, lds_mixed, threads) || mg.h.r + mg.w.r > 10) return SKR_ERR_UNSUPPORTED;  // (larger odd parts: hipFFT measured faster)
+#define SKR_PLANES_M(MODE) do {                                                                                                                  \
+    if (threads == 512) { SKR_ALLOW_LDS((colored_plane_mixed<MODE, float, 512>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, float, 512>), grid, dim3(512), lds_mixed, s, a, mg); } \
+    else { SKR_ALLOW_LDS((colored_plane_mixed<MODE, float, 1024>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, float, 1024>), grid, dim3(1024), lds_mixed, s, a, mg); }              \
+  } while (0)
+  if (mode == 0) SKR_PLANES_M(0); else SKR_PLANES_M(1);
+#undef SKR_PLANES_M
+  SKR_CHECK_LAUNCH();
+  return SKR_OK;
+}
+
+}  // namespace skr
+
 extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64, int64_t partial_slots,
                                  const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t d1, int32_t d2, int32_t d3,
                                  double exponent, int32_t has_energy, double energy, void* stream) {
@@ -1377,42 +1462,18 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   const bool pow2 = l3 >= 2 && l2 >= 1 && l1 >= 0 && d3 <= FFT_MAX_TILE && d2 <= FFT_MAX_TILE && d1 <= FFT_MAX_TILE;
   // planes whose sides are a power of two times an odd factor up to 63 (96, 112, 144, 160, 192 ...) under a power-of-two channel axis: colored_plane_mixed
   MixedGeom mg;
-  auto factor_axis = [](int d, MixedAxis& x) -> bool {
-    int v = d;
-    while (v % 2 == 0) v /= 2;
-    const int r = v;  // the odd part: one direct r-point combining pass
-    v = d / r;
-    if (r > 63 || v < 2 || d > 4096) return false;  // (d2 even and d3 % 4 == 0 are the plane kernel's own conditions)
-    int lg = 0;
-    while ((1 << lg) < v) ++lg;
-    x.n = d; x.r = r; x.a = lg; x.m = v; x.pitch = r * (v + 1);
-    x.magic_r = (uint32_t)((0x100000000ull + (uint32_t)r - 1) / (uint32_t)r);
-    return true;
-  };
   bool mixed = false;
   size_t lds_mixed = 0;
   int mixed_threads = 0;
-  if (!pow2 && l1 >= 0 && d1 <= 16 && d2 % 2 == 0 && d3 % 4 == 0 && factor_axis(d2, mg.h) && factor_axis(d3, mg.w) && getenv("SKR_FFT_NO_MIXED") == nullptr) {
-    const int64_t pairs = d2 / 2, wh = d3 / 2 + 1;
-    const size_t tile = (size_t)(pairs * mg.w.pitch > wh * mg.h.pitch ? pairs * mg.w.pitch : wh * mg.h.pitch);
-    lds_mixed = sizeof(float2) * ((size_t)d3 + d2 + mg.w.m / 2 + mg.h.m / 2 + tile);
-    mg.magic_wh = (uint32_t)((0x100000000ull + (uint32_t)wh - 1) / (uint32_t)wh);
-    // 512-thread blocks while every register-staged transpose fits 18 items per thread, else 1024 (3-D units only need the
-    // row-pair transposes to fit; 2-D units also the full half plane)
-    auto fits = [&](int threads) {
-      return pairs * d3 <= (int64_t)threads * PLANE_ITEMS && pairs * wh <= (int64_t)threads * PLANE_ITEMS && (int64_t)d2 * wh <= 2ll * threads * PLANE_ITEMS &&
-             (d1 > 1 || (int64_t)d2 * wh <= (int64_t)threads * PLANE_ITEMS);
-    };
-    mixed_threads = fits(512) ? 512 : (fits(1024) ? 1024 : 0);
-    mixed = lds_mixed <= 156 * 1024 && mixed_threads != 0 && d1 <= partial_slots;
-  }
+  if (!pow2 && l1 >= 0 && d1 <= 16 && getenv("SKR_FFT_NO_MIXED") == nullptr)
+    mixed = mixed_plane_geometry(d2, d3, d1 == 1, mg, lds_mixed, mixed_threads) && d1 <= partial_slots;
   if (!pow2 && !mixed) return SKR_ERR_UNSUPPORTED;  // (the caller takes skr_noise_colored_any: hipFFT)
   if (batch > 65535) return SKR_ERR_UNSUPPORTED;
   ColoredArgs a;
   a.spec = reinterpret_cast<float2*>(spec_c64); a.real_out = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
   a.stream = stream_id; a.batch = batch; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
   a.exponent_half_neg = (float)(-exponent / 2.0);
-  a.out = out; a.has_energy = has_energy; a.energy = energy; a.n_slots_c = 0;
+  a.out = out; a.has_energy = has_energy; a.energy = energy; a.n_slots_c = 0; a.raw = 0;
 #ifdef SKR_COLORED_TRACE
   a.trace = g_colored_trace;
 #endif

@@ -142,40 +142,46 @@ __global__ __launch_bounds__(256) void any_weights(const AnyArgs a) {
 // (line-private, no barriers after the twiddle table).  Lines of axis j are `inner` complex elements apart, inner = everything
 // below the axis.  MODE 0 forward, 1 inverse (both in place), 2 forward + radial weights of the full N-D frequency + inverse:
 // the outermost axis, which is transformed last on the way in and first on the way out.
-constexpr int AXIS_THREADS = 64;
+// Round 3: a block is FOUR waves over one tile of 64 lines -- the waves share the staged tile and split the d outputs of every
+// line between them (wave w: k = w, w + 4, ...), so a tile costs the same LDS as before but runs four times as many waves, and the
+// twiddle index (n k mod d) is uniform per wave.  (The one-wave version left ~7 waves per CU at video-latent sizes.)
+constexpr int AXIS_LINES = 64, AXIS_WAVES = 4, AXIS_THREADS = AXIS_LINES * AXIS_WAVES;
 template <int MODE>
 __global__ __launch_bounds__(AXIS_THREADS) void any_outer_axis(const AnyArgs a, int axis) {
   extern __shared__ float2 sh[];  // [d] twiddles, [d][64] values, [d][64] spectrum (MODE 2)
-  const int lane = threadIdx.x, d = a.outer[axis];
+  const int lane = threadIdx.x & (AXIS_LINES - 1), wave = threadIdx.x >> 6, d = a.outer[axis];
   float2* tw = sh;
   float2* v = tw + d;
-  float2* x = v + d * AXIS_THREADS;
-  for (int j = lane; j < d; j += AXIS_THREADS) {
+  float2* x = v + d * AXIS_LINES;
+  for (int j = threadIdx.x; j < d; j += AXIS_THREADS) {
     float sn, cs;
     sincospif(-2.0f * (float)j / (float)d, &sn, &cs);
     tw[j] = make_float2(cs, sn);
   }
-  __syncthreads();
   const int64_t plane = (int64_t)a.d1 * a.d2 * a.d3h;
   int64_t inner = plane, sample = plane;
   for (int j = 0; j < a.n_outer; ++j) { sample *= a.outer[j]; if (j > axis) inner *= a.outer[j]; }
   const int64_t lines = sample / d;
   float2* base = a.spec + (int64_t)blockIdx.y * sample;
-  for (int64_t q = (int64_t)blockIdx.x * AXIS_THREADS + lane; q < lines; q += (int64_t)gridDim.x * AXIS_THREADS) {
-    const int64_t hi = q / inner, lo = q - hi * inner;
+  for (int64_t q0 = (int64_t)blockIdx.x * AXIS_LINES; q0 < lines; q0 += (int64_t)gridDim.x * AXIS_LINES) {
+    const int64_t q = q0 + lane;
+    const bool on = q < lines;
+    const int64_t hi = on ? q / inner : 0, lo = on ? q - hi * inner : 0;
     float2* line = base + hi * d * inner + lo;
-    for (int n = 0; n < d; ++n) v[n * AXIS_THREADS + lane] = line[(int64_t)n * inner];
+    __syncthreads();  // (the tile of the trip before has been consumed; first trip: the twiddles are in place)
+    for (int n = wave; n < d; n += AXIS_WAVES) v[n * AXIS_LINES + lane] = on ? line[(int64_t)n * inner] : make_float2(0.f, 0.f);
+    __syncthreads();
     if (MODE == 1) {
-      for (int n = 0; n < d; ++n) {
+      for (int n = wave; n < d; n += AXIS_WAVES) {
         float2 acc = make_float2(0.f, 0.f);
         int idx = 0;  // (n * k) mod d
         for (int k = 0; k < d; ++k) {
-          const float2 t = tw[idx], u = v[k * AXIS_THREADS + lane];
+          const float2 t = tw[idx], u = v[k * AXIS_LINES + lane];
           acc.x += u.x * t.x + u.y * t.y;  // conj(t)
           acc.y += u.y * t.x - u.x * t.y;
           idx += n; if (idx >= d) idx -= d;
         }
-        line[(int64_t)n * inner] = acc;
+        if (on) line[(int64_t)n * inner] = acc;
       }
       continue;
     }
@@ -193,33 +199,34 @@ __global__ __launch_bounds__(AXIS_THREADS) void any_outer_axis(const AnyArgs a, 
         rest += fj * fj;
       }
     }
-    for (int k = 0; k < d; ++k) {
+    for (int k = wave; k < d; k += AXIS_WAVES) {
       float2 acc = make_float2(0.f, 0.f);
       int idx = 0;
       for (int n = 0; n < d; ++n) {
-        const float2 t = tw[idx], u = v[n * AXIS_THREADS + lane];
+        const float2 t = tw[idx], u = v[n * AXIS_LINES + lane];
         acc.x += u.x * t.x - u.y * t.y;
         acc.y += u.x * t.y + u.y * t.x;
         idx += k; if (idx >= d) idx -= d;
       }
-      if (MODE == 0) { line[(int64_t)k * inner] = acc; continue; }
+      if (MODE == 0) { if (on) line[(int64_t)k * inner] = acc; continue; }
       const float f0 = axis_freq(k, d);
       float radius = __builtin_amdgcn_sqrtf(f0 * f0 + rest) * a.inv_rmax;
       radius = radius < a.eps_clip ? a.eps_clip : radius;
       const float w = __builtin_amdgcn_exp2f(a.exponent_half_neg * __builtin_amdgcn_logf(radius));
-      x[k * AXIS_THREADS + lane] = make_float2(acc.x * w, acc.y * w);
+      x[k * AXIS_LINES + lane] = make_float2(acc.x * w, acc.y * w);
     }
     if (MODE == 2) {
-      for (int n = 0; n < d; ++n) {
+      __syncthreads();
+      for (int n = wave; n < d; n += AXIS_WAVES) {
         float2 acc = make_float2(0.f, 0.f);
         int idx = 0;
         for (int k = 0; k < d; ++k) {
-          const float2 t = tw[idx], u = x[k * AXIS_THREADS + lane];
+          const float2 t = tw[idx], u = x[k * AXIS_LINES + lane];
           acc.x += u.x * t.x + u.y * t.y;  // conj(t)
           acc.y += u.y * t.x - u.x * t.y;
           idx += n; if (idx >= d) idx -= d;
         }
-        line[(int64_t)n * inner] = acc;
+        if (on) line[(int64_t)n * inner] = acc;
       }
     }
   }
@@ -313,12 +320,30 @@ __global__ __launch_bounds__(256) void selftest_check_inverse(const SelfTest t) 
 
 }  // namespace
 
-// one attempt with the last `fft_rank` axes given to hipFFT and every axis outside them to the direct-DFT kernels
+// (skr_colored.hip) rfft2 / irfft2 of independent planes on the LDS plane kernels
+namespace skr {
+int colored_planes(int mode, float2* spec, double* plane_partials, float* real_out, const uint64_t* seeds, uint64_t stream_id,
+                   int64_t batch, int64_t planes, int32_t d2, int32_t d3, hipStream_t s);
+}
+
+// the plane kernels leave one (sum, sum of squares) per drawn plane: folded into the SLOTS white-noise slots of the sample that
+// any_finish reads (slot t = planes t, t + SLOTS, ... in that order)
+__global__ __launch_bounds__(SLOTS) void any_fold_plane_sums(const AnyArgs a, const double* plane_sums, int64_t planes) {
+  const int64_t smp = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t p = threadIdx.x; p < planes; p += SLOTS) { s1 += plane_sums[(smp * planes + p) * 2]; s2 += plane_sums[(smp * planes + p) * 2 + 1]; }
+  double* slot = a.partials + ((0 * a.batch + smp) * SLOTS + threadIdx.x) * 2;
+  slot[0] = s1; slot[1] = s2;
+}
+
+// one attempt with the last `fft_rank` axes given to hipFFT and every axis outside them to the direct-DFT kernels;
+// planes = true (fft_rank 2, noise drawn here): the last two axes on the LDS plane kernels of skr_colored.hip instead of hipFFT --
+// the white noise is drawn inside the forward plane kernel, so the fp32 buffer first carries the per-plane sums
 static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
                                const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
-                               double exponent, int32_t has_energy, double energy, void* stream, bool white_given, int fft_rank) {
-  FftApi& f = api();
-  if (!f.ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
+                               double exponent, int32_t has_energy, double energy, void* stream, bool white_given, int fft_rank, bool planes = false) {
+  if (planes && (white_given || fft_rank != 2 || rank < 3)) return SKR_ERR_UNSUPPORTED;
+  if (!planes && !api().ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
   const int full_rank = rank;
   const int32_t* full_dims = dims;
   AnyArgs a;
@@ -351,8 +376,9 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
 
   skr::DeviceGuard guard(out);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  Plans plans;
-  {
+  Plans plans{};
+  if (!planes) {
+    FftApi& f = api();
     std::lock_guard<std::mutex> lock(g_mutex);
     const int64_t fft_batch = batch * d0;
     const PlanKey key = std::make_tuple(guard.dev, s, rank, n[0], n[1], n[2], fft_batch);
@@ -419,16 +445,24 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
     plans = it->second;
   }
 
-  if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
-  if (f.r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
+  if (planes) {
+    if ((reinterpret_cast<uintptr_t>(a.real) & 7) != 0) return SKR_ERR_UNSUPPORTED;
+    double* plane_sums = reinterpret_cast<double*>(a.real);  // batch * d0 * 2 doubles <= batch * unit floats (a plane has >= 8 elements)
+    const int rc = skr::colored_planes(0, a.spec, plane_sums, nullptr, seeds_dev, stream_id, batch, d0, a.d2, a.d3, s);
+    if (rc != SKR_OK) return rc;
+    hipLaunchKernelGGL(any_fold_plane_sums, dim3((unsigned)batch), dim3(SLOTS), 0, s, a, plane_sums, d0);
+  } else {
+    if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+    if (api().r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
+  }
   if (a.n_outer > 0) {
     const int64_t sample = d0 * a.d1 * a.d2 * a.d3h;
     auto pass = [&](int mode, int axis) -> int {
       const int d = a.outer[axis];
       const int64_t lines = sample / d;
-      int64_t ab = (lines + AXIS_THREADS - 1) / AXIS_THREADS; if (ab > 4096) ab = 4096;
-      const size_t lds = sizeof(float2) * ((size_t)d + (mode == 2 ? 2 : 1) * (size_t)d * AXIS_THREADS);
+      int64_t ab = (lines + AXIS_LINES - 1) / AXIS_LINES; if (ab > 4096) ab = 4096;
+      const size_t lds = sizeof(float2) * ((size_t)d + (mode == 2 ? 2 : 1) * (size_t)d * AXIS_LINES);
       const void* fn = mode == 0 ? reinterpret_cast<const void*>(any_outer_axis<0>) : (mode == 1 ? reinterpret_cast<const void*>(any_outer_axis<1>) : reinterpret_cast<const void*>(any_outer_axis<2>));
       if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SKR_ERR_UNSUPPORTED;
       const dim3 grid((unsigned)ab, (unsigned)batch);
@@ -445,9 +479,13 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
     int64_t wb = ((int64_t)a.d1 * a.d2 * a.d3h * batch + 255) / 256; if (wb > 256 * 32) wb = 256 * 32;
     hipLaunchKernelGGL(any_weights, dim3((unsigned)wb), dim3(256), 0, s, a);
   }
-  if (f.c2r(plans.inv, a.spec, a.real) != 0) return SKR_ERR_LAUNCH;
+  if (planes) {
+    const int rc = skr::colored_planes(1, a.spec, nullptr, a.real, seeds_dev, stream_id, batch, d0, a.d2, a.d3, s);
+    if (rc != SKR_OK) return rc;
+  } else if (api().c2r(plans.inv, a.spec, a.real) != 0) return SKR_ERR_LAUNCH;
   hipLaunchKernelGGL(any_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
-  int64_t fb = (a.unit + 255) / 256; if (fb > 64) fb = 64;
+  int64_t fb = (a.unit + 1023) / 1024;  // (64 blocks per sample starved the chip at small batches: 33 us for one 4.8 M-element sample)
+  { const int64_t cap = batch >= 32 ? 64 : 2048 / batch; if (fb > cap) fb = cap; if (fb < 1) fb = 1; }
   dim3 grid((unsigned)fb, (unsigned)batch);
   switch (out_dtype) {
     case SKR_BF16: hipLaunchKernelGGL(any_finish<__bf16>, grid, dim3(256), 0, s, (__bf16*)out, a, has_energy, energy); break;
@@ -469,6 +507,16 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
   if (batch > 65535) return SKR_ERR_UNSUPPORTED;
   // hipFFT gets the last three axes; if that plan fails its self-check (SelfTest above), only the last axis -- 1-D real plans have
   // not shown the defect -- and the direct-DFT kernels take every other axis (each <= 128 long)
+  // 3-D units the dedicated kernels of skr_noise_colored do not take (a leading axis that is not a power of two <= 16: 3, 5, 12
+  // channels ...) whose planes fit the LDS plane kernels: planes there, the leading axis (<= 128 long) a direct DFT here -- no
+  // hipFFT, 20-25 % faster (tools/bench_colored_planes.py).  Measured and NOT routed this way: units with two or more outer axes
+  // (video latents, channels x frames x height x width: the frame axis costs two more direct-DFT passes where hipFFT's 3-D plan
+  // has it inside -- 0.135 vs 0.128 ms at 2 x (16, 21, 64, 64)) and planes with large odd factors (90 x 160: 0.44 vs 0.25 ms, the
+  // 45-term combining pass), see colored_planes' limit on the odd parts.
+  if (!white_given && rank == 3 && skr::g_fft_rank < 1) {
+    const int rcp = colored_any_attempt(out, out_dtype, spec_c64, scratch_f32, partials_f64, seeds_dev, stream_id, batch, rank, dims, exponent, has_energy, energy, stream, false, 2, true);
+    if (rcp != SKR_ERR_UNSUPPORTED) return rcp;
+  }
   int first = rank < 3 ? rank : 3;
   if (skr::g_fft_rank >= 1 && skr::g_fft_rank < first) first = skr::g_fft_rank;  // test switch (skr_set_tuning "fft_rank"): 1 exercises the fallback
   int rc = colored_any_attempt(out, out_dtype, spec_c64, scratch_f32, partials_f64, seeds_dev, stream_id, batch, rank, dims, exponent, has_energy, energy, stream, white_given, first);

@@ -307,7 +307,7 @@ def test_pyramid_through_wrapper(dev):
 
 
 @pytest.mark.parametrize("unit", [(4, 16, 16), (16, 16, 16), (1, 32, 64), (4, 128, 128), (16, 128, 128), (4, 64, 64), (16, 64, 64), (8, 32, 32), (2, 128, 64), (4, 32, 128), (128, 128), (1, 128, 128),
-                                  (16, 96, 96), (4, 96, 128), (4, 128, 96), (4, 160, 96), (4, 80, 80), (96, 96), (4, 112, 144), (4, 104, 152), (2, 168, 96), (56, 88), (4, 28, 44), (8, 136, 120), (1, 124, 116), (2, 244, 68), (4, 90, 160), (2, 30, 40), (2, 6, 4), (4, 120, 4), (2, 2, 12), (2, 12), (102, 4), (2, 48, 96), (8, 24, 12), (4, 96, 160), (1, 192, 96), (4, 160, 160), (2, 192, 192), (160, 160), (192, 192), (2, 320, 64), (2, 256, 256), (16, 256, 128), (4, 128, 512), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
+                                  (16, 96, 96), (4, 96, 128), (4, 128, 96), (4, 160, 96), (4, 80, 80), (96, 96), (4, 112, 144), (4, 104, 152), (2, 168, 96), (56, 88), (4, 28, 44), (8, 136, 120), (1, 124, 116), (2, 244, 68), (16, 13, 60, 104), (4, 5, 96, 96), (3, 96, 96), (12, 64, 64), (2, 3, 4, 40, 24), (5, 128, 128), (4, 90, 160), (2, 30, 40), (2, 6, 4), (4, 120, 4), (2, 2, 12), (2, 12), (102, 4), (2, 48, 96), (8, 24, 12), (4, 96, 160), (1, 192, 96), (4, 160, 160), (2, 192, 192), (160, 160), (192, 192), (2, 320, 64), (2, 256, 256), (16, 256, 128), (4, 128, 512), (2, 8, 256), (4, 96, 96), (16, 19, 13), (3, 40), (100,), (4, 1, 152, 104), (4, 256, 256), (256, 256), (2, 512, 64), (64, 64), (3, 4, 6, 8), (4, 5, 8, 16), (16, 3, 12, 10), (128, 3, 8, 8), (96, 2, 6, 10), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6), (5, 7, 3, 9, 10)])
 def test_colored(unit, dev):
     seeds = [31, 32]
     cases = [
@@ -647,7 +647,11 @@ def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, d
             d1, d2, d3 = ([1] + dims)[-3:]
             status = lib.skr_noise_colored(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), 256, sd.data_ptr(), 512, batch, d1, d2, d3, 1.0, 0, 0.0, st)
         else:
-            status = lib.skr_noise_colored_any(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), sd.data_ptr(), 512, batch, len(dims), (ctypes.c_int32 * len(dims))(*dims), 1.0, 0, 0.0, st)
+            assert lib.skr_set_tuning(b"fft_rank", 3) == 0  # hipFFT proper (3-D units would otherwise take the plane kernels + a direct outer-axis DFT)
+            try:
+                status = lib.skr_noise_colored_any(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), sd.data_ptr(), 512, batch, len(dims), (ctypes.c_int32 * len(dims))(*dims), 1.0, 0, 0.0, st)
+            finally:
+                assert lib.skr_set_tuning(b"fft_rank", 0) == 0
         assert status == 0, (route, status)
         torch.cuda.synchronize()
         outs.append(out.cpu())
