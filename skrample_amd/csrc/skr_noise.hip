@@ -165,29 +165,39 @@ struct PyramidArgs {
 // level geometry (reference noise.py:157-162,195-196): level i shrinks the RUNNING size by r_i**i,
 // r_i = 2 + 2*u_i, u_i = (philox word i of stream_base+255 >> 8) * 2^-24; stop at the first level with a
 // resized dimension of 1.  Same arithmetic as skrample_amd/pytorch/noise.py::pyramid_level_tables.
-__global__ void pyramid_geometry(const PyramidArgs a) {
-  const int64_t smp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (smp >= a.batch) return;
-  const uint64_t seed = a.seeds[smp];
-  uint32_t words[PYR_MAX_LEVELS];
-  for (int blk = 0; blk < PYR_MAX_LEVELS / 4; ++blk) {
-    u32x4 c{(uint32_t)blk, 0u, (uint32_t)(a.stream_levels + 255), (uint32_t)((a.stream_levels + 255) >> 32)};
-    c = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    words[blk * 4] = c.x; words[blk * 4 + 1] = c.y; words[blk * 4 + 2] = c.z; words[blk * 4 + 3] = c.w;
-  }
+// shrink factor of level i: r_i ** i, r_i = 2 + 2 u_i from word i of the geometry stream (Philox block i / 4)
+__device__ __forceinline__ double pyramid_level_shrink(const PyramidArgs& a, uint64_t seed, int i) {
+  u32x4 c{(uint32_t)(i >> 2), 0u, (uint32_t)(a.stream_levels + 255), (uint32_t)((a.stream_levels + 255) >> 32)};
+  c = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t word = (i & 3) == 0 ? c.x : ((i & 3) == 1 ? c.y : ((i & 3) == 2 ? c.z : c.w));
+  const double r = (double)(word >> 8) * 5.9604644775390625e-08 * 2.0 + 2.0;
+  return pow(r, (double)i);
+}
+// the running sizes from the eight shrink factors: (h_l, w_l) into hw[2 l], hw[2 l + 1]; returns the number of levels
+template <typename HW>
+__device__ __forceinline__ int pyramid_level_walk(const PyramidArgs& a, const double* shrink, HW&& put) {
   int64_t h = a.h, w = a.w;
   int n = 0;
   for (int i = 0; i < PYR_MAX_LEVELS; ++i) {
-    const double r = (double)(words[i] >> 8) * 5.9604644775390625e-08 * 2.0 + 2.0;
-    const double shrink = pow(r, (double)i);
-    if (a.resize_h) { h = (int64_t)((double)h / shrink); if (h < 1) h = 1; }
-    w = (int64_t)((double)w / shrink); if (w < 1) w = 1;
-    a.level_hw[(smp * PYR_MAX_LEVELS + i) * 2] = (int32_t)h;
-    a.level_hw[(smp * PYR_MAX_LEVELS + i) * 2 + 1] = (int32_t)w;
+    if (a.resize_h) { h = (int64_t)((double)h / shrink[i]); if (h < 1) h = 1; }
+    w = (int64_t)((double)w / shrink[i]); if (w < 1) w = 1;
+    put(i, (int32_t)h, (int32_t)w);
     n = i + 1;
     if (w <= 1 || (a.resize_h && h <= 1)) break;
   }
-  a.n_levels[smp] = n;
+  return n;
+}
+
+__global__ void pyramid_geometry(const PyramidArgs a) {  // (the any-shape kernels: their launches are sized from nothing but need the table)
+  const int64_t smp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (smp >= a.batch) return;
+  const uint64_t seed = a.seeds[smp];
+  double shrink[PYR_MAX_LEVELS];
+  for (int i = 0; i < PYR_MAX_LEVELS; ++i) shrink[i] = pyramid_level_shrink(a, seed, i);
+  a.n_levels[smp] = pyramid_level_walk(a, shrink, [&](int i, int32_t h, int32_t w) {
+    a.level_hw[(smp * PYR_MAX_LEVELS + i) * 2] = h;
+    a.level_hw[(smp * PYR_MAX_LEVELS + i) * 2 + 1] = w;
+  });
 }
 
 __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
@@ -215,14 +225,23 @@ __global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const Py
   const int slice = blockIdx.x;  // smp * lead + c
   const int smp = slice / a.lead, c = slice - smp * a.lead;
   const uint64_t seed = a.seeds[smp];
-  const int nl = a.n_levels[smp];
+  // Level geometry in the block itself (round 3; a launch of its own before: 5 us of a 76 us draw for eight numbers per sample):
+  // lane i draws word i and raises r_i to the i-th power, lane 0 walks the running sizes.  Same functions, same values.
+  __shared__ double s_shrink[PYR_MAX_LEVELS];
+  __shared__ int s_nl;
+  if (threadIdx.x < PYR_MAX_LEVELS) s_shrink[threadIdx.x] = pyramid_level_shrink(a, seed, (int)threadIdx.x);
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const int32_t* hw = a.level_hw + (int64_t)smp * PYR_MAX_LEVELS * 2;
+    const int nl = pyramid_level_walk(a, s_shrink, [&](int i, int32_t h, int32_t w) { s_lh[i] = h; s_lw[i] = w; });
+    s_nl = nl;
+    if (c == 0) {  // (the table stays readable on the host side: tests compare it with the specification)
+      for (int l = 0; l < nl; ++l) { a.level_hw[((int64_t)smp * PYR_MAX_LEVELS + l) * 2] = s_lh[l]; a.level_hw[((int64_t)smp * PYR_MAX_LEVELS + l) * 2 + 1] = s_lw[l]; }
+      a.n_levels[smp] = nl;
+    }
     const int skip = (nl - 1) - a.depth > 0 ? (nl - 1) - a.depth : 0;  // keep the depth+1 coarsest levels (noise.py:198-200)
     int off = 0;
     float wgt = 1.f;
     for (int l = 0; l < nl; ++l) {
-      s_lh[l] = hw[2 * l]; s_lw[l] = hw[2 * l + 1];
       s_off[l] = off;
       s_wgt[l] = l >= skip ? wgt : 0.f;
       s_sy[l] = (float)s_lh[l] / (float)a.h;
@@ -232,6 +251,7 @@ __global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const Py
     }
   }
   __syncthreads();
+  const int nl = s_nl;
   for (int l = 1; l < nl; ++l) {
     if (s_wgt[l] == 0.f) continue;
     const int n = s_lh[l] * s_lw[l];
@@ -607,9 +627,7 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   a.stream_base = stream_base; a.stream_levels = stream_levels; a.batch = batch; a.lead = (int32_t)lead; a.h = (int32_t)h; a.w = (int32_t)w;
   a.resize_h = resize_h; a.depth = depth; a.with_base = with_base; a.strength = (float)strength;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(skr::pyramid_geometry, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, a);
-  if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
-  const size_t lds_bytes = sizeof(float) * (size_t)bound;
+  const size_t lds_bytes = sizeof(float) * (size_t)bound;  // (the level geometry is worked out inside pass 1)
   if (lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
