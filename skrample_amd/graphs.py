@@ -11,7 +11,10 @@ of the frozen kernel arguments into a device-resident table (`skr_step_launch_in
 read row `index + k` when they run.  The captured loop then serves ANY schedule of its length -- other sigmas, flow shift
 (`mu`), begin index, stochasticity -- by rewriting the table (`CapturedLoop.retarget`, a dry run of the new scheduler on one
 sample plus one small copy; no re-capture), and keeps several schedules resident at once, selected per replay by moving the
-device-resident index (`loop(latents, slot=k)`).  The reference redoes this work on the host every step, with a device sync
+device-resident index (`loop(latents, slot=k)`).  The network's timestep argument is data as well: with `device_timesteps`
+(the default of an indexed capture) `model(x, t)` receives 0-d elements of ONE device tensor, as a diffusers pipeline's
+`for t in scheduler.timesteps` does, and re-targeting / switching slots rewrites that tensor -- a host float would be frozen into
+the captured network.  The reference redoes this work on the host every step, with a device sync
 (skrample/diffusers.py:565-567, skrample/scheduling.py:51-62, skrample/sampling/interface.py:34-59).
 """
 
@@ -25,10 +28,15 @@ import torch
 class CapturedLoop:
     "replayable sampling loop: `out = loop(initial_latents, seeds=None)`"
 
-    def __init__(self, graph: torch.cuda.CUDAGraph, static_in: torch.Tensor, static_out: torch.Tensor, seeds_dev: torch.Tensor | None, rows=None, runner=None):
+    def __init__(self, graph: torch.cuda.CUDAGraph, static_in: torch.Tensor, static_out: torch.Tensor, seeds_dev: torch.Tensor | None, rows=None, runner=None,
+                 static_times: torch.Tensor | None = None):
         self.graph, self.static_in, self.static_out, self.seeds_dev = graph, static_in, static_out, seeds_dev
         self.rows, self._runner = rows, runner  # _hip.IndexedRows of an indexed capture; runner(wrapper, x) = the captured loop body
         self._filled = {0}  # table slots that hold a schedule (the capture itself fills slot 0; the others start as zero rows)
+        # device_timesteps: the tensor whose elements the captured network reads as `t`, and each slot's values for it
+        self.static_times = static_times
+        self._times = {0: static_times.detach().cpu().clone()} if static_times is not None else {}
+        self._times_slot = 0
 
     @property
     def slots(self) -> int:
@@ -54,6 +62,13 @@ class CapturedLoop:
             raise _hip.SkrampleHipError(f"the new schedule issued {self.rows.cursor} launches, the captured loop has {self.rows.length}: re-capture")
         self.rows.upload(slot)
         self._filled.add(slot)
+        if self.static_times is not None:
+            times = wrapper.timesteps.detach().to("cpu", self.static_times.dtype)
+            if times.shape != self.static_times.shape:
+                raise _hip.SkrampleHipError(f"the new schedule has {times.numel()} timesteps, the captured loop {self.static_times.numel()}: re-capture")
+            self._times[slot] = times.clone()
+            if slot == self._times_slot:
+                self.static_times.copy_(self._times[slot])
 
     def __call__(self, latents: torch.Tensor, seeds: Sequence[int] | None = None, slot: int | None = None) -> torch.Tensor:
         self.static_in.copy_(latents)
@@ -63,6 +78,9 @@ class CapturedLoop:
             if slot not in self._filled:
                 raise ValueError(f"schedule slot {slot} has never been loaded: call retarget(wrapper, slot={slot}) first (its rows are all zero)")
             self.rows.index_dev.fill_(slot * self.rows.length)  # the device-resident step index: row = index + position in the loop
+            if self.static_times is not None and slot != self._times_slot:
+                self.static_times.copy_(self._times[slot])  # what the network reads as `t` (stream-ordered ahead of the replay)
+                self._times_slot = slot
         if seeds is not None:
             if self.seeds_dev is None:
                 raise ValueError("this loop draws no noise")
@@ -74,19 +92,32 @@ class CapturedLoop:
 
 
 def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], example: torch.Tensor, steps: int, seeds: Sequence[int] | None = None, warmup: int = 2,
-                          indexed: bool = False, slots: int = 4) -> CapturedLoop:
+                          indexed: bool = False, slots: int = 4, device_timesteps: bool | None = None) -> CapturedLoop:
     """Capture `for t in wrapper.timesteps: x = wrapper.step(model(x, t), t, x)` for `steps` steps.
 
     `wrapper` is any scheduler wrapper of skrample_amd.diffusers; `model(x, t)` must be capturable (pure device
     work); `example` fixes shape/dtype/device.  Warm-up passes run eagerly first so that every step program is
     lowered and every allocation pattern is known before capture.
+
+    `device_timesteps` (default: the value of `indexed`): `t` is a 0-d element of the scheduler's device-resident `timesteps`
+    tensor -- located by the wrapper through its storage offset, no read-back -- instead of a host float; the network then
+    follows a re-targeted schedule, because the tensor's contents are replaced with the rows.
     """
     dev = example.device
     static_in = example.clone()
     gen = list(seeds) if seeds is not None else None
+    if device_timesteps is None:
+        device_timesteps = indexed
 
     wrapper.set_timesteps(steps)
-    times = wrapper.timesteps.tolist()
+    static_times = None
+    if device_timesteps:
+        if wrapper.timesteps.device != dev:
+            wrapper.set_timesteps(steps, device=dev)
+        static_times = wrapper.timesteps  # (the scheduler remembers what it handed out for as long as this tensor lives)
+        times = [static_times[i] for i in range(static_times.numel())]
+    else:
+        times = wrapper.timesteps.tolist()
 
     def run(x):
         wrapper.reset_run()  # same schedule, same device seed vector; history and draw counter rewound
@@ -95,9 +126,10 @@ def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor],
         return x
 
     def run_other(other, x):  # the same loop body on another scheduler instance (re-targeting dry run, one sample)
-        other.set_timesteps(steps)
+        other.set_timesteps(steps, device=dev) if device_timesteps else other.set_timesteps(steps)
         sub = gen[: x.shape[0]] if gen is not None else None
-        for t in other.timesteps.tolist():
+        ts = other.timesteps
+        for t in ([ts[i] for i in range(ts.numel())] if device_timesteps else ts.tolist()):
             x = other.step(model(x, t), t, x, generator=sub, return_dict=False)[0]
         return x
 
@@ -135,4 +167,4 @@ def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor],
         with torch.cuda.graph(graph):
             static_out = run(static_in)
     seeds_dev = getattr(getattr(wrapper, "_noise_generator", None), "_seeds", None)
-    return CapturedLoop(graph, static_in, static_out, seeds_dev, rows, run_other)
+    return CapturedLoop(graph, static_in, static_out, seeds_dev, rows, run_other, static_times)

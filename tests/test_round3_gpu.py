@@ -258,6 +258,44 @@ def test_captured_loop_refuses_a_slot_that_was_never_loaded(dev):
     assert torch.equal(loop(x0, slot=0), ref)
 
 
+@pytest.mark.parametrize("kind", ["dpm2_sde", "rk4_sde"])
+def test_retargeted_loop_feeds_the_network_the_new_timesteps(kind, dev):
+    """An indexed capture hands the network 0-d elements of one device-resident `timesteps` tensor (as `for t in scheduler.timesteps`
+    does in a diffusers pipeline), and re-targeting / switching slots rewrites that tensor: a network that USES t follows the new
+    schedule.  (With host floats the first schedule's timesteps would be frozen into the captured network.)"""
+    from skrample_amd.graphs import capture_sampling_loop
+
+    shape, steps, seeds = (3, 4, 32, 32), 6, [5, 6, 7]
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    net = lambda x, t: x * (0.4 + t.to(torch.float32) / 2500).to(x.dtype) + 0.1 * x.abs()  # noqa: E731  (t: 0-d device tensor)
+    if kind == "dpm2_sde":
+        mk = lambda sch: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), sch)  # noqa: E731
+    else:
+        mk = lambda sch: PD.RKUltraWrapperScheduler(sch, sampler_order=4, stochasticity=1)  # noqa: E731
+    variants = [PS.Karras(PS.Scaled()), PS.Scaled(), PS.Exponential(PS.Scaled())]
+
+    def eager(w, x):
+        w.set_timesteps(steps, device=dev)
+        ts = w.timesteps
+        for i in range(ts.numel()):
+            x = w.step(net(x, ts[i]), ts[i], x, generator=seeds, return_dict=False)[0]
+        return x
+
+    want = [eager(mk(sch), x0) for sch in variants]
+    assert not torch.equal(want[0], want[1]) and not torch.equal(want[1], want[2])
+    loop = capture_sampling_loop(mk(variants[0]), net, x0, steps, seeds=seeds, indexed=True, slots=3)
+    assert loop.static_times is not None
+    assert torch.equal(loop(x0), want[0])
+    loop.retarget(mk(variants[1]), slot=1)
+    loop.retarget(mk(variants[2]), slot=2)
+    for k in (1, 2, 0, 2, 1):
+        assert torch.equal(loop(x0, slot=k), want[k]), (kind, k)
+    loop.retarget(mk(variants[1]), slot=0)  # the slot in use: its timesteps are replaced at once
+    assert torch.equal(loop(x0, slot=0), want[1])
+    assert torch.equal(loop(x0), want[1])
+
+
 WORKER = r"""
 import os, sys, torch
 sys.path.insert(0, {root!r})
