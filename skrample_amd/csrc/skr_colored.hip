@@ -891,10 +891,24 @@ struct MixedGeom {
 
 // MODE as colored_plane: 0 white -> half spectrum, 1 half spectrum -> real plane (result dtype), 2 both (2-D units)
 // THREADS: 512 (two blocks per CU for planes up to ~128 x 128) or 1024 (one block: 160- and 192-point sides)
-template <int MODE, typename T, int THREADS>
+constexpr MixedAxis const_mixed_axis(int d) {
+  int v = d;
+  while (v % 2 == 0) v /= 2;
+  const int r = v;
+  v = d / r;
+  int lg = 0;
+  while ((1 << lg) < v) ++lg;
+  return MixedAxis{d, r, lg, v, r * (v + 1), (uint32_t)((0x100000000ull + (uint32_t)r - 1) / (uint32_t)r)};
+}
+
+template <int MODE, typename T, int THREADS, int SIDE = 0>
 __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs a, const MixedGeom g) {
   extern __shared__ float2 smem[];
-  const MixedAxis ax_h = g.h, ax_w = g.w;
+  // SIDE: square planes of the common sizes with their geometry as compile-time constants -- every pitch multiply, digit
+  // reversal and loop bound folds (the same cure as colored_plane's CH / CW: 256 x (16, 96, 96) 0.389 -> 0.259 ms)
+  constexpr MixedAxis cax = const_mixed_axis(SIDE ? SIDE : 4);
+  const MixedAxis ax_h = SIDE ? cax : g.h, ax_w = SIDE ? cax : g.w;
+  const uint32_t magic_wh = SIDE ? (uint32_t)((0x100000000ull + (uint32_t)(SIDE / 2 + 1) - 1) / (uint32_t)(SIDE / 2 + 1)) : g.magic_wh;
   const int H = ax_h.n, W = ax_w.n, WH = W / 2 + 1, ldw = ax_w.pitch, ldh = ax_h.pitch, pairs = H >> 1;
   float2* tw_w = smem;                 // full circle, W entries
   float2* tw_h = tw_w + W;             // full circle, H entries
@@ -947,7 +961,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = threadIdx.x + i * THREADS;
         if (q < total) {
-          const int pr = div_magic(q, g.magic_wh), k = q - pr * WH;
+          const int pr = div_magic(q, magic_wh), k = q - pr * WH;
           const int kn = k == 0 ? 0 : W - k;
           const float2 zk = t1[pr * ldw + mixed_nat(ax_w, k)], zn = t1[pr * ldw + mixed_nat(ax_w, kn)];
           ra[i] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
@@ -959,7 +973,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = threadIdx.x + i * THREADS;
         if (q < total) {
-          const int pr = div_magic(q, g.magic_wh), k = q - pr * WH;
+          const int pr = div_magic(q, magic_wh), k = q - pr * WH;
           t2[k * ldh + mixed_pos(ax_h, 2 * pr)] = ra[i];
           t2[k * ldh + mixed_pos(ax_h, 2 * pr + 1)] = rb[i];
         }
@@ -970,7 +984,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
     if (MODE == 0) {
       block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
       for (int q = threadIdx.x; q < H * WH; q += THREADS) {
-        const int row = div_magic(q, g.magic_wh), k = q - row * WH;
+        const int row = div_magic(q, magic_wh), k = q - row * WH;
         plane[q] = t2[k * ldh + mixed_nat(ax_h, row)];
       }
       return;
@@ -1027,7 +1041,7 @@ __global__ __launch_bounds__(THREADS) void colored_plane_mixed(const ColoredArgs
       for (int i = 0; i < PLANE_ITEMS; ++i) {
         const int q = base + threadIdx.x + i * THREADS;
         if (q < total) {
-          const int row = div_magic(q, g.magic_wh), k = q - row * WH;
+          const int row = div_magic(q, magic_wh), k = q - row * WH;
           t2[k * ldh + mixed_pos(ax_h, row)] = rz[i];
         }
       }
@@ -1514,8 +1528,13 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   if (mixed) {
     a.n_slots = d1;
     dim3 grid((unsigned)d1, (unsigned)batch);
+    const int const_side = (d2 == d3 && getenv("SKR_FFT_NO_CONST_SIDE") == nullptr) ? d2 : 0;  // 96 / 160 / 192: compile-time geometry
+#define SKR_MIXED_SIDE(MODE, T, THREADS, SIDE) do { SKR_ALLOW_LDS((colored_plane_mixed<MODE, T, THREADS, SIDE>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, T, THREADS, SIDE>), grid, dim3(THREADS), lds_mixed, s, a, mg); } while (0)
 #define SKR_MIXED_T(MODE, T) do {                                                                                                              \
-      if (mixed_threads == 512) { SKR_ALLOW_LDS((colored_plane_mixed<MODE, T, 512>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, T, 512>), grid, dim3(512), lds_mixed, s, a, mg); } \
+      if (const_side == 96 && mixed_threads == 512 && sizeof(T) <= 4) SKR_MIXED_SIDE(MODE, T, 512, 96);                                          \
+      else if (const_side == 160 && mixed_threads == 1024 && sizeof(T) <= 4) SKR_MIXED_SIDE(MODE, T, 1024, 160);                                 \
+      else if (const_side == 192 && mixed_threads == 1024 && sizeof(T) <= 4 && MODE != 2) SKR_MIXED_SIDE((MODE == 2 ? 1 : MODE), T, 1024, 192);  \
+      else if (mixed_threads == 512) { SKR_ALLOW_LDS((colored_plane_mixed<MODE, T, 512>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, T, 512>), grid, dim3(512), lds_mixed, s, a, mg); } \
       else { SKR_ALLOW_LDS((colored_plane_mixed<MODE, T, 1024>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, T, 1024>), grid, dim3(1024), lds_mixed, s, a, mg); }              \
     } while (0)
 #define SKR_MIXED(MODE)                                             \
@@ -1539,6 +1558,7 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
     }
 #undef SKR_MIXED
 #undef SKR_MIXED_T
+#undef SKR_MIXED_SIDE
     return SKR_OK;
   }
   if (fused) {

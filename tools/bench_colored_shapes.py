@@ -1,5 +1,8 @@
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from skrample_amd import _hip
+if os.environ.get("SKR_LIB"):
+    _hip.LIB_PATH = os.path.abspath(os.environ["SKR_LIB"])
 from skrample_amd.pytorch import noise as PN
 from skrample_amd.common import Step
 for batch, unit in ((64, (4, 96, 96)), (64, (4, 128, 128)), (256, (16, 96, 96)), (256, (16, 128, 128)), (64, (4, 160, 160)), (64, (4, 192, 192)), (64, (4, 256, 256)),
