@@ -665,6 +665,34 @@ def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, d
         assert lib.skr_noise_colored(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), 256, sd.data_ptr(), 512, 1, 1, d2, d3, 1.0, 0, 0.0, _hip.current_stream_ptr(dev)) == 7
 
 
+@pytest.mark.parametrize("unit", [(4, 96, 96), (16, 96, 96), (96, 96), (2, 160, 160), (160, 160), (2, 192, 192)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_compile_time_geometry_planes_agree_with_the_runtime_kernel(unit, dtype, dev):
+    """96 / 160 / 192-point squares run an instantiation with its geometry folded in; SKR_FFT_NO_CONST_SIDE=1 takes the runtime-geometry kernel.
+    Same algorithm, same operation order -- but the compiler contracts multiply-adds differently around constants, so the two agree to fp32
+    rounding (a 16-bit result differs in the last place for well under 1 % of the elements), not bit for bit."""
+    import os
+
+    outs = []
+    for const in (True, False):
+        os.environ.pop("SKR_FFT_NO_CONST_SIDE", None)
+        if not const:
+            os.environ["SKR_FFT_NO_CONST_SIDE"] = "1"
+        try:
+            g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, [61, 62, 63], props=PN.ColoredProps(), dtype=dtype)
+            outs.append([g.generate(st).clone() for st in (None, Step(0.3, 0.4))])
+        finally:
+            os.environ.pop("SKR_FFT_NO_CONST_SIDE", None)
+    for a, b in zip(*outs):
+        a32, b32 = a.float(), b.float()
+        if dtype == torch.float32:
+            assert rel(a32.cpu(), b32.cpu()) < 1e-5
+        else:
+            assert (a32 != b32).float().mean().item() < 0.01
+            assert ((a32 - b32).abs() <= 2.0**-7 * torch.maximum(a32.abs(), b32.abs()) + 1e-6).all()
+        assert torch.isfinite(a32).all() and abs(a32.std().item() - 1.0) < 0.05
+
+
 @pytest.mark.parametrize("unit", [(4, 96, 96), (16, 19, 13), (3, 40), (3, 4, 6, 8), (16, 2, 8, 8), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6)])
 def test_colored_with_only_the_last_axis_on_hipfft(unit, dev):
     """The route taken when a multi-dimensional hipFFT plan fails its self-check (rocFFT 7.2 can return a wrong real 2-D / 3-D
