@@ -1451,7 +1451,7 @@ int colored_planes(int mode, float2* spec, double* plane_partials, float* real_o
   MixedGeom mg;
   size_t lds_mixed = 0;
   int threads = 0;
-  if (!mixed_plane_geometry(d2, d3, false, mg, lds_mixed, threads) || mg.h.r + mg.w.r > 10) return SKR_ERR_UNSUPPORTED;  // (larger odd parts: hipFFT measured faster)
+  if (getenv("SKR_FFT_NO_MIXED") != nullptr || !mixed_plane_geometry(d2, d3, false, mg, lds_mixed, threads) || mg.h.r + mg.w.r > 10) return SKR_ERR_UNSUPPORTED;  // (larger odd parts: hipFFT measured faster)
 #define SKR_PLANES_M(MODE) do {                                                                                                                  \
     if (threads == 512) { SKR_ALLOW_LDS((colored_plane_mixed<MODE, float, 512>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, float, 512>), grid, dim3(512), lds_mixed, s, a, mg); } \
     else { SKR_ALLOW_LDS((colored_plane_mixed<MODE, float, 1024>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, float, 1024>), grid, dim3(1024), lds_mixed, s, a, mg); }              \
