@@ -382,10 +382,12 @@ class SkrampleWrapperCore(abc.ABC):
             flat = sample.reshape(sample.shape[0], per_item)
             mids = flat[:, per_item // 2].to(torch.float64).cpu().tolist() if per_item else [0.0] * sample.shape[0]
             seeds = [int(v * 1e4 * (step.position() + 1)) for v in mids]
-        if not sample.is_cuda:  # host-resident latents (the reference's CPU path): torch's own generators, as the reference
-            if noise_type is not Random:
-                raise SkrampleHipError(f"{noise_type.__name__} noise is generated by HIP kernels; on CPU tensors only Random noise is available")
-            return HostRandomBatch(tuple(sample.shape[1:]), seeds, torch.float32)
+        if not sample.is_cuda:  # host-resident latents (the reference's CPU path): torch's own generators, drawn as the reference draws them
+            if noise_type is Random:
+                return HostRandomBatch(tuple(sample.shape[1:]), seeds, torch.float32)
+            from .pytorch.host_noise import HostStructuredBatch
+
+            return HostStructuredBatch(noise_type, tuple(sample.shape[1:]), seeds, noise_props, torch.float32)
         return BatchTensorNoise.from_batch_inputs(noise_type, unit_shape=tuple(sample.shape[1:]), seeds=seeds, props=noise_props, dtype=sample.dtype)
 
     def get_step_noise(self, step: Step, sample: Tensor, noise_type, noise_props, generator=None, dtype: torch.dtype | None = None, lazy_ok: bool = False):
