@@ -113,7 +113,7 @@ def _wl() -> dict[str, Workload]:
                 256, (16, 128, 128), 30, 1, 20, steady,
                 lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), noise_type=PN.Colored, noise_props=PN.ColoredProps(), alias_history=True),
                 "skr::step_kernel_k2<bf16_t, 10 + 1 operands> (two outputs); generator: colored_plane<0> + colored_outer_axis_regs<16> + colored_plane<1>",
-                (("step_kernel_k2<skr::bf16_t, 10, 1, false", 1), ("colored_plane<", 2), ("colored_outer_axis", 1)),
+                (("step_kernel_k2<skr::bf16_t, 10, 1, false", 1), ("colored_plane", 2), ("colored_outer_axis", 1)),
                 generator_bytes_note="Colored generator, unavoidable HBM traffic per draw: half spectrum (complex64) written, read + written by the channel-axis pass, read by the inverse, + bf16 result = 18.2 B/element",
                 oracle=lambda: _step_oracle("unipc", 3, 1.0, "linear", "flow", "colored"), cpu_sample=8,
             ),
@@ -135,7 +135,7 @@ def _wl() -> dict[str, Workload]:
                 64, (4, 256, 256), 100, 6, 6, (1, 2, 3, 4),
                 lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=6, stochasticity=1, noise_type=PN.Pyramid, noise_props=PN.PyramidProps(), alias_history=True),
                 "skr::step_kernel_rk1<bf16_t, K=2..7> x 6 stages (derivative + next stage input per launch); generator: pyramid_pass1 + normalise_pass2",
-                (("step_kernel_rk1<", 6), ("pyramid_pass1", 1), ("normalise_pass2", 1)),
+                (("step_kernel_rk1", 6), ("pyramid_pass1", 1), ("normalise_pass2", 1)),
                 generator_bytes_note="Pyramid generator: fp32 scratch written and re-read by the normalising pass + bf16 result = 10 B/element per draw",
                 oracle=lambda: _rk_oracle(), cpu_sample=8,
             ),
@@ -483,7 +483,7 @@ def wrapper_rate(wl: Workload, batch: int, dev: torch.device, shard, nbuf: int =
         seeds = [_Seed(sd) for sd in shard.seeds()]
         rate = None
         for _ in range(3):
-            w.set_timesteps(wl.schedule_steps)
+            w.set_timesteps(wl.schedule_steps if wl.calls > 1 else max(wl.schedule_steps, 100))  # (a longer window: start / stop of the region spread over more steps)
             ts = w.timesteps.tolist()
             ts = ts[: len(ts) // wl.calls * wl.calls]
             x = w.step(outs[0], ts[0], xs[0], generator=seeds, return_dict=False)[0]  # first call of a run also builds the per-sample generators
@@ -669,26 +669,47 @@ def main() -> None:
     launches_per_step = wl.calls
     last_noise = [None, None]
 
+    marked = [0]  # solver steps issued when `mark` was recorded
+
+    def issue(call, fresh) -> None:
+        p, ptrs, o0, o1, sd, patch = call
+        if fresh is not None:
+            for j in patch:
+                ptrs[j] = fresh
+        status = lib.skr_step_launch(p, ptrs, o0, o1, sd, numel, stream)
+        if status:
+            _hip.check(status, "skr_step_launch")
+
+    def draw_noise(noise_step):
+        fresh = generator.generate_lazy(noise_step)  # the wrapper's own call (diffusers.py::get_step_noise): 2-3 launches into a fresh tensor
+        last_noise[0], last_noise[1] = fresh, last_noise[0]  # (the previous draw stays alive while it may still be read)
+        return fresh.data_ptr()
+
     def run(count: int, offset: int = 0, mark=None, draw: bool = True) -> None:
-        "issue `count` solver steps: the generator's launches (when the config names one and `draw`), then the step launches"
-        launch = lib.skr_step_launch
+        """issue `count` solver steps: the generator's launches (when the config names one and `draw`), then the step launches.
+        Runge-Kutta configs (several wrapper calls per step) are issued STAGE-MAJOR over groups of `nsets` steps, one step per
+        buffer set: between two stages of one step the network runs in a real pipeline, so a stage must not find the tensors the
+        previous stage of its step just wrote still in the Infinity Cache -- here nsets - 1 launches on other sets lie in between."""
         n = len(plan_calls)
-        for i in range(count):
-            calls, noise_step = plan_calls[(offset + i) % n]
-            fresh = None
-            if noise_step is not None and draw:
-                fresh = generator.generate_lazy(noise_step)  # the wrapper's own call (diffusers.py::get_step_noise): 2-3 launches into a fresh tensor
-                last_noise[0], last_noise[1] = fresh, last_noise[0]  # (the previous draw stays alive while it may still be read)
-                fresh = fresh.data_ptr()
-            for p, ptrs, o0, o1, sd, patch in calls:
-                if fresh is not None:
-                    for j in patch:
-                        ptrs[j] = fresh
-                status = launch(p, ptrs, o0, o1, sd, numel, stream)
-                if status:
-                    _hip.check(status, "skr_step_launch")
-            if i == 0 and mark is not None:
-                mark.record()  # behind the first timed step: the steady-state clock excludes the cold-queue start of the region
+        if launches_per_step == 1:
+            for i in range(count):
+                calls, noise_step = plan_calls[(offset + i) % n]
+                issue(calls[0], draw_noise(noise_step) if noise_step is not None and draw else None)
+                if i == 0 and mark is not None:
+                    mark.record()  # behind the first timed step: the steady-state clock excludes the cold-queue start of the region
+                    marked[0] = 1
+            return
+        done = 0
+        while done < count:
+            group = [plan_calls[(offset + done + k) % n] for k in range(min(nsets, count - done))]
+            for j in range(launches_per_step):
+                for calls, noise_step in group:
+                    fresh = draw_noise(noise_step) if j == launches_per_step - 1 and noise_step is not None and draw else None  # drawn at the step's last stage, as the wrapper does
+                    issue(calls[j], fresh)
+            done += len(group)
+            if mark is not None and marked[0] == 0:
+                mark.record()
+                marked[0] = done
 
     try:  # HIP events on the launch stream, without the system-scope fence of torch's events (see _HipEvent)
         e0, e1, e_first, e_warm, f0, f1 = (_HipEvent(stream) for _ in range(6))
@@ -728,6 +749,7 @@ def main() -> None:
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     e0.record()
+    marked[0] = 0
     run(args.steps, offset=args.warmup, mark=e_first)
     e1.record()
     while not e1.query():  # poll for completion (a blocking synchronize wakes up tens of us late), then synchronize
@@ -742,7 +764,7 @@ def main() -> None:
     # `value` / ms_per_step).  Secondary (roofline.steady_state): steps 2..K, back to back behind the first one -- the number
     # rocprofv3's per-kernel average agrees with; K = 1 has no such window.
     span_ms = e0.elapsed_time(e1) / args.steps
-    steady_ms = e_first.elapsed_time(e1) / (args.steps - 1) if args.steps > 1 else span_ms
+    steady_ms = e_first.elapsed_time(e1) / (args.steps - marked[0]) if args.steps > marked[0] > 0 else span_ms
     # configs with a noise generator: a second region with the step launches alone (noise tensors already resident), after the
     # contract's region -- the 8(d) roofline of those configs is stated for the step kernel, "generator reported separately"
     kernels_ms = None
@@ -814,11 +836,16 @@ def main() -> None:
             },
             "traffic": breakdown.get(step_needle, traffic) if breakdown else traffic,
             "traffic_source": traffic_source,
+            # the same time priced on the bytes the step kernels actually moved (PMC): differs from `frac` where the implementation moves
+            # fewer bytes than SURVEY 8(d) counts (cfg5: stored derivatives are read as 2 B, 8(d) counts verbatim (x, out) pairs at 4 B)
+            "frac_on_measured_traffic": None,
             "algorithmic_bytes_per_step": algo_bytes,
             "algorithmic_bytes_per_element": wl.bytes_per_elem,
             "kernel": wl.kernel,
             "measured_d2d_memcpy": copy_gbs,  # hipMemcpy D2D of 512 MiB on this box, read+write GB/s
         }
+        if roofline["traffic"]:
+            roofline["frac_on_measured_traffic"] = roofline["traffic"] / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if launches_per_step == 1:
             roofline["algorithmic_bytes_per_launch"] = algo_bytes
         if wl.mix_ceiling:

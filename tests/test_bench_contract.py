@@ -33,8 +33,34 @@ def test_committed_bench_lines_follow_the_contract():
         assert d["config"]["per_gpu_batch"] == 256 and d["config"]["global_batch"] == 256
 
 
+def test_round4_lines_of_every_config_follow_the_contract():
+    "one committed line per BASELINE config (profiles/r04_bench_line*.json, `python bench.py --config <c>` on an MI355X)"
+    expect = {"": (256, 10), "_k20": (256, 10), "_cfg2": (64, 10), "_cfg3": (256, 26), "_cfg3c": (256, 30), "_cfg4": (256, 18), "_cfg5": (64, 100)}
+    units = {"_cfg3": 16 * 128 * 128, "_cfg3c": 16 * 128 * 128, "_cfg5": 4 * 256 * 256}
+    for tag, (batch, bytes_per_elem) in expect.items():
+        d = line(f"r04_bench_line{tag}.json")
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in d, (tag, key)
+        assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["unit"] == "steps/s"
+        assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]  # whole-job steps / wall time
+        assert d["config"]["per_gpu_batch"] == batch and "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        numel = batch * units.get(tag, 4 * 128 * 128)
+        assert r["algorithmic_bytes_per_step"] == numel * bytes_per_elem and r["algorithmic_bytes_per_element"] == bytes_per_elem
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_step"] / (r["us_per_step"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+        assert r["traffic"] is not None and r["traffic_source"].startswith("live")
+        if tag != "_cfg5":  # cfg5 moves FEWER bytes than 8(d) counts (derivatives stored as 2 B, counted as 4 B pairs): stated in DESIGN
+            assert 0.98 < r["traffic"] / r["algorithmic_bytes_per_step"] < 1.05
+        else:
+            assert 0.80 < r["traffic"] / r["algorithmic_bytes_per_step"] < 1.0
+        assert ("whole_step" in r) == (tag in ("_cfg3c", "_cfg5"))  # configs that name a noise generator report it separately
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "steps/s" and c["sample"]
+
+
 def test_bench_cli_parses_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup"):
+    for flag in ("--gpus", "--steps", "--warmup", "--config"):
         assert flag in out.stdout
