@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 10
+#define SKR_ABI_VERSION 11
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 /* Devices and streams: every entry point launches on the device that owns its output buffer (queried from the pointer when
@@ -122,6 +122,21 @@ typedef struct skr_step_row {
 int skr_step_launch_indexed(const skr_step_plan* plan, const void* const* inputs, void* out0, void* out1,
                             const uint64_t* seeds_dev, int64_t numel, const skr_step_row* rows_dev,
                             const int32_t* index_dev /* device int32, may be NULL */, int32_t row_offset, void* stream);
+
+/*
+ * Step programs -- a plan the library keeps, launched by handle.  Replaces the per-step host work of a REPLAYED step
+ * (skrample/diffusers.py:565-599 redoes the whole step algebra every call; skrample_amd lowers each distinct step once,
+ * sampling/program.py): the plan -- coefficients, dtypes, conversion kinds, sample size -- is handed over and validated once,
+ * a launch passes only what changes from call to call: operand / output / seed pointers and the two Philox stream ids.
+ * skr_program_launch(prog, ...) == skr_step_launch(plan with stream0 / stream1 replaced, ..., numel, stream), bit for bit.
+ * A program is immutable after creation and may be launched from several threads; destroy it when no launch is in flight
+ * on the host side (device work already enqueued is unaffected).
+ */
+typedef struct skr_program skr_program;
+int skr_program_create(const skr_step_plan* plan, int64_t numel, skr_program** out);
+int skr_program_launch(const skr_program* prog, const void* const* inputs, void* out0, void* out1,
+                       const uint64_t* seeds_dev, uint64_t stream0, uint64_t stream1, void* stream);
+void skr_program_destroy(skr_program* prog);
 
 /*
  * Noise generators -- replace skrample/pytorch/noise.py behind BatchTensorNoise.generate
@@ -250,6 +265,8 @@ const char* skr_build_info(void);
  *   "two_out"  2|1|0  compile-time one-trip kernel for two-output (UniPC / SPC) launches: 1 where it measured faster
  *                   (default), 2 wherever it is instantiated, 0 never
  *   "pace"     1|0  paced load issue in the one-trip kernels (default 1)
+ *   "two_nt"   -1|0|1  stores of two-output launches without in-kernel noise and >= 9 operands: non-temporal (1), write-through (0),
+ *                   by operand count where it measured faster (-1, the default)
  *   "rk_uv"    0|1|2|4  vectors per lane of the grid-stride Runge-Kutta stage kernel (0 = default)
  *   "rk_blk"   0|128|256  threads per workgroup of the one-trip Runge-Kutta stage kernel (0 = by operand count, the default:
  *                   128 for 4-6 operands, 256 otherwise)

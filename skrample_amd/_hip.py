@@ -14,7 +14,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 10
+ABI_VERSION = 11
 SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
@@ -27,6 +27,9 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_
 EXPORTS = (
     "skr_step_launch",
     "skr_step_launch_indexed",
+    "skr_program_create",
+    "skr_program_launch",
+    "skr_program_destroy",
     "skr_noise_random",
     "skr_noise_offset",
     "skr_noise_brownian",
@@ -198,6 +201,11 @@ class _HipModule(type(sys)):
 sys.modules[__name__].__class__ = _HipModule
 
 
+def hooks_clear() -> bool:
+    "no launch hook installed on this thread (the replayed-step fast path launches by program handle, which the hooks do not see)"
+    return getattr(_hooks, "indexed", None) is None and getattr(_hooks, "trace", None) is None
+
+
 def step_launch_raw(plan: StepPlanC, arr, out0_ptr, out1_ptr, seeds_ptr, numel: int, stream_ptr: int) -> int:
     "every skr_step_launch of the package goes through here (status returned, not checked)"
     lib = load()
@@ -234,6 +242,12 @@ def load() -> ctypes.CDLL:
         lib.skr_step_launch.restype = ctypes.c_int
         lib.skr_step_launch_indexed.argtypes = [ctypes.POINTER(StepPlanC), ctypes.POINTER(vp), vp, vp, vp, i64, vp, vp, i32, vp]
         lib.skr_step_launch_indexed.restype = ctypes.c_int
+        lib.skr_program_create.argtypes = [ctypes.POINTER(StepPlanC), i64, ctypes.POINTER(vp)]
+        lib.skr_program_create.restype = ctypes.c_int
+        lib.skr_program_launch.argtypes = [vp, ctypes.POINTER(vp), vp, vp, vp, u64, u64, vp]
+        lib.skr_program_launch.restype = ctypes.c_int
+        lib.skr_program_destroy.argtypes = [vp]
+        lib.skr_program_destroy.restype = None
         lib.skr_noise_random.argtypes = [vp, i32, vp, u64, i64, i64, vp]
         lib.skr_noise_random.restype = ctypes.c_int
         lib.skr_noise_offset.argtypes = [vp, i32, vp, u64, u64, i64, ctypes.POINTER(i64), i32, ctypes.c_uint32, ctypes.c_double, vp]

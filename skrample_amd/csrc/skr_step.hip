@@ -13,6 +13,7 @@
 
 #include "skr_device.h"
 #include "skr_step_common.h"
+#include <new>
 
 namespace skr {
 
@@ -585,6 +586,42 @@ extern "C" int skr_step_launch_indexed(const skr_step_plan* plan, const void* co
   return step_launch_impl(plan, inputs, out0, out1, seeds_dev, numel, stream, rows_dev, index_dev, row_offset);
 }
 
+// ---- step programs: a plan kept by the library, launched by handle ------------------------------------------------------------------
+// What is per launch stays per launch (operand / output / seed pointers, the two Philox stream ids); everything that depends on
+// the plan alone -- term counts, dtype combination, conversion kinds, shape consistency -- is checked once, when the program is made.
+struct skr_program {
+  skr_step_plan plan;
+  int64_t numel;
+};
+
+extern "C" int skr_program_create(const skr_step_plan* plan, int64_t numel, skr_program** out) {
+  if (!plan || !out) return SKR_ERR_NULL;
+  *out = nullptr;
+  const skr_step_plan& p = *plan;
+  if (p.n_terms < 0 || p.n_terms > SKR_MAX_TERMS || p.n_group_a < 0 || p.n_group_a > p.n_terms) return SKR_ERR_TERMS;
+  if (numel < 0) return SKR_ERR_SHAPE;
+  if (p.out0_dtype == SKR_NONE && p.out1_dtype == SKR_NONE) return SKR_ERR_NULL;
+  if (p.noise_mode != 0 && p.noise_mode != 1) return SKR_ERR_UNSUPPORTED;
+  if (p.convert_to < 0 || p.convert_to > 3 || p.convert_from < 0 || p.convert_from > 3) return SKR_ERR_UNSUPPORTED;
+  if ((p.convert_to || p.convert_from) && (p.n_group_a < 2 || p.out1_dtype == SKR_NONE)) return SKR_ERR_TERMS;
+  if (p.noise_mode == 1 && numel > 0) {
+    if (p.sample_numel <= 0 || numel % p.sample_numel != 0) return SKR_ERR_SHAPE;
+    if (p.sample_numel % 8 != 0) return SKR_ERR_UNSUPPORTED;
+  }
+  *out = new (std::nothrow) skr_program{p, numel};
+  return *out ? SKR_OK : SKR_ERR_LAUNCH;
+}
+
+extern "C" int skr_program_launch(const skr_program* prog, const void* const* inputs, void* out0, void* out1, const uint64_t* seeds_dev,
+                                  uint64_t stream0, uint64_t stream1, void* stream) {
+  if (!prog) return SKR_ERR_NULL;
+  skr_step_plan p = prog->plan;  // (a private copy: one program may be launched from several threads at once)
+  p.stream0 = stream0;
+  p.stream1 = stream1;
+  return step_launch_impl(&p, inputs, out0, out1, seeds_dev, prog->numel, stream, nullptr, nullptr, 0);
+}
+
+extern "C" void skr_program_destroy(skr_program* prog) { delete prog; }
 
 extern "C" int skr_last_hip_error(void) { return skr::g_last_hip_error; }
 
@@ -600,6 +637,7 @@ extern "C" int skr_set_tuning(const char* key, int32_t value) {
   else if (!strcmp(key, "rk_uv")) skr::g_tune.rk_uv = value;
   else if (!strcmp(key, "two_out")) skr::g_tune.two_out = value;
   else if (!strcmp(key, "pace")) skr::g_tune.pace = value;
+  else if (!strcmp(key, "two_nt")) skr::g_tune.two_nt = value;
   else if (!strcmp(key, "rk_blk")) skr::g_tune.rk_blk = (value == 128 || value == 256) ? value : 0;
   else return SKR_ERR_UNSUPPORTED;
   return SKR_OK;

@@ -13,7 +13,7 @@ namespace skr {
 
 // tuning switches (defaults = the measured best; initialised from the environment, changed with skr_set_tuning)
 struct Tuning {
-  int one_trip, xmap, tile, rk_uv, two_out, pace, rk_blk;
+  int one_trip, xmap, tile, rk_uv, two_out, pace, rk_blk, two_nt;
   Tuning() {
     const char* e;
     one_trip = !((e = getenv("SKR_ONE_TRIP")) && e[0] == '0');
@@ -22,6 +22,7 @@ struct Tuning {
     rk_uv = (e = getenv("SKR_RK_UV")) ? atoi(e) : 0;
     two_out = getenv("SKR_NO_TWO_OUT") == nullptr;
     pace = getenv("SKR_NO_PACE") == nullptr;
+    two_nt = (e = getenv("SKR_TWO_NT")) ? atoi(e) : -1;  // two-output launches without in-kernel noise: non-temporal stores (1), write-through (0), by operand count (-1)
     rk_blk = (e = getenv("SKR_RK_BLK")) ? atoi(e) : 0;  // threads per workgroup of the one-trip Runge-Kutta stage kernel: 0 = by operand count, 128, 256
   }
 };
@@ -200,7 +201,10 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
   return lo | (hi << 16);
 }
 
-template <typename T, typename Acc, bool TILE = false>
+// NT (tile layout only): non-temporal instead of write-through stores -- what tools/tune/tune_r3.hip measured 1.5 % faster for the
+// two-output launch with 10 + 1 operands and no arithmetic besides (km<..spb1,spf1>: 336.1 vs 341.2 us), the one traffic mix
+// where write-through did not win or tie
+template <typename T, typename Acc, bool TILE = false, bool NT = false>
 __device__ __forceinline__ void store8(void* base, int64_t vec, const Acc v[VEC]) {
   if constexpr (sizeof(T) == 2) {
     u32x4_t q;
@@ -209,7 +213,11 @@ __device__ __forceinline__ void store8(void* base, int64_t vec, const Acc v[VEC]
       if constexpr (std::is_same<T, bf16_t>::value) q[i] = pack_bf16((float)v[2 * i], (float)v[2 * i + 1]);
       else q[i] = pack_f16((float)v[2 * i], (float)v[2 * i + 1]);
     }
-    if constexpr (TILE) {
+    if constexpr (TILE && NT) {
+      u32x2_t* p = reinterpret_cast<u32x2_t*>(base);
+      __builtin_nontemporal_store(u32x2_t{q[0], q[1]}, p + group0<true>(vec));
+      __builtin_nontemporal_store(u32x2_t{q[2], q[3]}, p + group1<true>(vec));
+    } else if constexpr (TILE) {
       u32x2_t* p = reinterpret_cast<u32x2_t*>(base);
       store8_stream(p + group0<true>(vec), u32x2_t{q[0], q[1]});
       store8_stream(p + group1<true>(vec), u32x2_t{q[2], q[3]});
@@ -220,7 +228,10 @@ __device__ __forceinline__ void store8(void* base, int64_t vec, const Acc v[VEC]
     f32x4_t* p = reinterpret_cast<f32x4_t*>(base);
     f32x4_t a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     f32x4_t b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
-    if constexpr (TILE) {  // whole lines per wave instruction: write through
+    if constexpr (TILE && NT) {
+      __builtin_nontemporal_store(a, p + group0<true>(vec));
+      __builtin_nontemporal_store(b, p + group1<true>(vec));
+    } else if constexpr (TILE) {  // whole lines per wave instruction: write through
       store16_stream(p + group0<true>(vec), a);
       store16_stream(p + group1<true>(vec), b);
     } else {  // 32 B per lane = two half-covered lines per instruction: plain write-back stores, so L2 merges the halves

@@ -330,9 +330,10 @@ int launch_one_trip_rk(const StepArgs<float>& args, bool noise, hipStream_t stre
   if (noise && args.rows == nullptr && args.zeta0 != 0.f) return SKR_OK;  // (a noisy derivative does not occur; left to the general kernel)
   taken = true;
   const unsigned chunks = (unsigned)(args.numel / ((int64_t)BLOCK * VEC));
-  // 128-thread workgroups for the 4-6 operand stages (tools/bench_plan.py rk, same box: K=4 33.5 vs 34.0 us, K=5 38.7 vs 39.8, K=6 43.7 vs
-  // 45.2; K=2 / 3 lose 1-2 % with them and K >= 7 is unchanged); rk_blk = 128 / 256 forces one size
-  const bool small_blocks = g_tune.rk_blk == 128 || (g_tune.rk_blk == 0 && args.n_terms >= 4 && args.n_terms <= 6);
+  // 128-thread workgroups for the 2-6 operand stages (tools/bench_plan.py rk, same box: K=4 33.5 vs 34.0 us, K=5 38.7 vs 39.8, K=6 43.7 vs
+  // 45.2, K >= 7 unchanged; round 4, A/B/A/B on one box, profiles/r04_bench_plan_ab.txt: K=2 23.6-23.8 vs 24.1-24.2 us, K=3 29.16-29.26 vs
+  // 29.17-29.30 -- round 3 had read K=2 / 3 as 1-2 % slower from runs on different boxes); rk_blk = 128 / 256 forces one size
+  const bool small_blocks = g_tune.rk_blk == 128 || (g_tune.rk_blk == 0 && args.n_terms <= 6);
   if (small_blocks && chunks < 0x40000000u && bps_shift > -0x20000000) {
     if (args.n_terms <= 4) return noise ? launch_rk1<T, true, 4, 128>(args, chunks, bps_shift, stream) : launch_rk1<T, false, 4, 128>(args, chunks, bps_shift, stream);
     return noise ? launch_rk1<T, true, 8, 128>(args, chunks, bps_shift, stream) : launch_rk1<T, false, 8, 128>(args, chunks, bps_shift, stream);
@@ -363,9 +364,13 @@ struct TwoOutArgs {
   float c1[NMAX];
   RowRef tab;
 };
+// operand count from which the no-noise two-output launches store non-temporally.  Round-4 A/B/A/B through the library on one box
+// (tools/bench_plan.py ab, profiles/r04_bench_plan_ab.txt): 8 + 1 operands 294.0-295.1 us vs 299.4-299.9 us with write-through stores,
+// 10 + 1 (BASELINE config 3 with Colored noise tensors) 338.2-338.5 vs 346.0-346.1 us
+constexpr int NT_FROM_OPERANDS = 9;
 constexpr int two_out_nmax(int n) { return n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 12 ? 12 : (n <= 16 ? 16 : (n <= 20 ? 20 : 24)))); }
 
-template <typename TA, int NA, int NB, bool NOISE, bool PACE, bool TAB>
+template <typename TA, int NA, int NB, bool NOISE, bool PACE, bool TAB, bool NT = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out_nmax(NA + NB)> a) {
   const uint32_t c = chunk_of(blockIdx.x, a.xmap_lr);
   const int64_t v = (int64_t)c * BLOCK + threadIdx.x;
@@ -469,11 +474,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel_k2(const TwoOutArgs<two_out
 #pragma unroll
   for (int i = 0; i < VEC; ++i) s1[i] = fma_(chain, s0[i], s1[i]);
   if constexpr (NOISE) { if (n1) fma_noise8<float>(zeta1, z1, s1); }
-  store8<TA, float, true>(a.out1, v, s1);
-  store8<float, float, true>(a.out0, v, s0);
+  store8<TA, float, true, NT>(a.out1, v, s1);
+  store8<float, float, true, NT>(a.out0, v, s0);
 }
 
-template <typename TA, int NA, int NB, bool NOISE, bool PACE, bool TAB>
+template <typename TA, int NA, int NB, bool NOISE, bool PACE, bool TAB, bool NT = false>
 static int launch_k2(const StepArgs<float>& args, int bps_shift, hipStream_t stream) {
   constexpr int NMAX = two_out_nmax(NA + NB);
   const int64_t chunks = args.numel / ((int64_t)BLOCK * VEC);
@@ -487,12 +492,15 @@ static int launch_k2(const StepArgs<float>& args, int bps_shift, hipStream_t str
   ta.stream0 = args.stream0; ta.stream1 = args.stream1;
   ta.chain = args.chain; ta.zeta0 = args.zeta0; ta.zeta1 = args.zeta1;
   ta.tab = RowRef{args.rows, args.index, args.row_offset};
-  hipLaunchKernelGGL((step_kernel_k2<TA, NA, NB, NOISE, PACE, TAB>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, ta);
+  hipLaunchKernelGGL((step_kernel_k2<TA, NA, NB, NOISE, PACE, TAB, NT>), dim3((unsigned)chunks), dim3(BLOCK), 0, stream, ta);
   return finish_launch();
 }
 
 // the operand counts the samplers emit (tools/trace_plans.py): UniPC / SPC of order n give 2n+2 (+2 with a noise
 // tensor) 16-bit operands and the previous corrected state in fp32; their first steps have no fp32 operand yet
+// store policy of the no-noise two-output launches (see store8): "two_nt" 1 / 0 forces it, -1 = where it measured faster
+static bool nt_stores(int operands) { return g_tune.two_nt >= 0 ? g_tune.two_nt != 0 : NT_FROM_OPERANDS > 0 && operands >= NT_FROM_OPERANDS; }
+
 template <typename TA>
 int launch_one_trip_two(const StepArgs<float>& args, bool noise, bool group_b_f32, hipStream_t stream, bool& taken) {
   taken = false;
@@ -507,7 +515,10 @@ int launch_one_trip_two(const StepArgs<float>& args, bool noise, bool group_b_f3
   if (na == A && nb == B) {                                                                      \
     taken = true;                                                                                \
     if (args.rows != nullptr) return noise ? launch_k2<TA, A, B, true, true, true>(args, bps_shift, stream) : launch_k2<TA, A, B, false, false, true>(args, bps_shift, stream); \
-    if (!noise) return launch_k2<TA, A, B, false, false, false>(args, bps_shift, stream);       \
+    if (!noise) {                                                                                \
+      if constexpr (A + B >= 9) { if (nt_stores(A + B)) return launch_k2<TA, A, B, false, false, false, true>(args, bps_shift, stream); } \
+      return launch_k2<TA, A, B, false, false, false>(args, bps_shift, stream);                  \
+    }                                                                                            \
     return g_tune.pace ? launch_k2<TA, A, B, true, true, false>(args, bps_shift, stream) : launch_k2<TA, A, B, true, false, false>(args, bps_shift, stream); \
   }
   SKR_GO(2, 0) SKR_GO(3, 0) SKR_GO(4, 0) SKR_GO(4, 1) SKR_GO(6, 1) SKR_GO(7, 1) SKR_GO(8, 1) SKR_GO(10, 1)

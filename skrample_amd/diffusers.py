@@ -36,11 +36,11 @@ from torch import Tensor
 
 from . import scheduling
 from .common import DeltaPoint, MergeStrategy, Point, Step
-from .pytorch.noise import BatchTensorNoise, HostRandomBatch, Offset, Pyramid, Random, TensorNoiseCommon, TensorNoiseProps
+from .pytorch.noise import SUBSTREAMS, BatchTensorNoise, HostRandomBatch, Offset, Pyramid, Random, TensorNoiseCommon, TensorNoiseProps
 from . import _hip
 from .sampling import functional, interface, lazy, models, program, tableaux, traits
 from .sampling import structured as sampling
-from .sampling.lazy import LazyTensor, Lin, SkrampleHipError, lift
+from .sampling.lazy import LazyTensor, Lin, PhiloxNoise, SkrampleHipError, empty_output, lift
 from .sampling.models import DataModel, DiffusionModel, FlowModel, NoiseModel, VelocityModel
 from .sampling.structured import SampleInput, SKSamples, StructuredSampler
 from .scheduling import ScheduleCommon, ScheduleModifier, SkrampleSchedule, SubSchedule
@@ -382,6 +382,19 @@ class SkrampleWrapperCore(abc.ABC):
             flat = sample.reshape(sample.shape[0], per_item)
             mids = flat[:, per_item // 2].to(torch.float64).cpu().tolist() if per_item else [0.0] * sample.shape[0]
             seeds = [int(v * 1e4 * (step.position() + 1)) for v in mids]
+        from .pytorch import noise as _noise_mod
+
+        if sample.is_cuda and noise_type is Random and _noise_mod._private_vectors[0] == 0 and all(type(v) is int for v in seeds):
+            # white noise keyed by plain ints has no state but its draw counter: a run with the same seeds reuses the generator
+            # object (and its device seed vector) of the previous run instead of rebuilding both
+            key = (tuple(seeds), tuple(sample.shape[1:]), sample.dtype, sample.device)
+            hit = getattr(self, "_white_generator", None)
+            if hit is not None and hit[0] == key and not torch.cuda.is_current_stream_capturing():
+                hit[1]._draws = 0
+                return hit[1]
+            made = BatchTensorNoise.from_batch_inputs(noise_type, unit_shape=tuple(sample.shape[1:]), seeds=seeds, props=noise_props, dtype=sample.dtype)
+            self._white_generator = (key, made)
+            return made
         if not sample.is_cuda:  # host-resident latents (the reference's CPU path): torch's own generators, drawn as the reference draws them
             if noise_type is Random:
                 return HostRandomBatch(tuple(sample.shape[1:]), seeds, torch.float32)
@@ -623,6 +636,12 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._programs_for = None
         self._schedule = self.schedule  # pristine copy restored by set_timesteps
         self._calls = 0
+        # replayed steps of a run that walks the schedule in order (see _fast_step)
+        self._fast: dict = {}  # (first index of the run, index) -> _FastEntry
+        self._fast_ids = None  # the configuration objects the entries were learned under
+        self._hist_ptrs: list = []  # per history record: (sample ptr, model_output ptr, record.sample ptr)
+        self._run_seq = False  # every call of this run so far took the next schedule index
+        self._fast_hits = 0  # steps served by _fast_step (diagnostics / tests)
 
     @classmethod
     def from_diffusers_config(
@@ -682,6 +701,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
     def set_begin_index(self, begin_index: int = 0) -> None:
         super().set_begin_index(begin_index)
         self._calls = 0
+        self._run_seq = False
         self.fake_config["begin_index"] = begin_index
 
     def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None, sigmas=None, mu=None) -> None:
@@ -697,6 +717,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._previous = []
         self._raw_outputs = []
         self._raw_samples = []
+        self._hist_ptrs = []
+        self._run_seq = False
         self._alias_stamps = []
         self._alias_auto = None
         self._retire_noise_generator()
@@ -711,6 +733,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         lowered step programs stay.  Used by skrample_amd.graphs to re-run a loop inside a HIP-graph capture."""
         self._calls = 0
         self._previous, self._raw_outputs, self._raw_samples = [], [], []
+        self._hist_ptrs = []
+        self._run_seq = False
         self._alias_stamps = []
         self._alias_auto = None
         self._noise_ahead = None
@@ -734,8 +758,16 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         return self.sampler.scale_input(sample, Point(*self.schedule_np[idx]))
 
     def step(self, model_output: Tensor, timestep, sample: Tensor, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict: bool = True):
+        if type(timestep) is float and self._fast_ids is not None:
+            done = self._fast_step(model_output, timestep, sample, generator, return_dict)
+            if done is not None:
+                return done
         table = self._timestep_table()
         idx = self._lookup(table, timestep, self._index + self._calls)
+        if self._calls == 0:
+            self._run_seq = idx == self._index
+        elif idx != self._index + self._calls:
+            self._run_seq = False
         self._calls += 1
         step = Step.from_int(idx, len(table))
         keep = self.sampler.require_previous  # (a computed property: read once per step)
@@ -755,6 +787,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         owner = (self.sampler, self.model, self.schedule, self._steps, self.compute_scale)
         if self._programs_for != owner:  # frozen dataclasses: equal configuration <=> equal coefficients
             self._programs, self._programs_for = {}, owner
+            self._fast = {}
+        self._fast_ids = (self.sampler, self.model, self.schedule, self.compute_scale, self.noise_type, self.noise_props, self._steps)
         roles = program.Roles(sample, model_output, noise, self._previous, self._raw_outputs, self._raw_samples)
         key = (
             idx, tuple(rec.step for rec in self._previous), sample.dtype, model_output.dtype, tuple(sample.shape),
@@ -764,6 +798,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         prog = self._programs.get(key)
         if prog is not None and prog is not False:
             record = prog.run(roles, step, prediction, sample.device)
+            if record is not None and self._run_seq and (self._index, idx) not in self._fast:
+                self._fast_learn(prog, idx, step, table, sample, model_output, noise, keep)
         if record is None:
             tracing = prog is None and _hip.trace is None and isinstance(sample, Tensor) and sample.is_cuda
             if tracing:
@@ -779,19 +815,221 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
                 if tracing:
                     built = program.StepProgram.build(_hip.trace[0], roles, record, prediction) if len(_hip.trace) == 1 else None
                     self._programs[key] = built if built is not None else False
+                    if built is not None and self._run_seq and (self._index, idx) not in self._fast:
+                        self._fast_learn(built, idx, step, table, sample, model_output, noise, keep)
             finally:
                 if tracing:
                     _hip.trace = None
         self._previous.append(record)
         self._raw_outputs.append(model_output)
         self._raw_samples.append(sample)
+        on_device = isinstance(sample, Tensor) and sample.is_cuda and isinstance(model_output, Tensor)
+        self._hist_ptrs.append((sample.data_ptr(), model_output.data_ptr(), record.sample.data_ptr() if isinstance(record.sample, Tensor) else 0) if on_device else None)
         self._previous = self._previous[max(len(self._previous) - keep, 0) :]
         self._raw_outputs = self._raw_outputs[max(len(self._raw_outputs) - keep, 0) :]
         self._raw_samples = self._raw_samples[max(len(self._raw_samples) - keep, 0) :]
+        self._hist_ptrs = self._hist_ptrs[max(len(self._hist_ptrs) - keep, 0) :]
         if aliasing:
             self._alias_hold((sample, model_output), 2 * keep)
         self._issue_noise_ahead()  # behind this step's launch in host order: the step kernel is never kept waiting for it
         return self._finish(record.final, record.prediction, model_output, return_dict)
+
+
+    # ---- replayed steps of an in-order run: the fast path -----------------------------------------------------------------
+    # The step programs (sampling/program.py) already replace the step algebra by pointer binding; what is left per step is
+    # bookkeeping -- index lookup, program key, role resolution, operand checks, alias stamps, record and history upkeep --
+    # which at BASELINE config 2's size (a 7 us kernel) costs three times the kernel.  For a run that walks the schedule in
+    # order, everything but the tensors is a function of (first index of the run, index): `_fast_learn` keeps, per such pair, the
+    # program as a LIBRARY-side handle (skr_program_create), where each operand comes from (this call's sample / model_output, or
+    # a pointer remembered with a history record) and which Philox draws feed it; `_fast_step` then validates this call's two
+    # tensors, runs the alias guard, binds pointers and launches through skr_program_launch.  Anything out of the ordinary --
+    # another timestep than the next one, a tensor timestep, other dtypes / shapes / devices, noise drawn ahead, a launch hook
+    # (graph capture, tracing), structured noise, alias mode not settled -- returns None and the general path above runs.
+    # Results are the general path's bit for bit (tests/test_step_gpu.py::test_fast_steps_equal_the_general_path).
+    fast_steps = True  # class-level switch (tests compare both paths)
+
+    def _fast_learn(self, prog, idx: int, step: Step, table, sample: Tensor, model_output: Tensor, noise, keep: int) -> None:
+        key = (self._index, idx)
+        self._fast[key] = False  # (decided once per key)
+        if not self.fast_steps or _hip._raw_stream is None or self.invert_prediction or len(set(table)) != len(table) or not sample.is_cuda:
+            return
+        nprev = len(self._previous)
+        srcs = []
+        for role in prog.roles:
+            kind = role[0]
+            if kind == "x":
+                srcs.append((0, 0, 0))
+            elif kind == "o":
+                srcs.append((1, 0, 0))
+            elif kind in ("pi", "po", "px"):
+                if self._hist_ptrs[role[1]] is None or (kind == "px" and self._hist_ptrs[role[1]][2] == 0):
+                    return
+                srcs.append((2, role[1], {"pi": 0, "po": 1, "px": 2}[kind]))
+            else:
+                return  # a noise TENSOR among the operands (Offset / Pyramid / Colored / Brownian): general path
+        draws = []
+        for role in prog.noise_roles:
+            if role is None:
+                draws.append(None)
+            elif role == ("n",):
+                draws.append(0)
+            elif role[0] == "pn":
+                draws.append(role[1])
+            else:
+                return
+        uses_noise = noise is not None
+        if uses_noise and not (isinstance(noise, PhiloxNoise) and type(self._noise_generator) is BatchTensorNoise and self._noise_generator._kind is Random):
+            return
+        final_dtype = prog.out_dtypes[prog.final_out]
+        if final_dtype != model_output.dtype:
+            return
+        lib = _hip.load()
+        handle = ctypes.c_void_p()
+        if lib.skr_program_create(ctypes.byref(prog.plan), prog.numel, ctypes.byref(handle)) != 0 or not handle.value:
+            return
+        entry = _FastEntry()
+        weakref.finalize(entry, lib.skr_program_destroy, handle.value)
+        entry.handle, entry.prog, entry.srcs, entry.draws, entry.noise = handle.value, prog, tuple(srcs), tuple(draws), uses_noise
+        entry.arr = (ctypes.c_void_p * max(len(srcs), 1))()
+        entry.sdt, entry.odt, entry.shape, entry.device, entry.dev_index = sample.dtype, model_output.dtype, sample.shape, sample.device, sample.device.index
+        entry.step, entry.keep, entry.hist = step, keep, nprev
+        entry.o0dt, entry.o1dt = prog.out_dtypes
+        entry.final_out, entry.state_out, entry.pred = prog.final_out, prog.state_out, prog.pred
+        entry.stream0, entry.stream1 = prog.plan.stream0, prog.plan.stream1
+        entry.launch = lib.skr_program_launch
+        self._fast[key] = entry
+
+    def _fast_step(self, model_output, timestep: float, sample, generator, return_dict: bool):
+        ids = self._fast_ids
+        sched = self.schedule
+        if (self.sampler is not ids[0] or self.model is not ids[1] or self.compute_scale is not ids[3] or self.noise_type is not ids[4]
+                or self.noise_props is not ids[5] or self._steps != ids[6] or self.prefetch_noise):  # fmt: skip
+            return None
+        if sched is not ids[2]:
+            if sched != ids[2]:
+                return None
+            self._fast_ids = ids = (ids[0], ids[1], sched, ids[3], ids[4], ids[5], ids[6])
+        calls = self._calls
+        start = self._index
+        if calls and not self._run_seq:
+            return None
+        idx = start + calls
+        entry = self._fast.get((start, idx))
+        if not entry:
+            return None
+        table = self._timestep_list
+        if table is None or self._timestep_key[0] is not sched or self._timestep_key[1] != ids[6]:
+            table = self._timestep_table()
+        hooks = _hip._hooks
+        if idx >= len(table) or table[idx] != timestep or getattr(hooks, "indexed", None) is not None or getattr(hooks, "trace", None) is not None:
+            return None
+        shape = entry.shape
+        if (type(sample) is not Tensor or type(model_output) is not Tensor or sample.dtype is not entry.sdt or model_output.dtype is not entry.odt
+                or sample.shape != shape or model_output.shape != shape or not sample.is_contiguous() or not model_output.is_contiguous()):  # fmt: skip
+            return None
+        sp, op = sample.data_ptr(), model_output.data_ptr()
+        device = entry.device
+        if (sp | op) & 15 or sample.device != device or model_output.device != device:
+            return None
+        keep = entry.keep
+        hp = self._hist_ptrs
+        if len(hp) != entry.hist:
+            return None
+        stamps = self._alias_stamps
+        if keep:
+            if self.alias_history is not True and self._alias_auto != "alias":
+                return None
+            for t, ptr, version in stamps:  # the guard of the aliased history, as _alias_check
+                if t._version != version or t.data_ptr() != ptr:
+                    raise SkrampleHipError(self._ALIAS_HELP.format(what="was modified in place since"))
+                if ptr == op:
+                    raise SkrampleHipError(self._ALIAS_HELP.format(what="its buffer now holds this step's model_output"))
+                if ptr == sp and t is not sample:
+                    raise SkrampleHipError(self._ALIAS_HELP.format(what="its buffer now holds this step's sample"))
+        previous = self._previous
+        noise = None
+        seeds_ptr = None
+        s0, s1 = entry.stream0, entry.stream1
+        if entry.noise:
+            gen = self._noise_generator
+            if self._noise_ahead is not None or self._noise_done is not None or getattr(self, "_predrawn_noise", None) is not None:
+                return None
+            if gen is None:
+                gen = self._noise_generator = self._make_noise_generator(entry.step, sample, self.noise_type, self.noise_props, generator)
+            if type(gen) is not BatchTensorNoise or gen._kind is not Random:
+                return None
+            seeds = gen._seeds
+            if gen.batch_shape != shape:
+                return None
+            for d in entry.draws:  # history draws must be this generator's
+                if d is not None and d != 0:
+                    hn = previous[d].noise
+                    if type(hn) is not PhiloxNoise or hn.seeds is not seeds:
+                        return None
+            # ---- nothing below can refuse: the draw counter may move now
+            n = gen._draws
+            gen._draws = n + 1
+            noise = PhiloxNoise.quick(seeds, n * SUBSTREAMS, shape, device)
+            seeds_ptr = gen.seeds_ptr
+            d0, d1 = entry.draws
+            if d0 is not None:
+                s0 = noise.stream if d0 == 0 else previous[d0].noise.stream
+            if d1 is not None:
+                s1 = noise.stream if d1 == 0 else previous[d1].noise.stream
+        arr = entry.arr
+        j = 0
+        for code, k, f in entry.srcs:
+            arr[j] = sp if code == 0 else op if code == 1 else hp[k][f]
+            j += 1
+        out0 = empty_output(shape, entry.o0dt, device)
+        p0 = out0.data_ptr()
+        if entry.o1dt is not None:
+            out1 = empty_output(shape, entry.o1dt, device)
+            status = entry.launch(entry.handle, arr, p0, out1.data_ptr(), seeds_ptr, s0, s1, _hip._raw_stream(entry.dev_index))
+            final = out1 if entry.final_out else out0
+        else:
+            status = entry.launch(entry.handle, arr, p0, None, seeds_ptr, s0, s1, _hip._raw_stream(entry.dev_index))
+            final = out0
+        if status:
+            _hip.check(status, "skr_program_launch")
+        if entry.state_out is None:
+            rec_sample, rp = sample, sp
+        else:
+            rec_sample, rp = out0, p0
+        raw_outputs, raw_samples = self._raw_outputs, self._raw_samples
+        if entry.pred is None:
+            prediction = model_output
+        else:  # UniPC / SPC: the record's prediction is a form over this call's operands, materialised only if read
+            roles = program.Roles(sample, model_output, noise, previous, raw_outputs, raw_samples)
+            prediction = entry.prog.lazy_prediction(roles, shape, device)
+        record = object.__new__(SKSamples)
+        object.__setattr__(record, "__dict__", {"sample": rec_sample, "prediction": prediction, "step": entry.step, "noise": noise, "final": final})
+        if keep:
+            previous.append(record)
+            raw_outputs.append(model_output)
+            raw_samples.append(sample)
+            hp.append((sp, op, rp))
+            if len(previous) > keep:
+                del previous[0], raw_outputs[0], raw_samples[0], hp[0]
+            stamps.append((sample, sp, sample._version))
+            stamps.append((model_output, op, model_output._version))
+            extra = len(stamps) - 2 * keep
+            if extra > 0:
+                del stamps[:extra]
+        self._calls = calls + 1
+        if not calls:
+            self._run_seq = True  # (the run's first call took the run's first index)
+        self._fast_hits += 1
+        if entry.pred is not None:
+            return self._finish(final, prediction, model_output, return_dict)
+        return attr_dict(prev_sample=final, pred_original_sample=prediction) if return_dict else (final, prediction)
+
+
+class _FastEntry:
+    "what a replayed step of an in-order run needs besides today's tensors (SkrampleWrapperScheduler._fast_learn)"
+
+    __slots__ = ("handle", "prog", "srcs", "draws", "noise", "arr", "sdt", "odt", "shape", "device", "dev_index", "step", "keep", "hist", "o0dt", "o1dt",
+                 "final_out", "state_out", "pred", "stream0", "stream1", "launch", "__weakref__")  # fmt: skip
 
 
 @dataclasses.dataclass

@@ -103,6 +103,16 @@ def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor],
     tensor -- located by the wrapper through its storage offset, no read-back -- instead of a host float; the network then
     follows a re-targeted schedule, because the tensor's contents are replaced with the rows.
     """
+    from .pytorch import noise as _noise
+
+    _noise._private_vectors[0] += 1  # the loop's seed vector is overwritten in place by replays with new seeds: it is this loop's alone
+    try:
+        return _capture(wrapper, model, example, steps, seeds, warmup, indexed, slots, device_timesteps)
+    finally:
+        _noise._private_vectors[0] -= 1
+
+
+def _capture(wrapper, model, example: torch.Tensor, steps: int, seeds, warmup: int, indexed: bool, slots: int, device_timesteps) -> CapturedLoop:
     dev = example.device
     static_in = example.clone()
     gen = list(seeds) if seeds is not None else None
@@ -167,4 +177,7 @@ def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor],
         with torch.cuda.graph(graph):
             static_out = run(static_in)
     seeds_dev = getattr(getattr(wrapper, "_noise_generator", None), "_seeds", None)
+    from .pytorch.noise import forget_seed_vector
+
+    forget_seed_vector(seeds_dev)  # the graph reads this very buffer and replays may overwrite it: no other run may share it from now on
     return CapturedLoop(graph, static_in, static_out, seeds_dev, rows, run_other, static_times)

@@ -59,9 +59,31 @@ def seed_device(seed) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_seed_vectors: dict = {}  # (device, seed values) -> device int64 vector: read-only by convention, so runs with the same seeds share one upload
+
+
+_private_vectors = [0]  # > 0: seed vectors are neither looked up nor kept (skrample_amd.graphs captures loops that overwrite theirs in place)
+
+
+def forget_seed_vector(vector: torch.Tensor | None) -> None:
+    "a holder is about to overwrite `vector` in place (a captured loop replayed with new seeds): it must not be shared any longer"
+    for key in [k for k, v in _seed_vectors.items() if v is vector]:
+        del _seed_vectors[key]
+
+
 def seeds_tensor(values: Sequence[int], device: torch.device) -> torch.Tensor:
+    key = (device, tuple(values))
+    private = _private_vectors[0] > 0
+    hit = None if private else _seed_vectors.get(key)
+    if hit is not None:
+        return hit
     signed = [v - (1 << 64) if v >= (1 << 63) else v for v in values]
-    return torch.tensor(signed, dtype=torch.int64, device=device)
+    out = torch.tensor(signed, dtype=torch.int64, device=device)
+    if device.type == "cuda" and not private and not torch.cuda.is_current_stream_capturing():
+        if len(_seed_vectors) >= 8:
+            _seed_vectors.pop(next(iter(_seed_vectors)))
+        _seed_vectors[key] = out
+    return out
 
 
 @dataclass
@@ -657,8 +679,10 @@ class BatchTensorNoise(SkrampleTensorNoise):
         self._kind = type(first)
         self._device = first._device
         raw = self.generators.raw_seeds if isinstance(self.generators, _LazyGenerators) else [g.seed for g in self.generators]
-        self._seeds = seeds_tensor([seed_value(v) for v in raw], self._device)
+        self._seeds = seeds_tensor([v & 0xFFFFFFFFFFFFFFFF if type(v) is int else seed_value(v) for v in raw], self._device)
         self._state: dict = {}
+        self.seeds_ptr = self._seeds.data_ptr()
+        self.batch_shape = (len(raw), *first.shape)  # shape of one draw
 
     def _stream(self) -> int:
         n = self._draws

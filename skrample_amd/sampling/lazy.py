@@ -58,7 +58,14 @@ class PhiloxNoise:
 
     def __init__(self, seeds: torch.Tensor, stream: int, shape: Sequence[int], device: torch.device):
         self.seeds, self.stream, self.shape, self.device = seeds, int(stream), tuple(shape), device
-        self._cache: dict = {}
+        self._cache: dict | None = None
+
+    @classmethod
+    def quick(cls, seeds: torch.Tensor, stream: int, shape: tuple, device: torch.device) -> "PhiloxNoise":
+        "the same object without argument conversion (the replayed-step fast path makes one per step)"
+        self = cls.__new__(cls)
+        self.seeds, self.stream, self.shape, self.device, self._cache = seeds, stream, shape, device, None
+        return self
 
     @property
     def sample_numel(self) -> int:
@@ -69,6 +76,8 @@ class PhiloxNoise:
 
     def realize(self, dtype: torch.dtype = torch.float32) -> torch.Tensor:
         "materialise through skr_noise_random (any shape)"
+        if self._cache is None:
+            self._cache = {}
         if dtype not in self._cache:
             out = torch.empty(self.shape, dtype=dtype, device=self.device)
             lib = _hip.load()

@@ -166,18 +166,19 @@ class StepProgram:
         outs = (out0, out1)
         final = outs[self.final_out]
         sample = outs[self.state_out] if self.state_out is not None else roles.sample
-        if self.pred is None:
-            prediction = prediction_in
-        else:
-            terms, dtype = self.pred
-            bound = [(roles.get(r), c) for r, c in terms]  # bind now: the history window moves on
-
-            def make_form(bound=bound):
-                form = None
-                for leaf, c in bound:
-                    piece = Lin.leaf(leaf) * c
-                    form = piece if form is None else form + piece
-                return form
-
-            prediction = LazyTensor(None, dtype, form_fn=make_form, shape=self.shape, device=device, leaves=[leaf for leaf, _ in bound])
+        prediction = prediction_in if self.pred is None else self.lazy_prediction(roles, self.shape, device)
         return SKSamples(sample, prediction, step, roles.noise, final)
+
+    def lazy_prediction(self, roles: Roles, shape, device: torch.device) -> LazyTensor:
+        "the record's prediction as a form over today's operands, materialised only if somebody reads it"
+        terms, dtype = self.pred
+        bound = [(roles.get(r), c) for r, c in terms]  # bind now: the history window moves on
+
+        def make_form(bound=bound):
+            form = None
+            for leaf, c in bound:
+                piece = Lin.leaf(leaf) * c
+                form = piece if form is None else form + piece
+            return form
+
+        return LazyTensor(None, dtype, form_fn=make_form, shape=tuple(shape), device=device, leaves=[leaf for leaf, _ in bound])

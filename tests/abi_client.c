@@ -76,6 +76,25 @@ int main(void) {
   CHECK(hipMemcpy(y1, dy1, sizeof(float) * (N / 2), hipMemcpyDeviceToHost));
   if (memcmp(y, y1, sizeof(float) * (N / 2)) != 0) { fprintf(stderr, "noise depends on the batch it is drawn in\n"); return 1; }
 
+  /* a step program: the plan handed over once, launched by handle with today's pointers and stream ids -- same bits as
+   * skr_step_launch of the plan with those stream ids */
+  {
+    skr_program* prog = NULL;
+    CHECK(skr_program_create(&plan, N, &prog));
+    if (!prog) return 1;
+    plan.stream0 = 9;
+    CHECK(skr_step_launch(&plan, NULL, dy, NULL, dseeds, N, NULL));
+    CHECK(skr_program_launch(prog, NULL, dy1, NULL, dseeds, 9, 0, NULL));
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(y, dy, sizeof(float) * N, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(y1, dy1, sizeof(float) * N, hipMemcpyDeviceToHost));
+    if (memcmp(y, y1, sizeof(float) * N) != 0) { fprintf(stderr, "a program launch differs from the plan launch\n"); return 1; }
+    if (skr_program_launch(NULL, NULL, dy, NULL, dseeds, 0, 0, NULL) != SKR_ERR_NULL) return 1;
+    skr_program_destroy(prog);
+    plan.n_terms = -1;
+    if (skr_program_create(&plan, N, &prog) != SKR_ERR_TERMS || prog != NULL) return 1;
+    plan.n_terms = 0;
+  }
+
   /* argument checking happens before anything is launched */
   if (skr_step_launch(NULL, NULL, NULL, NULL, NULL, N, NULL) != SKR_ERR_NULL) return 1;
   printf("abi client ok: %s\n", skr_build_info());

@@ -47,6 +47,27 @@ def _reproducible_global_rngs(request):
     yield
 
 
+# ---- measured parity margins --------------------------------------------------------------------------------------------
+# With SKR_PARITY_MARGINS=<file> every parity comparison of the GPU suite appends what it MEASURED (one JSON line: test id,
+# family, measure, value, bar) -- tools/summarize_margins.py condenses the file into profiles/r04_parity_margins.txt, the
+# record the tolerances written in the tests are justified against.
+_current_test = [""]
+
+
+@pytest.fixture(autouse=True)
+def _margin_context(request):
+    _current_test[0] = request.node.nodeid
+    yield
+
+
+def note_margin(family: str, measure: str, value: float, bar: float | None = None) -> float:
+    path = os.environ.get("SKR_PARITY_MARGINS")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(json.dumps({"test": _current_test[0], "family": family, "measure": measure, "value": float(value), "bar": bar}) + "\n")
+    return value
+
+
 @pytest.fixture(scope="session")
 def kats():
     return json.load(open(os.path.join(GOLDEN, "reference_kats.json")))

@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from skr_oracle import noise as ON
+from conftest import note_margin
 from skrample_amd import _hip
 from skrample_amd.common import Step
 from skrample_amd.pytorch import noise as PN
@@ -20,6 +21,13 @@ from skrample_amd.pytorch._philox_host import philox_u32, uniform01
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5  # relative (inf-norm) tolerance for fp32 generator outputs
+# Two generators are long fp32 pipelines compared with ANOTHER fp32 pipeline (the oracle's torch ops), so part of any difference is the
+# reference's own rounding.  The measured maxima of the whole suite are in profiles/r04_parity_margins.txt (tools/summarize_margins.py;
+# MEASURED-MARGINS lines below are copied from it).  Where the plain 1e-5 is exceeded the wider bar is asserted TOGETHER with "no further
+# from the float64 evaluation of the same inputs than the reference's own fp32 result".
+PYRAMID_TOL = 2e-5
+COLORED_TOL = 5e-5
+COLORIZE_TOL = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -32,9 +40,27 @@ def spec_normal(seed: int, stream: int, shape) -> torch.Tensor:
     return torch.from_numpy(ON.philox_normal(seed, stream, int(np.prod(shape)))).reshape(tuple(shape))
 
 
-def rel(a: torch.Tensor, b: torch.Tensor) -> float:
+def rel(a: torch.Tensor, b: torch.Tensor, family: str | None = None, bar: float | None = None, exact: torch.Tensor | None = None) -> float:
+    """relative inf-norm error.  With `family` the MEASURED value is recorded (conftest.note_margin); with `exact` -- the float64
+    evaluation of the same inputs -- also how far the device result and the fp32 reference each sit from it."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    return ((a - b).abs().max() / b.abs().max()).item()
+    err = ((a - b).abs().max() / b.abs().max()).item()
+    if family is not None:
+        note_margin(family, "rel inf-norm error vs the fp32 oracle", err, bar)
+        if exact is not None:
+            e = exact.detach().cpu().double()
+            note_margin(family, "device vs float64 evaluation", ((a - e).abs().max() / e.abs().max()).item(), bar)
+            note_margin(family, "fp32 oracle vs float64 evaluation", ((b - e).abs().max() / e.abs().max()).item(), None)
+    return err
+
+
+def no_further_from_exact(got: torch.Tensor, ref32: torch.Tensor, exact: torch.Tensor, slack: float = 1.5, floor: float = 2e-6) -> bool:
+    """the bar where an fp32 pipeline of many roundings (FFT, interpolation + normalisation) cannot meet 1e-5 against ANOTHER fp32
+    pipeline: the device result is no further from the float64 evaluation of the same inputs than the reference's own fp32 result
+    (x `slack`; `floor` covers references that happen to land almost exactly)"""
+    g, r, e = (t.detach().cpu().double() for t in (got, ref32, exact))
+    scale = e.abs().max()
+    return ((g - e).abs().max() / scale).item() <= max(slack * ((r - e).abs().max() / scale).item(), floor)
 
 
 def test_host_philox_matches_oracle_and_device(dev):
@@ -78,7 +104,7 @@ def test_offset(unit, props, dev):
         for s in seeds:
             draws = [spec_normal(s, n * 256 + 1, ON.offset_shape(unit, dims)), spec_normal(s, n * 256, unit)]
             refs.append(ON.offset_noise(unit, ON.Replay(draws).randn, dims, props.strength))
-        assert rel(got, torch.stack(refs)) < TOL, (unit, props, n)
+        assert rel(got, torch.stack(refs), "offset", TOL) < TOL, (unit, props, n)
 
 
 @pytest.mark.parametrize("unit", [(4, 16, 16), (3, 5, 7)])
@@ -90,7 +116,7 @@ def test_brownian(unit, dev):
     got = {s: g.generate(s).cpu().double() for s in steps}
     for s, v in got.items():
         ref = torch.stack([ON.brownian_noise(seed, unit, s) for seed in seeds])
-        assert rel(v, ref) < TOL, s
+        assert rel(v, ref, "brownian (own specification)", TOL) < TOL, s
     a, b, ab = got[steps[0]], got[steps[1]], got[steps[2]]
     assert rel((a + b) * math.sqrt(0.05), ab * math.sqrt(0.1)) < 1e-5  # W(.35,.4) + W(.4,.45) = W(.35,.45)
     assert torch.equal(g.generate(Step(0.4, 0.35)).cpu().double(), a)  # direction-normalised, stateless
@@ -185,18 +211,19 @@ def test_pyramid_level_geometry():
             assert counts[b] == len(want) and [tuple(r) for r in table[b, : counts[b]].tolist()] == [tuple(x) for x in want]
 
 
-def pyramid_reference(unit, seed: int, stream: int, **kw) -> torch.Tensor:
-    "oracle pyramid fed the draws the specification assigns: base stream+0, level l stream+1+l, uniforms stream+255"
+def pyramid_reference(unit, seed: int, stream: int, double: bool = False, **kw) -> torch.Tensor:
+    "oracle pyramid fed the draws the specification assigns: base stream+0, level l stream+1+l, uniforms stream+255 (double: evaluated in float64)"
     uniforms = uniform01(np.array([seed], dtype=np.uint64), stream + 255, 8)[0].tolist()
     state = {"level": 0, "base_done": False}
+    cast = (lambda t: t.double()) if double else (lambda t: t)
 
     def randn(shape):
         if not state["base_done"]:
             state["base_done"] = True
-            return spec_normal(seed, stream, shape)
+            return cast(spec_normal(seed, stream, shape))
         l = state["level"]
         state["level"] += 1
-        return spec_normal(seed, stream + 1 + l, shape)
+        return cast(spec_normal(seed, stream + 1 + l, shape))
 
     it = iter(uniforms)
     return ON.pyramid_noise(unit, randn, lambda: next(it), **kw)
@@ -221,7 +248,8 @@ def test_pyramid(unit, kw, dev):
         for b in range(len(seeds)):
             assert np.array_equal(dev_levels[b * 16 : b * 16 + counts[b] * 2].reshape(-1, 2), table[b, : counts[b]])
         ref = torch.stack([pyramid_reference(unit, s, n * 256, **kw) for s in seeds])
-        assert rel(got, ref) < 2e-5, (unit, kw, n, rel(got, ref))
+        exact = torch.stack([pyramid_reference(unit, s, n * 256, double=True, **kw) for s in seeds])
+        assert rel(got, ref, "pyramid (LDS kernels)", PYRAMID_TOL, exact) < PYRAMID_TOL, (unit, kw, n, rel(got, ref))
         assert (got.reshape(3, -1).std(dim=1) - 1).abs().max() < 1e-4
 
 
@@ -234,7 +262,8 @@ def test_pyramid_any_shape(unit, kw, dev):
     for n in range(2):
         got = g.generate(None).cpu()
         ref = torch.stack([pyramid_reference(unit, s, n * 256, **kw) for s in seeds])
-        assert rel(got, ref) < 2e-5, (unit, kw, n, rel(got, ref))
+        exact = torch.stack([pyramid_reference(unit, s, n * 256, double=True, **kw) for s in seeds])
+        assert rel(got, ref, "pyramid (any-shape kernels)", PYRAMID_TOL, exact) < PYRAMID_TOL, (unit, kw, n, rel(got, ref))
     if unit != (1, 4, 4):
         assert "any_shape" in g._state
     h16 = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=props, dtype=torch.bfloat16).generate(None)
@@ -257,7 +286,8 @@ def test_pyramid_over_any_axis_pair(unit, dims, dev):
     for n in range(2):
         got = g.generate(None).cpu()
         ref = torch.stack([pyramid_reference(unit, s, n * 256, dims=dims) for s in seeds])
-        assert rel(got, ref) < 2e-5, (unit, dims, n, rel(got, ref))
+        exact = torch.stack([pyramid_reference(unit, s, n * 256, double=True, dims=dims) for s in seeds])
+        assert rel(got, ref, "pyramid (any axis pair)", PYRAMID_TOL, exact) < PYRAMID_TOL, (unit, dims, n, rel(got, ref))
         assert (got.reshape(len(seeds), -1).std(dim=1) - 1).abs().max() < 1e-4
     h16 = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=props, dtype=torch.bfloat16).generate(None)
     ref = torch.stack([pyramid_reference(unit, s, 0, dims=dims) for s in seeds])
@@ -290,7 +320,7 @@ def test_pyramid_static(dev):
 
             pyr = ON.pyramid_component(unit, lv, lambda: next(uniforms))
             refs.append(ON.pyramid_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), None, static_pyramid=pyr))
-        assert rel(got, torch.stack(refs)) < 2e-5, n
+        assert rel(got, torch.stack(refs), "pyramid (static)", PYRAMID_TOL) < PYRAMID_TOL, n
 
 
 def test_pyramid_through_wrapper(dev):
@@ -321,7 +351,9 @@ def test_colored(unit, dev):
         for n, st in enumerate(steps):
             got = g.generate(st).cpu()
             ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st, **kw) for s in seeds])
-            assert rel(got, ref) < 5e-5, (unit, props, st, rel(got, ref))
+            exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st, **kw) for s in seeds])
+            err = rel(got, ref, "colored", COLORED_TOL, exact)
+            assert err < TOL or (err < COLORED_TOL and no_further_from_exact(got, ref, exact)), (unit, props, st, err)
             if props.energy is not None:
                 assert (got.reshape(2, -1).std(dim=1) - abs(props.energy)).abs().max() < 1e-4
 
@@ -391,7 +423,7 @@ def test_colored_with_unipc_wrapper(dev):
         got = w.step(out.to(dev), t, x.to(dev), generator=seeds, return_dict=False)[0]
         noise = shadow.generate(Step.from_int(i, steps)).cpu()  # the same draw the wrapper's generator made
         ref = o.step(out, t, x, noise=noise)[0]
-        assert rel(got, ref) < 1e-5, i
+        assert rel(got, ref, "colored weights / misc", TOL) < 1e-5, i
         x = ref
 
 
@@ -488,7 +520,7 @@ def test_colorize_noise_equals_reference_fixtures(dev):
         got = PN.Colored.colorize_noise(white, exponent=PN.colored_exponent(step, props), energy=props.energy)
         ref = torch.from_numpy(fx[f"{tag}/out"])
         assert got.shape == ref.shape and got.dtype == torch.float32
-        assert rel(got, ref) < 2e-5, (tag, rel(got, ref))
+        assert rel(got, ref, "colorize_noise vs reference-recorded outputs", COLORIZE_TOL) < COLORIZE_TOL, (tag, rel(got, ref))
     # API behaviour of the utility (reference noise.py:337-403)
     w = torch.randn(1, 8, 1, 12, device=dev)
     assert PN.Colored.colorize_noise(w) is w
@@ -514,7 +546,7 @@ def test_colorize_noise_with_up_to_six_axes_equals_reference_fixtures(dev):
         exponent, energy = fx[f"{tag}/args"].tolist()
         got = PN.Colored.colorize_noise(white, exponent=exponent, energy=None if math.isnan(energy) else energy).cpu()
         ref = torch.from_numpy(fx[f"{tag}/out"])
-        assert got.shape == ref.shape and rel(got, ref) < 2e-5, (tag, rel(got, ref))
+        assert got.shape == ref.shape and rel(got, ref, "colorize_noise vs reference-recorded outputs (4-6 axes)", COLORIZE_TOL) < COLORIZE_TOL, (tag, rel(got, ref))
 
 
 def test_component_methods(dev):
@@ -531,7 +563,7 @@ def test_component_methods(dev):
             uniforms = iter(uniform01(np.array([78], dtype=np.uint64), n * 256 + 255, 8)[0].tolist())
             level = iter(range(8))
             ref = ON.pyramid_component(unit, lambda shape: spec_normal(78, n * 256 + 1 + next(level), shape), lambda: next(uniforms), **kw)
-            assert got.shape == unit and rel(got, ref) < 2e-5, (kw, n, rel(got, ref))
+            assert got.shape == unit and rel(got, ref, "pyramid component", PYRAMID_TOL) < PYRAMID_TOL, (kw, n, rel(got, ref))
 
 
 @pytest.mark.parametrize("kind", ["colored_unipc", "pyramid_dpm", "offset_euler", "pyramid_rk", "colored_white_start"])
@@ -655,7 +687,7 @@ def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, d
         assert status == 0, (route, status)
         torch.cuda.synchronize()
         outs.append(out.cpu())
-    assert rel(outs[0], outs[1]) < 2e-5, rel(outs[0], outs[1])
+    assert rel(outs[0], outs[1], "colored: LDS kernels vs the hipFFT route", COLORIZE_TOL) < COLORIZE_TOL, rel(outs[0], outs[1])
     assert abs(outs[0].std().item() - 1.0) < 0.05
     # a side with a factor the kernel does not handle is still refused (and served by hipFFT through the Python layer)
     spec = torch.empty(260 * 131, dtype=torch.complex64, device=dev)
@@ -706,6 +738,8 @@ def test_colored_with_only_the_last_axis_on_hipfft(unit, dev):
         for n, st in enumerate((None, Step(0.45, 0.5))):
             got = g.generate(st).cpu()
             ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
-            assert rel(got, ref) < 5e-5, (unit, st, rel(got, ref))
+            exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st) for s in seeds])
+            err = rel(got, ref, "colored (last axis on hipFFT, others direct DFT)", COLORED_TOL, exact)
+            assert err < TOL or (err < COLORED_TOL and no_further_from_exact(got, ref, exact)), (unit, st, err)
     finally:
         assert lib.skr_set_tuning(b"fft_rank", 0) == 0

@@ -1,0 +1,181 @@
+"""Round-4 device tests: the in-order replay fast path of SkrampleWrapperScheduler.step (library-side step programs,
+skr_program_create / skr_program_launch) against the general path, bit for bit; its refusals; the alias guard inside it."""
+
+import pytest
+import torch
+
+import skrample_amd.diffusers as PD
+import skrample_amd.scheduling as PS
+from skrample_amd import _hip
+from skrample_amd.pytorch import noise as PN
+from skrample_amd.sampling import lazy
+from skrample_amd.sampling import models as PM
+from skrample_amd.sampling import structured as PT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+MAKERS = {
+    # name: (factory, fast path expected to serve steps)
+    "dpm2_sde_karras": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled())), True),
+    "dpm3_ode": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=3), PS.Scaled()), True),
+    "euler_sde": (lambda: PD.SkrampleWrapperScheduler(PT.Euler(stochasticity=1), PS.Scaled()), True),
+    "euler_ode_flow": (lambda: PD.SkrampleWrapperScheduler(PT.Euler(), PS.Linear(), PM.FlowModel()), True),
+    "adams4_v_zsnr": (lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=4), PS.ZSNR(), PM.VelocityModel()), True),
+    "unipc3_sde_flow": (lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel()), True),
+    "unipc2_adams3_v": (lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=2, predictor=PT.Adams(order=3)), PS.Scaled(), PM.VelocityModel()), True),
+    "spc": (lambda: PD.SkrampleWrapperScheduler(PT.SPC(), PS.Scaled()), True),
+    "dpm2_alias_true": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), alias_history=True), True),
+    "dpm2_snapshots": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), alias_history=False), False),
+    "euler_inverted": (lambda: PD.SkrampleWrapperScheduler(PT.Euler(stochasticity=1), PS.Scaled(), invert_prediction=True), False),
+    "dpm2_offset_noise": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), noise_type=PN.Offset, noise_props=PN.OffsetProps()), False),
+    "dpm2_fp64_scale": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), compute_scale=torch.float64), None),
+}
+
+
+def trajectory(w, x0, outs, seeds, as_float=True):
+    w.set_timesteps(len(outs))
+    ts = w.timesteps.tolist() if as_float else list(w.timesteps)
+    x, traj = x0, []
+    for i, t in enumerate(ts):
+        prev, pred = w.step(outs[i], t, x, generator=seeds, return_dict=False)
+        traj.append((prev, torch.as_tensor(pred.materialize() if isinstance(pred, lazy.LazyTensor) else pred)))
+        x = prev
+    return traj
+
+
+@pytest.mark.parametrize("name", sorted(MAKERS))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_fast_steps_equal_the_general_path(name, dtype, dev):
+    mk, expect_fast = MAKERS[name]
+    shape, steps = (3, 4, 32, 32), 9
+    g = torch.Generator().manual_seed(41)
+    x0 = torch.randn(shape, generator=g).to(dtype).to(dev)
+    outs = [torch.randn(shape, generator=g).to(dtype).to(dev) for _ in range(steps)]
+    seeds = [5, 6, 7]
+    fast, general = mk(), mk()
+    general.fast_steps = False
+    want = trajectory(general, x0, outs, seeds)
+    for rep in range(4):
+        got = trajectory(fast, x0, outs, seeds)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a[0].dtype == b[0].dtype and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (name, rep, i)
+    assert general._fast_hits == 0
+    if expect_fast is None:
+        pass
+    elif expect_fast:
+        # from the second run on every step of an in-order run is served by the fast path ("auto" aliasing settles at the third call of a run)
+        assert fast._fast_hits >= 3 * (steps - 2), (name, fast._fast_hits)
+    else:
+        assert fast._fast_hits == 0, (name, fast._fast_hits)
+    # the return_dict form and 0-d tensor timesteps (general path) agree too
+    assert torch.equal(trajectory(fast, x0, outs, seeds, as_float=False)[-1][0], want[-1][0])
+    fast.set_timesteps(steps)
+    d = fast.step(outs[0], fast.timesteps.tolist()[0], x0, generator=seeds)
+    assert torch.equal(d.prev_sample, want[0][0]) and torch.equal(d["prev_sample"], want[0][0])
+
+
+def test_fast_path_refusals_fall_back_to_the_general_path(dev):
+    "another timestep than the next one, other shapes, a begin index: the general path serves them, with the same bits as a wrapper that never had a fast path"
+    mk = MAKERS["dpm2_alias_true"][0]
+    shape, steps = (2, 4, 32, 32), 8
+    g = torch.Generator().manual_seed(43)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps)]
+    fast, general = mk(), mk()
+    general.fast_steps = False
+    for _ in range(3):
+        trajectory(fast, x0, outs, [1, 2])
+    hits = fast._fast_hits
+    assert hits > 0
+
+    def odd_run(w):
+        w.set_timesteps(steps)
+        ts = w.timesteps.tolist()
+        res = []
+        x = x0
+        for i in (0, 1, 3, 4, 2, 5):  # out of order from the third call on
+            x = w.step(outs[i], ts[i], x, generator=[1, 2], return_dict=False)[0]
+            res.append(x)
+        return res
+
+    for a, b in zip(odd_run(fast), odd_run(general)):
+        assert torch.equal(a, b)
+    assert fast._fast_hits == hits + 2  # the two in-order calls only
+
+    def begin_run(w):  # an image-to-image style run: begin index 3
+        w.set_timesteps(steps)
+        w.set_begin_index(3)
+        ts = w.timesteps.tolist()
+        x, res = x0, []
+        for i in range(3, steps):
+            x = w.step(outs[i], ts[i], x, generator=[1, 2], return_dict=False)[0]
+            res.append(x)
+        return res
+
+    want = begin_run(general)
+    for rep in range(3):
+        for a, b in zip(begin_run(fast), want):
+            assert torch.equal(a, b)
+    # another batch size: entries are per shape, the general path re-learns
+    big = torch.cat([x0, x0])
+    bouts = [torch.cat([o, o]) for o in outs]
+    want = trajectory(general, big, bouts, [1, 2, 3, 4])
+    for rep in range(3):
+        for a, b in zip(trajectory(fast, big, bouts, [1, 2, 3, 4]), want):
+            assert torch.equal(a[0], b[0])
+
+
+def test_alias_guard_inside_the_fast_path(dev):
+    "a caller that starts reusing buffers once the fast path serves the steps still gets the error, never a wrong step"
+    mk = MAKERS["dpm2_alias_true"][0]
+    shape, steps = (2, 4, 16, 16), 6
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps)]
+    w = mk()
+    for _ in range(3):
+        trajectory(w, x0, outs, [1, 2])
+    assert w._fast_hits > 0
+    w.set_timesteps(steps)
+    ts = w.timesteps.tolist()
+    buf = torch.empty_like(outs[0])
+    buf.copy_(outs[0])
+    x = w.step(buf, ts[0], x0, generator=[1, 2], return_dict=False)[0]
+    buf.copy_(outs[1])  # the network writes its next output into the buffer the history still reads
+    with pytest.raises(_hip.SkrampleHipError, match="alias_history=False"):
+        w.step(buf, ts[1], x, generator=[1, 2], return_dict=False)
+    # static storage handed back as a new tensor object (no version bump)
+    w.set_timesteps(steps)
+    x = w.step(buf, ts[0], x0, generator=[1, 2], return_dict=False)[0]
+    with pytest.raises(_hip.SkrampleHipError, match="model_output"):
+        w.step(buf.view(shape), ts[1], x, generator=[1, 2], return_dict=False)
+
+
+def test_seed_vectors_are_shared_between_runs_but_never_with_a_captured_loop(dev):
+    from skrample_amd.graphs import capture_sampling_loop
+
+    a = PN.seeds_tensor([11, 12, 13], dev)
+    assert PN.seeds_tensor([11, 12, 13], dev) is a and PN.seeds_tensor([11, 12, 14], dev) is not a
+    shape = (3, 4, 32, 32)
+    g = torch.Generator(device=dev).manual_seed(3)
+    x0 = torch.randn(shape, device=dev, generator=g).bfloat16()
+    outs = [torch.randn(shape, device=dev, generator=g).bfloat16() for _ in range(4)]
+    n = [0]
+
+    def net(x, t):
+        n[0] += 1
+        return outs[n[0] % 4]
+
+    mk = MAKERS["dpm2_alias_true"][0]
+    loop = capture_sampling_loop(mk(), net, x0, 5, seeds=[11, 12, 13])
+    first = loop(x0).clone()
+    loop(x0, seeds=[21, 22, 23])  # overwrites the loop's own seed buffer in place
+    assert torch.equal(PN.seeds_tensor([11, 12, 13], dev).cpu(), torch.tensor([11, 12, 13]))  # a fresh upload, not the overwritten buffer
+    assert torch.equal(loop(x0, seeds=[11, 12, 13]), first)

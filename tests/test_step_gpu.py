@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 from cases import MODELS, NATIVE16_ORACLE, NATIVE16_TAGS, SAMPLERS, SCHEDULES, bf16_ulp, from_bits, native16_case, oracle_schedule
-from conftest import load_npz
+from conftest import note_margin, load_npz
 
 import skrample_amd.diffusers as PD
 import skrample_amd.scheduling as PS
@@ -59,15 +59,22 @@ def assert_close(got, ref, dtype, what="", flips=0.05):
     assert got.dtype == dtype and tuple(got.shape) == tuple(ref.shape), (what, got.dtype, got.shape)
     g, r = got.detach().cpu(), ref.detach().cpu()
     assert torch.isfinite(g.float()).all(), what
+    family = "step " + str(dtype).replace("torch.", "")
     if dtype in (torch.float32, torch.float64):
-        assert rel_err(g, r) <= REL_TOL_F32, (what, rel_err(g, r))
+        assert note_margin(family, "rel inf-norm error", rel_err(g, r), REL_TOL_F32) <= REL_TOL_F32, (what, rel_err(g, r))
     else:
         # 1 unit in the last place of the reference, plus the fp32 tolerance on the scale of the operands
         # (results near zero come from cancellation: their ulp is far below the fp32 noise floor of the terms)
         ulp = bf16_ulp(r) * (1 if dtype == torch.bfloat16 else 2.0**-3)  # fp16 has 3 more mantissa bits
-        ulp = ulp + REL_TOL_F32 * r.float().abs().max()
-        bad = (g.float() - r.float()).abs() > ulp
-        assert not bad.any(), (what, int(bad.sum()), (g.float() - r.float()).abs().max().item())
+        diff = (g.float() - r.float()).abs()
+        scale = r.float().abs().max().clamp_min(1e-30)
+        # what is MEASURED: the worst difference in last-place units, how much of the additive term an element needed beyond its one
+        # unit (as a fraction of max|ref|; the bar allows REL_TOL_F32), and the share of elements that differ at all
+        note_margin(family, "max |diff| in units of the reference's last place", (diff / ulp).max().item(), None)
+        note_margin(family, "max (|diff| - 1 ulp) / max|ref|", ((diff - ulp).clamp_min(0).max() / scale).item(), REL_TOL_F32)
+        note_margin(family, "share of elements differing in the last place", (g != r).float().mean().item(), flips)
+        bad = diff > ulp + REL_TOL_F32 * scale
+        assert not bad.any(), (what, int(bad.sum()), diff.max().item())
         assert (g != r).float().mean().item() < flips, (what, "too many last-place flips", (g != r).float().mean().item())
 
 

@@ -115,6 +115,11 @@ if __name__ == "__main__":
     if which in ("all", "rk"):
         for k in (2, 3, 4, 5, 6, 7, 8):
             bench(f"rk stage K={k}", 64, 4 * 256 * 256, k, 0, False, False, rk=True, switches=[OLD, NEW])
+    if which == "ab":  # round 4: the two findings of the round-3 harness, A/B/A/B through the library on one box
+        for k in (2, 3, 4):
+            bench(f"rk stage K={k}", 64, 4 * 256 * 256, k, 0, False, False, rk=True, switches=[{"rk_blk": 256}, {"rk_blk": 128}] * 3)
+        for na in (8, 10):
+            bench(f"two-out NA={na} NB=1 (no in-kernel noise)", 256, S16, na, 1, True, False, switches=[{"two_nt": 0}, {"two_nt": 1}] * 3)
     if which in ("all", "f32"):
         for k in (2, 4):
             bench(f"K={k} f32 -> f32 + philox", 256, S4, k, 0, False, True, dtype=torch.float32, switches=[OLD, NEW, {"pace": 0}])

@@ -74,8 +74,10 @@ if has colored; then
   echo "colored part done"
 fi
 if has margins; then
-  (cd $R && SKR_PARITY_MARGINS=$O/profiles/r04_parity_margins.jsonl $T 900 python3 -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/margins_pytest.log 2>&1) || { echo "gpu tests failed"; tail -15 $O/margins_pytest.log; }
+  rm -f /tmp/r4_margins.jsonl
+  (cd $R && SKR_PARITY_MARGINS=/tmp/r4_margins.jsonl $T 900 python3 -m pytest tests -m gpu -q -p no:cacheprovider > $O/margins_pytest.log 2>&1) || { echo "gpu tests failed"; tail -15 $O/margins_pytest.log; }
   tail -3 $O/margins_pytest.log
+  (cd $R && python3 tools/summarize_margins.py /tmp/r4_margins.jsonl $O/profiles/r04_parity_margins.txt > /dev/null) || echo "summarize_margins failed"
   echo "margins part done"
 fi
 du -sh $R/gpurun_out || true
