@@ -22,7 +22,8 @@ DTYPE_CODE = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32, torc
 CODE_DTYPE = {v: k for k, v in DTYPE_CODE.items()}
 
 LIB_NAME = "libskrample_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
+# (SKR_HIP_LIB: a differently built library for A/B measurements -- tools/ only; the product loads the in-tree one)
+LIB_PATH = os.environ.get("SKR_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
 
 EXPORTS = (
     "skr_step_launch",

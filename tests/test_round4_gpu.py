@@ -54,6 +54,8 @@ def trajectory(w, x0, outs, seeds, as_float=True):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_fast_steps_equal_the_general_path(name, dtype, dev):
     mk, expect_fast = MAKERS[name]
+    if name == "dpm2_fp64_scale" and dtype != torch.float32:
+        pytest.skip("compute_scale=float64 takes fp32 / fp64 tensors (the library has no 16-bit-in, fp64-accumulate kernel)")
     shape, steps = (3, 4, 32, 32), 9
     g = torch.Generator().manual_seed(41)
     x0 = torch.randn(shape, generator=g).to(dtype).to(dev)
