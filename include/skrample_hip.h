@@ -251,6 +251,10 @@ int skr_colorize(void* out, int32_t out_dtype, void* spec_c64, float* white_f32,
 int skr_power_blend(void* out, int32_t out_dtype, const void* a, int32_t a_dtype, const void* b, int32_t b_dtype, double p,
                     double c, double power, int64_t numel, void* stream);
 
+/* Diagnostics counters of this process (tests assert that a shape did NOT go to the vendor FFT): "hipfft_plans" = hipFFT plan pairs
+ * created so far, "hipfft_execs" = forward hipFFT transforms run so far; -1 for an unknown key. */
+int64_t skr_stat(const char* key);
+
 int skr_abi_version(void);
 const char* skr_strerror(int status);
 int skr_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */

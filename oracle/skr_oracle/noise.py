@@ -302,9 +302,55 @@ def brownian_value(seed: int, n: int, t: float, depth: int) -> np.ndarray:
     return (1 - f) * w_lo + f * w_hi
 
 
-def brownian_noise(seed: int, shape, step, max_steps: int = 10_000) -> torch.Tensor:
-    "Brownian.generate (noise.py:238-242): step.normal().clamp(), then tree(t0, t1) / sqrt(distance); fp64 result"
+def brownian_grid_value(seed: int, n: int, t: float, grid: int, depth: int) -> np.ndarray:
+    """W(t) on the path built over the `grid`-cell partition of [0, 1] (the product's round-4 construction, restated on arrays):
+    grid points by bisection of the index range -- W(1) = Z_0 and, for the index interval (lo, hi) with heap index h and
+    mid = (lo + hi) // 2,  W(mid/N) = ((hi-mid) W(lo/N) + (mid-lo) W(hi/N)) / (hi-lo) + sqrt((mid-lo)(hi-mid) / ((hi-lo) N)) Z_h,
+    Z_h = philox_normal(seed, 2^63 | 2^61 | h) -- then a dyadic bridge inside the cell, Z = philox_normal(seed, 2^63 | 2^60 | cell << 24 | h)."""
+
+    def point(j: int) -> np.ndarray:
+        lo, hi, node = 0, grid, 1
+        w_lo, w_hi = np.zeros(n), philox_normal(seed, BROWNIAN_STREAMS | 0, n).astype(np.float64)
+        while True:
+            if j == lo:
+                return w_lo
+            if j == hi:
+                return w_hi
+            mid = (lo + hi) // 2
+            z = philox_normal(seed, BROWNIAN_STREAMS | (1 << 61) | node, n).astype(np.float64)
+            w_mid = ((hi - mid) * w_lo + (mid - lo) * w_hi) / (hi - lo) + math.sqrt((mid - lo) * (hi - mid) / ((hi - lo) * grid)) * z
+            if j < mid:
+                hi, w_hi, node = mid, w_mid, 2 * node
+            else:
+                lo, w_lo, node = mid, w_mid, 2 * node + 1
+
+    j = round(t * grid)
+    if 0 <= j <= grid and j / grid == t:
+        return point(j)
+    cell = min(int(t * grid), grid - 1)
+    if not cell / grid < t < (cell + 1) / grid:
+        cell = cell - 1 if t < cell / grid else cell + 1
+    lo, hi, node = cell / grid, (cell + 1) / grid, 1
+    w_lo, w_hi = point(cell), point(cell + 1)
+    for _ in range(max(depth - (grid - 1).bit_length(), 2)):
+        if t == lo or t == hi:
+            break
+        mid = 0.5 * (lo + hi)
+        z = philox_normal(seed, BROWNIAN_STREAMS | (1 << 60) | (cell << 24) | node, n).astype(np.float64)
+        w_mid = 0.5 * (w_lo + w_hi) + 0.5 * math.sqrt(hi - lo) * z
+        if t < mid:
+            hi, w_hi, node = mid, w_mid, 2 * node
+        else:
+            lo, w_lo, node = mid, w_mid, 2 * node + 1
+    f = (t - lo) / (hi - lo)
+    return (1 - f) * w_lo + f * w_hi
+
+
+def brownian_noise(seed: int, shape, step, max_steps: int = 10_000, grid: int | None = None) -> torch.Tensor:
+    """Brownian.generate (noise.py:238-242): step.normal().clamp(), then tree(t0, t1) / sqrt(distance); fp64 result.
+    `grid` = N: the generator's path is the one built over the N-cell partition (what a generator first asked Step.from_int(k, N) uses)."""
     t0, t1 = stp_clamp(stp_normal(step))
     n, depth = math.prod(shape), brownian_depth(max_steps)
-    inc = brownian_value(seed, n, t1, depth) - brownian_value(seed, n, t0, depth)
+    value = (lambda t: brownian_grid_value(seed, n, t, grid, depth)) if grid else (lambda t: brownian_value(seed, n, t, depth))
+    inc = value(t1) - value(t0)
     return torch.from_numpy(inc / math.sqrt(t1 - t0)).reshape(tuple(shape))

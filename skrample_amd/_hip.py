@@ -48,6 +48,7 @@ EXPORTS = (
     "skr_last_hip_error",
     "skr_build_info",
     "skr_set_tuning",
+    "skr_stat",
 )
 
 
@@ -278,6 +279,8 @@ def load() -> ctypes.CDLL:
         lib.skr_strerror.restype = ctypes.c_char_p
         lib.skr_last_hip_error.restype = ctypes.c_int
         lib.skr_build_info.restype = ctypes.c_char_p
+        lib.skr_stat.argtypes = [ctypes.c_char_p]
+        lib.skr_stat.restype = ctypes.c_int64
         lib.skr_set_tuning.argtypes = [ctypes.c_char_p, i32]
         lib.skr_set_tuning.restype = ctypes.c_int
         if lib.skr_abi_version() != ABI_VERSION:

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <map>
 #include <set>
@@ -15,6 +16,7 @@
 #include "skr_device.h"
 #include "../../include/skrample_hip.h"
 #include "skr_philox.h"
+#include "skr_dft.h"
 
 namespace skr { int g_fft_rank = 0; }
 
@@ -64,6 +66,7 @@ std::map<PlanKey, Plans> g_plans;
 std::set<PlanKey> g_bad_plans;  // plans whose self-check failed
 uint64_t g_plan_clock = 0;
 constexpr size_t MAX_PLANS = 32;
+int64_t g_hipfft_plans = 0, g_hipfft_execs = 0;  // skr_stat("hipfft_plans" / "hipfft_execs"): plan pairs created, forward transforms run
 
 constexpr int SLOTS = 256;  // partial-sum slots per sample (one per block of the stats kernels)
 
@@ -232,6 +235,91 @@ __global__ __launch_bounds__(AXIS_THREADS) void any_outer_axis(const AnyArgs a, 
   }
 }
 
+// ---- TWO outer axes in one pass (round 4): channels x frames of a video latent, [C][T][plane] ---------------------------------------
+// any_outer_axis moves the whole spectrum through HBM once per call, and a unit with two outer axes needs three calls (frames forward;
+// channels forward + weights + inverse; frames inverse).  Here a block stages a tile of L consecutive plane positions with ALL C x T
+// values of each (two LDS buffers of C T L complex), runs the frame-axis direct DFT from one buffer into the other, the channel axis
+// (a power of two <= 16) as a register transform with the radial weights of the full 4-D frequency in between, the frame axis back,
+// and stores: one read and one write of the spectrum instead of three.  Values are unnormalised like any_outer_axis (1/N in any_finish).
+constexpr int TWO_THREADS = 256;
+template <int C>
+__global__ __launch_bounds__(TWO_THREADS) void any_outer_two(const AnyArgs a, int L, int logL) {
+  extern __shared__ float2 sh[];  // [T] twiddles, A [C T L], B [C T L]
+  const int T = a.outer[1];
+  float2* tw = sh;
+  float2* A = tw + T;
+  float2* B = A + (size_t)C * T * L;
+  for (int j = threadIdx.x; j < T; j += TWO_THREADS) {
+    float sn, cs;
+    sincospif(-2.0f * (float)j / (float)T, &sn, &cs);
+    tw[j] = make_float2(cs, sn);
+  }
+  const int64_t plane = (int64_t)a.d1 * a.d2 * a.d3h, sample = plane * C * T;
+  float2* base = a.spec + (int64_t)blockIdx.y * sample;
+  const int CT = C * T, items = CT << logL, lmask = L - 1;
+  for (int64_t p0 = (int64_t)blockIdx.x * L; p0 < plane; p0 += (int64_t)gridDim.x * L) {
+    __syncthreads();  // (the tile of the trip before has been stored; first trip: the twiddles are in place)
+    for (int i = threadIdx.x; i < items; i += TWO_THREADS) {
+      const int l = i & lmask, ct = i >> logL;
+      A[i] = p0 + l < plane ? base[(int64_t)ct * plane + p0 + l] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    // frames forward: A -> B, item (c, k, l); the twiddle index (n k) mod T is uniform over the L lanes of an item group
+    for (int i = threadIdx.x; i < items; i += TWO_THREADS) {
+      const int l = i & lmask, ck = i >> logL, c = ck / T, k = ck - c * T;
+      const float2* src = A + ((size_t)c * T << logL) + l;
+      float2 acc = make_float2(0.f, 0.f);
+      int idx = 0;
+      for (int n = 0; n < T; ++n) {
+        const float2 t = tw[idx], u = src[(size_t)n << logL];
+        acc.x += u.x * t.x - u.y * t.y;
+        acc.y += u.x * t.y + u.y * t.x;
+        idx += k; if (idx >= T) idx -= T;
+      }
+      B[i] = acc;
+    }
+    __syncthreads();
+    // channels: item (t, l) holds its C values in registers: forward, weights of the full frequency, inverse; B in place
+    for (int i = threadIdx.x; i < (T << logL); i += TWO_THREADS) {
+      const int l = i & lmask, t = i >> logL;
+      float2 v[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[c] = B[(((size_t)c * T + t) << logL) + l];
+      skr::dft_n<C, false>(v);
+      const int64_t p = p0 + l < plane ? p0 + l : 0;
+      const int k3 = (int)(p % a.d3h), k2 = (int)((p / a.d3h) % a.d2);
+      const float f2 = a.d2 > 1 ? axis_freq(k2, a.d2) : 0.f, f3 = (float)k3 / (float)a.d3, ft = axis_freq(t, T);
+      const float rest = f2 * f2 + f3 * f3 + ft * ft;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float fc = axis_freq(c, C);
+        float radius = __builtin_amdgcn_sqrtf(fc * fc + rest) * a.inv_rmax;
+        radius = radius < a.eps_clip ? a.eps_clip : radius;
+        const float w = __builtin_amdgcn_exp2f(a.exponent_half_neg * __builtin_amdgcn_logf(radius));
+        v[c] = make_float2(v[c].x * w, v[c].y * w);
+      }
+      skr::dft_n<C, true>(v);
+#pragma unroll
+      for (int c = 0; c < C; ++c) B[(((size_t)c * T + t) << logL) + l] = v[c];
+    }
+    __syncthreads();
+    // frames inverse: B -> global
+    for (int i = threadIdx.x; i < items; i += TWO_THREADS) {
+      const int l = i & lmask, cn = i >> logL, c = cn / T, n = cn - c * T;
+      const float2* src = B + ((size_t)c * T << logL) + l;
+      float2 acc = make_float2(0.f, 0.f);
+      int idx = 0;
+      for (int k = 0; k < T; ++k) {
+        const float2 t = tw[idx], u = src[(size_t)k << logL];
+        acc.x += u.x * t.x + u.y * t.y;  // conj(t)
+        acc.y += u.y * t.x - u.x * t.y;
+        idx += n; if (idx >= T) idx -= T;
+      }
+      if (p0 + l < plane) base[(int64_t)cn * plane + p0 + l] = acc;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void any_stats(const AnyArgs a) {
   const int64_t smp = blockIdx.y;
   const float scale = 1.0f / (float)a.unit;
@@ -343,6 +431,9 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
                                const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
                                double exponent, int32_t has_energy, double energy, void* stream, bool white_given, int fft_rank, bool planes = false) {
   if (planes && (white_given || fft_rank != 2 || rank < 3)) return SKR_ERR_UNSUPPORTED;
+  // (rank 4 on the plane kernels: the two outer axes go through any_outer_two -- channels a power of two <= 16, frames <= 32)
+  if (planes && rank == 4 && !((dims[0] == 2 || dims[0] == 4 || dims[0] == 8 || dims[0] == 16) && dims[1] <= 32)) return SKR_ERR_UNSUPPORTED;
+  if (planes && rank > 4) return SKR_ERR_UNSUPPORTED;
   if (!planes && !api().ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
   const int full_rank = rank;
   const int32_t* full_dims = dims;
@@ -439,6 +530,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
           return SKR_ERR_LIBRARY;
         }
       }
+      ++g_hipfft_plans;
       it = g_plans.emplace(key, p).first;
     }
     it->second.last_use = ++g_plan_clock;
@@ -454,6 +546,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   } else {
     if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+    ++g_hipfft_execs;
     if (api().r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
   }
   if (a.n_outer > 0) {
@@ -472,9 +565,26 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
       return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
     };
     int rc;
+    if (planes && a.n_outer == 2) {  // one pass for both outer axes
+      const int C = a.outer[0], T = a.outer[1];
+      int logL = 6;
+      while (logL > 3 && ((size_t)C * T << logL) > 4096) --logL;  // two buffers of C T L complex: <= 64 KiB
+      if (((size_t)C * T << logL) > 6144) return SKR_ERR_UNSUPPORTED;
+      const int L = 1 << logL;
+      const int64_t plane = (int64_t)a.d1 * a.d2 * a.d3h;
+      int64_t tiles = (plane + L - 1) / L; if (tiles > 65535) tiles = 65535;
+      const size_t lds = sizeof(float2) * ((size_t)T + 2 * ((size_t)C * T << logL));
+      const dim3 grid((unsigned)tiles, (unsigned)batch);
+#define SKR_TWO(CC) do { if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(any_outer_two<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SKR_ERR_UNSUPPORTED; \
+                         hipLaunchKernelGGL(any_outer_two<CC>, grid, dim3(TWO_THREADS), lds, s, a, L, logL); } while (0)
+      switch (C) { case 2: SKR_TWO(2); break; case 4: SKR_TWO(4); break; case 8: SKR_TWO(8); break; default: SKR_TWO(16); break; }
+#undef SKR_TWO
+      if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;
+    } else {
     for (int j = a.n_outer - 1; j >= 1; --j) if ((rc = pass(0, j)) != SKR_OK) return rc;
     if ((rc = pass(2, 0)) != SKR_OK) return rc;  // outermost: forward, weights, inverse
     for (int j = 1; j < a.n_outer; ++j) if ((rc = pass(1, j)) != SKR_OK) return rc;
+    }
   } else {
     int64_t wb = ((int64_t)a.d1 * a.d2 * a.d3h * batch + 255) / 256; if (wb > 256 * 32) wb = 256 * 32;
     hipLaunchKernelGGL(any_weights, dim3((unsigned)wb), dim3(256), 0, s, a);
@@ -513,7 +623,7 @@ static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float*
   // (video latents, channels x frames x height x width: the frame axis costs two more direct-DFT passes where hipFFT's 3-D plan
   // has it inside -- 0.135 vs 0.128 ms at 2 x (16, 21, 64, 64)) and planes with large odd factors (90 x 160: 0.44 vs 0.25 ms, the
   // 45-term combining pass), see colored_planes' limit on the odd parts.
-  if (!white_given && rank == 3 && skr::g_fft_rank < 1) {
+  if (!white_given && (rank == 3 || rank == 4) && skr::g_fft_rank < 1) {
     const int rcp = colored_any_attempt(out, out_dtype, spec_c64, scratch_f32, partials_f64, seeds_dev, stream_id, batch, rank, dims, exponent, has_energy, energy, stream, false, 2, true);
     if (rcp != SKR_ERR_UNSUPPORTED) return rcp;
   }
@@ -536,4 +646,12 @@ extern "C" int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c6
 extern "C" int skr_colorize(void* out, int32_t out_dtype, void* spec_c64, float* white_f32, double* partials_f64, int64_t batch, int32_t rank,
                             const int32_t* dims, double exponent, int32_t has_energy, double energy, void* stream) {
   return colored_any_impl(out, out_dtype, spec_c64, white_f32, partials_f64, nullptr, 0, batch, rank, dims, exponent, has_energy, energy, stream, true);
+}
+
+extern "C" int64_t skr_stat(const char* key) {
+  if (!key) return -1;
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!strcmp(key, "hipfft_plans")) return g_hipfft_plans;
+  if (!strcmp(key, "hipfft_execs")) return g_hipfft_execs;
+  return -1;
 }

@@ -544,6 +544,84 @@ def brownian_path(t: float, depth: int) -> dict[int, float]:
     return {k: (1 - f) * w_lo.get(k, 0.0) + f * w_hi.get(k, 0.0) for k in {*w_lo, *w_hi}}
 
 
+# ---- the schedule's own partition (round 4) ----------------------------------------------------------------------------
+# A sampling run asks for Step.from_int(k, N): both endpoints are points of the N-cell partition of [0, 1], never dyadic for the usual
+# N (20, 30, 50), so the dyadic tree above walks all `depth` = 19 levels for each of them -- 20 normals per element and endpoint.
+# A generator whose FIRST query is one cell of such a partition therefore fixes N for its lifetime and builds its path on the
+# partition instead: W at the grid points by bisection of the INDEX range (W(1) = Z_0, then for the index interval (lo, hi) with
+# heap index h and mid = (lo + hi) // 2 the bridge  W(mid/N) = ((hi-mid) W(lo/N) + (mid-lo) W(hi/N)) / (hi-lo)
+# + sqrt((mid-lo)(hi-mid) / ((hi-lo) N)) Z_h ), ceil(log2 N) levels, and W inside a cell by the dyadic bridge between the cell's two
+# grid values (the levels that are left of `depth`).  Grid queries -- every step of a run, RK stages included -- cost 5-6 normals per
+# endpoint instead of 20; any other query stays consistent with them because it is evaluated on the SAME path.  What changes against
+# the pure dyadic tree: the path of a seed now depends on the partition the generator was first asked about (a generator first asked
+# an off-partition step keeps the dyadic tree).  torchsde's values cannot be reproduced either way (module header).
+BROWNIAN_GRID_NODE = 1 << 61  # stream namespace of index-bisection nodes (| heap index)
+BROWNIAN_CELL_NODE = 1 << 60  # stream namespace of in-cell bridge nodes (| cell << 24 | heap index inside the cell)
+BROWNIAN_MAX_GRID = 1 << 20
+
+
+def brownian_grid_index(t: float, n: int) -> int | None:
+    "j with j / n == t exactly (the float Step.from_int produces), else None"
+    j = round(t * n)
+    return j if 0 <= j <= n and j / n == t else None
+
+
+def brownian_grid_of(time_from: float, time_to: float) -> int | None:
+    "N if (time_from, time_to) is exactly one cell of the N-cell partition of [0, 1] (what Step.from_int(k, N) yields), else None"
+    width = time_to - time_from
+    if not width > 0:
+        return None
+    n = round(1.0 / width)
+    if not 1 <= n <= BROWNIAN_MAX_GRID:
+        return None
+    j = brownian_grid_index(time_from, n)
+    return n if j is not None and brownian_grid_index(time_to, n) == j + 1 else None
+
+
+def brownian_grid_point(j: int, n: int) -> dict[int, float]:
+    "W(j / n) as weights over the terminal normal (key 0) and the index-bisection normals (keys BROWNIAN_GRID_NODE | heap index)"
+    lo, hi, node = 0, n, 1
+    w_lo: dict[int, float] = {}
+    w_hi: dict[int, float] = {0: 1.0}
+    while True:
+        if j == lo:
+            return dict(w_lo) if w_lo else {0: 0.0}
+        if j == hi:
+            return dict(w_hi)
+        mid = (lo + hi) // 2
+        a, b = (hi - mid) / (hi - lo), (mid - lo) / (hi - lo)
+        w_mid = {k: a * w_lo.get(k, 0.0) + b * w_hi.get(k, 0.0) for k in {*w_lo, *w_hi}}
+        w_mid[BROWNIAN_GRID_NODE | node] = math.sqrt((mid - lo) * (hi - mid) / ((hi - lo) * n))
+        if j < mid:
+            hi, w_hi, node = mid, w_mid, 2 * node
+        else:
+            lo, w_lo, node = mid, w_mid, 2 * node + 1
+
+
+def brownian_grid_path(t: float, n: int, depth: int) -> dict[int, float]:
+    "W(t) on the path built over the n-cell partition: a grid point, or the dyadic bridge inside its cell"
+    j = brownian_grid_index(t, n)
+    if j is not None:
+        return brownian_grid_point(j, n)
+    cell = min(int(t * n), n - 1)
+    if not cell / n < t < (cell + 1) / n:  # (rounding of t * n at a cell boundary)
+        cell = cell - 1 if t < cell / n else cell + 1
+    lo, hi, node = cell / n, (cell + 1) / n, 1
+    w_lo, w_hi = brownian_grid_point(cell, n), brownian_grid_point(cell + 1, n)
+    for _ in range(max(depth - (n - 1).bit_length(), 2)):
+        if t == lo or t == hi:
+            break
+        mid = 0.5 * (lo + hi)
+        w_mid = {k: 0.5 * (w_lo.get(k, 0.0) + w_hi.get(k, 0.0)) for k in {*w_lo, *w_hi}}
+        w_mid[BROWNIAN_CELL_NODE | (cell << 24) | node] = 0.5 * math.sqrt(hi - lo)
+        if t < mid:
+            hi, w_hi, node = mid, w_mid, 2 * node
+        else:
+            lo, w_lo, node = mid, w_mid, 2 * node + 1
+    f = (t - lo) / (hi - lo)
+    return {k: (1 - f) * w_lo.get(k, 0.0) + f * w_hi.get(k, 0.0) for k in {*w_lo, *w_hi}}
+
+
 @lru_cache(maxsize=4096)
 def brownian_increment(time_from: float, time_to: float, depth: int) -> tuple[tuple[int, ...], tuple[float, ...]]:
     "(node ids, weights) of (W(time_to) - W(time_from)) / sqrt(time_to - time_from); unit variance up to the leaf interpolation"
@@ -556,11 +634,13 @@ def brownian_increment(time_from: float, time_to: float, depth: int) -> tuple[tu
 
 
 @lru_cache(maxsize=4096)
-def brownian_endpoints(time_from: float | None, time_to: float, depth: int) -> tuple[tuple[int, ...], tuple[float, ...], tuple[float, ...]]:
+def brownian_endpoints(time_from: float | None, time_to: float, depth: int, grid: int | None = None) -> tuple[tuple[int, ...], tuple[float, ...], tuple[float, ...]]:
     """(ascending node ids, weights of W(time_to), weights of W(time_from)) over the union of both paths; with
-    time_from = None only W(time_to)'s own nodes (the caller has W(time_from) cached)"""
-    b = brownian_path(time_to, depth)
-    a = brownian_path(time_from, depth) if time_from is not None else {}
+    time_from = None only W(time_to)'s own nodes (the caller has W(time_from) cached).  `grid` = N: the path built over the
+    N-cell partition (brownian_grid_path) instead of the dyadic tree."""
+    path = (lambda t: brownian_grid_path(t, grid, depth)) if grid else (lambda t: brownian_path(t, depth))
+    b = path(time_to)
+    a = path(time_from) if time_from is not None else {}
     nodes = tuple(sorted({*a, *b}))
     return nodes, tuple(b.get(k, 0.0) for k in nodes), tuple(a.get(k, 0.0) for k in nodes)
 
@@ -591,8 +671,10 @@ class Brownian(TensorNoiseCommon):
         if cache is None or tuple(cache.shape) != shape or cache.device != seeds.device:
             cache = state["brownian_cache"] = torch.empty(shape, dtype=torch.float32, device=seeds.device)
             state["brownian_cache_time"] = None
+        if "brownian_grid" not in state:  # the first query decides which path this generator draws from (see "the schedule's own partition")
+            state["brownian_grid"] = brownian_grid_of(t0, t1)
         hit = state.get("brownian_cache_time") == t0
-        nodes, w_to, w_from = brownian_endpoints(None if hit else t0, t1, depth)
+        nodes, w_to, w_from = brownian_endpoints(None if hit else t0, t1, depth, state["brownian_grid"])
         if len(nodes) > 64:
             raise SkrampleHipError(f"Brownian max_steps={props.max_steps} needs {len(nodes)} tree nodes per query (limit 64)")
         out = torch.empty(shape, dtype=dtype, device=seeds.device)

@@ -15,7 +15,7 @@ from skrample_amd import _hip
 
 def test_library_exports_header_symbols():
     header = open(os.path.join(ROOT, "include", "skrample_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(skr_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|void|const char\*)\s+(skr_\w+)\s*\(", header, flags=re.M))
     assert declared == set(_hip.EXPORTS), (declared, set(_hip.EXPORTS))
     assert os.path.isfile(_hip.LIB_PATH), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
     lib = ctypes.CDLL(_hip.LIB_PATH)

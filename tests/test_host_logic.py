@@ -426,6 +426,48 @@ def test_brownian_tree_weights_follow_the_brownian_law():
             assert abs(lhs - both.get(node, 0.0) * math.sqrt(2 / n)) < 1e-12
 
 
+def test_brownian_partition_path_follows_the_brownian_law():
+    """round 4: a generator first asked one cell of an N-cell partition builds its path over that partition (index bisection for the grid
+    points, a dyadic bridge inside a cell).  Same law, exactly on the grid -- Var W(j/N) = j/N, Cov = min -- and to the leaf width off it;
+    grid queries need ceil(log2 N) + 1 normals per endpoint instead of depth + 1 = 20."""
+    import random
+
+    from skrample_amd.common import Step
+    from skrample_amd.pytorch.noise import brownian_depth, brownian_endpoints, brownian_grid_of, brownian_grid_path, brownian_grid_point
+
+    depth = brownian_depth(10_000)
+    dot = lambda a, b: sum(v * b.get(k, 0.0) for k, v in a.items())
+    for n in (1, 2, 7, 20, 30, 50, 1000):
+        pts = {j: brownian_grid_point(j, n) for j in range(0, n + 1, max(1, n // 25))}
+        for j, w in pts.items():
+            assert len(w) <= (n - 1).bit_length() + 1
+            for i, v in pts.items():
+                assert abs(dot(w, v) - min(i, j) / n) < 1e-15
+        for k in range(n):
+            assert brownian_grid_of(*Step.from_int(k, n)) == n  # what a sampling run asks for
+    assert brownian_grid_of(0.35, 0.45) is None and brownian_grid_of(0.1234, 0.2) is None and brownian_grid_of(0.4, 0.4) is None
+    rng = random.Random(3)
+    leaf = 4 * 2.0**-depth
+    for n in (20, 30):
+        for _ in range(100):
+            s, t = sorted((rng.random(), rng.random()))
+            ws, wt = brownian_grid_path(s, n, depth), brownian_grid_path(t, n, depth)
+            assert abs(dot(ws, ws) - s) <= leaf and abs(dot(wt, wt) - t) <= leaf and abs(dot(ws, wt) - s) <= leaf and len(wt) <= 64
+            j = int(t * n)  # consistency with the grid: Cov(W(t), W(j/n)) = j/n
+            assert abs(dot(wt, brownian_grid_point(j, n)) - j / n) <= leaf
+    # a step of a 20-step run: 5 normals for both endpoints together, 36 on the dyadic tree; additivity over adjacent cells
+    nodes, w_to, w_from = brownian_endpoints(0.35, 0.4, depth, 20)
+    assert len(nodes) <= 6 and len(brownian_endpoints(0.35, 0.4, depth, None)[0]) > 30
+    a = {k: x - y for k, x, y in zip(nodes, w_to, w_from)}
+    nodes, w_to, w_from = brownian_endpoints(0.4, 0.45, depth, 20)
+    b = {k: x - y for k, x, y in zip(nodes, w_to, w_from)}
+    nodes, w_to, w_from = brownian_endpoints(0.35, 0.45, depth, 20)
+    ab = {k: x - y for k, x, y in zip(nodes, w_to, w_from)}
+    for k in {*a, *b, *ab}:
+        assert abs(a.get(k, 0.0) + b.get(k, 0.0) - ab.get(k, 0.0)) < 1e-15
+    assert abs(dot(a, a) - 0.05) < 1e-15 and abs(dot(a, b)) < 1e-15
+
+
 def test_brownian_oracle_is_an_independent_restatement():
     "the oracle bisects on arrays, the product walks weights: same function of the same Philox normals"
     from skr_oracle import noise as ON
@@ -437,6 +479,12 @@ def test_brownian_oracle_is_an_independent_restatement():
         mine = sum(w * ON.philox_normal(5, BROWNIAN_STREAMS | h, n).astype(np.float64) for h, w in zip(nodes, weights))
         ref = ON.brownian_noise(5, (n,), (t0, t1)).numpy()
         assert np.abs(mine - ref).max() < 1e-9
+    from skrample_amd.pytorch.noise import brownian_endpoints
+
+    for t0, t1 in ((0.35, 0.4), (0.0, 0.05), (0.95, 1.0), (0.5, 0.75), (0.35, 0.45), (0.123, 0.777), (0.36, 0.39)):  # the partition path (grid = 20)
+        nodes, w_to, w_from = brownian_endpoints(t0, t1, depth, 20)
+        mine = sum((a - b) * ON.philox_normal(5, BROWNIAN_STREAMS | h, n).astype(np.float64) for h, a, b in zip(nodes, w_to, w_from)) / math.sqrt(t1 - t0)
+        assert np.abs(mine - ON.brownian_noise(5, (n,), (t0, t1), grid=20).numpy()).max() < 1e-9
     # reference call-site arithmetic: direction-normalised and clamped steps (noise.py:241)
     assert torch.equal(ON.brownian_noise(5, (n,), (0.4, 0.35)), ON.brownian_noise(5, (n,), (0.35, 0.4)))
     assert torch.equal(ON.brownian_noise(5, (n,), (1.0, 1.05)), ON.brownian_noise(5, (n,), (0.95, 1.0)))

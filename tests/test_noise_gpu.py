@@ -114,9 +114,20 @@ def test_brownian(unit, dev):
     g = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, props=PN.BrownianProps(), dtype=torch.float32)
     steps = [Step(0.35, 0.4), Step(0.4, 0.45), Step(0.35, 0.45), Step(0.0, 0.05), Step(0.95, 1.0), Step(0.5, 0.75)]
     got = {s: g.generate(s).cpu().double() for s in steps}
+    assert g._state["brownian_grid"] == 20  # the first query was one cell of the 20-cell partition: the path is built over that partition
     for s, v in got.items():
-        ref = torch.stack([ON.brownian_noise(seed, unit, s) for seed in seeds])
+        ref = torch.stack([ON.brownian_noise(seed, unit, s, grid=20) for seed in seeds])
         assert rel(v, ref, "brownian (own specification)", TOL) < TOL, s
+    # a generator first asked an off-partition step keeps the dyadic tree; any later query is served from that one path
+    d = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, props=PN.BrownianProps(), dtype=torch.float32)
+    for s in (Step(0.123, 0.777), Step(0.35, 0.4), Step(0.4, 0.45), Step(0.35, 0.45)):
+        v = d.generate(s).cpu().double()
+        assert d._state["brownian_grid"] is None
+        assert rel(v, torch.stack([ON.brownian_noise(seed, unit, s) for seed in seeds]), "brownian (own specification)", TOL) < TOL, s
+    # off-grid queries of a partition generator: inside a cell, and across cells
+    for s in (Step(0.36, 0.39), Step(0.123, 0.777), Step(0.349, 0.4)):
+        v = g.generate(s).cpu().double()
+        assert rel(v, torch.stack([ON.brownian_noise(seed, unit, s, grid=20) for seed in seeds]), "brownian (own specification)", TOL) < TOL, s
     a, b, ab = got[steps[0]], got[steps[1]], got[steps[2]]
     assert rel((a + b) * math.sqrt(0.05), ab * math.sqrt(0.1)) < 1e-5  # W(.35,.4) + W(.4,.45) = W(.35,.45)
     assert torch.equal(g.generate(Step(0.4, 0.35)).cpu().double(), a)  # direction-normalised, stateless

@@ -181,3 +181,46 @@ def test_seed_vectors_are_shared_between_runs_but_never_with_a_captured_loop(dev
     loop(x0, seeds=[21, 22, 23])  # overwrites the loop's own seed buffer in place
     assert torch.equal(PN.seeds_tensor([11, 12, 13], dev).cpu(), torch.tensor([11, 12, 13]))  # a fresh upload, not the overwritten buffer
     assert torch.equal(loop(x0, seeds=[11, 12, 13]), first)
+
+
+@pytest.mark.parametrize("unit", [(4, 5, 96, 96), (16, 21, 64, 64), (2, 8, 32, 32), (8, 3, 16, 48), (16, 32, 16, 16), (4, 7, 128, 128)])
+def test_video_units_run_on_hand_written_kernels_only(unit, dev):
+    """4-axis units (channels x frames x height x width) whose channel count is a power of two <= 16, with <= 32 frames and planes the
+    LDS plane kernels take: planes on those kernels, BOTH outer axes in one fused pass (any_outer_two) -- no hipFFT plan is created and no
+    hipFFT transform runs (skr_stat counters); against the oracle, and against the hipFFT route on the same seeds"""
+    import os
+
+    import numpy as np
+    from conftest import note_margin
+    from skr_oracle import noise as ON
+    from skrample_amd.common import Step
+
+    lib = _hip.load()
+    seeds = [31, 32]
+
+    def spec_normal(seed, stream, shape):
+        return torch.from_numpy(ON.philox_normal(seed, stream, int(np.prod(shape)))).reshape(tuple(shape))
+
+    plans, execs = lib.skr_stat(b"hipfft_plans"), lib.skr_stat(b"hipfft_execs")
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
+    outs = []
+    for n, st in enumerate((None, Step(0.45, 0.5))):
+        got = g.generate(st).cpu()
+        outs.append(got)
+        ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
+        exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st) for s in seeds])
+        err = ((got.double() - ref.double()).abs().max() / ref.double().abs().max()).item()
+        note_margin("colored (4-axis units, plane kernels + fused outer axes)", "rel inf-norm error vs the fp32 oracle", err, 5e-5)
+        far = ((got.double() - exact).abs().max() / exact.abs().max()).item()
+        near = ((ref.double() - exact).abs().max() / exact.abs().max()).item()
+        assert err < 1e-5 or (err < 5e-5 and far <= max(1.5 * near, 2e-6)), (unit, st, err, far, near)
+    assert lib.skr_stat(b"hipfft_plans") == plans and lib.skr_stat(b"hipfft_execs") == execs, "a hipFFT plan was created / run for a shape the hand-written kernels cover"
+    os.environ["SKR_FFT_NO_PLANES"] = "1"
+    try:
+        h = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
+        via_hipfft = [h.generate(st).cpu() for st in (None, Step(0.45, 0.5))]
+    finally:
+        del os.environ["SKR_FFT_NO_PLANES"]
+    assert lib.skr_stat(b"hipfft_execs") > execs  # (the comparison route did use it)
+    for a, b in zip(outs, via_hipfft):
+        assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5

@@ -7,7 +7,7 @@ import torch
 from skrample_amd.pytorch import noise as PN
 from skrample_amd.common import Step
 
-for batch, unit in ((2, (16, 13, 60, 104)), (2, (16, 21, 64, 64)), (4, (16, 8, 96, 96)), (64, (3, 96, 96)), (64, (12, 64, 64)), (16, (5, 128, 128)), (1, (16, 21, 90, 160))):
+for batch, unit in ((2, (16, 13, 60, 104)), (2, (16, 21, 64, 64)), (8, (16, 21, 64, 64)), (4, (16, 8, 96, 96)), (8, (4, 5, 96, 96)), (32, (4, 5, 96, 96)), (4, (16, 16, 128, 128)), (64, (3, 96, 96)), (64, (12, 64, 64)), (16, (5, 128, 128)), (1, (16, 21, 90, 160))):
     row = []
     outs = []
     for planes in (True, False):

@@ -5,6 +5,21 @@
 // and the hardware ids (XCC, SE, CU) come back, so the timeline of every CU can be rebuilt on the host.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSKR_COLORED_TRACE -o tune_colored tune_colored.hip
 //   ./tune_colored [batch=256] > timeline.txt
+// -DSKR_STUB_DRAW (round 4): the Philox / Box-Muller draw replaced by a four-instruction hash, to MEASURE the generator's share of the
+// forward kernel (the product source is untouched: its normal4 calls are renamed by the macro below, after the real header is in)
+#ifdef SKR_STUB_DRAW
+#include "../../skrample_amd/csrc/skr_philox.h"
+namespace skr {
+__device__ __forceinline__ void stub_normal4(uint64_t seed, uint64_t stream, uint64_t blk, float z[4]) {
+  const uint32_t h = ((uint32_t)blk * 2654435761u) ^ (uint32_t)seed ^ (uint32_t)stream;
+  z[0] = __uint_as_float(0x3f800000u | (h & 0x7fffffu)) - 1.5f;
+  z[1] = __uint_as_float(0x3f800000u | ((h >> 3) & 0x7fffffu)) - 1.5f;
+  z[2] = __uint_as_float(0x3f800000u | ((h >> 6) & 0x7fffffu)) - 1.5f;
+  z[3] = __uint_as_float(0x3f800000u | ((h >> 9) & 0x7fffffu)) - 1.5f;
+}
+}  // namespace skr
+#define normal4 stub_normal4
+#endif
 #include "../../skrample_amd/csrc/skr_colored.hip"
 #include <cstdio>
 #include <vector>
