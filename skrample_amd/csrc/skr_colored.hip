@@ -201,6 +201,68 @@ __device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, i
   __syncthreads();
 }
 
+// 128-point lines, round 4: stages 3-6 in ONE pass.  With n = 16 n1 + n2 the 8-point pass leaves A_n2[k1] = sum_n1 x[16 n1 + n2] W_8^(n1 k1)
+// at position 8 bitrev4(n2) + k1 of its line (the input sits in bit-reversed order), and
+//     X[k1 + 8 k2] = sum_n2 ( W_128^(n2 k1) A_n2[k1] ) W_16^(n2 k2):
+// an item -- (line, k1) -- takes its sixteen values, multiplies them by their twiddles (table of the FULL circle: n2 k1 <= 105) and
+// transforms them in registers; the results go back over the sixteen inputs in natural order (or to global memory: TO_GLOBAL as in
+// fft_tile).  Against the two radix-2^2 passes this replaces: one LDS round trip and one barrier instead of two, one twiddle read
+// per point instead of three per four, and the index arithmetic of one item per sixteen points instead of two per four.
+// Consecutive lanes take consecutive lines (pitch 129 complex: conflict-free 8-byte accesses).
+template <bool INVERSE, bool SKIP8, bool TO_GLOBAL>
+__device__ __forceinline__ void fft_tile_128(float2* buf, const float2* tw_full, int L, float2* gout = nullptr, int gpitch = 0) {
+  constexpr int N = 128, ld = N + 1;
+  const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
+  if constexpr (!SKIP8) {
+    __syncthreads();
+    const int total = L * (N >> 3);
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+      const int g = (int)__umulhi((uint32_t)t, magic), line = t - g * L;
+      float2* p = buf + line * ld + 8 * g;
+      float2 v[8];
+      v[0] = p[0]; v[4] = p[1]; v[2] = p[2]; v[6] = p[3]; v[1] = p[4]; v[5] = p[5]; v[3] = p[6]; v[7] = p[7];
+      dft8<INVERSE>(v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = v[k];
+    }
+  }
+  __syncthreads();
+  const int total = L * 8;
+  for (int t = threadIdx.x; t < total; t += blockDim.x) {
+    const int k1 = (int)__umulhi((uint32_t)t, magic), line = t - k1 * L;
+    float2* p = buf + line * ld + k1;
+    float2 v[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = p[8 * (int)(__builtin_bitreverse32((unsigned)n2) >> 28)];
+    const float2* w = tw_full;
+#pragma unroll
+    for (int n2 = 1; n2 < 16; ++n2) {
+      w += k1;  // W_128^(n2 k1)
+      float2 c = *w;
+      if (INVERSE) c.y = -c.y;
+      v[n2] = cmul(v[n2], c);
+    }
+    dft16<INVERSE>(v);
+    if constexpr (TO_GLOBAL) {
+      float2* g = gout + (int64_t)k1 * gpitch + line;
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) g[(int64_t)(8 * k2) * gpitch] = v[k2];
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) p[8 * k2] = v[k2];
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void make_twiddles_full(float2* tw, int N) {  // exp(-2 pi i k / N) for the whole circle, k < N
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    float s, c;
+    sincospif(-2.0f * (float)k / (float)N, &s, &c);
+    tw[k] = make_float2(c, s);
+  }
+}
+
 __device__ __forceinline__ void make_twiddles(float2* tw, int N) {
   for (int k = threadIdx.x; k < N / 2; k += blockDim.x) {
     float s, c;
@@ -440,14 +502,16 @@ template <int MODE, typename T, int CH, int CW, bool COH = false>
 __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, int logW_rt, const int64_t smp, const int i1, float2* smem) {
   const int logH = CH ? CH : logH_rt, logW = CW ? CW : logW_rt;
   const int H = CH ? (1 << CH) : a.d2, W = CW ? (1 << CW) : a.d3, WH = CW ? (1 << CW) / 2 + 1 : a.d3h, ldw = W + 1, ldh = H + 1, pairs = H >> 1;
+  // (the twiddle region holds W + H entries: the 128-point lines of the compile-time 128 x 128 instantiation index the full circle)
+  constexpr bool R16_W = CW == 7, R16_H = CH == 7 && CW >= 3;  // 128-point lines: 8-point pass + ONE radix-16 pass (fft_tile_128)
   float2* tw_w = smem;
-  float2* tw_h = tw_w + W / 2;
-  float2* t1 = tw_h + H / 2;  // row-pair tile
-  float2* t2 = t1;            // column tile (aliases t1)
+  float2* tw_h = tw_w + W;
+  float2* t1 = tw_h + H;  // row-pair tile
+  float2* t2 = t1;        // column tile (aliases t1)
   const uint32_t magic_wh = (uint32_t)((0x100000000ull + (uint32_t)WH - 1) / (uint32_t)WH);  // q / WH == umulhi(q, magic) for q < 2^16
   SKR_STAMP(0);
-  make_twiddles(tw_w, W);
-  make_twiddles(tw_h, H);
+  if constexpr (R16_W) make_twiddles_full(tw_w, W); else make_twiddles(tw_w, W);
+  if constexpr (R16_H) make_twiddles_full(tw_h, H); else make_twiddles(tw_h, H);
   float2* plane = a.spec + ((smp * a.d1 + i1) * (int64_t)H) * WH;
   double s1 = 0.0, s2 = 0.0;
   double fa[4] = {0.0, 0.0, 0.0, 0.0};  // MODE 1, first wave: this lane's share of the sample's partial sums (white s1 s2, coloured s1 s2)
@@ -476,7 +540,8 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
     }
     s1 = (double)ws1; s2 = (double)ws2;
     SKR_STAMP(1);
-    fft_tile<false>(t1, tw_w, W, logW, pairs);
+    if constexpr (R16_W) fft_tile_128<false, false, false>(t1, tw_w, pairs);
+    else fft_tile<false>(t1, tw_w, W, logW, pairs);
     SKR_STAMP(2);
     constexpr bool FUSE_COL = CH >= 5 && (CH & 1) && CW >= 3;  // 128-row planes: the column transform opens with an 8-point pass
     if constexpr (FUSE_COL) {
@@ -518,7 +583,8 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
         if (q < MAIN) put8(1 + (q & (W / 2 - 1)), q >> (CW - 1), va[r], vb[r]);
       }
       if (threadIdx.x < P0) put8(0, threadIdx.x, va[ROUNDS], vb[ROUNDS]);
-      fft_tile<false, true, MODE == 0, COH>(t2, tw_h, H, logH, WH, plane, WH);
+      if constexpr (R16_H) fft_tile_128<false, true, MODE == 0>(t2, tw_h, WH, plane, WH);
+      else fft_tile<false, true, MODE == 0, COH>(t2, tw_h, H, logH, WH, plane, WH);
     } else {
     {
       // untangle the row pairs into the column tile (bit-reversed along H for the column transform)
@@ -645,7 +711,8 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
     SKR_STAMP(1);
   }
 
-  fft_tile<true, MODE == 1 && CH >= 5 && (CH & 1) && CW >= 3>(t2, tw_h, H, logH, WH);
+  if constexpr (R16_H) fft_tile_128<true, MODE == 1, false>(t2, tw_h, WH);
+  else fft_tile<true, MODE == 1 && CH >= 5 && (CH & 1) && CW >= 3>(t2, tw_h, H, logH, WH);
   SKR_STAMP(2);
   constexpr bool FUSE_ROW = CW >= 5 && (CW & 1) && CH >= 2;  // 128-point rows: the row transform opens with an 8-point pass
   if constexpr (FUSE_ROW) {
@@ -723,7 +790,8 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
       factor_sh = a.raw ? 1.0f : rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
     }
   }
-  fft_tile<true, FUSE_ROW>(t1, tw_w, W, logW, pairs);
+  if constexpr (R16_W) fft_tile_128<true, FUSE_ROW, false>(t1, tw_w, pairs);
+  else fft_tile<true, FUSE_ROW>(t1, tw_w, W, logW, pairs);
   SKR_STAMP(3);
   const float scale = a.raw ? 1.0f : 1.0f / ((float)a.d1 * (float)H * (float)W);
   const float factor = MODE == 2 ? (float)s1 : factor_sh;
@@ -774,14 +842,6 @@ __device__ __forceinline__ int mixed_pos(const MixedAxis& x, int n) {
 __device__ __forceinline__ int mixed_nat(const MixedAxis& x, int k) { return k + (k >> x.a); }
 // q / d by multiply-high with magic = ceil(2^32 / d) (exact for q < 2^16); d = 1 has no 32-bit magic (it wraps to 0): q itself
 __device__ __forceinline__ int div_magic(int q, uint32_t magic) { return magic == 0u ? q : (int)__umulhi((uint32_t)q, magic); }
-
-__device__ __forceinline__ void make_twiddles_full(float2* tw, int n) {  // exp(-2 pi i k / n), k < n
-  for (int k = threadIdx.x; k < n; k += blockDim.x) {
-    float s, c;
-    sincospif(-2.0f * (float)k / (float)n, &s, &c);
-    tw[k] = make_float2(c, s);
-  }
-}
 
 // the combining pass of the odd factor, over `lines` lines of the tile (in place; r = 1: nothing to do).
 // r = 3, 5: one thread per output group, the r twiddled inputs in registers.
@@ -1287,7 +1347,7 @@ int colored_planes(int mode, float2* spec, double* plane_partials, float* real_o
   const int l3 = ilog2_exact(d3), l2 = ilog2_exact(d2);
   const int64_t d3h = a.d3h;
   const size_t tile_points = (size_t)(d2 / 2) * (d3 + 1) > (size_t)d3h * (d2 + 1) ? (size_t)(d2 / 2) * (d3 + 1) : (size_t)d3h * (d2 + 1);
-  const size_t lds_plane = sizeof(float2) * ((size_t)d3 / 2 + d2 / 2 + tile_points);
+  const size_t lds_plane = sizeof(float2) * ((size_t)d3 + d2 + tile_points);  // twiddles of both axes (full circle) + the tile
   const bool pow2_plane = l3 >= 2 && l2 >= 1 && lds_plane <= 150 * 1024 && (int64_t)(d2 / 2) * d3 <= PLANE_THREADS * PLANE_ITEMS &&
                           (int64_t)(d2 / 2) * d3h <= PLANE_THREADS * PLANE_ITEMS && (int64_t)d2 * d3h <= 2ll * PLANE_THREADS * PLANE_ITEMS;
   if (pow2_plane) {
@@ -1359,7 +1419,7 @@ extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, f
   const int64_t d3h = a.d3h;
   // fused plane kernels when one d2 x d3 plane (+ its half spectrum) fits the CU's LDS
   const size_t tile_points = (size_t)(d2 / 2) * (d3 + 1) > (size_t)d3h * (d2 + 1) ? (size_t)(d2 / 2) * (d3 + 1) : (size_t)d3h * (d2 + 1);
-  const size_t lds_plane = sizeof(float2) * ((size_t)d3 / 2 + d2 / 2 + tile_points);
+  const size_t lds_plane = sizeof(float2) * ((size_t)d3 + d2 + tile_points);  // twiddles of both axes (full circle) + the tile
   const bool fused = lds_plane <= 150 * 1024 && (int64_t)(d2 / 2) * d3 <= PLANE_THREADS * PLANE_ITEMS && (int64_t)(d2 / 2) * d3h <= PLANE_THREADS * PLANE_ITEMS &&
                      (nd == 2 || d1 <= 16) && d3 % 4 == 0 && getenv("SKR_FFT_NO_FUSE") == nullptr;
   auto outer_axis = [&]() -> int {
