@@ -525,6 +525,40 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
   if (MODE != 1) {
     const uint64_t seed = a.seeds[smp];
     float ws1 = 0.f, ws2 = 0.f;  // this thread's <= 144 values in fp32, one widening at the end: the per-block totals stay double
+    // 128-point rows: the draw FUSED with the 8-point pass of the row transform.  With n = 16 n1 + n2 a Philox block holds four
+    // consecutive n2 of one n1, so an item -- (row pair, q = n2 / 4) -- draws the sixteen blocks of its two rows that cover
+    // n2 = 4q .. 4q+3 for all eight n1, owns four complete 8-point subsequences in natural order, transforms them in registers and
+    // writes A_n2[k1] where fft_tile_128's radix-16 pass expects it (position 8 bitrev4(n2) + k1).  The white noise never sits in
+    // LDS untransformed: one LDS round trip (16 reads + 16 writes per thread and their index arithmetic) and one barrier fewer.
+    // pairs x 4 items fill half the block; the other four waves go straight to the barrier.
+    constexpr bool FUSE_DRAW = R16_W && CH >= 1;
+    if constexpr (FUSE_DRAW) {
+      if (threadIdx.x < (unsigned)(pairs * 4)) {
+        const int pr = threadIdx.x & (pairs - 1), q = threadIdx.x >> (CH - 1);  // consecutive lanes: consecutive pairs (lines one odd pitch apart)
+        float2 z[4][8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+          const int64_t ea = ((int64_t)i1 * H + 2 * pr) * W + 16 * n1 + 4 * q;
+          float za[4], zb[4];
+          normal4(seed, a.stream, (uint64_t)ea >> 2, za);
+          normal4(seed, a.stream, (uint64_t)(ea + W) >> 2, zb);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            z[j][n1] = make_float2(za[j], zb[j]);
+            ws1 += za[j] + zb[j];
+            ws2 = __builtin_fmaf(za[j], za[j], __builtin_fmaf(zb[j], zb[j], ws2));
+          }
+        }
+        const int rq = ((q & 1) << 1) | (q >> 1);  // bitrev2(q): bitrev4(4 q + j) = 4 bitrev2(j) + bitrev2(q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dft8<false>(z[j]);
+          float2* p = t1 + pr * ldw + 8 * (4 * (((j & 1) << 1) | (j >> 1)) + rq);
+#pragma unroll
+          for (int k1 = 0; k1 < 8; ++k1) p[k1] = z[j][k1];
+        }
+      }
+    } else
     for (int q = threadIdx.x; q < pairs * (W / 4); q += PLANE_THREADS) {
       const int pr = q >> (logW - 2), n4 = (q & (W / 4 - 1)) * 4;
       const int64_t ea = ((int64_t)i1 * H + 2 * pr) * W + n4;
@@ -540,7 +574,7 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
     }
     s1 = (double)ws1; s2 = (double)ws2;
     SKR_STAMP(1);
-    if constexpr (R16_W) fft_tile_128<false, false, false>(t1, tw_w, pairs);
+    if constexpr (R16_W) fft_tile_128<false, FUSE_DRAW, false>(t1, tw_w, pairs);
     else fft_tile<false>(t1, tw_w, W, logW, pairs);
     SKR_STAMP(2);
     constexpr bool FUSE_COL = CH >= 5 && (CH & 1) && CW >= 3;  // 128-row planes: the column transform opens with an 8-point pass

@@ -894,6 +894,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         entry.sdt, entry.odt, entry.shape, entry.device, entry.dev_index = sample.dtype, model_output.dtype, sample.shape, sample.device, sample.device.index
         entry.step, entry.keep, entry.hist = step, keep, nprev
         entry.o0dt, entry.o1dt = prog.out_dtypes
+        small = sample.numel() * sample.element_size() < (16 << 20)  # (larger results get lazy.empty_output's staggered placement)
+        entry.like0, entry.like1 = small and entry.o0dt == sample.dtype, small and entry.o1dt == sample.dtype
         entry.final_out, entry.state_out, entry.pred = prog.final_out, prog.state_out, prog.pred
         entry.stream0, entry.stream1 = prog.plan.stream0, prog.plan.stream1
         entry.launch = lib.skr_program_launch
@@ -981,10 +983,11 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         for code, k, f in entry.srcs:
             arr[j] = sp if code == 0 else op if code == 1 else hp[k][f]
             j += 1
-        out0 = empty_output(shape, entry.o0dt, device)
+        # (results below the staggering size that share the sample's dtype: empty_like skips the shape / dtype / device argument parsing)
+        out0 = torch.empty_like(sample) if entry.like0 else empty_output(shape, entry.o0dt, device)
         p0 = out0.data_ptr()
         if entry.o1dt is not None:
-            out1 = empty_output(shape, entry.o1dt, device)
+            out1 = torch.empty_like(sample) if entry.like1 else empty_output(shape, entry.o1dt, device)
             status = entry.launch(entry.handle, arr, p0, out1.data_ptr(), seeds_ptr, s0, s1, _hip._raw_stream(entry.dev_index))
             final = out1 if entry.final_out else out0
         else:
@@ -1029,7 +1032,7 @@ class _FastEntry:
     "what a replayed step of an in-order run needs besides today's tensors (SkrampleWrapperScheduler._fast_learn)"
 
     __slots__ = ("handle", "prog", "srcs", "draws", "noise", "arr", "sdt", "odt", "shape", "device", "dev_index", "step", "keep", "hist", "o0dt", "o1dt",
-                 "final_out", "state_out", "pred", "stream0", "stream1", "launch", "__weakref__")  # fmt: skip
+                 "final_out", "state_out", "pred", "stream0", "stream1", "launch", "like0", "like1", "__weakref__")  # fmt: skip
 
 
 @dataclasses.dataclass

@@ -21,13 +21,16 @@ from skrample_amd.pytorch._philox_host import philox_u32, uniform01
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5  # relative (inf-norm) tolerance for fp32 generator outputs
-# Two generators are long fp32 pipelines compared with ANOTHER fp32 pipeline (the oracle's torch ops), so part of any difference is the
-# reference's own rounding.  The measured maxima of the whole suite are in profiles/r04_parity_margins.txt (tools/summarize_margins.py;
-# MEASURED-MARGINS lines below are copied from it).  Where the plain 1e-5 is exceeded the wider bar is asserted TOGETHER with "no further
-# from the float64 evaluation of the same inputs than the reference's own fp32 result".
-PYRAMID_TOL = 2e-5
-COLORED_TOL = 5e-5
-COLORIZE_TOL = 2e-5
+# Round 3 asserted 2e-5 (Pyramid, colorize) and 5e-5 (Colored) here without a measured number beside them.  Round 4 measured every
+# comparison of the suite (profiles/r04_parity_margins.txt; float64 evaluations of the same inputs recorded next to the fp32 oracle):
+#   Colored   device vs fp32 oracle: median 4.2e-7, MAX 8.9e-7 over 414 comparisons (device vs float64 5.8e-7, oracle vs float64 3.4e-7)
+#   Pyramid   device vs fp32 oracle: MAX 3.8e-7 (LDS kernels), 3.5e-7 (any-shape kernels; vs float64 2.4e-6 where the oracle itself is 2.3e-6 off)
+#   colorize_noise vs the REFERENCE's recorded outputs: MAX 3.0e-7;  LDS kernels vs the hipFFT route: 4.8e-7
+# so every generator bar is the stated 1e-5 now (10x or more above the measured maxima); `no_further_from_exact` stays as the rule a
+# wider bar would have to be justified by, and is asserted for the two longest pipelines anyway.
+PYRAMID_TOL = TOL
+COLORED_TOL = TOL
+COLORIZE_TOL = TOL
 
 
 @pytest.fixture(scope="module")
@@ -364,7 +367,7 @@ def test_colored(unit, dev):
             ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st, **kw) for s in seeds])
             exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st, **kw) for s in seeds])
             err = rel(got, ref, "colored", COLORED_TOL, exact)
-            assert err < TOL or (err < COLORED_TOL and no_further_from_exact(got, ref, exact)), (unit, props, st, err)
+            assert err < TOL and no_further_from_exact(got, ref, exact, slack=3.0), (unit, props, st, err)
             if props.energy is not None:
                 assert (got.reshape(2, -1).std(dim=1) - abs(props.energy)).abs().max() < 1e-4
 
@@ -751,6 +754,6 @@ def test_colored_with_only_the_last_axis_on_hipfft(unit, dev):
             ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
             exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st) for s in seeds])
             err = rel(got, ref, "colored (last axis on hipFFT, others direct DFT)", COLORED_TOL, exact)
-            assert err < TOL or (err < COLORED_TOL and no_further_from_exact(got, ref, exact)), (unit, st, err)
+            assert err < TOL and no_further_from_exact(got, ref, exact, slack=3.0), (unit, st, err)
     finally:
         assert lib.skr_set_tuning(b"fft_rank", 0) == 0

@@ -210,10 +210,10 @@ def test_video_units_run_on_hand_written_kernels_only(unit, dev):
         ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
         exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st) for s in seeds])
         err = ((got.double() - ref.double()).abs().max() / ref.double().abs().max()).item()
-        note_margin("colored (4-axis units, plane kernels + fused outer axes)", "rel inf-norm error vs the fp32 oracle", err, 5e-5)
+        note_margin("colored (4-axis units, plane kernels + fused outer axes)", "rel inf-norm error vs the fp32 oracle", err, 1e-5)
         far = ((got.double() - exact).abs().max() / exact.abs().max()).item()
         near = ((ref.double() - exact).abs().max() / exact.abs().max()).item()
-        assert err < 1e-5 or (err < 5e-5 and far <= max(1.5 * near, 2e-6)), (unit, st, err, far, near)
+        assert err < 1e-5 and far <= max(3.0 * near, 2e-6), (unit, st, err, far, near)  # (measured: 5.0e-7 at most, profiles/r04_parity_margins.txt)
     assert lib.skr_stat(b"hipfft_plans") == plans and lib.skr_stat(b"hipfft_execs") == execs, "a hipFFT plan was created / run for a shape the hand-written kernels cover"
     os.environ["SKR_FFT_NO_PLANES"] = "1"
     try:
@@ -223,4 +223,4 @@ def test_video_units_run_on_hand_written_kernels_only(unit, dev):
         del os.environ["SKR_FFT_NO_PLANES"]
     assert lib.skr_stat(b"hipfft_execs") > execs  # (the comparison route did use it)
     for a, b in zip(outs, via_hipfft):
-        assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5
+        assert ((a - b).abs().max() / b.abs().max()).item() < 1e-5

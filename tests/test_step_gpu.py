@@ -30,6 +30,11 @@ from skrample_amd.sampling import structured as PT
 
 pytestmark = pytest.mark.gpu
 REL_TOL_F32 = 1e-5  # stated tolerance for floating-point parity (north_star)
+# 16-bit results: "within 1 unit in the last place of the reference's result" needs an additive term for elements that are cancellation
+# residues (their last place is far below the fp32 rounding noise of their terms).  Round 3 allowed 1e-5 * max|ref| for it without a
+# measured number; measured over every 16-bit comparison of the GPU and CPU suites (profiles/r04_parity_margins.txt): at most 8.6e-8 *
+# max|ref| on bf16 results (640 comparisons), 2.8e-8 on fp16 (220), 0 through the host executor.  The term is 1e-6 now.
+ADDITIVE_16 = 1e-6
 
 
 @pytest.fixture(scope="module")
@@ -70,10 +75,11 @@ def assert_close(got, ref, dtype, what="", flips=0.05):
         scale = r.float().abs().max().clamp_min(1e-30)
         # what is MEASURED: the worst difference in last-place units, how much of the additive term an element needed beyond its one
         # unit (as a fraction of max|ref|; the bar allows REL_TOL_F32), and the share of elements that differ at all
-        note_margin(family, "max |diff| in units of the reference's last place", (diff / ulp).max().item(), None)
-        note_margin(family, "max (|diff| - 1 ulp) / max|ref|", ((diff - ulp).clamp_min(0).max() / scale).item(), REL_TOL_F32)
+        big = r.float().abs() >= 1e-3 * scale  # (an element that is a cancellation residue has a last place far below the fp32 noise of its terms)
+        note_margin(family, "max |diff| in units of the reference's last place (elements >= 1e-3 max|ref|)", (diff[big] / ulp[big]).max().item() if big.any() else 0.0, None)
+        note_margin(family, "max (|diff| - 1 ulp) / max|ref|", ((diff - ulp).clamp_min(0).max() / scale).item(), ADDITIVE_16)
         note_margin(family, "share of elements differing in the last place", (g != r).float().mean().item(), flips)
-        bad = diff > ulp + REL_TOL_F32 * scale
+        bad = diff > ulp + ADDITIVE_16 * scale
         assert not bad.any(), (what, int(bad.sum()), diff.max().item())
         assert (g != r).float().mean().item() < flips, (what, "too many last-place flips", (g != r).float().mean().item())
 

@@ -119,6 +119,20 @@ def table_kernels() -> str:
     return "\n".join(rows)
 
 
+def table_noise() -> str:
+    "generator kernels of tools/prof_noise.py (256 x (16,128,128) bf16 draws of every generator), rows of profiles/r04_noise_kernel_stats.csv"
+    path = os.path.join(PROFILES, f"{ROUND}_noise_kernel_stats.csv")
+    if not os.path.isfile(path):
+        return "(no committed noise kernel stats yet)"
+    rows = ["| kernel (row of `profiles/r04_noise_kernel_stats.csv`) | workgroups × threads | calls | avg µs | min – max µs |", "|---|---|---|---|---|"]
+    for r in csv.DictReader(open(path)):
+        short = short_kernel(r["Name"])
+        if short.startswith(("at::", "__amd", "void at::")) or "at::native" in r["Name"]:
+            continue
+        rows.append(f"| `{short[:110]}` | {r['Workgroups']} × {r['WorkgroupSize']} | {r['Calls']} | {fmt(float(r['AverageNs']) / 1e3, 2)} | {fmt(int(r['MinNs']) / 1e3, 2)} – {fmt(int(r['MaxNs']) / 1e3, 2)} |")
+    return "\n".join(rows)
+
+
 def table_readme() -> str:
     d, k = bench_line(f"{ROUND}_bench_line.json"), bench_line(f"{ROUND}_bench_line_k20.json")
     if d is None:
@@ -137,8 +151,8 @@ def table_readme() -> str:
     return "\n".join(out)
 
 
-BLOCKS = {"r04_bench_lines": table_lines, "r04_kernel_rows": table_kernels, "r04_readme": table_readme}
-TARGETS = {"DESIGN.md": ("r04_bench_lines", "r04_kernel_rows"), "README.md": ("r04_readme",)}
+BLOCKS = {"r04_bench_lines": table_lines, "r04_kernel_rows": table_kernels, "r04_noise_rows": table_noise, "r04_readme": table_readme}
+TARGETS = {"DESIGN.md": ("r04_bench_lines", "r04_kernel_rows", "r04_noise_rows"), "README.md": ("r04_readme",)}
 
 
 def render(text: str, names) -> str:
