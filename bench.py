@@ -388,7 +388,8 @@ def cpu_baseline(wl: Workload, seconds: float, world: int) -> dict:
     and with 16 threads (elementwise passes over a few MB do not scale to a whole socket) -- and the faster of the two is reported."""
     default_threads = torch.get_num_threads()
     trials = {}
-    for threads in sorted({default_threads, min(16, default_threads)}):
+    # (torch.distributed.run exports OMP_NUM_THREADS=1: the 16-thread trial is taken from the machine's core count, not from torch's default)
+    for threads in sorted({default_threads, min(16, max(default_threads, os.cpu_count() or 1))}):
         trials[threads] = _cpu_port_rate(wl, seconds / 2, threads)
     torch.set_num_threads(default_threads)
     best = max(trials, key=lambda k: trials[k][0])
