@@ -224,3 +224,32 @@ def test_video_units_run_on_hand_written_kernels_only(unit, dev):
     assert lib.skr_stat(b"hipfft_execs") > execs  # (the comparison route did use it)
     for a, b in zip(outs, via_hipfft):
         assert ((a - b).abs().max() / b.abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize("config", ["headline", "cfg3c", "cfg5"])
+def test_bench_line_of_a_config_on_the_device(config):
+    """`python bench.py --config <c>` end to end on the device (short run, no CPU baseline / counter passes): one JSON line with the
+    contract's keys, the config's own shape and 8(d) bytes, the step kernels' time from HIP events, and for the configs that name a
+    noise generator the separate whole-step figures"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--steps", "12", "--warmup", "3", "--precondition", "12",
+                          "--no-cpu-baseline", "--no-traffic", "--no-extras"], capture_output=True, text=True, timeout=600)  # fmt: skip
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-500:]  # ONE line on stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["steps"] == 12 and d["warmup"] == 3 and d["n_gpus"] == 1 and d["config"]["name"] == config and d["unit"] == "steps/s"
+    per_elem = {"headline": 10, "cfg3c": 30, "cfg5": 100}[config]
+    r = d["roofline"]
+    assert r["algorithmic_bytes_per_element"] == per_elem and r["bound"] == "hbm" and 0.2 < r["frac"] < 1.0
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert ("whole_step" in r) == (config != "headline")
+    if config != "headline":
+        assert r["whole_step"]["us_per_step"] > r["us_per_step"] and r["whole_step"]["generator_us_per_step"] > 0
