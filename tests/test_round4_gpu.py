@@ -237,7 +237,7 @@ def test_bench_line_of_a_config_on_the_device(config):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--steps", "12", "--warmup", "3", "--precondition", "12",
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--steps", "12", "--warmup", "3", "--precondition", "12", "--sets", "4",
                           "--no-cpu-baseline", "--no-traffic", "--no-extras"], capture_output=True, text=True, timeout=600)  # fmt: skip
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
