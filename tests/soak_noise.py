@@ -130,7 +130,7 @@ def case_brownian():
         if abs(st.time_to - st.time_from) < 2.0 / ms:
             continue
         got = g.generate(st).cpu().double()
-        ref = torch.stack([ON.brownian_noise(s, unit, st, ms) for s in seeds])
+        ref = torch.stack([ON.brownian_noise(s, unit, st, ms, grid=g._state["brownian_grid"]) for s in seeds])  # (the first query fixed the path: partition or dyadic)
         # unit-variance output = scale * (W(to) - W(from)) with both path values accumulated in fp32: the error floor is absolute
         # (~1e-6), so on units of a few elements, whose largest value can be small by chance, it is measured against >= 1
         err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1.0)
