@@ -210,14 +210,14 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
 }
 
 constexpr int PYR_UNROLLED = 5;  // levels 1..4 are unrolled (and cached per column strip); deeper levels are rare and tiny
-constexpr int PYR_THREADS = 512;  // 8 waves per block: two 70 KiB blocks per CU keep 16 waves in flight
+constexpr int PYR_THREADS = 512;  // 8 waves per block (the strip kernel's 165 registers allow one such block per CU; 128 registers with spills were no faster)
 
 // STRIP: the block width divides THREADS, so a thread keeps its 4 columns for a RUN of consecutive rows: the
 // horizontally interpolated level rows (top / bottom) stay in registers while the coarse source row does not change
 // and slide (bottom -> top) when it advances by one.
 // THREADS: 512 for large planes; 256 for small ones, where it doubles the rows of a run.
 template <bool STRIP, int THREADS>
-__global__ __launch_bounds__(THREADS, STRIP ? 2 : 4) void pyramid_pass1(const PyramidArgs a) {
+__global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP ? 2 : 4)) void pyramid_pass1(const PyramidArgs a) {
   extern __shared__ float lds[];  // levels >= 1, back to back
   __shared__ double red[2][THREADS / 64];
   __shared__ int s_lh[PYR_MAX_LEVELS], s_lw[PYR_MAX_LEVELS], s_off[PYR_MAX_LEVELS];
@@ -631,15 +631,21 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   if (lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
   }
   const int64_t w4 = w / 4;
   const dim3 grid1((unsigned)(batch * lead));
-  static const int forced = [] { const char* e = getenv("SKR_PYR_MODE"); return e ? atoi(e) : 0; }();  // tuning switch: 1 generic, 2 strip/512, 3 strip/256
+  static const int forced = [] { const char* e = getenv("SKR_PYR_MODE"); return e ? atoi(e) : 0; }();  // tuning switch: 1 generic, 2 strip/512, 3 strip/256, 4 strip/1024
   // strips pay off when a thread visits enough rows to amortise its tap table; small planes get there with 256-lane blocks
   const bool strip512 = skr::PYR_THREADS % w4 == 0 && h / (skr::PYR_THREADS / w4) >= 12;
   const bool strip256 = lds_bytes <= 48 * 1024 && 256 % w4 == 0 && h / (256 / w4) >= 12;
-  const int mode = forced ? forced : (strip512 ? 2 : (strip256 ? 3 : 1));
-  if (mode == 2 && strip512) hipLaunchKernelGGL((skr::pyramid_pass1<true, 512>), grid1, dim3(512), lds_bytes, s, a);
+  // the strip kernel holds 165 registers, so a CU runs ONE 512-lane block (2 waves per SIMD) whatever the LDS would allow: where the
+  // runs stay long enough, 1024 lanes (4 waves per SIMD at 128 registers, 19 of them spilled) hide more of the Philox / Box-Muller
+  // dependency chains -- 72.9 against 75.9 us per draw at 64 x (4, 256, 256)
+  const bool strip1024 = 1024 % w4 == 0 && h / (1024 / w4) >= 12;
+  const int mode = forced ? forced : (strip1024 ? 4 : (strip512 ? 2 : (strip256 ? 3 : 1)));
+  if (mode == 4 && strip1024) hipLaunchKernelGGL((skr::pyramid_pass1<true, 1024>), grid1, dim3(1024), lds_bytes, s, a);
+  else if (mode == 2 && strip512) hipLaunchKernelGGL((skr::pyramid_pass1<true, 512>), grid1, dim3(512), lds_bytes, s, a);
   else if (mode == 3 && strip256) hipLaunchKernelGGL((skr::pyramid_pass1<true, 256>), grid1, dim3(256), lds_bytes, s, a);
   else hipLaunchKernelGGL((skr::pyramid_pass1<false, 512>), grid1, dim3(512), lds_bytes, s, a);
   if (hipGetLastError() != hipSuccess) return SKR_ERR_LAUNCH;

@@ -245,7 +245,7 @@ def pyramid_reference(unit, seed: int, stream: int, double: bool = False, **kw) 
 
 @pytest.mark.parametrize(
     ("unit", "kw"),
-    [((4, 16, 16), {}), ((4, 32, 24), {}), ((16, 16, 16), {}), ((4, 128, 128), {}), ((4, 256, 256), {}), ((4, 64, 64), dict(strength=0.6, depth=1)), ((8, 64), dict(dims=(-1,)))],  # (4-D unit shapes fail inside the reference itself)
+    [((4, 16, 16), {}), ((4, 32, 24), {}), ((16, 16, 16), {}), ((4, 128, 128), {}), ((4, 256, 256), {}), ((2, 128, 512), {}), ((1, 400, 128), {}), ((4, 64, 64), dict(strength=0.6, depth=1)), ((8, 64), dict(dims=(-1,)))],  # (4-D unit shapes fail inside the reference itself)
 )
 def test_pyramid(unit, kw, dev):
     seeds = [21, 22, 23]
