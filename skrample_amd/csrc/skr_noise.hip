@@ -217,7 +217,7 @@ constexpr int PYR_THREADS = 512;  // 8 waves per block (the strip kernel's 165 r
 // and slide (bottom -> top) when it advances by one.
 // THREADS: 512 for large planes; 256 for small ones, where it doubles the rows of a run.
 template <bool STRIP, int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP ? 2 : 4)) void pyramid_pass1(const PyramidArgs a) {
+__global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP && THREADS > 256 ? 2 : 4)) void pyramid_pass1(const PyramidArgs a) {
   extern __shared__ float lds[];  // levels >= 1, back to back
   __shared__ double red[2][THREADS / 64];
   __shared__ int s_lh[PYR_MAX_LEVELS], s_lw[PYR_MAX_LEVELS], s_off[PYR_MAX_LEVELS];
@@ -322,7 +322,9 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP ? 2 : 4)) voi
     // column strips over a run of consecutive rows: the horizontal taps of the first PYR_CACHED levels (packed
     // xa | xb << 16 and the blend weight) are computed once per thread, and the horizontally interpolated source rows
     // (top / bottom) once per coarse row instead of once per pixel
-    constexpr int PYR_CACHED = PYR_UNROLLED;
+    // 256-lane blocks serve small planes, whose level 4 is a point or two: without its cache the kernel fits 128 registers and a CU holds
+    // 16 waves instead of 12 (cfg3 shape 262 -> 251 us per draw); the 1024-lane kernel was faster WITH the cache and 19 spilled registers
+    constexpr int PYR_CACHED = THREADS <= 256 ? PYR_UNROLLED - 1 : PYR_UNROLLED;
     const int xg = threadIdx.x % w4, x0 = xg * 4, groups = THREADS / w4;
     const int run = (a.h + groups - 1) / groups, ya = (threadIdx.x / w4) * run, yz = ya + run < a.h ? ya + run : a.h;
     int tap_idx[PYR_CACHED][4], cy0[PYR_CACHED], cy1[PYR_CACHED];
