@@ -1413,14 +1413,44 @@ int colored_planes(int mode, float2* spec, double* plane_partials, float* real_o
 
 }  // namespace skr
 
+static int colored_batch(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64, int64_t partial_slots,
+                         const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t d1, int32_t d2, int32_t d3,
+                         double exponent, int32_t has_energy, double energy, void* stream);
+
 extern "C" int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64, int64_t partial_slots,
                                  const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t d1, int32_t d2, int32_t d3,
                                  double exponent, int32_t has_energy, double energy, void* stream) {
   skr::DeviceGuard device_guard(out);
-  using namespace skr;
   if (batch < 0 || d1 < 1 || d2 < 2 || d3 < 4) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
   if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || !seeds_dev) return SKR_ERR_NULL;
+  // Samples are independent, and the half spectrum of a batch is written once and read three times (forward planes -> channel axis ->
+  // inverse planes).  Groups of samples whose spectrum fits the 256 MB Infinity Cache go through the three kernels one after the other,
+  // over the SAME spectrum buffer, so that those re-reads are served on the chip instead of from HBM.
+  static const int64_t group_mb = [] { const char* e = getenv("SKR_COLORED_GROUP_MB"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+  const int64_t per_sample = (int64_t)d1 * d2 * (d3 / 2 + 1) * (int64_t)sizeof(float2);
+  int64_t group = batch;
+  if (group_mb > 0 && d1 > 1 && per_sample * batch > group_mb * (1ll << 20)) {
+    group = group_mb * (1ll << 20) / per_sample;
+    if (group < 1) group = 1;
+    const int64_t n_groups = (batch + group - 1) / group;
+    group = (batch + n_groups - 1) / n_groups;  // even groups
+  }
+  const size_t esz = out_dtype == SKR_F64 ? 8 : (out_dtype == SKR_F32 ? 4 : 2);
+  const int64_t unit = (int64_t)d1 * d2 * d3;
+  for (int64_t s0 = 0; s0 < batch; s0 += group) {
+    const int64_t n = batch - s0 < group ? batch - s0 : group;
+    const int rc = colored_batch(static_cast<char*>(out) + (size_t)(s0 * unit) * esz, out_dtype, spec_c64, scratch_f32, partials_f64 + s0 * 4 * partial_slots, partial_slots,
+                                 seeds_dev + s0, stream_id, n, d1, d2, d3, exponent, has_energy, energy, stream);
+    if (rc != SKR_OK) return rc;
+  }
+  return SKR_OK;
+}
+
+static int colored_batch(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64, int64_t partial_slots,
+                         const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t d1, int32_t d2, int32_t d3,
+                         double exponent, int32_t has_energy, double energy, void* stream) {
+  using namespace skr;
   const int l3 = ilog2_exact(d3), l2 = ilog2_exact(d2), l1 = d1 == 1 ? 0 : ilog2_exact(d1);
   const bool pow2 = l3 >= 2 && l2 >= 1 && l1 >= 0 && d3 <= FFT_MAX_TILE && d2 <= FFT_MAX_TILE && d1 <= FFT_MAX_TILE;
   // planes whose sides are a power of two times an odd factor up to 63 (96, 112, 144, 160, 192 ...) under a power-of-two channel axis: colored_plane_mixed
