@@ -256,15 +256,15 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP && THREADS > 
     if (s_wgt[l] == 0.f) continue;
     const int n = s_lh[l] * s_lw[l];
     float* g = lds + s_off[l];
-    for (int i4 = threadIdx.x * 4; i4 < n; i4 += THREADS * 4) {  // level tensor is [lead][lh][lw]; 4 normals per Philox call
-      const int64_t e = (int64_t)c * n + i4;
-      const int64_t blk = e >> 2;
-      const int lane0 = (int)(e & 3);
-      float z[8];
-      normal4(seed, a.stream_levels + 1 + l, (uint64_t)blk, z);
-      if (lane0) normal4(seed, a.stream_levels + 1 + l, (uint64_t)blk + 1, z + 4);
+    // level tensor is [lead][lh][lw]: this plane owns elements [c n, (c + 1) n) of the level's stream, element e = normal e % 4 of Philox
+    // block e / 4.  One thread per BLOCK (not per 4 elements of the plane: a plane that starts inside a block would draw every block twice)
+    const int64_t e_lo = (int64_t)c * n, b_hi = (e_lo + n + 3) >> 2;
+    for (int64_t b = (e_lo >> 2) + threadIdx.x; b < b_hi; b += THREADS) {
+      float z[4];
+      normal4(seed, a.stream_levels + 1 + l, (uint64_t)b, z);
+      const int at = (int)((b << 2) - e_lo);  // -3 .. n - 1
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (i4 + j < n) g[i4 + j] = z[lane0 + j];
+      for (int j = 0; j < 4; ++j) if (at + j >= 0 && at + j < n) g[at + j] = z[j];
     }
   }
   __syncthreads();
