@@ -171,7 +171,24 @@ __device__ __forceinline__ double pyramid_level_shrink(const PyramidArgs& a, uin
   c = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   const uint32_t word = (i & 3) == 0 ? c.x : ((i & 3) == 1 ? c.y : ((i & 3) == 2 ? c.z : c.w));
   const double r = (double)(word >> 8) * 5.9604644775390625e-08 * 2.0 + 2.0;
-  return pow(r, (double)i);
+  // r ** i, i < 8, by squaring in double-double arithmetic (error 2^-100 before the final rounding: the correctly rounded power, which
+  // is what the C library's pow returns to Python); the general pow() was 1 us of every block's start for an integer exponent below 8
+  double h = 1.0, l = 0.0, bh = r, bl = 0.0;
+  auto mul = [](double& xh, double& xl, double yh, double yl) {
+    const double p = xh * yh;
+    double e = fma(xh, yh, -p);
+    e = fma(xh, yl, e);
+    e = fma(xl, yh, e);
+    const double t = p + e;
+    xl = e - (t - p);
+    xh = t;
+  };
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (i & (1 << k)) mul(h, l, bh, bl);
+    mul(bh, bl, bh, bl);
+  }
+  return h;
 }
 // the running sizes from the eight shrink factors: (h_l, w_l) into hw[2 l], hw[2 l + 1]; returns the number of levels
 template <typename HW>
@@ -231,8 +248,19 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP && THREADS > 
   __shared__ int s_nl;
   if (threadIdx.x < PYR_MAX_LEVELS) s_shrink[threadIdx.x] = pyramid_level_shrink(a, seed, (int)threadIdx.x);
   __syncthreads();
+  if (threadIdx.x < 2) {  // the running sizes (pyramid_level_walk's arithmetic), widths in lane 0 and heights in lane 1
+    const bool heights = threadIdx.x == 1;
+    int64_t d = heights ? a.h : a.w;
+    int* sizes = heights ? s_lh : s_lw;
+    for (int i = 0; i < PYR_MAX_LEVELS; ++i) {
+      if (!heights || a.resize_h) { d = (int64_t)((double)d / s_shrink[i]); if (d < 1) d = 1; }
+      sizes[i] = (int)d;
+    }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const int nl = pyramid_level_walk(a, s_shrink, [&](int i, int32_t h, int32_t w) { s_lh[i] = h; s_lw[i] = w; });
+    int nl = 0;
+    for (int i = 0; i < PYR_MAX_LEVELS; ++i) { nl = i + 1; if (s_lw[i] <= 1 || (a.resize_h && s_lh[i] <= 1)) break; }
     s_nl = nl;
     if (c == 0) {  // (the table stays readable on the host side: tests compare it with the specification)
       for (int l = 0; l < nl; ++l) { a.level_hw[((int64_t)smp * PYR_MAX_LEVELS + l) * 2] = s_lh[l]; a.level_hw[((int64_t)smp * PYR_MAX_LEVELS + l) * 2 + 1] = s_lw[l]; }

@@ -267,6 +267,23 @@ def test_pyramid(unit, kw, dev):
         assert (got.reshape(3, -1).std(dim=1) - 1).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("unit", [(1, 256, 256), (1, 96, 640), (1, 30, 90)])
+def test_pyramid_level_geometry_on_the_device_many_seeds(unit, dev):
+    """the level sizes hinge on int(size / r**i): the device's r**i (squaring in double-double arithmetic) must be the double Python's
+    float ** int gives, for every seed -- 6000 samples x 8 levels per shape, on the LDS kernels and on the any-shape geometry kernel"""
+    seeds = list(range(7000, 13000))
+    props = PN.PyramidProps()
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Pyramid, unit, seeds, props=props, dtype=torch.bfloat16)
+    g.generate(None)
+    lead, h, w, resize_h = PN.Pyramid._geometry(unit, props)
+    table, counts = PN.pyramid_level_tables((h, w), resize_h, uniform01(np.array(seeds, dtype=np.uint64), 255, PN.PYRAMID_MAX_LEVELS))
+    dev_levels = g._state["levels"].cpu().numpy()
+    assert np.array_equal(dev_levels[len(seeds) * 16 :], counts)
+    got = dev_levels[: len(seeds) * 16].reshape(len(seeds), 8, 2)
+    keep = np.arange(8)[None, :, None] < counts[:, None, None]
+    assert np.array_equal(np.where(keep, got, 0), np.where(keep, table, 0))
+
+
 @pytest.mark.parametrize(("unit", "kw"), [((2, 30, 90), {}), ((3, 27, 18), dict(strength=0.6)), ((1, 400, 400), {}), ((2, 7), dict(dims=(-1,))), ((3, 50), dict(dims=(-1,), depth=1)), ((1, 4, 4), {})])
 def test_pyramid_any_shape(unit, kw, dev):
     "widths that are not multiples of 4 and planes beyond the LDS level stage take the global-memory fallback; same oracle, same bar"
