@@ -3,7 +3,7 @@
 #          trace    (rocprofv3 --kernel-trace --stats of the same bench commands -> profiles/r04_kernel_stats_<config>.csv)
 #          pmc      (headline PMC / SQ passes -> r04_pmc_traffic.json, r04_sq_counters.json)
 #          plans    (cold-buffer plan launches: kernel trace + counters)
-#          micro    (bench_plan / bench_graph), noise, colored (SQ counters of the Colored kernels), margins (measured parity maxima)
+#          micro    (bench_plan / bench_graph), noise, colored / pyramid (SQ counters of those generators' kernels), margins (measured parity maxima)
 # The raw rocprofv3 output stays in /tmp on the box (hundreds of MB); only the condensed files come back, under
 # gpurun_out/r4c/profiles/ -- copy what is to be judged from there into profiles/.
 set -e
@@ -15,13 +15,16 @@ PARTS="${@:-bench trace}"
 cd /tmp && export TMPDIR=/tmp
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 T="timeout -k 10"
-CONFIGS="headline cfg2 cfg3 cfg3c cfg4 cfg5"
+CONFIGS="${R4_CONFIGS:-headline cfg2 cfg3 cfg3c cfg4 cfg5}"   # R4_CONFIGS="cfg5" refreshes one configuration
 stats_csv() { ls $1/*kernel_stats.csv $1/*/*kernel_stats.csv 2>/dev/null | head -1; }
 B="python3 $R/bench.py"
 if has bench; then
-  $T 400 $B > $O/profiles/r04_bench_line.json 2> $O/bench.err
-  $T 300 $B --steps 20 --warmup 5 > $O/profiles/r04_bench_line_k20.json 2>> $O/bench.err
-  for c in cfg2 cfg3 cfg3c cfg4 cfg5; do
+  case " $CONFIGS " in *" headline "*)
+    $T 400 $B > $O/profiles/r04_bench_line.json 2> $O/bench.err
+    $T 300 $B --steps 20 --warmup 5 > $O/profiles/r04_bench_line_k20.json 2>> $O/bench.err;;
+  esac
+  for c in $CONFIGS; do
+    [ $c = headline ] && continue
     $T 400 $B --config $c > $O/profiles/r04_bench_line_$c.json 2>> $O/bench.err || { echo "bench $c failed"; tail -5 $O/bench.err; }
     echo "bench $c done"
   done
@@ -72,6 +75,16 @@ if has colored; then
   $T 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU --kernel-trace -d $RAW/col_sq2 -o n --output-format csv -- $C > $O/col_sq2.log 2>&1 || echo "second colored SQ pass failed"
   python3 $R/tools/summarize_counters.py $O/profiles/r04_colored_sq_counters.json colored_ $RAW/col_trace $RAW/col_sq $RAW/col_sq2 > $O/summarize_colored.log 2>&1 || echo "summarize colored failed"
   echo "colored part done"
+fi
+if has pyramid; then
+  C="python3 $R/tools/prof_pyramid.py"
+  $C 2>&1 | grep Pyramid > $O/profiles/r04_prof_pyramid.txt
+  $T 300 rocprofv3 --kernel-trace --stats -d $RAW/pyr_trace -o n --output-format csv -- $C > $O/pyr_trace.log 2>&1
+  $T 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace -d $RAW/pyr_sq -o n --output-format csv -- $C > $O/pyr_sq.log 2>&1
+  $T 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU --kernel-trace -d $RAW/pyr_sq2 -o n --output-format csv -- $C > $O/pyr_sq2.log 2>&1 || echo "second pyramid SQ pass failed"
+  python3 $R/tools/summarize_counters.py $O/profiles/r04_pyramid_sq_counters.json pyramid_pass1 $RAW/pyr_trace $RAW/pyr_sq $RAW/pyr_sq2 > $O/summarize_pyramid.log 2>&1 || echo "summarize pyramid failed"
+  (cd $R && python3 tools/kernel_stats.py $RAW/pyr_trace $O/profiles/r04_pyramid_kernel_stats.csv > $O/kernel_stats_pyr.log 2>&1) || echo "kernel_stats pyramid failed"
+  echo "pyramid part done"
 fi
 if has margins; then
   rm -f /tmp/r4_margins.jsonl

@@ -97,9 +97,9 @@ def main() -> None:
             out["rng_share_of_the_forward_kernel"] = {"with_philox_us": nums[0], "draw_stubbed_us": nums[1], "share": 1 - nums[1] / nums[0], "source": "profiles/r04_colored_rng_share.txt"}
     # ---- Pyramid main pass at 64 x (4, 256, 256): two full-resolution normals per pixel (base + level 0) cannot be avoided
     try:
-        m = counters("r04_pyramid_sq_counters.json", "pyramid_pass1<true, 512>")
-        spi = mix("r04_pyramid_isa_mix.json", "pyramid_pass1<true, 512>")
-        px_per_thread = 256 * 256 / 512
+        m = counters("r04_pyramid_sq_counters.json", "pyramid_pass1<true, 1024>")  # (the 256 x 256 planes of cfg5 take the 1024-lane strip kernel)
+        spi = mix("r04_pyramid_isa_mix.json", "pyramid_pass1<true, 1024>")
+        px_per_thread = 256 * 256 / 1024
         draw = 2 * (px_per_thread / 4) * n4
         out["pyramid_pass1 (256x256 plane per block)"] = {
             "draw_slots_per_wave": draw, "note": "the level blends (1 FMA per pixel and level with the interpolated coarse rows in registers) and the statistics add ~8 slots per pixel",
