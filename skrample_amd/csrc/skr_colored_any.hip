@@ -18,7 +18,12 @@
 #include "skr_philox.h"
 #include "skr_dft.h"
 
-namespace skr { int g_fft_rank = 0; }
+namespace skr {
+int g_fft_rank = 0;
+int g_use_hipfft = -1;  // skr_set_tuning("hipfft"): 1 = the inner axes on hipFFT, 0 = on skr_fft_own.hip, -1 = by the environment (SKR_FFT_HIPFFT set: hipFFT)
+// (skr_fft_own.hip) rfftn / irfftn of any axis lengths on the LDS tile transform
+int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s);
+}
 
 namespace {
 
@@ -66,7 +71,7 @@ std::map<PlanKey, Plans> g_plans;
 std::set<PlanKey> g_bad_plans;  // plans whose self-check failed
 uint64_t g_plan_clock = 0;
 constexpr size_t MAX_PLANS = 32;
-int64_t g_hipfft_plans = 0, g_hipfft_execs = 0;  // skr_stat("hipfft_plans" / "hipfft_execs"): plan pairs created, forward transforms run
+int64_t g_hipfft_plans = 0, g_hipfft_execs = 0, g_own_execs = 0;  // skr_stat("hipfft_plans" / "hipfft_execs" / "own_fft_execs"): plan pairs created, forward transforms run by hipFFT / by skr_fft_own.hip
 
 constexpr int SLOTS = 256;  // partial-sum slots per sample (one per block of the stats kernels)
 
@@ -434,7 +439,16 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   // (rank 4 on the plane kernels: the two outer axes go through any_outer_two -- channels a power of two <= 16, frames <= 32)
   if (planes && rank == 4 && !((dims[0] == 2 || dims[0] == 4 || dims[0] == 8 || dims[0] == 16) && dims[1] <= 32)) return SKR_ERR_UNSUPPORTED;
   if (planes && rank > 4) return SKR_ERR_UNSUPPORTED;
-  if (!planes && !api().ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
+  // The transforms of the inner axes: the engine's own (skr_fft_own.hip: any length up to 2048, powers of two up to 4096) unless
+  // SKR_FFT_HIPFFT is set or an axis is longer than that; hipFFT only then.
+  static const bool env_hipfft = getenv("SKR_FFT_HIPFFT") != nullptr;
+  const bool prefer_hipfft = skr::g_use_hipfft < 0 ? env_hipfft : skr::g_use_hipfft != 0;
+  bool own = !planes && !prefer_hipfft;
+  for (int i = (rank > fft_rank ? rank - fft_rank : 0); own && i < rank; ++i) {
+    const int d = dims[i];
+    own = (d & (d - 1)) == 0 ? d <= 4096 : d <= 2048;
+  }
+  if (!planes && !own && !api().ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
   const int full_rank = rank;
   const int32_t* full_dims = dims;
   AnyArgs a;
@@ -468,7 +482,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   skr::DeviceGuard guard(out);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Plans plans{};
-  if (!planes) {
+  if (!planes && !own) {
     FftApi& f = api();
     std::lock_guard<std::mutex> lock(g_mutex);
     const int64_t fft_batch = batch * d0;
@@ -546,8 +560,14 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   } else {
     if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
-    ++g_hipfft_execs;
-    if (api().r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
+    if (own) {
+      ++g_own_execs;
+      const int rc = skr::own_rfftn(guard.dev, false, a.real, a.spec, batch * d0, n[0], n[1], n[2], s);
+      if (rc != SKR_OK) return rc;
+    } else {
+      ++g_hipfft_execs;
+      if (api().r2c(plans.fwd, a.real, a.spec) != 0) return SKR_ERR_LAUNCH;
+    }
   }
   if (a.n_outer > 0) {
     const int64_t sample = d0 * a.d1 * a.d2 * a.d3h;
@@ -591,6 +611,9 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   }
   if (planes) {
     const int rc = skr::colored_planes(1, a.spec, nullptr, a.real, seeds_dev, stream_id, batch, d0, a.d2, a.d3, s);
+    if (rc != SKR_OK) return rc;
+  } else if (own) {
+    const int rc = skr::own_rfftn(guard.dev, true, a.real, a.spec, batch * d0, n[0], n[1], n[2], s);
     if (rc != SKR_OK) return rc;
   } else if (api().c2r(plans.inv, a.spec, a.real) != 0) return SKR_ERR_LAUNCH;
   hipLaunchKernelGGL(any_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
@@ -653,5 +676,6 @@ extern "C" int64_t skr_stat(const char* key) {
   std::lock_guard<std::mutex> lock(g_mutex);
   if (!strcmp(key, "hipfft_plans")) return g_hipfft_plans;
   if (!strcmp(key, "hipfft_execs")) return g_hipfft_execs;
+  if (!strcmp(key, "own_fft_execs")) return g_own_execs;
   return -1;
 }

@@ -1,0 +1,329 @@
+// Real N-D transforms of ANY axis lengths on the engine's own LDS tile transform (round 4): what skr_colored_any.hip asked hipFFT for.
+//
+// Reference: skrample/pytorch/noise.py:395-425 calls torch.fft.rfftn / irfftn over the unit's axes, whatever their lengths (152 x 104
+// latents, odd heights, 13 frames ...).  The plane kernels of skr_colored.hip take powers of two and 2^a x (odd <= 63); everything else
+// went to a vendor library.  Here an axis of length n is transformed
+//   * directly by fft_tile when n is a power of two (<= 4096), and otherwise
+//   * by Bluestein's chirp-z identity  n k = (n^2 + k^2 - (k - n)^2) / 2 :
+//       X[k] = w[k] * sum_j (x[j] w[j]) conj(w[k - j]),   w[k] = exp(-i pi k^2 / n),
+//     a cyclic convolution of length m = 2^ceil(log2(2n - 1)) done with two tile transforms of m points: a = x w zero-padded -> FFT_m,
+//     times K = FFT_m(conj(w) wrapped) (a table per length, computed once in float64), inverse FFT_m, times w.  Any n <= 2048.
+//     The first transform is decimation in frequency (natural order in, bit-reversed out: fft_tile_dif below, which also applies K,
+//     stored bit-reversed, in its last pass) and the second fft_tile's decimation in time (bit-reversed in, natural out): no
+//     permutation pass and no scattered LDS access anywhere in the convolution.
+// Angles are reduced exactly (k^2 mod 2n in integers) and evaluated in float64 when the tables are built; the transforms run in fp32
+// like the rest of the generator.  The inverse transform is conj(DFT(conj(x))), so one set of tables and one code path serve both signs.
+// The last axis is real: two real lines ride one complex transform (z = a + i b) and are untangled with the Hermitian symmetry, the
+// same trick as the plane kernels' row pairs; its inverse builds z's full spectrum from the two half spectra (the imaginary parts of
+// the DC and Nyquist bins are ignored, as a C2R transform does).  Results are unnormalised both ways, like the library transforms they
+// replace (any_finish divides by N).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "skr_device.h"
+#include "../../include/skrample_hip.h"
+#include "skr_fft_tile.h"
+
+namespace skr {
+
+struct OwnAxis {
+  int32_t n, m, logm;    // m: size of the tile transform -- n itself for a power of two, else the power of two >= 2 n - 1
+  const float2* chirp;   // w[k], k < n (nullptr: power of two, no chirp)
+  const float2* kernel;  // FFT_m(b), b[j] = conj(w[j]) for |j| < n (indices mod m), 0 elsewhere; BIT-REVERSED order (position p holds bin bitrev(p))
+};
+
+namespace {
+
+constexpr int OWN_MAX_M = 4096;
+
+// ---- tables --------------------------------------------------------------------------------------------------------------------------
+// one block; dynamic LDS: m double2.  Radix-2 DIT in float64, twiddles from sincospi of exactly reduced arguments.
+__global__ __launch_bounds__(256) void own_tables(float2* chirp, float2* kernel, int n, int m, int logm) {
+  extern __shared__ double2 bl[];
+  auto w_conj = [&](int q) {  // conj(w[q]) = exp(+i pi q^2 / n)
+    const int64_t r = ((int64_t)q * q) % (2 * (int64_t)n);
+    double s, c;
+    sincospi((double)r / (double)n, &s, &c);
+    return make_double2(c, s);
+  };
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    const double2 v = w_conj(k);
+    chirp[k] = make_float2((float)v.x, (float)-v.y);
+  }
+  for (int j = threadIdx.x; j < m; j += blockDim.x) {
+    double2 v = make_double2(0.0, 0.0);
+    if (j < n) v = w_conj(j);
+    else if (m - j < n) v = w_conj(m - j);
+    bl[__brev((unsigned)j) >> (32 - logm)] = v;
+  }
+  for (int s = 0; s < logm; ++s) {
+    __syncthreads();
+    const int h = 1 << s;
+    for (int t = threadIdx.x; t < m / 2; t += blockDim.x) {
+      const int pos = t & (h - 1), i0 = ((t >> s) << (s + 1)) + pos;
+      double sn, cs;
+      sincospi(-(double)pos / (double)h, &sn, &cs);  // exp(-2 pi i pos / (2h))
+      const double2 a = bl[i0], b = bl[i0 + h];
+      const double2 bw = make_double2(b.x * cs - b.y * sn, b.x * sn + b.y * cs);
+      bl[i0] = make_double2(a.x + bw.x, a.y + bw.y);
+      bl[i0 + h] = make_double2(a.x - bw.x, a.y - bw.y);
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < m; j += blockDim.x) kernel[__brev((unsigned)j) >> (32 - logm)] = make_float2((float)bl[j].x, (float)bl[j].y);
+}
+
+// ---- the transform of a tile ---------------------------------------------------------------------------------------------------------
+// Decimation in frequency over L lines of N points (pitch N + 1): natural order in, bit-reversed order out, forward sign.  Two radix-2
+// stages per LDS round trip like fft_tile: an item takes the points p, p + q, p + 2q, p + 3q of a block of 4q through the stages of span
+// 2q and q; one twiddle read (W_4q^j; W_2q^j is its square, W_4q^(j+q) = -i W_4q^j).  A last radix-2 stage when log2 N is odd.
+// `table` (bit-reversed order, like the output) multiplies the results in the last pass.
+__device__ __forceinline__ void fft_tile_dif(float2* buf, const float2* tw, int N, int logN, int L, const float2* table) {
+  const int ld = N + 1;
+  const bool by_line = L >= 32;
+  const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
+  int span = logN;  // log2 of the current block size
+  for (; span >= 2; span -= 2) {
+    const int q = 1 << (span - 2), step = N >> span;
+    const bool last = span == 2;
+    __syncthreads();
+    const int total = L * (N >> 2);
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+      int line, kk;
+      if (by_line && q < 32) { kk = (int)__umulhi((uint32_t)t, magic); line = t - kk * L; }
+      else { line = t >> (logN - 2); kk = t & ((N >> 2) - 1); }
+      const int j = kk & (q - 1), at = ((kk >> (span - 2)) << span) + j;
+      float2* p = buf + line * ld + at;
+      const float2 x0 = p[0], x1 = p[q], x2 = p[2 * q], x3 = p[3 * q];
+      const float2 w1 = tw[j * step];
+      const float2 w2 = make_float2(__builtin_fmaf(w1.x, w1.x, -(w1.y * w1.y)), 2.f * w1.x * w1.y);
+      const float2 y0 = cadd(x0, x2), y2 = cmul(csub(x0, x2), w1), y1 = cadd(x1, x3), y3 = mul_i<false>(cmul(csub(x1, x3), w1));
+      float2 z0 = cadd(y0, y1), z1 = cmul(csub(y0, y1), w2), z2 = cadd(y2, y3), z3 = cmul(csub(y2, y3), w2);
+      if (last && table) { z0 = cmul(z0, table[at]); z1 = cmul(z1, table[at + 1]); z2 = cmul(z2, table[at + 2]); z3 = cmul(z3, table[at + 3]); }
+      p[0] = z0; p[q] = z1; p[2 * q] = z2; p[3 * q] = z3;
+    }
+  }
+  if (span == 1) {
+    __syncthreads();
+    const int total = L * (N >> 1);
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+      int line, kk;
+      if (by_line) { kk = (int)__umulhi((uint32_t)t, magic); line = t - kk * L; }
+      else { line = t >> (logN - 1); kk = t & ((N >> 1) - 1); }
+      float2* p = buf + line * ld + 2 * kk;
+      float2 z0 = cadd(p[0], p[1]), z1 = csub(p[0], p[1]);
+      if (table) { z0 = cmul(z0, table[2 * kk]); z1 = cmul(z1, table[2 * kk + 1]); }
+      p[0] = z0; p[1] = z1;
+    }
+  }
+}
+
+// tile: L lines of pitch m + 1, filled by own_put: x[k] at bit-reversed positions (power of two), or x[k] w[k] in natural order with
+// zeros from n on (Bluestein).  On exit position k < n holds the forward DFT -- for Bluestein short of the factor w[k] / m (own_get).
+__device__ __forceinline__ void own_transform(float2* tile, const float2* tw, const OwnAxis& ax, int L) {
+  if (!ax.chirp) { fft_tile<false>(tile, tw, ax.m, ax.logm, L); return; }
+  fft_tile_dif(tile, tw, ax.m, ax.logm, L, ax.kernel);
+  fft_tile<true>(tile, tw, ax.m, ax.logm, L);  // (every pass opens with a barrier)
+}
+template <bool INVERSE>
+__device__ __forceinline__ void own_put(float2* line, const OwnAxis& ax, int k, float2 v) {
+  if (INVERSE) v.y = -v.y;
+  if (ax.chirp) line[k] = cmul(v, ax.chirp[k]);
+  else line[brev((unsigned)k, ax.logm)] = v;
+}
+template <bool INVERSE>
+__device__ __forceinline__ float2 own_get(const float2* line, const OwnAxis& ax, int k, float inv_m) {
+  float2 y = line[k];
+  if (ax.chirp) { y = cmul(y, ax.chirp[k]); y.x *= inv_m; y.y *= inv_m; }
+  if (INVERSE) y.y = -y.y;
+  return y;
+}
+// Bluestein: positions n .. m - 1 of every line are zero (a power of two fills every position).  No barrier: the lines' other
+// positions are written by own_put, and the transform's first pass opens with one.
+__device__ __forceinline__ void own_clear(float2* tile, const OwnAxis& ax, int L) {
+  if (!ax.chirp) return;
+  const int pad = ax.m - ax.n;
+  for (int t = threadIdx.x; t < L * pad; t += blockDim.x) {
+    const int line = t / pad, k = ax.n + (t - line * pad);
+    tile[line * (ax.m + 1) + k] = make_float2(0.f, 0.f);
+  }
+}
+
+// ---- last axis: real lines <-> half spectra, two lines per transform --------------------------------------------------------------
+// A wave takes a pair of lines at a time and walks it 64 values per step: runs of 4-byte / 8-byte accesses along the line, no division.
+__global__ __launch_bounds__(FFT_THREADS) void own_last_forward(const float* real, float2* spec, int64_t lines, OwnAxis ax, int L) {
+  extern __shared__ float2 smem[];
+  float2* tw = smem;
+  float2* tile = smem + ax.m / 2;
+  const int n = ax.n, nh = n / 2 + 1, ld = ax.m + 1;
+  const float inv_m = 1.0f / (float)ax.m;
+  const int64_t pairs = (lines + 1) / 2, p0 = (int64_t)blockIdx.x * L;
+  const int here = (int)(pairs - p0 < L ? pairs - p0 : L);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+  make_twiddles(tw, ax.m);
+  own_clear(tile, ax, L);
+  for (int pl = wave; pl < here; pl += waves) {
+    const int64_t la = 2 * (p0 + pl), lb = la + 1;
+    const float* ra = real + la * n;
+    const float* rb = lb < lines ? real + lb * n : nullptr;
+    for (int k = lane; k < n; k += 64) own_put<false>(tile + pl * ld, ax, k, make_float2(ra[k], rb ? rb[k] : 0.f));
+  }
+  own_transform(tile, tw, ax, L);
+  for (int pl = wave; pl < here; pl += waves) {
+    const int64_t la = 2 * (p0 + pl), lb = la + 1;
+    float2* sa = spec + la * nh;
+    float2* sb = lb < lines ? spec + lb * nh : nullptr;
+    for (int k = lane; k < nh; k += 64) {
+      const float2 zk = own_get<false>(tile + pl * ld, ax, k, inv_m), zn = own_get<false>(tile + pl * ld, ax, k ? n - k : 0, inv_m);
+      sa[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+      if (sb) sb[k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    }
+  }
+}
+
+__global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* spec, float* real, int64_t lines, OwnAxis ax, int L) {
+  extern __shared__ float2 smem[];
+  float2* tw = smem;
+  float2* tile = smem + ax.m / 2;
+  const int n = ax.n, nh = n / 2 + 1, ld = ax.m + 1;
+  const float inv_m = 1.0f / (float)ax.m;
+  const int64_t pairs = (lines + 1) / 2, p0 = (int64_t)blockIdx.x * L;
+  const int here = (int)(pairs - p0 < L ? pairs - p0 : L);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+  make_twiddles(tw, ax.m);
+  own_clear(tile, ax, L);
+  for (int pl = wave; pl < here; pl += waves) {
+    const int64_t la = 2 * (p0 + pl), lb = la + 1;
+    const float2* sa = spec + la * nh;
+    const float2* sb = lb < lines ? spec + lb * nh : nullptr;
+    for (int k = lane; k < n; k += 64) {
+      const int f = k < nh ? k : n - k;
+      float2 xa = sa[f], xb = sb ? sb[f] : make_float2(0.f, 0.f);
+      if (f == 0 || 2 * f == n) { xa.y = 0.f; xb.y = 0.f; }
+      if (k >= nh) { xa.y = -xa.y; xb.y = -xb.y; }
+      own_put<true>(tile + pl * ld, ax, k, make_float2(xa.x - xb.y, xa.y + xb.x));
+    }
+  }
+  own_transform(tile, tw, ax, L);
+  for (int pl = wave; pl < here; pl += waves) {
+    const int64_t la = 2 * (p0 + pl), lb = la + 1;
+    float* ra = real + la * n;
+    float* rb = lb < lines ? real + lb * n : nullptr;
+    for (int k = lane; k < n; k += 64) {
+      const float2 z = own_get<true>(tile + pl * ld, ax, k, inv_m);
+      ra[k] = z.x;
+      if (rb) rb[k] = z.y;
+    }
+  }
+}
+
+// ---- any other axis: complex, in place; line l = (o, i), element k at (o n + k) inner + i ------------------------------------------
+// L is a power of two <= FFT_THREADS: a thread keeps ONE line (consecutive lanes = consecutive i: runs of 8-byte accesses along the
+// fastest axis, LDS lines an odd pitch apart) and walks its elements FFT_THREADS / L apart; one 64-bit division per thread.
+template <bool INVERSE>
+__global__ __launch_bounds__(FFT_THREADS) void own_strided(float2* spec, int64_t lines, int64_t inner, OwnAxis ax, int L, int logL) {
+  extern __shared__ float2 smem[];
+  float2* tw = smem;
+  float2* tile = smem + ax.m / 2;
+  const int n = ax.n, ld = ax.m + 1;
+  const float inv_m = 1.0f / (float)ax.m;
+  const int64_t l0 = (int64_t)blockIdx.x * L;
+  const int here = (int)(lines - l0 < L ? lines - l0 : L);
+  const int pl = threadIdx.x & (L - 1), k0 = threadIdx.x >> logL, kstep = blockDim.x >> logL;
+  make_twiddles(tw, ax.m);
+  own_clear(tile, ax, L);
+  float2* base = nullptr;
+  if (pl < here) {
+    const int64_t l = l0 + pl, o = l / inner, i = l - o * inner;
+    base = spec + o * n * inner + i;
+    for (int k = k0; k < n; k += kstep) own_put<INVERSE>(tile + pl * ld, ax, k, base[(int64_t)k * inner]);
+  }
+  own_transform(tile, tw, ax, L);
+  if (pl < here)
+    for (int k = k0; k < n; k += kstep) base[(int64_t)k * inner] = own_get<INVERSE>(tile + pl * ld, ax, k, inv_m);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------------
+std::mutex g_own_mutex;
+std::map<std::tuple<int, int>, OwnAxis> g_own_axes;  // (device, n) -> tables; a few KB each, kept for the life of the process
+
+int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
+  if (n < 2) return SKR_ERR_SHAPE;
+  if ((n & (n - 1)) == 0) {
+    if (n > OWN_MAX_M) return SKR_ERR_UNSUPPORTED;
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    ax = OwnAxis{n, n, lg, nullptr, nullptr};
+    return SKR_OK;
+  }
+  int lg = 1;
+  while ((1 << lg) < 2 * n - 1) ++lg;
+  const int m = 1 << lg;
+  if (m > OWN_MAX_M) return SKR_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(g_own_mutex);
+  const auto key = std::make_tuple(dev, n);
+  auto it = g_own_axes.find(key);
+  if (it == g_own_axes.end()) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return SKR_ERR_UNSUPPORTED;  // tables are allocated outside stream capture: run the shape once eagerly first
+    }
+    float2* buf = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&buf), sizeof(float2) * (size_t)(n + m)) != hipSuccess) { (void)hipGetLastError(); return SKR_ERR_LAUNCH; }
+    const size_t lds = sizeof(double2) * (size_t)m;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(own_tables), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipFree(buf); return SKR_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(own_tables, dim3(1), dim3(256), lds, s, buf, buf + n, n, m, lg);
+    if (hipGetLastError() != hipSuccess) { (void)hipFree(buf); return SKR_ERR_LAUNCH; }
+    it = g_own_axes.emplace(key, OwnAxis{n, m, lg, buf, buf + n}).first;
+    // (other streams of this device may use the tables next: they are written once, here, before the first use on `s`; a second
+    //  stream racing that first launch would need an event -- generators of one device share the caller's stream in this engine)
+  }
+  ax = it->second;
+  return SKR_OK;
+}
+
+int tile_lines(const OwnAxis& ax) { const int L = FFT_MAX_TILE / ax.m; return L < 1 ? 1 : (L > FFT_THREADS ? FFT_THREADS : L); }  // a power of two
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+size_t tile_bytes(const OwnAxis& ax, int L) { return sizeof(float2) * ((size_t)ax.m / 2 + (size_t)L * (ax.m + 1)); }
+
+template <typename K, typename... A>
+int own_launch(K kernel, int64_t blocks, const OwnAxis& ax, int L, hipStream_t s, A... args) {
+  if (blocks < 1) return SKR_OK;
+  if (blocks > 0x7fffffffll) return SKR_ERR_UNSUPPORTED;
+  const size_t lds = tile_bytes(ax, L);
+  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(FFT_THREADS), lds, s, args...);
+  return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// rfftn / irfftn over the last three axes n0 x n1 x n2 (leading ones may be 1) of `entries` independent units:
+// real [entries][n0][n1][n2] fp32  <->  spec [entries][n0][n1][n2/2 + 1] complex64.  SKR_ERR_UNSUPPORTED: an axis beyond the tile
+// (a power of two > 4096, any other length > 2048), or tables needed during stream capture.
+int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s) {
+  OwnAxis a0{}, a1{}, a2{};
+  int rc;
+  if ((rc = own_axis(dev, n2, s, a2)) != SKR_OK) return rc;
+  if (n1 > 1 && (rc = own_axis(dev, n1, s, a1)) != SKR_OK) return rc;
+  if (n0 > 1 && (rc = own_axis(dev, n0, s, a0)) != SKR_OK) return rc;
+  const int64_t n2h = n2 / 2 + 1, lines2 = entries * n0 * n1, lines1 = entries * n0 * n2h, lines0 = entries * n1 * n2h;
+  const int L2 = tile_lines(a2), L1 = n1 > 1 ? tile_lines(a1) : 1, L0 = n0 > 1 ? tile_lines(a0) : 1;
+  if (!inverse) {
+    if ((rc = own_launch(own_last_forward, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float*)real, spec, lines2, a2, L2)) != SKR_OK) return rc;
+    if (n1 > 1 && (rc = own_launch(own_strided<false>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
+    if (n0 > 1 && (rc = own_launch(own_strided<false>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
+  } else {
+    if (n0 > 1 && (rc = own_launch(own_strided<true>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
+    if (n1 > 1 && (rc = own_launch(own_strided<true>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
+    if ((rc = own_launch(own_last_inverse, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float2*)spec, real, lines2, a2, L2)) != SKR_OK) return rc;
+  }
+  return SKR_OK;
+}
+
+}  // namespace skr

@@ -625,12 +625,13 @@ extern "C" void skr_program_destroy(skr_program* prog) { delete prog; }
 
 extern "C" int skr_last_hip_error(void) { return skr::g_last_hip_error; }
 
-namespace skr { extern int g_fft_rank; }  // skr_colored_any.hip: trailing axes given to hipFFT (0 = up to three)
+namespace skr { extern int g_fft_rank, g_use_hipfft; }  // skr_colored_any.hip: trailing axes given to the FFT (0 = up to three); hipFFT instead of skr_fft_own.hip
 
 extern "C" int skr_set_tuning(const char* key, int32_t value) {
   if (!key) return SKR_ERR_NULL;
-  if (!strcmp(key, "reset")) { skr::g_tune = skr::Tuning(); skr::g_fft_rank = 0; }
+  if (!strcmp(key, "reset")) { skr::g_tune = skr::Tuning(); skr::g_fft_rank = 0; skr::g_use_hipfft = -1; }
   else if (!strcmp(key, "fft_rank")) skr::g_fft_rank = value;
+  else if (!strcmp(key, "hipfft")) skr::g_use_hipfft = value;
   else if (!strcmp(key, "one_trip")) skr::g_tune.one_trip = value;
   else if (!strcmp(key, "xmap")) skr::g_tune.xmap = value;
   else if (!strcmp(key, "tile")) skr::g_tune.tile = value;
