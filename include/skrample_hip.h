@@ -220,10 +220,13 @@ int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scrat
                       void* stream);
 
 /* Same generator for per-sample shapes that are not powers of two (rank 1-6 after dropping size-1 dims, any
- * sizes >= 2): identical pipeline with the transforms delegated to hipFFT (dlopen'ed on first use; returns
- * SKR_ERR_UNSUPPORTED when libhipfft.so is absent).  Rank 4-6 (e.g. channels x frames x height x width): hipFFT
- * takes the inner three axes, every outer axis (<= 128 long) is a direct DFT kernel, the outermost one fused with
- * the radial weights.  Workspaces: spec_c64 = batch*prod(dims[:-1])*(dims[-1]/2+1)
+ * sizes >= 2): identical pipeline; the real N-D transform of the inner (up to three) axes runs on the library's own
+ * any-length kernels (skr_fft_own.hip: powers of two directly, every other length <= 2048 through Bluestein's chirp-z on
+ * the same LDS tile transform; its per-length tables are allocated on first use, outside stream capture).  hipFFT
+ * (dlopen'ed on first use) serves only axes longer than that, or everything when asked for (skr_set_tuning "hipfft" /
+ * SKR_FFT_HIPFFT); SKR_ERR_UNSUPPORTED when it is needed and libhipfft.so is absent.  Rank 4-6 (e.g. channels x frames x
+ * height x width): every outer axis (<= 128 long) is a direct DFT kernel, the outermost one fused with the radial
+ * weights.  Workspaces: spec_c64 = batch*prod(dims[:-1])*(dims[-1]/2+1)
  * complex64, scratch_f32 = batch*prod(dims), partials_f64 = 4*batch*256 doubles. */
 int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
                           const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank,
@@ -252,7 +255,8 @@ int skr_power_blend(void* out, int32_t out_dtype, const void* a, int32_t a_dtype
                     double c, double power, int64_t numel, void* stream);
 
 /* Diagnostics counters of this process (tests assert that a shape did NOT go to the vendor FFT): "hipfft_plans" = hipFFT plan pairs
- * created so far, "hipfft_execs" = forward hipFFT transforms run so far; -1 for an unknown key. */
+ * created so far, "hipfft_execs" = forward hipFFT transforms run so far, "own_fft_execs" = forward N-D transforms run by the library's
+ * own any-length kernels so far; -1 for an unknown key. */
 int64_t skr_stat(const char* key);
 
 int skr_abi_version(void);

@@ -1258,8 +1258,11 @@ int colored_planes(int mode, float2* spec, double* plane_partials, float* real_o
   MixedGeom mg;
   size_t lds_mixed = 0;
   int threads = 0;
-  static const int odd_limit = [] { const char* e = getenv("SKR_FFT_ODD_LIMIT"); return e ? atoi(e) : 10; }();  // (measurement switch)
-  if (getenv("SKR_FFT_NO_MIXED") != nullptr || !mixed_plane_geometry(d2, d3, false, mg, lds_mixed, threads) || mg.h.r + mg.w.r > odd_limit) return SKR_ERR_UNSUPPORTED;  // (larger odd parts: hipFFT measured faster)
+  // (measurement switch.  Rounds 3-4 stopped at odd parts summing to 10: beyond that hipFFT's 3-D plan was faster than planes here + a direct
+  //  outer-axis pass.  The N-D transform is the library's own since (skr_fft_own.hip), and every plane this kernel can hold beats it:
+  //  5 x 60 x 104 100 against 196 us, 12 x 168 x 96 115 against 245, 16 x 13 x 60 x 104 322 against 542.)
+  static const int odd_limit = [] { const char* e = getenv("SKR_FFT_ODD_LIMIT"); return e ? atoi(e) : 1 << 20; }();
+  if (getenv("SKR_FFT_NO_MIXED") != nullptr || !mixed_plane_geometry(d2, d3, false, mg, lds_mixed, threads) || mg.h.r + mg.w.r > odd_limit) return SKR_ERR_UNSUPPORTED;
 #define SKR_PLANES_M(MODE) do {                                                                                                                  \
     if (threads == 512) { SKR_ALLOW_LDS((colored_plane_mixed<MODE, float, 512>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, float, 512>), grid, dim3(512), lds_mixed, s, a, mg); } \
     else { SKR_ALLOW_LDS((colored_plane_mixed<MODE, float, 1024>), lds_mixed); hipLaunchKernelGGL((colored_plane_mixed<MODE, float, 1024>), grid, dim3(1024), lds_mixed, s, a, mg); }              \

@@ -339,16 +339,30 @@ __global__ __launch_bounds__(256) void any_stats(const AnyArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void any_finish(T* out, const AnyArgs a, int has_energy, double energy) {
   const int64_t smp = blockIdx.y;
-  double w1 = 0, w2 = 0, c1 = 0, c2 = 0;
-  for (int s = 0; s < SLOTS; ++s) {
-    const double* pw = a.partials + ((0 * a.batch + smp) * SLOTS + s) * 2;
-    const double* pc = a.partials + ((1 * a.batch + smp) * SLOTS + s) * 2;
-    w1 += pw[0]; w2 += pw[1]; c1 += pc[0]; c2 += pc[1];
+  // The sample's four sums over the SLOTS partials: by the first wave (lane l takes slots l, l + 64, ... in that order, then a fixed-order
+  // shuffle tree), one LDS word for everybody else.  (Every thread used to walk all 256 slots in a loop of dependent loads: 40 us of a
+  // 57 us kernel at 64 x (16, 66, 130).)
+  __shared__ float factor_sh;
+  if (threadIdx.x < 64) {
+    double t[4] = {0, 0, 0, 0};
+    for (int s = threadIdx.x; s < SLOTS; s += 64) {
+      const double* pw = a.partials + ((0 * a.batch + smp) * SLOTS + s) * 2;
+      const double* pc = a.partials + ((1 * a.batch + smp) * SLOTS + s) * 2;
+      t[0] += pw[0]; t[1] += pw[1]; t[2] += pc[0]; t[3] += pc[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      for (int o = 32; o > 0; o >>= 1) t[i] += __shfl_down(t[i], o);
+    if (threadIdx.x == 0) {
+      const double n = (double)a.unit;
+      const double wstd = sqrt((t[1] - t[0] * t[0] / n) / (n - 1.0)), cstd = sqrt((t[3] - t[2] * t[2] / n) / (n - 1.0));
+      float f = 1.0f / (float)a.unit;
+      if ((float)cstd > 1e-8f) f *= has_energy ? (float)energy / (float)cstd : (float)wstd / (float)cstd;
+      factor_sh = f;
+    }
   }
-  const double n = (double)a.unit;
-  const double wstd = sqrt((w2 - w1 * w1 / n) / (n - 1.0)), cstd = sqrt((c2 - c1 * c1 / n) / (n - 1.0));
-  float factor = 1.0f / (float)a.unit;
-  if ((float)cstd > 1e-8f) factor *= has_energy ? (float)energy / (float)cstd : (float)wstd / (float)cstd;
+  __syncthreads();
+  const float factor = factor_sh;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)gridDim.x * 256) out[smp * a.unit + e] = (T)(a.real[smp * a.unit + e] * factor);
 }
 

@@ -688,7 +688,7 @@ def test_capture_after_steps_with_noise_drawn_ahead(dev):
 @pytest.mark.parametrize("unit", [(4, 96, 96), (16, 96, 96), (96, 96), (4, 96, 128), (4, 160, 96), (2, 80, 80), (8, 24, 12), (4, 160, 160), (2, 192, 192), (160, 160),
                                   (4, 112, 144), (4, 104, 152), (2, 168, 96), (56, 88), (4, 28, 44), (1, 124, 116), (8, 136, 120), (2, 184, 100), (2, 108, 104), (16, 36, 52), (2, 244, 68), (4, 132, 140), (252, 68), (4, 90, 160), (2, 30, 40), (1, 126, 100), (8, 18, 12), (2, 6, 4), (4, 120, 4), (2, 2, 12), (2, 12), (102, 4)])
 def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, dev):
-    """Planes whose sides are a power of two (>= 4) times an odd factor up to 63 (latents of 768 / 896 / 1152 / 1216 / 1280 / 1344-pixel images ...) take the hand-written mixed-radix plane kernel
+    """(Round 4: the same shapes through the library's own any-length transforms as a third route.)  Planes whose sides are a power of two (>= 4) times an odd factor up to 63 (latents of 768 / 896 / 1152 / 1216 / 1280 / 1344-pixel images ...) take the hand-written mixed-radix plane kernel
     (round 3) -- `skr_noise_colored` itself answers OK for them, where it used to refuse everything but powers of two -- and the
     result agrees with the hipFFT route (`skr_noise_colored_any`) on the same seeds, which the oracle tests above pin."""
     import ctypes
@@ -700,7 +700,7 @@ def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, d
     half = n // dims[-1] * (dims[-1] // 2 + 1)
     sd = PN.seeds_tensor(seeds, dev)
     outs = []
-    for route in ("lds", "hipfft"):
+    for route in ("lds", "own", "hipfft"):
         spec = torch.empty(batch * half, dtype=torch.complex64, device=dev)
         scratch = torch.empty(batch * n, dtype=torch.float32, device=dev)
         partials = torch.empty(4 * batch * 256, dtype=torch.float64, device=dev)
@@ -710,17 +710,23 @@ def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, d
             d1, d2, d3 = ([1] + dims)[-3:]
             status = lib.skr_noise_colored(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), 256, sd.data_ptr(), 512, batch, d1, d2, d3, 1.0, 0, 0.0, st)
         else:
-            assert lib.skr_set_tuning(b"fft_rank", 3) == 0  # hipFFT proper (3-D units would otherwise take the plane kernels + a direct outer-axis DFT)
+            # the N-D transform proper (3-D units would otherwise take the plane kernels + a direct outer-axis DFT): the library's own
+            # any-length kernels (skr_fft_own.hip, the default) or hipFFT
+            assert lib.skr_set_tuning(b"fft_rank", 3) == 0 and lib.skr_set_tuning(b"hipfft", 1 if route == "hipfft" else 0) == 0
+            before = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_execs")
             try:
                 status = lib.skr_noise_colored_any(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), sd.data_ptr(), 512, batch, len(dims), (ctypes.c_int32 * len(dims))(*dims), 1.0, 0, 0.0, st)
             finally:
-                assert lib.skr_set_tuning(b"fft_rank", 0) == 0
+                assert lib.skr_set_tuning(b"fft_rank", 0) == 0 and lib.skr_set_tuning(b"hipfft", -1) == 0
+            after = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_execs")
+            assert (after[0] - before[0], after[1] - before[1]) == ((0, 1) if route == "hipfft" else (1, 0)), (route, before, after)
         assert status == 0, (route, status)
         torch.cuda.synchronize()
         outs.append(out.cpu())
-    assert rel(outs[0], outs[1], "colored: LDS kernels vs the hipFFT route", COLORIZE_TOL) < COLORIZE_TOL, rel(outs[0], outs[1])
+    assert rel(outs[0], outs[2], "colored: LDS kernels vs the hipFFT route", COLORIZE_TOL) < COLORIZE_TOL, rel(outs[0], outs[2])
+    assert rel(outs[1], outs[2], "colored: own any-length transforms vs the hipFFT route", COLORIZE_TOL) < COLORIZE_TOL, rel(outs[1], outs[2])
     assert abs(outs[0].std().item() - 1.0) < 0.05
-    # a side with a factor the kernel does not handle is still refused (and served by hipFFT through the Python layer)
+    # a side with a factor the plane kernel does not handle is still refused there (and served by skr_noise_colored_any through the Python layer)
     spec = torch.empty(260 * 131, dtype=torch.complex64, device=dev)
     scratch = torch.empty(260 * 260, dtype=torch.float32, device=dev)
     out = torch.empty(260 * 260, dtype=torch.float32, device=dev)
@@ -756,13 +762,15 @@ def test_compile_time_geometry_planes_agree_with_the_runtime_kernel(unit, dtype,
         assert torch.isfinite(a32).all() and abs(a32.std().item() - 1.0) < 0.05
 
 
+@pytest.mark.parametrize("hipfft", [0, 1])
 @pytest.mark.parametrize("unit", [(4, 96, 96), (16, 19, 13), (3, 40), (3, 4, 6, 8), (16, 2, 8, 8), (3, 4, 5, 6, 8), (2, 3, 2, 5, 4, 6)])
-def test_colored_with_only_the_last_axis_on_hipfft(unit, dev):
+def test_colored_with_only_the_last_axis_on_hipfft(unit, hipfft, dev):
     """The route taken when a multi-dimensional hipFFT plan fails its self-check (rocFFT 7.2 can return a wrong real 2-D / 3-D
-    plan in a process that has made many others -- tools/fft_probe.py): the last axis on a 1-D hipFFT plan, every other axis on
-    the direct-DFT kernels.  Forced here through skr_set_tuning("fft_rank", 1) and held to the same oracle bar."""
+    plan in a process that has made many others -- tools/fft_probe.py): the last axis on a 1-D plan, every other axis on
+    the direct-DFT kernels.  Forced here through skr_set_tuning("fft_rank", 1) and held to the same oracle bar -- with the last axis on
+    the library's own transform (hipfft = 0, the default since round 4) and on hipFFT."""
     lib = _hip.load()
-    assert lib.skr_set_tuning(b"fft_rank", 1) == 0
+    assert lib.skr_set_tuning(b"fft_rank", 1) == 0 and lib.skr_set_tuning(b"hipfft", hipfft) == 0
     try:
         seeds = [31, 32]
         g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
@@ -770,7 +778,29 @@ def test_colored_with_only_the_last_axis_on_hipfft(unit, dev):
             got = g.generate(st).cpu()
             ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
             exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st) for s in seeds])
-            err = rel(got, ref, "colored (last axis on hipFFT, others direct DFT)", COLORED_TOL, exact)
+            err = rel(got, ref, "colored (last axis on %s, others direct DFT)" % ("hipFFT" if hipfft else "the own transform"), COLORED_TOL, exact)
             assert err < TOL and no_further_from_exact(got, ref, exact, slack=3.0), (unit, st, err)
     finally:
-        assert lib.skr_set_tuning(b"fft_rank", 0) == 0
+        assert lib.skr_set_tuning(b"fft_rank", 0) == 0 and lib.skr_set_tuning(b"hipfft", -1) == 0
+
+
+@pytest.mark.parametrize("unit", [(4, 97, 97), (4, 30, 90), (3, 250, 250), (2, 66, 130), (1, 45, 96), (2, 134, 64), (3, 7, 11, 13), (2, 1025), (1, 3, 2050), (4, 720, 1280), (2, 3, 5), (5, 1300)])
+def test_awkward_shapes_run_on_the_own_transforms(unit, dev):
+    """odd sides, widths that are not multiples of 4, odd parts beyond 63, primes, lengths next to a power of two, a 720 x 1280 plane: every
+    axis length up to 2048 runs on skr_fft_own.hip (Bluestein over the LDS tile transform) -- no hipFFT plan is made, no hipFFT transform
+    runs -- and meets the oracle bar; a longer axis (2050) is the one thing hipFFT still serves"""
+    lib = _hip.load()
+    seeds = [61, 62]
+    before = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_plans"), lib.skr_stat(b"hipfft_execs")
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
+    for n, st in enumerate((None, Step(0.45, 0.5))):
+        got = g.generate(st).cpu()
+        ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
+        exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st) for s in seeds])
+        err = rel(got, ref, "colored (own any-length transforms)", COLORED_TOL, exact)
+        assert err < TOL and no_further_from_exact(got, ref, exact, slack=3.0), (unit, st, err)
+    after = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_plans"), lib.skr_stat(b"hipfft_execs")
+    if max(unit) <= 2048:
+        assert after[0] - before[0] == 2 and after[1:] == before[1:], (unit, before, after)
+    else:
+        assert after[0] == before[0] and after[2] - before[2] == 2, (unit, before, after)

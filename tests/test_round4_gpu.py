@@ -216,11 +216,13 @@ def test_video_units_run_on_hand_written_kernels_only(unit, dev):
         assert err < 1e-5 and far <= max(3.0 * near, 2e-6), (unit, st, err, far, near)  # (measured: 5.0e-7 at most, profiles/r04_parity_margins.txt)
     assert lib.skr_stat(b"hipfft_plans") == plans and lib.skr_stat(b"hipfft_execs") == execs, "a hipFFT plan was created / run for a shape the hand-written kernels cover"
     os.environ["SKR_FFT_NO_PLANES"] = "1"
+    assert lib.skr_set_tuning(b"hipfft", 1) == 0  # (the N-D transform on hipFFT: the library's own any-length kernels are the default)
     try:
         h = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
         via_hipfft = [h.generate(st).cpu() for st in (None, Step(0.45, 0.5))]
     finally:
         del os.environ["SKR_FFT_NO_PLANES"]
+        assert lib.skr_set_tuning(b"hipfft", -1) == 0
     assert lib.skr_stat(b"hipfft_execs") > execs  # (the comparison route did use it)
     for a, b in zip(outs, via_hipfft):
         assert ((a - b).abs().max() / b.abs().max()).item() < 1e-5

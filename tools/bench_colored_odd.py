@@ -1,7 +1,8 @@
 """Colored draws on planes with large odd factors (60 x 104: 15 and 13; 90 x 160: 45 and 5) and video units built on them: the hand-written
 route (mixed-radix plane kernels; for 4-axis units + the fused outer-axis pass) against hipFFT (SKR_FFT_NO_MIXED=1 SKR_FFT_NO_PLANES=1),
 same seeds, with the hipFFT counters of each side (skr_stat) so that the route taken is on record.
-Run with SKR_FFT_ODD_LIMIT=200 to let colored_planes take planes whose odd parts sum to more than 10."""
+Since the N-D transform became the library's own (round 4) colored_planes takes every plane it can hold; SKR_FFT_ODD_LIMIT=10 restores
+the limit of rounds 3-4 (odd parts summing to more than 10 went to the N-D transform) for comparison."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
