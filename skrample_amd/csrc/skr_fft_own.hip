@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void own_tables(float2* chirp, float2* kernel,
 // `table` (bit-reversed order, like the output) multiplies the results in the last pass.
 __device__ __forceinline__ void fft_tile_dif(float2* buf, const float2* tw, int N, int logN, int L, const float2* table) {
   const int ld = N + 1;
-  const bool by_line = L >= 32;
+  const bool by_line = L >= 2;  // (small spans: consecutive lanes on consecutive LINES, an odd pitch apart -- see fft_tile)
   const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
   int span = logN;  // log2 of the current block size
   for (; span >= 2; span -= 2) {
@@ -125,9 +125,9 @@ __device__ __forceinline__ void fft_tile_dif(float2* buf, const float2* tw, int 
 // tile: L lines of pitch m + 1, filled by own_put: x[k] at bit-reversed positions (power of two), or x[k] w[k] in natural order with
 // zeros from n on (Bluestein).  On exit position k < n holds the forward DFT -- for Bluestein short of the factor w[k] / m (own_get).
 __device__ __forceinline__ void own_transform(float2* tile, const float2* tw, const OwnAxis& ax, int L) {
-  if (!ax.chirp) { fft_tile<false>(tile, tw, ax.m, ax.logm, L); return; }
+  if (!ax.chirp) { fft_tile<false>(tile, tw, ax.m, ax.logm, L, nullptr, 0, true); return; }
   fft_tile_dif(tile, tw, ax.m, ax.logm, L, ax.kernel);
-  fft_tile<true>(tile, tw, ax.m, ax.logm, L);  // (every pass opens with a barrier)
+  fft_tile<true>(tile, tw, ax.m, ax.logm, L, nullptr, 0, true);  // (every pass opens with a barrier)
 }
 template <bool INVERSE>
 __device__ __forceinline__ void own_put(float2* line, const OwnAxis& ax, int k, float2 v) {
@@ -278,10 +278,9 @@ int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
     const size_t lds = sizeof(double2) * (size_t)m;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(own_tables), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipFree(buf); return SKR_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(own_tables, dim3(1), dim3(256), lds, s, buf, buf + n, n, m, lg);
-    if (hipGetLastError() != hipSuccess) { (void)hipFree(buf); return SKR_ERR_LAUNCH; }
+    // the tables are shared by every stream of the device from here on: finished before anybody can look them up (once per length)
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return SKR_ERR_LAUNCH; }
     it = g_own_axes.emplace(key, OwnAxis{n, m, lg, buf, buf + n}).first;
-    // (other streams of this device may use the tables next: they are written once, here, before the first use on `s`; a second
-    //  stream racing that first launch would need an event -- generators of one device share the caller's stream in this engine)
   }
   ax = it->second;
   return SKR_OK;

@@ -55,13 +55,15 @@ __device__ __forceinline__ float2 twid(const float2* tw, int idx) {
 // line l goes to gout[n * gpitch + l] (the forward plane kernel's half spectrum: lines are frequency columns, so with
 // consecutive lanes on consecutive lines every store instruction covers a run of a spectrum row); the tile is dead afterwards.
 template <bool INVERSE, bool SKIP8 = false, bool TO_GLOBAL = false, bool COH = false>
-__device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, int logN, int L, float2* gout = nullptr, int gpitch = 0) {
+__device__ __forceinline__ void fft_tile(float2* buf, const float2* tw, int N, int logN, int L, float2* gout = nullptr, int gpitch = 0, bool few_lines_by_line = false) {
   const int half_n = N >> 1, ld = N + 1;
   // Work-item -> (line, k) mapping.  Early stages (butterfly span h < 32) touch points 4h apart, which lands
   // consecutive k on the same LDS banks; there consecutive lanes take consecutive LINES instead (line stride
   // N+1 complex is odd, so 32 lanes cover all 64 banks and share one twiddle).  t / L by multiply-high
   // (exact for t, L < 2^16).
-  const bool by_line = L >= 32;
+  // (few_lines_by_line, skr_fft_own.hip: also for 2 ... 16 lines -- L lines x 64 / L neighbouring items per wave still spread an 8-byte
+  //  access over 32 bank pairs, where 64 neighbouring items of ONE line sit 4h points apart on 8 of them)
+  const bool by_line = L >= 32 || (few_lines_by_line && L >= 2);
   const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
   int s = 0;
   if constexpr (SKIP8) {
