@@ -75,13 +75,27 @@ def case_pyramid_extreme():
         assert rel(got, ref) < 2e-5, ("pyramid", unit, kw, n, rel(got, ref))
 
 def case_colored_mixed():
-    "even heights, widths 4 * k: the mixed-radix plane kernel where the odd part is <= 63 and the plane fits LDS, hipFFT otherwise"
+    "even heights, widths 4 * k: the mixed-radix plane kernel where the odd part is <= 63 and the plane fits LDS, the own N-D transform otherwise"
     while True:
         h, w = 2 * rng.randint(3, 100), 4 * rng.randint(1, 50)
         if h * w <= 36000:
             break
     lead = rng.choice((None, 1, 2, 4, 8))
     unit = (h, w) if lead is None else (lead, h, w)
+    T.test_colored.__wrapped__(unit, dev) if hasattr(T.test_colored, "__wrapped__") else T.test_colored(unit, dev)
+
+def case_colored_awkward():
+    "any side lengths -- odd, prime, next to a power of two, not multiples of 4: the library's own any-length transforms (skr_fft_own.hip)"
+    nd = rng.choice((1, 2, 2, 3, 3, 4))
+    pick = lambda hi: rng.choice((rng.randint(2, hi), rng.randint(2, hi), rng.choice((3, 5, 7, 11, 13, 17, 31, 33, 63, 65, 67, 97, 127, 129, 131, 255, 257)), 2 * rng.randint(1, hi // 2) + 1))
+    while True:
+        unit = tuple(min(pick(300), 300) for _ in range(nd))
+        if nd == 1:
+            unit = (rng.choice((1, 2, 3)), rng.choice((rng.randint(2, 2048), 1025, 2047, 2048, 1031)))
+        if nd == 4:
+            unit = (rng.choice((2, 3, 4)), rng.randint(2, 9)) + tuple(min(d, 40) for d in unit[2:])
+        if int(np.prod(unit)) <= (1 << 19):
+            break
     T.test_colored.__wrapped__(unit, dev) if hasattr(T.test_colored, "__wrapped__") else T.test_colored(unit, dev)
 
 def diag_colored(unit):
@@ -137,7 +151,9 @@ def case_brownian():
         assert err < 1e-5, ("brownian", unit, st, ms, err)
 
 for i in range(n_cases):
-    for fn in ((case_offset, case_pyramid, case_pyramid_extreme, case_colored, case_colored_mixed, case_colored_extreme, case_brownian) if not os.environ.get("SOAK_ONLY") else (globals()["case_" + os.environ["SOAK_ONLY"]],)):
+    if i % 20 == 0:
+        print(f"case {i} of {n_cases}, failures so far: {bad}", flush=True)  # (a silent GPU box is taken for a hung one)
+    for fn in ((case_offset, case_pyramid, case_pyramid_extreme, case_colored, case_colored_mixed, case_colored_extreme, case_colored_awkward, case_brownian) if not os.environ.get("SOAK_ONLY") else (globals()["case_" + os.environ["SOAK_ONLY"]],)):
         state = rng.getstate()
         try:
             fn()
@@ -152,6 +168,6 @@ for i in range(n_cases):
             except Exception as e2:
                 print("   the same case again: fails again --", str(e2)[:200])
             rng.setstate(after)
-            if fn in (case_colored, case_colored_mixed, case_colored_extreme):
+            if fn in (case_colored, case_colored_mixed, case_colored_extreme, case_colored_awkward):
                 diag_colored(e.args[0][0] if e.args and isinstance(e.args[0], tuple) else None)
 print("done, failures:", bad)
