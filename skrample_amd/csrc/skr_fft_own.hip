@@ -6,8 +6,11 @@
 //   * directly by fft_tile when n is a power of two (<= 4096), and otherwise
 //   * by Bluestein's chirp-z identity  n k = (n^2 + k^2 - (k - n)^2) / 2 :
 //       X[k] = w[k] * sum_j (x[j] w[j]) conj(w[k - j]),   w[k] = exp(-i pi k^2 / n),
-//     a cyclic convolution of length m = 2^ceil(log2(2n - 1)) done with two tile transforms of m points: a = x w zero-padded -> FFT_m,
-//     times K = FFT_m(conj(w) wrapped) (a table per length, computed once in float64), inverse FFT_m, times w.  Any n <= 2048.
+//     a cyclic convolution of any length m >= 2n - 1 done with two transforms of m points: a = x w zero-padded -> FFT_m, times
+//     K = FFT_m(conj(w) wrapped) (a table per length, computed once in float64), inverse FFT_m, times w.  Any n <= 2048.
+//     m = r p with p a power of two and r = 1, 3 or 5, whichever is cheapest (130 points: 320 instead of 512; 1280: 2560 instead of
+//     4096): the tile holds a line as r segments of p points, one radix-r pass (own_radix) splits FFT_m into r transforms of p points
+//     on the way in and joins them on the way out.
 //     The first transform is decimation in frequency (natural order in, bit-reversed out: fft_tile_dif below, which also applies K,
 //     stored bit-reversed, in its last pass) and the second fft_tile's decimation in time (bit-reversed in, natural out): no
 //     permutation pass and no scattered LDS access anywhere in the convolution.
@@ -31,9 +34,10 @@
 namespace skr {
 
 struct OwnAxis {
-  int32_t n, m, logm;    // m: size of the tile transform -- n itself for a power of two, else the power of two >= 2 n - 1
-  const float2* chirp;   // w[k], k < n (nullptr: power of two, no chirp)
-  const float2* kernel;  // FFT_m(b), b[j] = conj(w[j]) for |j| < n (indices mod m), 0 elsewhere; BIT-REVERSED order (position p holds bin bitrev(p))
+  int32_t n, m, p, logp, r;  // m = r p: size of the convolution (n itself, r = 1, for a power of two); p a power of two, r in {1, 3, 5}
+  const float2* chirp;       // w[k], k < n (nullptr: power of two, no chirp)
+  const float2* kernel;      // K = FFT_m(b), b[j] = conj(w[j]) for |j| < n (indices mod m), 0 elsewhere, in the order the forward
+                             // transform leaves a line: position s p + q holds bin r bitrev_p(q) + s
 };
 
 namespace {
@@ -41,48 +45,40 @@ namespace {
 constexpr int OWN_MAX_M = 4096;
 
 // ---- tables --------------------------------------------------------------------------------------------------------------------------
-// one block; dynamic LDS: m double2.  Radix-2 DIT in float64, twiddles from sincospi of exactly reduced arguments.
-__global__ __launch_bounds__(256) void own_tables(float2* chirp, float2* kernel, int n, int m, int logm) {
-  extern __shared__ double2 bl[];
+// One thread per table entry; the 2n - 1 non-zero terms of the kernel's transform summed directly in float64 with exactly reduced
+// angles (a few ms once per length and process).
+__global__ __launch_bounds__(256) void own_tables(float2* chirp, float2* kernel, int n, int m, int p, int logp, int r) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
   auto w_conj = [&](int q) {  // conj(w[q]) = exp(+i pi q^2 / n)
-    const int64_t r = ((int64_t)q * q) % (2 * (int64_t)n);
-    double s, c;
-    sincospi((double)r / (double)n, &s, &c);
-    return make_double2(c, s);
+    const int64_t t = ((int64_t)q * q) % (2 * (int64_t)n);
+    double sn, cs;
+    sincospi((double)t / (double)n, &sn, &cs);
+    return make_double2(cs, sn);
   };
-  for (int k = threadIdx.x; k < n; k += blockDim.x) {
-    const double2 v = w_conj(k);
-    chirp[k] = make_float2((float)v.x, (float)-v.y);
+  if (e < n) {
+    const double2 v = w_conj(e);
+    chirp[e] = make_float2((float)v.x, (float)-v.y);
   }
-  for (int j = threadIdx.x; j < m; j += blockDim.x) {
-    double2 v = make_double2(0.0, 0.0);
-    if (j < n) v = w_conj(j);
-    else if (m - j < n) v = w_conj(m - j);
-    bl[__brev((unsigned)j) >> (32 - logm)] = v;
+  if (e >= m) return;
+  const int s = e / p, q = e - s * p;
+  const int64_t bin = (int64_t)r * (__brev((unsigned)q) >> (32 - logp)) + s;  // (p = 1 cannot happen: m >= 3)
+  double re = 1.0, im = 0.0;  // j = 0: conj(w[0]) = 1
+  for (int j = 1; j < n; ++j) {  // b[j] = b[m - j] = conj(w[j]): 2 b cos(2 pi j bin / m)
+    const double2 bj = w_conj(j);
+    double sn, cs;
+    sincospi(2.0 * (double)((j * bin) % m) / (double)m, &sn, &cs);
+    re += 2.0 * bj.x * cs;
+    im += 2.0 * bj.y * cs;
   }
-  for (int s = 0; s < logm; ++s) {
-    __syncthreads();
-    const int h = 1 << s;
-    for (int t = threadIdx.x; t < m / 2; t += blockDim.x) {
-      const int pos = t & (h - 1), i0 = ((t >> s) << (s + 1)) + pos;
-      double sn, cs;
-      sincospi(-(double)pos / (double)h, &sn, &cs);  // exp(-2 pi i pos / (2h))
-      const double2 a = bl[i0], b = bl[i0 + h];
-      const double2 bw = make_double2(b.x * cs - b.y * sn, b.x * sn + b.y * cs);
-      bl[i0] = make_double2(a.x + bw.x, a.y + bw.y);
-      bl[i0 + h] = make_double2(a.x - bw.x, a.y - bw.y);
-    }
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < m; j += blockDim.x) kernel[__brev((unsigned)j) >> (32 - logm)] = make_float2((float)bl[j].x, (float)bl[j].y);
+  kernel[e] = make_float2((float)re, (float)im);
 }
 
 // ---- the transform of a tile ---------------------------------------------------------------------------------------------------------
 // Decimation in frequency over L lines of N points (pitch N + 1): natural order in, bit-reversed order out, forward sign.  Two radix-2
 // stages per LDS round trip like fft_tile: an item takes the points p, p + q, p + 2q, p + 3q of a block of 4q through the stages of span
 // 2q and q; one twiddle read (W_4q^j; W_2q^j is its square, W_4q^(j+q) = -i W_4q^j).  A last radix-2 stage when log2 N is odd.
-// `table` (bit-reversed order, like the output) multiplies the results in the last pass.
-__device__ __forceinline__ void fft_tile_dif(float2* buf, const float2* tw, int N, int logN, int L, const float2* table) {
+// `table` multiplies the results in the last pass: line l takes table + (l mod table_lines) N, entries in the output's (bit-reversed) order.
+__device__ __forceinline__ void fft_tile_dif(float2* buf, const float2* tw, int N, int logN, int L, const float2* table, int table_lines) {
   const int ld = N + 1;
   const bool by_line = L >= 2;  // (small spans: consecutive lanes on consecutive LINES, an odd pitch apart -- see fft_tile)
   const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)L - 1) / (uint32_t)L);
@@ -103,7 +99,10 @@ __device__ __forceinline__ void fft_tile_dif(float2* buf, const float2* tw, int 
       const float2 w2 = make_float2(__builtin_fmaf(w1.x, w1.x, -(w1.y * w1.y)), 2.f * w1.x * w1.y);
       const float2 y0 = cadd(x0, x2), y2 = cmul(csub(x0, x2), w1), y1 = cadd(x1, x3), y3 = mul_i<false>(cmul(csub(x1, x3), w1));
       float2 z0 = cadd(y0, y1), z1 = cmul(csub(y0, y1), w2), z2 = cadd(y2, y3), z3 = cmul(csub(y2, y3), w2);
-      if (last && table) { z0 = cmul(z0, table[at]); z1 = cmul(z1, table[at + 1]); z2 = cmul(z2, table[at + 2]); z3 = cmul(z3, table[at + 3]); }
+      if (last && table) {
+        const float2* tb = table + (line % table_lines) * N + at;
+        z0 = cmul(z0, tb[0]); z1 = cmul(z1, tb[1]); z2 = cmul(z2, tb[2]); z3 = cmul(z3, tb[3]);
+      }
       p[0] = z0; p[q] = z1; p[2 * q] = z2; p[3 * q] = z3;
     }
   }
@@ -116,28 +115,90 @@ __device__ __forceinline__ void fft_tile_dif(float2* buf, const float2* tw, int 
       else { line = t >> (logN - 1); kk = t & ((N >> 1) - 1); }
       float2* p = buf + line * ld + 2 * kk;
       float2 z0 = cadd(p[0], p[1]), z1 = csub(p[0], p[1]);
-      if (table) { z0 = cmul(z0, table[2 * kk]); z1 = cmul(z1, table[2 * kk + 1]); }
+      if (table) {
+        const float2* tb = table + (line % table_lines) * N + 2 * kk;
+        z0 = cmul(z0, tb[0]); z1 = cmul(z1, tb[1]);
+      }
       p[0] = z0; p[1] = z1;
     }
   }
 }
 
-// tile: L lines of pitch m + 1, filled by own_put: x[k] at bit-reversed positions (power of two), or x[k] w[k] in natural order with
-// zeros from n on (Bluestein).  On exit position k < n holds the forward DFT -- for Bluestein short of the factor w[k] / m (own_get).
-__device__ __forceinline__ void own_transform(float2* tile, const float2* tw, const OwnAxis& ax, int L) {
-  if (!ax.chirp) { fft_tile<false>(tile, tw, ax.m, ax.logm, L, nullptr, 0, true); return; }
-  fft_tile_dif(tile, tw, ax.m, ax.logm, L, ax.kernel);
-  fft_tile<true>(tile, tw, ax.m, ax.logm, L, nullptr, 0, true);  // (every pass opens with a barrier)
+// ---- radix-r pass between FFT_m and r transforms of p points (m = r p) --------------------------------------------------------------
+// A logical line is r consecutive tile lines (segments) of p points: x[t p + j] at (segment t, offset j).  Decimation in frequency,
+//     y_s[j] = W_m^(j s) sum_t x[t p + j] W_r^(t s),      X[r k + s] = FFT_p(y_s)[k],
+// in place over the r segments (an item owns offset j of all of them); JOIN = the transposed pass of the way back,
+//     y[t p + j] = sum_s W_r^(-t s) W_m^(-j s) z_s[j],    z_s = FFT_p^-1 of the bins r k + s.
+template <bool INV> __device__ __forceinline__ void dft3(float2 v[3]) {
+  constexpr float h = 0.86602540378443864676f;
+  const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+  const float2 c = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+  const float2 e = INV ? make_float2(-h * d.y, h * d.x) : make_float2(h * d.y, -h * d.x);  // -+ i h d
+  v[0] = cadd(v[0], t); v[1] = cadd(c, e); v[2] = csub(c, e);
+}
+template <bool INV> __device__ __forceinline__ void dft5(float2 v[5]) {
+  constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+  const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+  const float2 a1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+  const float2 a2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+  float2 b1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y), b2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+  b1 = INV ? make_float2(-b1.y, b1.x) : make_float2(b1.y, -b1.x);  // -+ i b
+  b2 = INV ? make_float2(-b2.y, b2.x) : make_float2(b2.y, -b2.x);
+  v[0] = cadd(v[0], cadd(t1, t2));
+  v[1] = cadd(a1, b1); v[4] = csub(a1, b1); v[2] = cadd(a2, b2); v[3] = csub(a2, b2);
+}
+template <int R, bool JOIN>
+__device__ __forceinline__ void own_radix(float2* tile, const float2* twm /* exp(-2 pi i j / m), j < p */, int p, int logp, int L, int logL) {
+  const int pitch = p + 1;
+  __syncthreads();
+  for (int t = threadIdx.x; t < (L << logp); t += blockDim.x) {
+    const int l = t & (L - 1), j = t >> logL;  // consecutive lanes: consecutive logical lines, R (p + 1) points apart -- an odd pitch
+    float2* q = tile + l * R * pitch + j;
+    float2 v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = q[i * pitch];
+    float2 w = twm[j];
+    if (JOIN) w.y = -w.y;
+    if (JOIN) {
+      float2 ws = w;
+#pragma unroll
+      for (int i = 1; i < R; ++i) { v[i] = cmul(v[i], ws); ws = cmul(ws, w); }
+    }
+    if constexpr (R == 3) dft3<JOIN>(v); else dft5<JOIN>(v);
+    if (!JOIN) {
+      float2 ws = w;
+#pragma unroll
+      for (int i = 1; i < R; ++i) { v[i] = cmul(v[i], ws); ws = cmul(ws, w); }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) q[i * pitch] = v[i];
+  }
+}
+
+// The tile: L logical lines, each r segments of p points, every segment p + 1 apart.  own_put fills it: x[k] at the bit-reversed
+// position (power of two), or x[k] w[k] in natural order (segment k / p, offset k % p) with own_clear's zeros from n on (Bluestein).
+// After own_transform position k < n holds the forward DFT -- for Bluestein short of the factor w[k] / m, which own_get applies.
+__device__ __forceinline__ int own_at(const OwnAxis& ax, int k) { return (k >> ax.logp) * (ax.p + 1) + (k & (ax.p - 1)); }
+__device__ __forceinline__ float2* own_line(float2* tile, const OwnAxis& ax, int l) { return tile + l * ax.r * (ax.p + 1); }
+__device__ __forceinline__ void own_transform(float2* tile, const float2* tw, const float2* twm, const OwnAxis& ax, int L, int logL) {
+  if (!ax.chirp) { fft_tile<false>(tile, tw, ax.p, ax.logp, L, nullptr, 0, true); return; }
+  if (ax.r == 3) own_radix<3, false>(tile, twm, ax.p, ax.logp, L, logL);
+  else if (ax.r == 5) own_radix<5, false>(tile, twm, ax.p, ax.logp, L, logL);
+  fft_tile_dif(tile, tw, ax.p, ax.logp, L * ax.r, ax.kernel, ax.r);
+  fft_tile<true>(tile, tw, ax.p, ax.logp, L * ax.r, nullptr, 0, true);  // (every pass opens with a barrier, and the transform ends with one)
+  if (ax.r == 3) own_radix<3, true>(tile, twm, ax.p, ax.logp, L, logL);
+  else if (ax.r == 5) own_radix<5, true>(tile, twm, ax.p, ax.logp, L, logL);
+  if (ax.r != 1) __syncthreads();
 }
 template <bool INVERSE>
 __device__ __forceinline__ void own_put(float2* line, const OwnAxis& ax, int k, float2 v) {
   if (INVERSE) v.y = -v.y;
-  if (ax.chirp) line[k] = cmul(v, ax.chirp[k]);
-  else line[brev((unsigned)k, ax.logm)] = v;
+  if (ax.chirp) line[own_at(ax, k)] = cmul(v, ax.chirp[k]);
+  else line[brev((unsigned)k, ax.logp)] = v;
 }
 template <bool INVERSE>
 __device__ __forceinline__ float2 own_get(const float2* line, const OwnAxis& ax, int k, float inv_m) {
-  float2 y = line[k];
+  float2 y = line[ax.chirp ? own_at(ax, k) : k];
   if (ax.chirp) { y = cmul(y, ax.chirp[k]); y.x *= inv_m; y.y *= inv_m; }
   if (INVERSE) y.y = -y.y;
   return y;
@@ -149,52 +210,63 @@ __device__ __forceinline__ void own_clear(float2* tile, const OwnAxis& ax, int L
   const int pad = ax.m - ax.n;
   for (int t = threadIdx.x; t < L * pad; t += blockDim.x) {
     const int line = t / pad, k = ax.n + (t - line * pad);
-    tile[line * (ax.m + 1) + k] = make_float2(0.f, 0.f);
+    own_line(tile, ax, line)[own_at(ax, k)] = make_float2(0.f, 0.f);
   }
+}
+// LDS of a block: twiddles of the p-point transforms (p / 2), exp(-2 pi i j / m) for j < p (r > 1 only), the tile
+__device__ __forceinline__ void own_setup(float2* smem, const OwnAxis& ax, float2*& tw, float2*& twm, float2*& tile) {
+  tw = smem;
+  twm = smem + ax.p / 2;
+  tile = twm + (ax.r > 1 ? ax.p : 0);
+  make_twiddles(tw, ax.p);
+  if (ax.r > 1)
+    for (int j = threadIdx.x; j < ax.p; j += blockDim.x) {
+      float sn, cs;
+      sincospif(-2.0f * (float)j / (float)ax.m, &sn, &cs);
+      twm[j] = make_float2(cs, sn);
+    }
 }
 
 // ---- last axis: real lines <-> half spectra, two lines per transform --------------------------------------------------------------
 // A wave takes a pair of lines at a time and walks it 64 values per step: runs of 4-byte / 8-byte accesses along the line, no division.
-__global__ __launch_bounds__(FFT_THREADS) void own_last_forward(const float* real, float2* spec, int64_t lines, OwnAxis ax, int L) {
+__global__ __launch_bounds__(FFT_THREADS) void own_last_forward(const float* real, float2* spec, int64_t lines, OwnAxis ax, int L, int logL) {
   extern __shared__ float2 smem[];
-  float2* tw = smem;
-  float2* tile = smem + ax.m / 2;
-  const int n = ax.n, nh = n / 2 + 1, ld = ax.m + 1;
+  float2 *tw, *twm, *tile;
+  own_setup(smem, ax, tw, twm, tile);
+  const int n = ax.n, nh = n / 2 + 1;
   const float inv_m = 1.0f / (float)ax.m;
   const int64_t pairs = (lines + 1) / 2, p0 = (int64_t)blockIdx.x * L;
   const int here = (int)(pairs - p0 < L ? pairs - p0 : L);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
-  make_twiddles(tw, ax.m);
   own_clear(tile, ax, L);
   for (int pl = wave; pl < here; pl += waves) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
     const float* ra = real + la * n;
     const float* rb = lb < lines ? real + lb * n : nullptr;
-    for (int k = lane; k < n; k += 64) own_put<false>(tile + pl * ld, ax, k, make_float2(ra[k], rb ? rb[k] : 0.f));
+    for (int k = lane; k < n; k += 64) own_put<false>(own_line(tile, ax, pl), ax, k, make_float2(ra[k], rb ? rb[k] : 0.f));
   }
-  own_transform(tile, tw, ax, L);
+  own_transform(tile, tw, twm, ax, L, logL);
   for (int pl = wave; pl < here; pl += waves) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
     float2* sa = spec + la * nh;
     float2* sb = lb < lines ? spec + lb * nh : nullptr;
     for (int k = lane; k < nh; k += 64) {
-      const float2 zk = own_get<false>(tile + pl * ld, ax, k, inv_m), zn = own_get<false>(tile + pl * ld, ax, k ? n - k : 0, inv_m);
+      const float2 zk = own_get<false>(own_line(tile, ax, pl), ax, k, inv_m), zn = own_get<false>(own_line(tile, ax, pl), ax, k ? n - k : 0, inv_m);
       sa[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
       if (sb) sb[k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
     }
   }
 }
 
-__global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* spec, float* real, int64_t lines, OwnAxis ax, int L) {
+__global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* spec, float* real, int64_t lines, OwnAxis ax, int L, int logL) {
   extern __shared__ float2 smem[];
-  float2* tw = smem;
-  float2* tile = smem + ax.m / 2;
-  const int n = ax.n, nh = n / 2 + 1, ld = ax.m + 1;
+  float2 *tw, *twm, *tile;
+  own_setup(smem, ax, tw, twm, tile);
+  const int n = ax.n, nh = n / 2 + 1;
   const float inv_m = 1.0f / (float)ax.m;
   const int64_t pairs = (lines + 1) / 2, p0 = (int64_t)blockIdx.x * L;
   const int here = (int)(pairs - p0 < L ? pairs - p0 : L);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
-  make_twiddles(tw, ax.m);
   own_clear(tile, ax, L);
   for (int pl = wave; pl < here; pl += waves) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
@@ -205,16 +277,16 @@ __global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* sp
       float2 xa = sa[f], xb = sb ? sb[f] : make_float2(0.f, 0.f);
       if (f == 0 || 2 * f == n) { xa.y = 0.f; xb.y = 0.f; }
       if (k >= nh) { xa.y = -xa.y; xb.y = -xb.y; }
-      own_put<true>(tile + pl * ld, ax, k, make_float2(xa.x - xb.y, xa.y + xb.x));
+      own_put<true>(own_line(tile, ax, pl), ax, k, make_float2(xa.x - xb.y, xa.y + xb.x));
     }
   }
-  own_transform(tile, tw, ax, L);
+  own_transform(tile, tw, twm, ax, L, logL);
   for (int pl = wave; pl < here; pl += waves) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
     float* ra = real + la * n;
     float* rb = lb < lines ? real + lb * n : nullptr;
     for (int k = lane; k < n; k += 64) {
-      const float2 z = own_get<true>(tile + pl * ld, ax, k, inv_m);
+      const float2 z = own_get<true>(own_line(tile, ax, pl), ax, k, inv_m);
       ra[k] = z.x;
       if (rb) rb[k] = z.y;
     }
@@ -227,43 +299,53 @@ __global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* sp
 template <bool INVERSE>
 __global__ __launch_bounds__(FFT_THREADS) void own_strided(float2* spec, int64_t lines, int64_t inner, OwnAxis ax, int L, int logL) {
   extern __shared__ float2 smem[];
-  float2* tw = smem;
-  float2* tile = smem + ax.m / 2;
-  const int n = ax.n, ld = ax.m + 1;
+  float2 *tw, *twm, *tile;
+  own_setup(smem, ax, tw, twm, tile);
+  const int n = ax.n;
   const float inv_m = 1.0f / (float)ax.m;
   const int64_t l0 = (int64_t)blockIdx.x * L;
   const int here = (int)(lines - l0 < L ? lines - l0 : L);
   const int pl = threadIdx.x & (L - 1), k0 = threadIdx.x >> logL, kstep = blockDim.x >> logL;
-  make_twiddles(tw, ax.m);
   own_clear(tile, ax, L);
   float2* base = nullptr;
   if (pl < here) {
     const int64_t l = l0 + pl, o = l / inner, i = l - o * inner;
     base = spec + o * n * inner + i;
-    for (int k = k0; k < n; k += kstep) own_put<INVERSE>(tile + pl * ld, ax, k, base[(int64_t)k * inner]);
+    for (int k = k0; k < n; k += kstep) own_put<INVERSE>(own_line(tile, ax, pl), ax, k, base[(int64_t)k * inner]);
   }
-  own_transform(tile, tw, ax, L);
+  own_transform(tile, tw, twm, ax, L, logL);
   if (pl < here)
-    for (int k = k0; k < n; k += kstep) base[(int64_t)k * inner] = own_get<INVERSE>(tile + pl * ld, ax, k, inv_m);
+    for (int k = k0; k < n; k += kstep) base[(int64_t)k * inner] = own_get<INVERSE>(own_line(tile, ax, pl), ax, k, inv_m);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
 std::mutex g_own_mutex;
 std::map<std::tuple<int, int>, OwnAxis> g_own_axes;  // (device, n) -> tables; a few KB each, kept for the life of the process
 
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// m = r p >= 2 n - 1 with the least work: p log2 p butterflies per segment plus the radix-r pass
+void own_size(int n, int& m, int& p, int& r) {
+  double best = 1e30;
+  for (int rr : {1, 3, 5})
+    for (int pp = 2; pp * rr <= OWN_MAX_M; pp *= 2) {
+      if (pp * rr < 2 * n - 1) continue;
+      const double cost = (double)pp * rr * (ilog2(pp) + (rr > 1 ? 2.5 : 0.0));
+      if (cost < best) { best = cost; m = pp * rr; p = pp; r = rr; }
+      break;
+    }
+}
+
 int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
   if (n < 2) return SKR_ERR_SHAPE;
   if ((n & (n - 1)) == 0) {
     if (n > OWN_MAX_M) return SKR_ERR_UNSUPPORTED;
-    int lg = 0;
-    while ((1 << lg) < n) ++lg;
-    ax = OwnAxis{n, n, lg, nullptr, nullptr};
+    ax = OwnAxis{n, n, n, ilog2(n), 1, nullptr, nullptr};
     return SKR_OK;
   }
-  int lg = 1;
-  while ((1 << lg) < 2 * n - 1) ++lg;
-  const int m = 1 << lg;
-  if (m > OWN_MAX_M) return SKR_ERR_UNSUPPORTED;
+  if (2 * n - 1 > OWN_MAX_M) return SKR_ERR_UNSUPPORTED;
+  int m = 0, p = 0, r = 0;
+  own_size(n, m, p, r);
   std::lock_guard<std::mutex> lock(g_own_mutex);
   const auto key = std::make_tuple(dev, n);
   auto it = g_own_axes.find(key);
@@ -275,20 +357,22 @@ int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
     }
     float2* buf = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&buf), sizeof(float2) * (size_t)(n + m)) != hipSuccess) { (void)hipGetLastError(); return SKR_ERR_LAUNCH; }
-    const size_t lds = sizeof(double2) * (size_t)m;
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(own_tables), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipFree(buf); return SKR_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(own_tables, dim3(1), dim3(256), lds, s, buf, buf + n, n, m, lg);
+    hipLaunchKernelGGL(own_tables, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, buf, buf + n, n, m, p, ilog2(p), r);
     // the tables are shared by every stream of the device from here on: finished before anybody can look them up (once per length)
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return SKR_ERR_LAUNCH; }
-    it = g_own_axes.emplace(key, OwnAxis{n, m, lg, buf, buf + n}).first;
+    it = g_own_axes.emplace(key, OwnAxis{n, m, p, ilog2(p), r, buf, buf + n}).first;
   }
   ax = it->second;
   return SKR_OK;
 }
 
-int tile_lines(const OwnAxis& ax) { const int L = FFT_MAX_TILE / ax.m; return L < 1 ? 1 : (L > FFT_THREADS ? FFT_THREADS : L); }  // a power of two
-int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-size_t tile_bytes(const OwnAxis& ax, int L) { return sizeof(float2) * ((size_t)ax.m / 2 + (size_t)L * (ax.m + 1)); }
+// logical lines per block: a power of two, about FFT_MAX_TILE points
+int tile_lines(const OwnAxis& ax) {
+  int L = 1;
+  while (2 * L * ax.m <= FFT_MAX_TILE && 2 * L <= FFT_THREADS) L *= 2;
+  return L;
+}
+size_t tile_bytes(const OwnAxis& ax, int L) { return sizeof(float2) * ((size_t)ax.p / 2 + (ax.r > 1 ? (size_t)ax.p : 0) + (size_t)L * ax.r * (ax.p + 1)); }
 
 template <typename K, typename... A>
 int own_launch(K kernel, int64_t blocks, const OwnAxis& ax, int L, hipStream_t s, A... args) {
@@ -314,13 +398,13 @@ int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries,
   const int64_t n2h = n2 / 2 + 1, lines2 = entries * n0 * n1, lines1 = entries * n0 * n2h, lines0 = entries * n1 * n2h;
   const int L2 = tile_lines(a2), L1 = n1 > 1 ? tile_lines(a1) : 1, L0 = n0 > 1 ? tile_lines(a0) : 1;
   if (!inverse) {
-    if ((rc = own_launch(own_last_forward, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float*)real, spec, lines2, a2, L2)) != SKR_OK) return rc;
+    if ((rc = own_launch(own_last_forward, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float*)real, spec, lines2, a2, L2, ilog2(L2))) != SKR_OK) return rc;
     if (n1 > 1 && (rc = own_launch(own_strided<false>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
     if (n0 > 1 && (rc = own_launch(own_strided<false>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
   } else {
     if (n0 > 1 && (rc = own_launch(own_strided<true>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
     if (n1 > 1 && (rc = own_launch(own_strided<true>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
-    if ((rc = own_launch(own_last_inverse, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float2*)spec, real, lines2, a2, L2)) != SKR_OK) return rc;
+    if ((rc = own_launch(own_last_inverse, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float2*)spec, real, lines2, a2, L2, ilog2(L2))) != SKR_OK) return rc;
   }
   return SKR_OK;
 }
