@@ -410,8 +410,9 @@ class Pyramid(TensorNoiseCommon):
 class Colored(TensorNoiseCommon):
     """Power-law coloured noise: white Philox noise shaped in the Fourier domain by f^(-exponent/2), the
     exponent moving from `color_start` to `color_end` over the schedule; per-sample std preserved (or set to
-    `energy`).  Power-of-two shapes (every BASELINE config) run on the hand-written LDS FFT kernels; any other
-    shape takes the same pipeline with the transforms done by hipFFT."""
+    `energy`).  Power-of-two shapes (every BASELINE config) and planes with sides 2^a x (odd <= 63) run on the hand-written LDS
+    plane kernels; any other shape takes the same pipeline axis by axis on the library's own any-length transforms
+    (csrc/skr_fft_own.hip: Bluestein on the same LDS tile transform; axes up to 2048 long, powers of two up to 4096)."""
 
     @classmethod
     def from_inputs(cls, shape, seed, props=ColoredProps(), dtype=torch.float32):
@@ -437,7 +438,8 @@ class Colored(TensorNoiseCommon):
     def colorize_noise(white: torch.Tensor, exponent: float = 0.0, energy: float | None = None) -> torch.Tensor:
         """Colour an existing white-noise tensor with the power-law spectrum f^(-exponent), normalised back to the
         input's std (or to `energy`).  Size-1 dimensions are excluded from the transform; no batching -- the whole
-        tensor is one sample (reference noise.py:337-403).  Any shape with 1-6 transform axes (hipFFT + direct outer-axis DFTs)."""
+        tensor is one sample (reference noise.py:337-403).  Any shape with 1-6 transform axes (the library's own
+        any-length transforms on the inner three + direct outer-axis DFTs)."""
         import ctypes
 
         _hip.require_device(white, "white noise")
