@@ -97,13 +97,21 @@ __device__ __forceinline__ void block_sums(double s1, double s2, double* slot) {
   if (threadIdx.x == 0) { slot[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]; slot[1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]; }
 }
 
-// white noise (one lane per Philox block of a sample) + per-block sums; grid = (SLOTS, batch)
+// The statistics kernels run with 1 ... SLOTS blocks per sample (stats_blocks: small samples do not pay for 256 nearly empty blocks and
+// their reductions -- 78 + 74 us of a 292 us draw at 256 x (4, 30, 90)); any_finish sums all SLOTS slots, so block x zeroes the slots
+// x + gridDim.x, x + 2 gridDim.x, ... nobody writes.
+__device__ __forceinline__ void clear_unused_slots(double* sample_slots) {
+  if (threadIdx.x == 0)
+    for (int s = blockIdx.x + gridDim.x; s < SLOTS; s += gridDim.x) { sample_slots[2 * s] = 0.0; sample_slots[2 * s + 1] = 0.0; }
+}
+
+// white noise (one lane per Philox block of a sample) + per-block sums; grid = (stats_blocks, batch)
 __global__ __launch_bounds__(256) void any_white(const AnyArgs a) {
   const int64_t smp = blockIdx.y;
   const uint64_t seed = a.seeds[smp];
   const int64_t blocks = (a.unit + 3) / 4;
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < blocks; b += (int64_t)SLOTS * 256) {
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < blocks; b += (int64_t)gridDim.x * 256) {
     float z[4];
     skr::normal4(seed, a.stream, (uint64_t)b, z);
 #pragma unroll
@@ -113,17 +121,19 @@ __global__ __launch_bounds__(256) void any_white(const AnyArgs a) {
     }
   }
   block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * SLOTS + blockIdx.x) * 2);
+  clear_unused_slots(a.partials + (0 * a.batch + smp) * SLOTS * 2);
 }
 
 // the white noise is already in a.real (colorize_noise on a caller's tensor): only its statistics are needed
 __global__ __launch_bounds__(256) void any_white_stats(const AnyArgs a) {
   const int64_t smp = blockIdx.y;
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)SLOTS * 256) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)gridDim.x * 256) {
     const float v = a.real[smp * a.unit + e];
     s1 += (double)v; s2 += (double)v * (double)v;
   }
   block_sums(s1, s2, a.partials + ((0 * a.batch + smp) * SLOTS + blockIdx.x) * 2);
+  clear_unused_slots(a.partials + (0 * a.batch + smp) * SLOTS * 2);
 }
 
 __device__ __forceinline__ float axis_freq(int k, int d) { const int m = k < d - k ? k : d - k; return (float)m / (float)d; }
@@ -329,11 +339,12 @@ __global__ __launch_bounds__(256) void any_stats(const AnyArgs a) {
   const int64_t smp = blockIdx.y;
   const float scale = 1.0f / (float)a.unit;
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)SLOTS * 256) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.unit; e += (int64_t)gridDim.x * 256) {
     const float v = a.real[smp * a.unit + e] * scale;
     s1 += (double)v; s2 += (double)v * (double)v;
   }
   block_sums(s1, s2, a.partials + ((1 * a.batch + smp) * SLOTS + blockIdx.x) * 2);
+  clear_unused_slots(a.partials + (1 * a.batch + smp) * SLOTS * 2);
 }
 
 template <typename T>
@@ -441,6 +452,12 @@ __global__ __launch_bounds__(SLOTS) void any_fold_plane_sums(const AnyArgs a, co
   for (int64_t p = threadIdx.x; p < planes; p += SLOTS) { s1 += plane_sums[(smp * planes + p) * 2]; s2 += plane_sums[(smp * planes + p) * 2 + 1]; }
   double* slot = a.partials + ((0 * a.batch + smp) * SLOTS + threadIdx.x) * 2;
   slot[0] = s1; slot[1] = s2;
+}
+
+// blocks per sample of the statistics kernels: at least four items per thread, at most one block per slot
+static unsigned stats_blocks(int64_t items) {
+  const int64_t b = (items + 1023) / 1024;
+  return (unsigned)(b < 1 ? 1 : (b > SLOTS ? SLOTS : b));
 }
 
 // one attempt with the last `fft_rank` axes given to hipFFT and every axis outside them to the direct-DFT kernels;
@@ -572,8 +589,8 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
     if (rc != SKR_OK) return rc;
     hipLaunchKernelGGL(any_fold_plane_sums, dim3((unsigned)batch), dim3(SLOTS), 0, s, a, plane_sums, d0);
   } else {
-    if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(any_white, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+    if (white_given) hipLaunchKernelGGL(any_white_stats, dim3(stats_blocks(a.unit), (unsigned)batch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(any_white, dim3(stats_blocks((a.unit + 3) / 4), (unsigned)batch), dim3(256), 0, s, a);
     if (own) {
       ++g_own_execs;
       const int rc = skr::own_rfftn(guard.dev, false, a.real, a.spec, batch * d0, n[0], n[1], n[2], s);
@@ -630,7 +647,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
     const int rc = skr::own_rfftn(guard.dev, true, a.real, a.spec, batch * d0, n[0], n[1], n[2], s);
     if (rc != SKR_OK) return rc;
   } else if (api().c2r(plans.inv, a.spec, a.real) != 0) return SKR_ERR_LAUNCH;
-  hipLaunchKernelGGL(any_stats, dim3(SLOTS, (unsigned)batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(any_stats, dim3(stats_blocks(a.unit), (unsigned)batch), dim3(256), 0, s, a);
   int64_t fb = (a.unit + 1023) / 1024;  // (64 blocks per sample starved the chip at small batches: 33 us for one 4.8 M-element sample)
   { const int64_t cap = batch >= 32 ? 64 : 2048 / batch; if (fb > cap) fb = cap; if (fb < 1) fb = 1; }
   dim3 grid((unsigned)fb, (unsigned)batch);

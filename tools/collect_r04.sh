@@ -3,7 +3,8 @@
 #          trace    (rocprofv3 --kernel-trace --stats of the same bench commands -> profiles/r04_kernel_stats_<config>.csv)
 #          pmc      (headline PMC / SQ passes -> r04_pmc_traffic.json, r04_sq_counters.json)
 #          plans    (cold-buffer plan launches: kernel trace + counters)
-#          micro    (bench_plan / bench_graph), noise, colored / pyramid (SQ counters of those generators' kernels), margins (measured parity maxima)
+#          micro    (bench_plan / bench_graph), noise, colored / pyramid (SQ counters of those generators' kernels), fftown (awkward Colored shapes: own transforms vs hipFFT),
+#          margins (measured parity maxima)
 # The raw rocprofv3 output stays in /tmp on the box (hundreds of MB); only the condensed files come back, under
 # gpurun_out/r4c/profiles/ -- copy what is to be judged from there into profiles/.
 set -e
@@ -85,6 +86,10 @@ if has pyramid; then
   python3 $R/tools/summarize_counters.py $O/profiles/r04_pyramid_sq_counters.json pyramid_pass1 $RAW/pyr_trace $RAW/pyr_sq $RAW/pyr_sq2 > $O/summarize_pyramid.log 2>&1 || echo "summarize pyramid failed"
   (cd $R && python3 tools/kernel_stats.py $RAW/pyr_trace $O/profiles/r04_pyramid_kernel_stats.csv > $O/kernel_stats_pyr.log 2>&1) || echo "kernel_stats pyramid failed"
   echo "pyramid part done"
+fi
+if has fftown; then
+  { echo "# python tools/bench_fft_own.py (one MI355X, round 4): whole Colored draws, fp32 results; rows with 0 transforms run on the LDS plane kernels whatever the setting"; $T 300 python3 $R/tools/bench_fft_own.py 2>&1 | grep -v amdgpu.ids; } > $O/profiles/r04_bench_fft_own.txt
+  echo "fftown part done"
 fi
 if has margins; then
   rm -f /tmp/r4_margins.jsonl
