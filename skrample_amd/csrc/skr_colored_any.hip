@@ -477,7 +477,8 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   bool own = !planes && !prefer_hipfft;
   for (int i = (rank > fft_rank ? rank - fft_rank : 0); own && i < rank; ++i) {
     const int d = dims[i];
-    own = (d & (d - 1)) == 0 ? d <= 4096 : d <= 2048;
+    auto pow2 = [](int v) { return v >= 1 && (v & (v - 1)) == 0; };
+    own = (pow2(d) || (d % 3 == 0 && pow2(d / 3)) || (d % 5 == 0 && pow2(d / 5))) ? d <= 4096 : d <= 2048;
   }
   if (!planes && !own && !api().ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
   const int full_rank = rank;

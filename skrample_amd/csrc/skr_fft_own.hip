@@ -3,7 +3,10 @@
 // Reference: skrample/pytorch/noise.py:395-425 calls torch.fft.rfftn / irfftn over the unit's axes, whatever their lengths (152 x 104
 // latents, odd heights, 13 frames ...).  The plane kernels of skr_colored.hip take powers of two and 2^a x (odd <= 63); everything else
 // went to a vendor library.  Here an axis of length n is transformed
-//   * directly by fft_tile when n is a power of two (<= 4096), and otherwise
+//   * directly by fft_tile when n is a power of two (<= 4096);
+//   * directly, as r = 3 or 5 interleaved sub-sequences of p = 2^a points (n = r p <= 4096: 6, 12, 24 ... 3072 and 10, 20 ... 2560),
+//     each through fft_tile, joined by one radix-r pass (own_radix);
+//   * otherwise
 //   * by Bluestein's chirp-z identity  n k = (n^2 + k^2 - (k - n)^2) / 2 :
 //       X[k] = w[k] * sum_j (x[j] w[j]) conj(w[k - j]),   w[k] = exp(-i pi k^2 / n),
 //     a cyclic convolution of any length m >= 2n - 1 done with two transforms of m points: a = x w zero-padded -> FFT_m, times
@@ -147,7 +150,9 @@ template <bool INV> __device__ __forceinline__ void dft5(float2 v[5]) {
   v[0] = cadd(v[0], cadd(t1, t2));
   v[1] = cadd(a1, b1); v[4] = csub(a1, b1); v[2] = cadd(a2, b2); v[3] = csub(a2, b2);
 }
-template <int R, bool JOIN>
+// FWD_JOIN: the joining pass with the forward sign -- the last step of a DIRECT transform of n = r p points whose r decimated
+// sub-sequences x[r i + s] were transformed in the segments:  X[t p + j] = sum_s W_r^(t s) W_n^(j s) Z_s[j].
+template <int R, bool JOIN, bool FWD_JOIN = false>
 __device__ __forceinline__ void own_radix(float2* tile, const float2* twm /* exp(-2 pi i j / m), j < p */, int p, int logp, int L, int logL) {
   const int pitch = p + 1;
   __syncthreads();
@@ -158,13 +163,13 @@ __device__ __forceinline__ void own_radix(float2* tile, const float2* twm /* exp
 #pragma unroll
     for (int i = 0; i < R; ++i) v[i] = q[i * pitch];
     float2 w = twm[j];
-    if (JOIN) w.y = -w.y;
+    if (JOIN && !FWD_JOIN) w.y = -w.y;
     if (JOIN) {
       float2 ws = w;
 #pragma unroll
       for (int i = 1; i < R; ++i) { v[i] = cmul(v[i], ws); ws = cmul(ws, w); }
     }
-    if constexpr (R == 3) dft3<JOIN>(v); else dft5<JOIN>(v);
+    if constexpr (R == 3) dft3<JOIN && !FWD_JOIN>(v); else dft5<JOIN && !FWD_JOIN>(v);
     if (!JOIN) {
       float2 ws = w;
 #pragma unroll
@@ -181,7 +186,13 @@ __device__ __forceinline__ void own_radix(float2* tile, const float2* twm /* exp
 __device__ __forceinline__ int own_at(const OwnAxis& ax, int k) { return (k >> ax.logp) * (ax.p + 1) + (k & (ax.p - 1)); }
 __device__ __forceinline__ float2* own_line(float2* tile, const OwnAxis& ax, int l) { return tile + l * ax.r * (ax.p + 1); }
 __device__ __forceinline__ void own_transform(float2* tile, const float2* tw, const float2* twm, const OwnAxis& ax, int L, int logL) {
-  if (!ax.chirp) { fft_tile<false>(tile, tw, ax.p, ax.logp, L, nullptr, 0, true); return; }
+  if (!ax.chirp) {
+    fft_tile<false>(tile, tw, ax.p, ax.logp, L * ax.r, nullptr, 0, true);
+    if (ax.r == 3) own_radix<3, true, true>(tile, twm, ax.p, ax.logp, L, logL);
+    else if (ax.r == 5) own_radix<5, true, true>(tile, twm, ax.p, ax.logp, L, logL);
+    if (ax.r != 1) __syncthreads();
+    return;
+  }
   if (ax.r == 3) own_radix<3, false>(tile, twm, ax.p, ax.logp, L, logL);
   else if (ax.r == 5) own_radix<5, false>(tile, twm, ax.p, ax.logp, L, logL);
   fft_tile_dif(tile, tw, ax.p, ax.logp, L * ax.r, ax.kernel, ax.r);
@@ -194,11 +205,15 @@ template <bool INVERSE>
 __device__ __forceinline__ void own_put(float2* line, const OwnAxis& ax, int k, float2 v) {
   if (INVERSE) v.y = -v.y;
   if (ax.chirp) line[own_at(ax, k)] = cmul(v, ax.chirp[k]);
-  else line[brev((unsigned)k, ax.logp)] = v;
+  else if (ax.r == 1) line[brev((unsigned)k, ax.logp)] = v;
+  else {  // direct, n = r p: x[r i + s] to segment s, bit-reversed position of i
+    const int i = ax.r == 3 ? (int)__umulhi((uint32_t)k, 0x55555556u) : (int)__umulhi((uint32_t)k, 0x33333334u), sgm = k - i * ax.r;
+    line[sgm * (ax.p + 1) + (int)brev((unsigned)i, ax.logp)] = v;
+  }
 }
 template <bool INVERSE>
 __device__ __forceinline__ float2 own_get(const float2* line, const OwnAxis& ax, int k, float inv_m) {
-  float2 y = line[ax.chirp ? own_at(ax, k) : k];
+  float2 y = line[(ax.chirp || ax.r != 1) ? own_at(ax, k) : k];
   if (ax.chirp) { y = cmul(y, ax.chirp[k]); y.x *= inv_m; y.y *= inv_m; }
   if (INVERSE) y.y = -y.y;
   return y;
@@ -343,6 +358,11 @@ int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
     ax = OwnAxis{n, n, n, ilog2(n), 1, nullptr, nullptr};
     return SKR_OK;
   }
+  for (int rr : {3, 5})  // r interleaved power-of-two sub-sequences: no chirp, no padding
+    if (n % rr == 0 && ((n / rr) & (n / rr - 1)) == 0 && n / rr >= 2 && n <= OWN_MAX_M) {
+      ax = OwnAxis{n, n, n / rr, ilog2(n / rr), rr, nullptr, nullptr};
+      return SKR_OK;
+    }
   if (2 * n - 1 > OWN_MAX_M) return SKR_ERR_UNSUPPORTED;
   int m = 0, p = 0, r = 0;
   own_size(n, m, p, r);
