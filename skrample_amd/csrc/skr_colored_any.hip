@@ -477,8 +477,13 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   bool own = !planes && !prefer_hipfft;
   for (int i = (rank > fft_rank ? rank - fft_rank : 0); own && i < rank; ++i) {
     const int d = dims[i];
-    auto pow2 = [](int v) { return v >= 1 && (v & (v - 1)) == 0; };
-    own = (pow2(d) || (d % 3 == 0 && pow2(d / 3)) || (d % 5 == 0 && pow2(d / 5))) ? d <= 4096 : d <= 2048;
+    own = d <= 2048;  // Bluestein's limit
+    if (!own && d <= 4096) {  // a direct length of skr_fft_own.hip: 2^a, or 2^a 3^b 5^c with a >= 1 and b + c <= 3
+      int rest = d, odd = 0;
+      while (rest % 5 == 0 && odd < 3) { rest /= 5; ++odd; }
+      while (rest % 3 == 0 && odd < 3) { rest /= 3; ++odd; }
+      own = (rest & (rest - 1)) == 0 && (odd == 0 || rest >= 2);
+    }
   }
   if (!planes && !own && !api().ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
   const int full_rank = rank;

@@ -4,8 +4,9 @@
 // latents, odd heights, 13 frames ...).  The plane kernels of skr_colored.hip take powers of two and 2^a x (odd <= 63); everything else
 // went to a vendor library.  Here an axis of length n is transformed
 //   * directly by fft_tile when n is a power of two (<= 4096);
-//   * directly, as r = 3 or 5 interleaved sub-sequences of p = 2^a points (n = r p <= 4096: 6, 12, 24 ... 3072 and 10, 20 ... 2560),
-//     each through fft_tile, joined by one radix-r pass (own_radix);
+//   * directly when n = 2^a 3^b 5^c (a >= 1, b + c <= 3, n <= 4096: 6, 10, 12, 20, 30, 60, 90, 120, 250, 720, 1280 ...): the
+//     r = 3^b 5^c interleaved sub-sequences of 2^a points each go through fft_tile and are joined by b + c radix-3 / radix-5 passes
+//     (own_radix), innermost decimation first;
 //   * otherwise
 //   * by Bluestein's chirp-z identity  n k = (n^2 + k^2 - (k - n)^2) / 2 :
 //       X[k] = w[k] * sum_j (x[j] w[j]) conj(w[k - j]),   w[k] = exp(-i pi k^2 / n),
@@ -37,7 +38,8 @@
 namespace skr {
 
 struct OwnAxis {
-  int32_t n, m, p, logp, r;  // m = r p: size of the convolution (n itself, r = 1, for a power of two); p a power of two, r in {1, 3, 5}
+  int32_t n, m, p, logp, r;  // m = r p: size of the tile's transform (n itself when no chirp is needed); p a power of two, r odd
+  int32_t nlev, rad[3];      // r = rad[0] * ... * rad[nlev - 1], each 3 or 5 (outermost decimation first); Bluestein: at most one level
   const float2* chirp;       // w[k], k < n (nullptr: power of two, no chirp)
   const float2* kernel;      // K = FFT_m(b), b[j] = conj(w[j]) for |j| < n (indices mod m), 0 elsewhere, in the order the forward
                              // transform leaves a line: position s p + q holds bin r bitrev_p(q) + s
@@ -150,19 +152,23 @@ template <bool INV> __device__ __forceinline__ void dft5(float2 v[5]) {
   v[0] = cadd(v[0], cadd(t1, t2));
   v[1] = cadd(a1, b1); v[4] = csub(a1, b1); v[2] = cadd(a2, b2); v[3] = csub(a2, b2);
 }
-// FWD_JOIN: the joining pass with the forward sign -- the last step of a DIRECT transform of n = r p points whose r decimated
-// sub-sequences x[r i + s] were transformed in the segments:  X[t p + j] = sum_s W_r^(t s) W_n^(j s) Z_s[j].
+// FWD_JOIN: the joining pass with the forward sign -- a step of a DIRECT transform whose R decimated sub-sequences x[R i + s] were
+// transformed in the segments:  X[t q + j] = sum_s W_R^(t s) W_(R q)^(j s) Z_s[j],  q = the segments' length.
+// Levels: a logical line is `lines` tile lines; at this level it splits into `groups` independent joins of R segments, each segment
+// `seg` tile lines (seg p points, natural order: point j at tile line j / p, offset j % p).  twl = exp(-2 pi i j / (R seg p)), j < seg p.
 template <int R, bool JOIN, bool FWD_JOIN = false>
-__device__ __forceinline__ void own_radix(float2* tile, const float2* twm /* exp(-2 pi i j / m), j < p */, int p, int logp, int L, int logL) {
-  const int pitch = p + 1;
+__device__ __forceinline__ void own_radix(float2* tile, const float2* twl, int p, int logp, int L, int logL, int lines, int seg, int groups) {
+  const int pitch = p + 1, q = seg << logp, per_line = groups * q;
   __syncthreads();
-  for (int t = threadIdx.x; t < (L << logp); t += blockDim.x) {
-    const int l = t & (L - 1), j = t >> logL;  // consecutive lanes: consecutive logical lines, R (p + 1) points apart -- an odd pitch
-    float2* q = tile + l * R * pitch + j;
+  for (int t = threadIdx.x; t < L * per_line; t += blockDim.x) {
+    const int l = t & (L - 1), rest = t >> logL;  // consecutive lanes: consecutive logical lines, lines (p + 1) points apart -- an odd pitch
+    const int g = groups == 1 ? 0 : rest / q, j = rest - g * q;
+    float2* at = tile + (l * lines + g * R * seg + (j >> logp)) * pitch + (j & (p - 1));
+    const int hop = seg * pitch;
     float2 v[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) v[i] = q[i * pitch];
-    float2 w = twm[j];
+    for (int i = 0; i < R; ++i) v[i] = at[i * hop];
+    float2 w = twl[j];
     if (JOIN && !FWD_JOIN) w.y = -w.y;
     if (JOIN) {
       float2 ws = w;
@@ -176,8 +182,13 @@ __device__ __forceinline__ void own_radix(float2* tile, const float2* twm /* exp
       for (int i = 1; i < R; ++i) { v[i] = cmul(v[i], ws); ws = cmul(ws, w); }
     }
 #pragma unroll
-    for (int i = 0; i < R; ++i) q[i * pitch] = v[i];
+    for (int i = 0; i < R; ++i) at[i * hop] = v[i];
   }
+}
+template <bool JOIN, bool FWD_JOIN>
+__device__ __forceinline__ void own_radix_any(int R, float2* tile, const float2* twl, int p, int logp, int L, int logL, int lines, int seg, int groups) {
+  if (R == 3) own_radix<3, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups);
+  else own_radix<5, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups);
 }
 
 // The tile: L logical lines, each r segments of p points, every segment p + 1 apart.  own_put fills it: x[k] at the bit-reversed
@@ -186,34 +197,41 @@ __device__ __forceinline__ void own_radix(float2* tile, const float2* twm /* exp
 __device__ __forceinline__ int own_at(const OwnAxis& ax, int k) { return (k >> ax.logp) * (ax.p + 1) + (k & (ax.p - 1)); }
 __device__ __forceinline__ float2* own_line(float2* tile, const OwnAxis& ax, int l) { return tile + l * ax.r * (ax.p + 1); }
 __device__ __forceinline__ void own_transform(float2* tile, const float2* tw, const float2* twm, const OwnAxis& ax, int L, int logL) {
-  if (!ax.chirp) {
+  if (!ax.chirp) {  // direct: the r decimated sub-sequences through fft_tile, then the joins from the innermost level outwards
     fft_tile<false>(tile, tw, ax.p, ax.logp, L * ax.r, nullptr, 0, true);
-    if (ax.r == 3) own_radix<3, true, true>(tile, twm, ax.p, ax.logp, L, logL);
-    else if (ax.r == 5) own_radix<5, true, true>(tile, twm, ax.p, ax.logp, L, logL);
-    if (ax.r != 1) __syncthreads();
+    int seg = 1, groups = ax.r;
+    const float2* twl = twm;
+    for (int lev = ax.nlev - 1; lev >= 0; --lev) {
+      groups /= ax.rad[lev];
+      own_radix_any<true, true>(ax.rad[lev], tile, twl, ax.p, ax.logp, L, logL, ax.r, seg, groups);
+      twl += seg << ax.logp;
+      seg *= ax.rad[lev];
+    }
+    if (ax.nlev) __syncthreads();
     return;
   }
-  if (ax.r == 3) own_radix<3, false>(tile, twm, ax.p, ax.logp, L, logL);
-  else if (ax.r == 5) own_radix<5, false>(tile, twm, ax.p, ax.logp, L, logL);
+  if (ax.nlev) own_radix_any<false, false>(ax.rad[0], tile, twm, ax.p, ax.logp, L, logL, ax.r, 1, 1);
   fft_tile_dif(tile, tw, ax.p, ax.logp, L * ax.r, ax.kernel, ax.r);
   fft_tile<true>(tile, tw, ax.p, ax.logp, L * ax.r, nullptr, 0, true);  // (every pass opens with a barrier, and the transform ends with one)
-  if (ax.r == 3) own_radix<3, true>(tile, twm, ax.p, ax.logp, L, logL);
-  else if (ax.r == 5) own_radix<5, true>(tile, twm, ax.p, ax.logp, L, logL);
-  if (ax.r != 1) __syncthreads();
+  if (ax.nlev) { own_radix_any<true, false>(ax.rad[0], tile, twm, ax.p, ax.logp, L, logL, ax.r, 1, 1); __syncthreads(); }
 }
 template <bool INVERSE>
 __device__ __forceinline__ void own_put(float2* line, const OwnAxis& ax, int k, float2 v) {
   if (INVERSE) v.y = -v.y;
   if (ax.chirp) line[own_at(ax, k)] = cmul(v, ax.chirp[k]);
-  else if (ax.r == 1) line[brev((unsigned)k, ax.logp)] = v;
-  else {  // direct, n = r p: x[r i + s] to segment s, bit-reversed position of i
-    const int i = ax.r == 3 ? (int)__umulhi((uint32_t)k, 0x55555556u) : (int)__umulhi((uint32_t)k, 0x33333334u), sgm = k - i * ax.r;
-    line[sgm * (ax.p + 1) + (int)brev((unsigned)i, ax.logp)] = v;
+  else {  // direct: x[k] to the tile line of its residues (outermost decimation first), bit-reversed position of what is left of k
+    int rest = k, tl = 0;
+    for (int lev = 0; lev < ax.nlev; ++lev) {
+      const int q = ax.rad[lev] == 3 ? (int)__umulhi((uint32_t)rest, 0x55555556u) : (int)__umulhi((uint32_t)rest, 0x33333334u);
+      tl = tl * ax.rad[lev] + (rest - q * ax.rad[lev]);
+      rest = q;
+    }
+    line[tl * (ax.p + 1) + (int)brev((unsigned)rest, ax.logp)] = v;
   }
 }
 template <bool INVERSE>
 __device__ __forceinline__ float2 own_get(const float2* line, const OwnAxis& ax, int k, float inv_m) {
-  float2 y = line[(ax.chirp || ax.r != 1) ? own_at(ax, k) : k];
+  float2 y = line[own_at(ax, k)];  // (r = 1: k itself)
   if (ax.chirp) { y = cmul(y, ax.chirp[k]); y.x *= inv_m; y.y *= inv_m; }
   if (INVERSE) y.y = -y.y;
   return y;
@@ -228,18 +246,31 @@ __device__ __forceinline__ void own_clear(float2* tile, const OwnAxis& ax, int L
     own_line(tile, ax, line)[own_at(ax, k)] = make_float2(0.f, 0.f);
   }
 }
-// LDS of a block: twiddles of the p-point transforms (p / 2), exp(-2 pi i j / m) for j < p (r > 1 only), the tile
+// LDS of a block: twiddles of the p-point transforms (p / 2), the joins' twiddles level by level from the innermost
+// (level with segments of q points joined R at a time: exp(-2 pi i j / (R q)), j < q), the tile
+__device__ __host__ __forceinline__ int own_join_entries(const OwnAxis& ax) {
+  int total = 0, seg = 1;
+  for (int lev = ax.nlev - 1; lev >= 0; --lev) { total += seg * ax.p; seg *= ax.rad[lev]; }
+  return total;
+}
 __device__ __forceinline__ void own_setup(float2* smem, const OwnAxis& ax, float2*& tw, float2*& twm, float2*& tile) {
   tw = smem;
   twm = smem + ax.p / 2;
-  tile = twm + (ax.r > 1 ? ax.p : 0);
+  tile = twm + own_join_entries(ax);
   make_twiddles(tw, ax.p);
-  if (ax.r > 1)
-    for (int j = threadIdx.x; j < ax.p; j += blockDim.x) {
+  float2* twl = twm;
+  int seg = 1;
+  for (int lev = ax.nlev - 1; lev >= 0; --lev) {
+    const int q = seg * ax.p;
+    const float scale = -2.0f / (float)(q * ax.rad[lev]);
+    for (int j = threadIdx.x; j < q; j += blockDim.x) {
       float sn, cs;
-      sincospif(-2.0f * (float)j / (float)ax.m, &sn, &cs);
-      twm[j] = make_float2(cs, sn);
+      sincospif(scale * (float)j, &sn, &cs);
+      twl[j] = make_float2(cs, sn);
     }
+    twl += q;
+    seg *= ax.rad[lev];
+  }
 }
 
 // ---- last axis: real lines <-> half spectra, two lines per transform --------------------------------------------------------------
@@ -355,14 +386,18 @@ int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
   if (n < 2) return SKR_ERR_SHAPE;
   if ((n & (n - 1)) == 0) {
     if (n > OWN_MAX_M) return SKR_ERR_UNSUPPORTED;
-    ax = OwnAxis{n, n, n, ilog2(n), 1, nullptr, nullptr};
+    ax = OwnAxis{n, n, n, ilog2(n), 1, 0, {1, 1, 1}, nullptr, nullptr};
     return SKR_OK;
   }
-  for (int rr : {3, 5})  // r interleaved power-of-two sub-sequences: no chirp, no padding
-    if (n % rr == 0 && ((n / rr) & (n / rr - 1)) == 0 && n / rr >= 2 && n <= OWN_MAX_M) {
-      ax = OwnAxis{n, n, n / rr, ilog2(n / rr), rr, nullptr, nullptr};
+  {  // n = 2^a 3^b 5^c with a >= 1 and b + c <= 3: interleaved power-of-two sub-sequences, no chirp, no padding
+    int rest = n, nlev = 0, rad[3] = {1, 1, 1}, r = 1;
+    while (rest % 5 == 0 && nlev < 3) { rad[nlev++] = 5; rest /= 5; r *= 5; }
+    while (rest % 3 == 0 && nlev < 3) { rad[nlev++] = 3; rest /= 3; r *= 3; }
+    if (nlev > 0 && rest >= 2 && (rest & (rest - 1)) == 0 && n <= OWN_MAX_M) {
+      ax = OwnAxis{n, n, rest, ilog2(rest), r, nlev, {rad[0], rad[1], rad[2]}, nullptr, nullptr};
       return SKR_OK;
     }
+  }
   if (2 * n - 1 > OWN_MAX_M) return SKR_ERR_UNSUPPORTED;
   int m = 0, p = 0, r = 0;
   own_size(n, m, p, r);
@@ -380,7 +415,7 @@ int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
     hipLaunchKernelGGL(own_tables, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, buf, buf + n, n, m, p, ilog2(p), r);
     // the tables are shared by every stream of the device from here on: finished before anybody can look them up (once per length)
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return SKR_ERR_LAUNCH; }
-    it = g_own_axes.emplace(key, OwnAxis{n, m, p, ilog2(p), r, buf, buf + n}).first;
+    it = g_own_axes.emplace(key, OwnAxis{n, m, p, ilog2(p), r, r > 1 ? 1 : 0, {r, 1, 1}, buf, buf + n}).first;
   }
   ax = it->second;
   return SKR_OK;
@@ -392,7 +427,7 @@ int tile_lines(const OwnAxis& ax) {
   while (2 * L * ax.m <= FFT_MAX_TILE && 2 * L <= FFT_THREADS) L *= 2;
   return L;
 }
-size_t tile_bytes(const OwnAxis& ax, int L) { return sizeof(float2) * ((size_t)ax.p / 2 + (ax.r > 1 ? (size_t)ax.p : 0) + (size_t)L * ax.r * (ax.p + 1)); }
+size_t tile_bytes(const OwnAxis& ax, int L) { return sizeof(float2) * ((size_t)ax.p / 2 + (size_t)own_join_entries(ax) + (size_t)L * ax.r * (ax.p + 1)); }
 
 template <typename K, typename... A>
 int own_launch(K kernel, int64_t blocks, const OwnAxis& ax, int L, hipStream_t s, A... args) {
