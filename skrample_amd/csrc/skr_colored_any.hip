@@ -22,7 +22,8 @@ namespace skr {
 int g_fft_rank = 0;
 int g_use_hipfft = -1;  // skr_set_tuning("hipfft"): 1 = the inner axes on hipFFT, 0 = on skr_fft_own.hip, -1 = by the environment (SKR_FFT_HIPFFT set: hipFFT)
 // (skr_fft_own.hip) rfftn / irfftn of any axis lengths on the LDS tile transform
-int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s);
+int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s, bool skip_outer);
+int own_outer_weighted(int dev, float2* spec, int64_t entries, int n0, int n1, int n2, float inv_rmax, float eps_clip, float exponent_half_neg, hipStream_t s);
 }
 
 namespace {
@@ -505,6 +506,9 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   }
   int n[3] = {1, 1, 1};
   for (int i = 0; i < rank; ++i) n[3 - rank + i] = dims[i];
+  // own transforms of a unit without outer axes and with at least two transformed axes: the outermost one runs forward, weights, inverse fused
+  static const bool no_fuse_outer = getenv("SKR_FFT_NO_FUSE_OUTER") != nullptr;
+  const bool own_fused = own && full_rank <= 3 && n[1] > 1 && !no_fuse_outer;
   a.real = scratch_f32; a.spec = reinterpret_cast<float2*>(spec_c64); a.partials = partials_f64; a.seeds = seeds_dev; a.stream = stream_id;
   a.batch = batch; a.d1 = n[0]; a.d2 = n[1]; a.d3 = n[2]; a.d3h = n[2] / 2 + 1; a.unit = d0 * n[0] * n[1] * n[2];
   a.exponent_half_neg = (float)(-exponent / 2.0);
@@ -599,7 +603,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
     else hipLaunchKernelGGL(any_white, dim3(stats_blocks((a.unit + 3) / 4), (unsigned)batch), dim3(256), 0, s, a);
     if (own) {
       ++g_own_execs;
-      const int rc = skr::own_rfftn(guard.dev, false, a.real, a.spec, batch * d0, n[0], n[1], n[2], s);
+      const int rc = skr::own_rfftn(guard.dev, false, a.real, a.spec, batch * d0, n[0], n[1], n[2], s, own_fused);
       if (rc != SKR_OK) return rc;
     } else {
       ++g_hipfft_execs;
@@ -642,6 +646,9 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
     if ((rc = pass(2, 0)) != SKR_OK) return rc;  // outermost: forward, weights, inverse
     for (int j = 1; j < a.n_outer; ++j) if ((rc = pass(1, j)) != SKR_OK) return rc;
     }
+  } else if (own_fused) {  // the outermost transformed axis forward, the weights, and the same axis back: one pass (skr_fft_own.hip)
+    const int rc = skr::own_outer_weighted(guard.dev, a.spec, batch, n[0], n[1], n[2], a.inv_rmax, a.eps_clip, a.exponent_half_neg, s);
+    if (rc != SKR_OK) return rc;
   } else {
     int64_t wb = ((int64_t)a.d1 * a.d2 * a.d3h * batch + 255) / 256; if (wb > 256 * 32) wb = 256 * 32;
     hipLaunchKernelGGL(any_weights, dim3((unsigned)wb), dim3(256), 0, s, a);
@@ -650,7 +657,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
     const int rc = skr::colored_planes(1, a.spec, nullptr, a.real, seeds_dev, stream_id, batch, d0, a.d2, a.d3, s);
     if (rc != SKR_OK) return rc;
   } else if (own) {
-    const int rc = skr::own_rfftn(guard.dev, true, a.real, a.spec, batch * d0, n[0], n[1], n[2], s);
+    const int rc = skr::own_rfftn(guard.dev, true, a.real, a.spec, batch * d0, n[0], n[1], n[2], s, own_fused);
     if (rc != SKR_OK) return rc;
   } else if (api().c2r(plans.inv, a.spec, a.real) != 0) return SKR_ERR_LAUNCH;
   hipLaunchKernelGGL(any_stats, dim3(stats_blocks(a.unit), (unsigned)batch), dim3(256), 0, s, a);

@@ -364,6 +364,68 @@ __global__ __launch_bounds__(FFT_THREADS) void own_strided(float2* spec, int64_t
     for (int k = k0; k < n; k += kstep) base[(int64_t)k * inner] = own_get<INVERSE>(own_line(tile, ax, pl), ax, k, inv_m);
 }
 
+// ---- the OUTERMOST of the transformed axes: forward, radial weights, inverse in one tile residency ------------------------------------
+// (what colored_outer_axis is to the plane kernels: the weights need the full transform, and the way back starts with this very axis, so
+// the spectrum makes one round trip through HBM instead of three -- strided forward, a weights kernel, strided inverse.)
+// A thread keeps its line's values (at most 16: L m <= 4096 points on 256 threads) in registers between the two transforms.
+struct OwnWeights {
+  int32_t n0, n1, n2;  // the unit's (up to) three transform axes; this pass runs along n0, or along n1 when n0 == 1
+  float inv_rmax, eps_clip, exponent_half_neg;
+};
+__device__ __forceinline__ float own_axis_freq(int k, int d) { const int m = k < d - k ? k : d - k; return (float)m / (float)d; }
+
+__global__ __launch_bounds__(FFT_THREADS) void own_strided_weighted(float2* spec, int64_t lines, int64_t inner, OwnAxis ax, int L, int logL, OwnWeights wp) {
+  extern __shared__ float2 smem[];
+  float2 *tw, *twm, *tile;
+  own_setup(smem, ax, tw, twm, tile);
+  const int n = ax.n;
+  const float inv_m = 1.0f / (float)ax.m;
+  const int64_t l0 = (int64_t)blockIdx.x * L;
+  const int here = (int)(lines - l0 < L ? lines - l0 : L);
+  const int pl = threadIdx.x & (L - 1), k0 = threadIdx.x >> logL, kstep = blockDim.x >> logL;
+  own_clear(tile, ax, L);
+  float2* base = nullptr;
+  float rest_sq = 0.f;  // the other axes' share of the squared radius: the same for the whole line
+  if (pl < here) {
+    const int64_t l = l0 + pl, o = l / inner, i = l - o * inner;
+    base = spec + o * n * inner + i;
+    const int n2h = wp.n2 / 2 + 1;
+    if (wp.n0 > 1) {
+      const int k2 = (int)(i / n2h), k3 = (int)(i - (int64_t)k2 * n2h);
+      const float f2 = own_axis_freq(k2, wp.n1), f3 = (float)k3 / (float)wp.n2;
+      rest_sq = f2 * f2 + f3 * f3;
+    } else {
+      const float f3 = (float)i / (float)wp.n2;
+      rest_sq = f3 * f3;
+    }
+    for (int k = k0; k < n; k += kstep) own_put<false>(own_line(tile, ax, pl), ax, k, base[(int64_t)k * inner]);
+  }
+  own_transform(tile, tw, twm, ax, L, logL);
+  float2 hold[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = k0 + j * kstep;
+    if (pl < here && k < n) {
+      const float f = own_axis_freq(k, n);
+      float radius = __builtin_amdgcn_sqrtf(f * f + rest_sq) * wp.inv_rmax;
+      radius = radius < wp.eps_clip ? wp.eps_clip : radius;
+      const float w = __builtin_amdgcn_exp2f(wp.exponent_half_neg * __builtin_amdgcn_logf(radius));  // (any_weights' arithmetic)
+      const float2 y = own_get<false>(own_line(tile, ax, pl), ax, k, inv_m);
+      hold[j] = make_float2(y.x * w, y.y * w);
+    }
+  }
+  __syncthreads();  // everybody has read the forward result: the tile is free for the way back
+  own_clear(tile, ax, L);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = k0 + j * kstep;
+    if (pl < here && k < n) own_put<true>(own_line(tile, ax, pl), ax, k, hold[j]);
+  }
+  own_transform(tile, tw, twm, ax, L, logL);
+  if (pl < here)
+    for (int k = k0; k < n; k += kstep) base[(int64_t)k * inner] = own_get<true>(own_line(tile, ax, pl), ax, k, inv_m);
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
 std::mutex g_own_mutex;
 std::map<std::tuple<int, int>, OwnAxis> g_own_axes;  // (device, n) -> tables; a few KB each, kept for the life of the process
@@ -444,7 +506,8 @@ int own_launch(K kernel, int64_t blocks, const OwnAxis& ax, int L, hipStream_t s
 // rfftn / irfftn over the last three axes n0 x n1 x n2 (leading ones may be 1) of `entries` independent units:
 // real [entries][n0][n1][n2] fp32  <->  spec [entries][n0][n1][n2/2 + 1] complex64.  SKR_ERR_UNSUPPORTED: an axis beyond the tile
 // (a power of two > 4096, any other length > 2048), or tables needed during stream capture.
-int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s) {
+// skip_outer: leave out the outermost transformed axis (n0, or n1 when n0 == 1) -- own_outer_weighted does it both ways in one pass.
+int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s, bool skip_outer) {
   OwnAxis a0{}, a1{}, a2{};
   int rc;
   if ((rc = own_axis(dev, n2, s, a2)) != SKR_OK) return rc;
@@ -452,16 +515,31 @@ int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries,
   if (n0 > 1 && (rc = own_axis(dev, n0, s, a0)) != SKR_OK) return rc;
   const int64_t n2h = n2 / 2 + 1, lines2 = entries * n0 * n1, lines1 = entries * n0 * n2h, lines0 = entries * n1 * n2h;
   const int L2 = tile_lines(a2), L1 = n1 > 1 ? tile_lines(a1) : 1, L0 = n0 > 1 ? tile_lines(a0) : 1;
+  const bool do0 = n0 > 1 && !skip_outer, do1 = n1 > 1 && !(skip_outer && n0 == 1);
   if (!inverse) {
     if ((rc = own_launch(own_last_forward, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float*)real, spec, lines2, a2, L2, ilog2(L2))) != SKR_OK) return rc;
-    if (n1 > 1 && (rc = own_launch(own_strided<false>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
-    if (n0 > 1 && (rc = own_launch(own_strided<false>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
+    if (do1 && (rc = own_launch(own_strided<false>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
+    if (do0 && (rc = own_launch(own_strided<false>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
   } else {
-    if (n0 > 1 && (rc = own_launch(own_strided<true>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
-    if (n1 > 1 && (rc = own_launch(own_strided<true>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
+    if (do0 && (rc = own_launch(own_strided<true>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
+    if (do1 && (rc = own_launch(own_strided<true>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
     if ((rc = own_launch(own_last_inverse, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float2*)spec, real, lines2, a2, L2, ilog2(L2))) != SKR_OK) return rc;
   }
   return SKR_OK;
+}
+
+// forward transform, radial weights (of the full frequency of the n0 x n1 x n2 unit) and inverse transform along the outermost axis, in place;
+// needs n1 > 1 (a unit with the last axis alone keeps the separate weights kernel)
+int own_outer_weighted(int dev, float2* spec, int64_t entries, int n0, int n1, int n2, float inv_rmax, float eps_clip, float exponent_half_neg, hipStream_t s) {
+  if (n1 <= 1) return SKR_ERR_UNSUPPORTED;
+  OwnAxis ax{};
+  const int n = n0 > 1 ? n0 : n1;
+  int rc;
+  if ((rc = own_axis(dev, n, s, ax)) != SKR_OK) return rc;
+  const int64_t n2h = n2 / 2 + 1, inner = n0 > 1 ? (int64_t)n1 * n2h : n2h, lines = n0 > 1 ? entries * n1 * n2h : entries * n0 * n2h;
+  const int L = tile_lines(ax);
+  const OwnWeights wp{n0, n1, n2, inv_rmax, eps_clip, exponent_half_neg};
+  return own_launch(own_strided_weighted, (lines + L - 1) / L, ax, L, s, spec, lines, inner, ax, L, ilog2(L), wp);
 }
 
 }  // namespace skr
