@@ -753,13 +753,17 @@ def main() -> None:
     marked[0] = 0
     run(args.steps, offset=args.warmup, mark=e_first)
     e1.record()
+    t_issued = time.perf_counter()
     while not e1.query():  # poll for completion (a blocking synchronize wakes up tens of us late), then synchronize
         pass
+    t_seen = time.perf_counter()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
+    if os.environ.get("SKR_BENCH_TIMELINE"):  # where the wall clock of a short window goes, host side (us from t0)
+        print(f"[timeline] launches issued {1e6 * (t_issued - t0):.1f} | completion seen {1e6 * (t_seen - t0):.1f} | synchronized {1e6 * wall:.1f} | event span {1e3 * e0.elapsed_time(e1):.1f}", file=sys.stderr)
     # HIP events on the launch stream.  PRIMARY clock of the roofline keys: the whole timed region, e0 -> e1 over all K steps
     # (the stream is empty when the region starts, so the first launch's cold-queue dispatch latency is inside it, as it is inside
     # `value` / ms_per_step).  Secondary (roofline.steady_state): steps 2..K, back to back behind the first one -- the number
