@@ -740,10 +740,18 @@ def main() -> None:
     precondition = args.precondition if args.precondition is not None else max(20, min(1000, int(21000.0 / ideal_us)))
     run(precondition)
     torch.cuda.synchronize(dev)
+    stream_query = None  # hipStreamQuery while polling: the runtime retires finished launches during the wait, not inside synchronize()
+    if not os.environ.get("SKR_BENCH_NO_STREAM_POLL"):
+        try:
+            stream_query = _HipEvent.runtime().hipStreamQuery
+            stream_query.argtypes = [ctypes.c_void_p]
+        except Exception:
+            stream_query = None
     run(args.warmup)
     e_warm.record()
     while not e_warm.query():  # poll, then synchronize: a blocking wait returns tens of us late, and the GPU would sit idle
-        pass                   # (and start the timed region from a colder state) for that long
+        if stream_query is not None:  # (and start the timed region from a colder state) for that long
+            stream_query(stream)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -757,13 +765,6 @@ def main() -> None:
     # Poll for completion (a blocking synchronize wakes up tens of us late), then synchronize.  The poll also asks the stream for its
     # status: the runtime then retires finished launches while the host has nothing else to do, instead of all K of them inside
     # torch.cuda.synchronize() (13-22 us after the work was known to be complete, 4-5 us this way: profiles/r04_k20_timeline.txt).
-    stream_query = None
-    if not os.environ.get("SKR_BENCH_NO_STREAM_POLL"):
-        try:
-            stream_query = _HipEvent.runtime().hipStreamQuery
-            stream_query.argtypes = [ctypes.c_void_p]
-        except Exception:
-            stream_query = None
     while not e1.query():
         if stream_query is not None:
             stream_query(stream)
