@@ -151,7 +151,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--config", default="headline", choices=["headline", "cfg2", "cfg3", "cfg3c", "cfg4", "cfg5"], help="BASELINE.json workload (default: the headline DPM-2 launch at B=256)")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the config's own)")
     ap.add_argument("--sets", type=int, default=6, help="rotating buffer sets (>= 4; raised until the footprint passes 1 GB)")
-    ap.add_argument("--precondition", type=int, default=None, help="untimed conditioning steps before the warm-up (default ~26 ms worth; see the comment at its use)")
+    ap.add_argument("--precondition", type=int, default=None, help="untimed conditioning steps before the warm-up (default ~80 ms worth; see the comment at its use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 FETCH_SIZE / WRITE_SIZE passes (roofline.traffic falls back to the committed summary)")
@@ -735,9 +735,11 @@ def main() -> None:
     # tables of all buffer sets are in their steady state however small W and K are.  `--drift 4000` shows why it has to be this
     # long: from a cold start the launch time rises to 26.3-26.4 us between launches ~100 and ~350 (power management settling),
     # comes back by launch ~600 and then stays at 25.7-25.85 us for as long as the run lasts; a K=20 window opened after 300
-    # launches sat in that transient.  The count is reported in the JSON line (config.precondition_steps).
+    # launches sat in that transient.  Round 4: on other boxes the settling takes ~1500 launches (26.8 us for the first 500, 26.2-26.3
+    # to ~1000, 26.0-26.1 from there on), so the conditioning is ~80 ms of launches now (3000 at the headline size).  The count is
+    # reported in the JSON line (config.precondition_steps).
     ideal_us = numel * wl.bytes_per_elem / (HBM_PEAK_GBS * 1e3)
-    precondition = args.precondition if args.precondition is not None else max(20, min(1000, int(21000.0 / ideal_us)))
+    precondition = args.precondition if args.precondition is not None else max(20, min(3000, int(63000.0 / ideal_us)))
     run(precondition)
     torch.cuda.synchronize(dev)
     stream_query = None  # hipStreamQuery while polling: the runtime retires finished launches during the wait, not inside synchronize()
