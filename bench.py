@@ -573,7 +573,7 @@ def measure_traffic(wl: Workload, batch: int, steps: int = 40) -> tuple[float | 
 # ---------------------------------------------------------------------------------------------------------------------------
 def main() -> None:
     args = parse()
-    from skrample_amd.sharding import BatchShard, aggregate_rate, max_over_ranks
+    from skrample_amd.sharding import BatchShard, TimedRegion, aggregate_rate, max_over_ranks, rank_spread
 
     wl = _wl()[args.config]
     heavy = wl.name in ("cfg3", "cfg3c", "cfg5")
@@ -755,10 +755,10 @@ def main() -> None:
         if stream_query is not None:  # (and start the timed region from a colder state) for that long
             stream_query(stream)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
+    # The contract's window: barrier + synchronise on both sides, but each rank reads its clock right after ITS OWN synchronise and
+    # only then joins the closing barrier (sharding.TimedRegion) -- the engine has no collective, so none is billed to the K steps.
+    region = TimedRegion(dist, sync=lambda: torch.cuda.synchronize(dev))
+    t0 = region.open()
     e0.record()
     marked[0] = 0
     run(args.steps, offset=args.warmup, mark=e_first)
@@ -771,11 +771,7 @@ def main() -> None:
         if stream_query is not None:
             stream_query(stream)
     t_seen = time.perf_counter()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
+    wall = region.close()
     if os.environ.get("SKR_BENCH_TIMELINE"):  # where the wall clock of a short window goes, host side (us from t0)
         print(f"[timeline] launches issued {1e6 * (t_issued - t0):.1f} | completion seen {1e6 * (t_seen - t0):.1f} | synchronized {1e6 * wall:.1f} | event span {1e3 * e0.elapsed_time(e1):.1f}", file=sys.stderr)
     # HIP events on the launch stream.  PRIMARY clock of the roofline keys: the whole timed region, e0 -> e1 over all K steps
@@ -795,7 +791,9 @@ def main() -> None:
         torch.cuda.synchronize(dev)
         kernels_ms = f0.elapsed_time(f1) / args.steps
 
-    vals = max_over_ranks([wall, span_ms, steady_ms, kernels_ms or 0.0], dist, dev if backend == "nccl" else None)  # the slowest rank defines the step time
+    coll_dev = dev if backend == "nccl" else None
+    ranks = rank_spread({"wall_us_per_step": wall * 1e6 / args.steps, "span_us_per_step": span_ms * 1e3, "steady_us_per_step": steady_ms * 1e3}, dist, coll_dev)
+    vals = max_over_ranks([wall, span_ms, steady_ms, kernels_ms or 0.0], dist, coll_dev)  # the slowest rank defines the step time
     wall, span_ms, steady_ms, kernels_ms = vals[0], vals[1], vals[2], (vals[3] if generator is not None else None)
 
     extras = rank == 0 and not args.no_extras
@@ -862,6 +860,8 @@ def main() -> None:
             "algorithmic_bytes_per_element": wl.bytes_per_elem,
             "kernel": wl.kernel,
             "measured_d2d_memcpy": copy_gbs,  # hipMemcpy D2D of 512 MiB on this box, read+write GB/s
+            # every rank's own clocks (min / max / per rank): each wall is read after that rank's own synchronise, before the closing barrier
+            "ranks": ranks,
         }
         if roofline["traffic"]:
             roofline["frac_on_measured_traffic"] = roofline["traffic"] / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -9,7 +9,8 @@ from __future__ import annotations
 
 import dataclasses
 import os
-from collections.abc import Mapping
+import time
+from collections.abc import Callable, Mapping
 
 
 @dataclasses.dataclass(frozen=True)
@@ -63,6 +64,64 @@ def max_over_ranks(values: list[float], dist=None, device=None) -> list[float]:
     t = torch.tensor(values, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.tolist()
+
+
+def _group_ready(dist) -> bool:
+    return dist is not None and dist.is_available() and dist.is_initialized()
+
+
+class TimedRegion:
+    """The benchmark's timed window on one rank.  `open()` aligns the ranks (barrier + device synchronise) and starts the
+    clock; `close()` synchronises THIS rank's device, reads the clock, and only then joins the closing barrier -- so the
+    wall time a rank reports holds its own work and nothing of the collective ("a single barrier ... for
+    timing alignment only"; the engine itself has no exchange step to bill).  The slowest rank still defines the job's
+    step time: that is `max_over_ranks` over the walls, taken after the region.
+
+    `sync` = the rank's device synchronise (torch.cuda.synchronize on a GPU rank, nothing on a CPU rehearsal),
+    `barrier` = the collective (default dist.barrier; tests pass one that dawdles)."""
+
+    def __init__(self, dist=None, sync: Callable[[], None] | None = None, barrier: Callable[[], None] | None = None, clock: Callable[[], float] = time.perf_counter):
+        self.sync = sync or (lambda: None)
+        self.barrier = barrier or (dist.barrier if _group_ready(dist) else (lambda: None))
+        self.clock = clock
+        self.t0: float | None = None
+        self.wall: float | None = None
+
+    def open(self) -> float:
+        self.barrier()
+        self.sync()
+        self.t0 = self.clock()
+        return self.t0
+
+    def close(self) -> float:
+        assert self.t0 is not None, "close() before open()"
+        self.sync()
+        self.wall = self.clock() - self.t0  # read BEFORE the closing collective
+        self.barrier()
+        self.sync()
+        return self.wall
+
+
+def rank_spread(values: Mapping[str, float], dist=None, device=None) -> dict:
+    """Per-rank view of a few timings for the bench line (`roofline.ranks`): for each key the min, the max and every rank's
+    own value in rank order, plus the number of ranks the process group actually holds -- skew between ranks is then visible
+    in the one JSON line instead of hidden inside a MAX."""
+    keys = list(values)
+    mine = [float(values[k]) for k in keys]
+    if not _group_ready(dist):
+        rows, seen = [mine], 1
+    else:
+        import torch
+
+        t = torch.tensor(mine, dtype=torch.float64, device=device)
+        got = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(got, t)
+        rows, seen = [g.tolist() for g in got], dist.get_world_size()
+    out: dict = {"n_ranks_seen": seen}
+    for j, k in enumerate(keys):
+        col = [r[j] for r in rows]
+        out[k] = {"min": min(col), "max": max(col), "per_rank": col}
+    return out
 
 
 def aggregate_rate(units_per_rank: int, world: int, seconds: float) -> float:
