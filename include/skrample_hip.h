@@ -39,6 +39,7 @@ enum skr_status {
   SKR_ERR_LAUNCH = 6,      /* hipLaunchKernel failed (see skr_last_hip_error) */
   SKR_ERR_UNSUPPORTED = 7, /* valid request outside what the kernels cover */
   SKR_ERR_LIBRARY = 8,     /* an external library failed its self-check: a new hipFFT plan transformed unit impulses wrongly (skr_noise_colored_any / skr_colorize) */
+  SKR_ERR_CAPTURE = 9,     /* the stream is capturing and this shape's first use must build per-length tables or plans: run it once eagerly first */
 };
 
 enum skr_dtype { SKR_BF16 = 0, SKR_F16 = 1, SKR_F32 = 2, SKR_F64 = 3, SKR_NONE = -1 };

@@ -22,6 +22,7 @@ extern "C" const char* skr_strerror(int status) {
     case SKR_ERR_SHAPE: return "inconsistent numel / sample_numel / shape";
     case SKR_ERR_LAUNCH: return "hip kernel launch failed";
     case SKR_ERR_UNSUPPORTED: return "request outside kernel coverage";
+    case SKR_ERR_CAPTURE: return "first use of this shape needs tables / plans that are built outside stream capture: run the shape once eagerly, then capture";
     case SKR_ERR_LIBRARY: return "hipFFT returned a wrong transform in its self-check (rocFFT plan defect): not used";
     default: return "unknown status";
   }

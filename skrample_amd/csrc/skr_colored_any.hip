@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <set>
 #include <mutex>
@@ -22,6 +23,7 @@ namespace skr {
 int g_fft_rank = 0;
 int g_use_hipfft = -1;  // skr_set_tuning("hipfft"): 1 = the inner axes on hipFFT, 0 = on skr_fft_own.hip, -1 = by the environment (SKR_FFT_HIPFFT set: hipFFT)
 // (skr_fft_own.hip) rfftn / irfftn of any axis lengths on the LDS tile transform
+int own_prepare(int dev, int n0, int n1, int n2, hipStream_t s);
 int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s, bool skip_outer);
 int own_outer_weighted(int dev, float2* spec, int64_t entries, int n0, int n1, int n2, float inv_rmax, float eps_clip, float exponent_half_neg, hipStream_t s);
 }
@@ -72,7 +74,7 @@ std::map<PlanKey, Plans> g_plans;
 std::set<PlanKey> g_bad_plans;  // plans whose self-check failed
 uint64_t g_plan_clock = 0;
 constexpr size_t MAX_PLANS = 32;
-int64_t g_hipfft_plans = 0, g_hipfft_execs = 0, g_own_execs = 0;  // skr_stat("hipfft_plans" / "hipfft_execs" / "own_fft_execs"): plan pairs created, forward transforms run by hipFFT / by skr_fft_own.hip
+std::atomic<int64_t> g_hipfft_plans{0}, g_hipfft_execs{0}, g_own_execs{0};  // skr_stat("hipfft_plans" / "hipfft_execs" / "own_fft_execs"): plan pairs created, forward transforms run by hipFFT / by skr_fft_own.hip
 
 constexpr int SLOTS = 256;  // partial-sum slots per sample (one per block of the stats kernels)
 
@@ -508,7 +510,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   for (int i = 0; i < rank; ++i) n[3 - rank + i] = dims[i];
   // own transforms of a unit without outer axes and with at least two transformed axes: the outermost one runs forward, weights, inverse fused
   static const bool no_fuse_outer = getenv("SKR_FFT_NO_FUSE_OUTER") != nullptr;
-  const bool own_fused = own && full_rank <= 3 && n[1] > 1 && !no_fuse_outer;
+  const bool own_fused = own && a.n_outer == 0 && n[1] > 1 && !no_fuse_outer;  // (with outer axes the any_outer_axis passes carry the weights: every own axis must then run)
   a.real = scratch_f32; a.spec = reinterpret_cast<float2*>(spec_c64); a.partials = partials_f64; a.seeds = seeds_dev; a.stream = stream_id;
   a.batch = batch; a.d1 = n[0]; a.d2 = n[1]; a.d3 = n[2]; a.d3h = n[2] / 2 + 1; a.unit = d0 * n[0] * n[1] * n[2];
   a.exponent_half_neg = (float)(-exponent / 2.0);
@@ -556,7 +558,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
         if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
           (void)hipGetLastError();
           f.destroy(p.fwd); f.destroy(p.inv);
-          return SKR_ERR_UNSUPPORTED;  // plans are created (and checked) outside stream capture: run the shape once eagerly first
+          return SKR_ERR_CAPTURE;  // plans are created (and checked) outside stream capture: run the shape once eagerly first
         }
         SelfTest t;
         float* test_real = a.real;
@@ -592,6 +594,11 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
     plans = it->second;
   }
 
+  if (own) {  // every table the transforms will need, BEFORE the first launch of this attempt (a first-use Bluestein length under stream
+    // capture must not leave half a draw recorded in the caller's graph)
+    const int rc = skr::own_prepare(guard.dev, n[0], n[1], n[2], s);
+    if (rc != SKR_OK) return rc;
+  }
   if (planes) {
     if ((reinterpret_cast<uintptr_t>(a.real) & 7) != 0) return SKR_ERR_UNSUPPORTED;
     double* plane_sums = reinterpret_cast<double*>(a.real);  // batch * d0 * 2 doubles <= batch * unit floats (a plane has >= 8 elements)

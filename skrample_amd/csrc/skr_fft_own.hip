@@ -470,7 +470,7 @@ int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
       (void)hipGetLastError();
-      return SKR_ERR_UNSUPPORTED;  // tables are allocated outside stream capture: run the shape once eagerly first
+      return SKR_ERR_CAPTURE;  // tables are allocated outside stream capture: run the shape once eagerly first
     }
     float2* buf = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&buf), sizeof(float2) * (size_t)(n + m)) != hipSuccess) { (void)hipGetLastError(); return SKR_ERR_LAUNCH; }
@@ -502,6 +502,18 @@ int own_launch(K kernel, int64_t blocks, const OwnAxis& ax, int L, hipStream_t s
 }
 
 }  // namespace
+
+// the per-length tables of every axis, built now (own_rfftn / own_outer_weighted then only look them up); SKR_ERR_CAPTURE when a
+// table is missing and `s` is capturing
+int own_prepare(int dev, int n0, int n1, int n2, hipStream_t s) {
+  OwnAxis ax{};
+  for (int n : {n2, n1, n0}) {
+    if (n <= 1) continue;
+    const int rc = own_axis(dev, n, s, ax);
+    if (rc != SKR_OK) return rc;
+  }
+  return SKR_OK;
+}
 
 // rfftn / irfftn over the last three axes n0 x n1 x n2 (leading ones may be 1) of `entries` independent units:
 // real [entries][n0][n1][n2] fp32  <->  spec [entries][n0][n1][n2/2 + 1] complex64.  SKR_ERR_UNSUPPORTED: an axis beyond the tile

@@ -497,6 +497,10 @@ static int pick_in(StepArgs<Acc>& a, const skr_step_plan& p, hipStream_t s) {
   if constexpr (std::is_same<Acc, double>::value) {
     if (da == SKR_F64 && db == SKR_F64) return pick_out<double, double, double>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
     if (da == SKR_F32 && (db == SKR_F32 || db == SKR_F64)) return pick_out<float, double, double>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    // 16-bit latents under compute_scale=float64 (skrample/diffusers.py:575-579 casts whatever it is handed): widened exactly, accumulated in
+    // double, rounded once to the 16-bit result (or kept as fp64 state)
+    if (da == SKR_BF16 && (db == SKR_BF16 || db == SKR_F64)) return pick_out<bf16_t, double, double>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
+    if (da == SKR_F16 && (db == SKR_F16 || db == SKR_F64)) return pick_out<f16_t, double, double>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);
     return SKR_ERR_DTYPE;
   } else {
     if (da == SKR_BF16 && db == SKR_BF16) return pick_out<bf16_t, bf16_t, float>(a, da, p.out0_dtype, p.out1_dtype, noise, conv, s);

@@ -640,6 +640,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._fast: dict = {}  # (first index of the run, index) -> _FastEntry
         self._fast_ids = None  # the configuration objects the entries were learned under
         self._hist_ptrs: list = []  # per history record: (sample ptr, model_output ptr, record.sample ptr)
+        self._hist_sigs: list = []  # per history record: (sample dtype, model_output dtype, record.sample dtype, shape, device) -- what a replayed step binds blind
         self._run_seq = False  # every call of this run so far took the next schedule index
         self._fast_hits = 0  # steps served by _fast_step (diagnostics / tests)
 
@@ -718,6 +719,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._raw_outputs = []
         self._raw_samples = []
         self._hist_ptrs = []
+        self._hist_sigs = []
         self._run_seq = False
         self._alias_stamps = []
         self._alias_auto = None
@@ -734,6 +736,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._calls = 0
         self._previous, self._raw_outputs, self._raw_samples = [], [], []
         self._hist_ptrs = []
+        self._hist_sigs = []
         self._run_seq = False
         self._alias_stamps = []
         self._alias_auto = None
@@ -825,10 +828,14 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         self._raw_samples.append(sample)
         on_device = isinstance(sample, Tensor) and sample.is_cuda and isinstance(model_output, Tensor)
         self._hist_ptrs.append((sample.data_ptr(), model_output.data_ptr(), record.sample.data_ptr() if isinstance(record.sample, Tensor) else 0) if on_device else None)
+        # what the pointers point at: a replayed step binds them without looking (its kernel was built for ONE dtype / size per operand), so
+        # the signature of every record is compared against the one the entry was learned under (_fast_step)
+        self._hist_sigs.append((sample.dtype, model_output.dtype, record.sample.dtype if isinstance(record.sample, Tensor) else None, tuple(sample.shape), sample.device) if on_device else None)
         self._previous = self._previous[max(len(self._previous) - keep, 0) :]
         self._raw_outputs = self._raw_outputs[max(len(self._raw_outputs) - keep, 0) :]
         self._raw_samples = self._raw_samples[max(len(self._raw_samples) - keep, 0) :]
         self._hist_ptrs = self._hist_ptrs[max(len(self._hist_ptrs) - keep, 0) :]
+        self._hist_sigs = self._hist_sigs[max(len(self._hist_sigs) - keep, 0) :]
         if aliasing:
             self._alias_hold((sample, model_output), 2 * keep)
         self._issue_noise_ahead()  # behind this step's launch in host order: the step kernel is never kept waiting for it
@@ -893,6 +900,8 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
         entry.arr = (ctypes.c_void_p * max(len(srcs), 1))()
         entry.sdt, entry.odt, entry.shape, entry.device, entry.dev_index = sample.dtype, model_output.dtype, sample.shape, sample.device, sample.device.index
         entry.step, entry.keep, entry.hist = step, keep, nprev
+        entry.hist_sigs = list(self._hist_sigs)  # the records this step's history operands were lowered against
+        entry.sig = (sample.dtype, model_output.dtype, prog.out_dtypes[0] if prog.state_out is not None else sample.dtype, tuple(sample.shape), sample.device)
         entry.o0dt, entry.o1dt = prog.out_dtypes
         small = sample.numel() * sample.element_size() < (16 << 20)  # (larger results get lazy.empty_output's staggered placement)
         entry.like0, entry.like1 = small and entry.o0dt == sample.dtype, small and entry.o1dt == sample.dtype
@@ -935,7 +944,7 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
             return None
         keep = entry.keep
         hp = self._hist_ptrs
-        if len(hp) != entry.hist:
+        if len(hp) != entry.hist or self._hist_sigs != entry.hist_sigs:  # (a record left by a general-path call of another shape / dtype: not this entry's history)
             return None
         stamps = self._alias_stamps
         if keep:
@@ -1012,8 +1021,10 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
             raw_outputs.append(model_output)
             raw_samples.append(sample)
             hp.append((sp, op, rp))
+            sigs = self._hist_sigs
+            sigs.append(entry.sig)
             if len(previous) > keep:
-                del previous[0], raw_outputs[0], raw_samples[0], hp[0]
+                del previous[0], raw_outputs[0], raw_samples[0], hp[0], sigs[0]
             stamps.append((sample, sp, sample._version))
             stamps.append((model_output, op, model_output._version))
             extra = len(stamps) - 2 * keep
@@ -1032,7 +1043,7 @@ class _FastEntry:
     "what a replayed step of an in-order run needs besides today's tensors (SkrampleWrapperScheduler._fast_learn)"
 
     __slots__ = ("handle", "prog", "srcs", "draws", "noise", "arr", "sdt", "odt", "shape", "device", "dev_index", "step", "keep", "hist", "o0dt", "o1dt",
-                 "final_out", "state_out", "pred", "stream0", "stream1", "launch", "like0", "like1", "__weakref__")  # fmt: skip
+                 "final_out", "state_out", "pred", "stream0", "stream1", "launch", "like0", "like1", "hist_sigs", "sig", "__weakref__")  # fmt: skip
 
 
 @dataclasses.dataclass

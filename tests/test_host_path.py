@@ -10,7 +10,7 @@ import pytest
 import torch
 from cases import MODELS, NATIVE16_TAGS, SAMPLERS, SCHEDULES, oracle_schedule
 from conftest import load_npz
-from test_step_gpu import EXTRA2_WRAPPERS, EXTRA3_WRAPPERS, EXTRA_WRAPPERS, FIXTURE_WRAPPERS, Injected, assert_close, native16_engine_vs_reference, replay_fixture
+from test_step_gpu import EXTRA2_WRAPPERS, EXTRA3_WRAPPERS, EXTRA4_WRAPPERS, EXTRA_WRAPPERS, FIXTURE_WRAPPERS, Injected, assert_close, native16_engine_vs_reference, replay_fixture
 
 import skrample_amd.diffusers as PD
 import skrample_amd.scheduling as PS
@@ -53,6 +53,14 @@ def test_high_order_fixtures_on_cpu(name):
     blob = load_npz("steps_extra3.npz")
     fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
     mk, dt = EXTRA3_WRAPPERS[name]
+    replay_fixture(mk(), fx, dt, CPU, name)
+
+
+@pytest.mark.parametrize("name", EXTRA4_WRAPPERS)
+def test_float64_compute_scale_on_16_bit_latents_on_cpu(name):
+    blob = load_npz("steps_extra4.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
+    mk, dt = EXTRA4_WRAPPERS[name]
     replay_fixture(mk(), fx, dt, CPU, name)
 
 

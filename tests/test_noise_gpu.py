@@ -784,6 +784,31 @@ def test_colored_with_only_the_last_axis_on_hipfft(unit, hipfft, dev):
         assert lib.skr_set_tuning(b"fft_rank", 0) == 0 and lib.skr_set_tuning(b"hipfft", -1) == 0
 
 
+@pytest.mark.parametrize("hipfft", [0, 1])
+@pytest.mark.parametrize("unit", [(5, 19, 13), (3, 30, 90), (6, 97, 14), (3, 4, 6, 10), (2, 3, 5, 6, 9)])
+def test_colored_with_two_axes_on_the_transform_and_the_rest_direct(unit, hipfft, dev):
+    """skr_set_tuning("fft_rank", 2): the last two axes on the N-D transform, every axis in front of them on the direct-DFT kernels,
+    which then carry the radial weights -- so the own route must run BOTH of its axes (it skipped the outer one of the two
+    whenever the unit had at most three axes, leaving that axis untransformed under the weights).  Awkward lengths, own route and hipFFT,
+    same oracle bar as every other route."""
+    lib = _hip.load()
+    assert lib.skr_set_tuning(b"fft_rank", 2) == 0 and lib.skr_set_tuning(b"hipfft", hipfft) == 0
+    try:
+        seeds = [41, 42]
+        before = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_execs")
+        g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
+        for n, st in enumerate((None, Step(0.45, 0.5))):
+            got = g.generate(st).cpu()
+            ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
+            exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st) for s in seeds])
+            err = rel(got, ref, "colored (last two axes on %s, others direct DFT)" % ("hipFFT" if hipfft else "the own transforms"), COLORED_TOL, exact)
+            assert err < TOL and no_further_from_exact(got, ref, exact, slack=3.0), (unit, st, err)
+        after = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_execs")
+        assert (after[0] - before[0] > 0, after[1] - before[1] > 0) == ((False, True) if hipfft else (True, False)), (before, after)
+    finally:
+        assert lib.skr_set_tuning(b"fft_rank", 0) == 0 and lib.skr_set_tuning(b"hipfft", -1) == 0
+
+
 def _own_length(d: int) -> bool:
     "an axis length skr_fft_own.hip takes: anything up to 2048 (Bluestein), and up to 4096 the direct ones -- 2^a 3^b 5^c, a >= 1, b + c <= 3"
     if d <= 2048:

@@ -180,6 +180,53 @@ def test_high_order_step_fixtures(name):
         x = prev
 
 
+F64_CASES = {  # tests/golden/steps_extra4.npz (round 5): compute_scale=float64 over 16-bit latents
+    "dpm2_f64_bf16": (lambda n: OW.StepDriver(OA.make("dpm", 2, eta=1), OS.scaled(), "eps", compute=torch.float64), torch.bfloat16),
+    "unipc3_f64_f16": (lambda n: OW.StepDriver(OA.make("unipc", 3, eta=1), OS.linear(), "flow", compute=torch.float64), torch.float16),
+    "adams4_f64_bf16": (lambda n: OW.StepDriver(OA.make("adams", 4), OS.zsnr(), "v", compute=torch.float64), torch.bfloat16),
+}
+
+
+@pytest.mark.parametrize("name", F64_CASES)
+def test_float64_compute_scale_step_fixtures(name):
+    "oracle == reference SkrampleWrapperScheduler.step with compute_scale=float64 on bf16 / fp16 tensors, bit for bit"
+    blob = load_npz("steps_extra4.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
+    mk, dt = F64_CASES[name]
+    n = len(fx["timesteps"])
+    drv = mk(n)
+    drv.set_timesteps(n)
+    assert np.array_equal(drv.timesteps.numpy(), fx["timesteps"])
+    x = from_bits(fx["x0"], dt)
+    for i in range(n):
+        noise = torch.from_numpy(fx["noises"][i]) if fx["noises"].size else None
+        prev, pred = drv.step(from_bits(fx["outs"][i], dt), drv.timesteps[i], x, noise=noise)
+        assert torch.equal(prev, from_bits(fx["prev"][i], dt)), (name, i)
+        assert torch.equal(pred, from_bits(fx["pred"][i], dt)), (name, i)
+        x = prev
+
+
+def test_float64_compute_scale_runge_kutta_fixture():
+    "oracle RKDriver == reference RKUltraWrapperScheduler.step with compute_scale=float64 on bf16 tensors"
+    blob = load_npz("steps_extra4.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith("rku4_f64_bf16/")}
+    dt = torch.bfloat16
+    drv = OW.RKDriver(OK.pick_tableau(4), OS.scaled(), "eps", "data", 0.5, compute=torch.float64)
+    drv.set_timesteps(3)
+    assert np.array_equal(drv.timesteps.numpy(), fx["timesteps"])
+    x = from_bits(fx["x0"], dt)
+    used = 0
+    for i in range(len(fx["timesteps"])):
+        def noise_fn(step=None):
+            nonlocal used
+            used += 1
+            return torch.from_numpy(fx["noises"][used - 1])
+        prev = drv.step(from_bits(fx["outs"][i], dt), drv.timesteps[i], x, noise_fn=noise_fn)
+        assert torch.equal(prev, from_bits(fx["prev"][i], dt)), i
+        x = prev
+    assert used == int(fx["noise_used"])
+
+
 def test_pyramid_dims_fixtures():
     """Pyramid over other `dims` subsets (reference noise.py:146-193): the oracle reproduces what the reference returned for the
     axis pairs it accepts; the single non-trailing axes it rejects (RuntimeError inside its own permute) are recorded as such"""

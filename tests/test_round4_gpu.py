@@ -54,8 +54,6 @@ def trajectory(w, x0, outs, seeds, as_float=True):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_fast_steps_equal_the_general_path(name, dtype, dev):
     mk, expect_fast = MAKERS[name]
-    if name == "dpm2_fp64_scale" and dtype != torch.float32:
-        pytest.skip("compute_scale=float64 takes fp32 / fp64 tensors (the library has no 16-bit-in, fp64-accumulate kernel)")
     shape, steps = (3, 4, 32, 32), 9
     g = torch.Generator().manual_seed(41)
     x0 = torch.randn(shape, generator=g).to(dtype).to(dev)
@@ -132,6 +130,48 @@ def test_fast_path_refusals_fall_back_to_the_general_path(dev):
     for rep in range(3):
         for a, b in zip(trajectory(fast, big, bouts, [1, 2, 3, 4]), want):
             assert torch.equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("maker", ["dpm2_alias_true", "adams4_v_zsnr"])
+def test_fast_path_checks_what_its_history_pointers_point_at(maker, dev):
+    """a replayed step binds its history operands by remembered raw pointers.  A record appended by a general-path call of
+    ANOTHER dtype (same run, one step handed over as fp32) must not be bound by the next step's entry, which was learned over bf16
+    history: it is refused (general path, which re-lowers for the mixed history) and the bits are those of a wrapper without a fast path."""
+    mk = MAKERS[maker][0]
+    shape, steps = (2, 4, 32, 32), 8
+    g = torch.Generator().manual_seed(47)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps)]
+    fast, general = mk(), mk()
+    general.fast_steps = False
+    for _ in range(3):
+        trajectory(fast, x0, outs, [1, 2])
+    assert fast._fast_hits > 0
+
+    def run(w, odd_at, odd):
+        w.set_timesteps(steps)
+        ts = w.timesteps.tolist()
+        x, res = x0, []
+        for i in range(steps):
+            xi, oi = (odd(x), odd(outs[i])) if i == odd_at else (x, outs[i])
+            x = w.step(oi, ts[i], xi, generator=[1, 2], return_dict=False)[0]
+            x = x.to(torch.bfloat16) if x.dtype != torch.bfloat16 else x
+            res.append(x)
+        return res
+
+    for odd_at in (2, 4):
+        want = run(general, odd_at, lambda t: t.float())
+        hits = fast._fast_hits
+        got = run(fast, odd_at, lambda t: t.float())
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        assert 0 < fast._fast_hits - hits < steps - 1  # the odd step and the steps whose history holds its record went the general way
+    # and a plain run afterwards is served by the entries again
+    want = trajectory(general, x0, outs, [1, 2])
+    hits = fast._fast_hits
+    for a, b in zip(trajectory(fast, x0, outs, [1, 2]), want):
+        assert torch.equal(a[0], b[0])
+    assert fast._fast_hits - hits >= steps - 2
 
 
 def test_alias_guard_inside_the_fast_path(dev):

@@ -140,8 +140,17 @@ EXTRA3_WRAPPERS = {
 }
 
 
-def replay_fixture(w, fx, dtype, dev, name):
-    "teacher-forced replay: every step sees exactly the inputs the reference saw"
+# round 5 (tests/golden/steps_extra4.npz): compute_scale=float64 over 16-bit latents (fp64 accumulation, one rounding to the 16-bit result)
+EXTRA4_WRAPPERS = {
+    "dpm2_f64_bf16": (lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), compute_scale=torch.float64), torch.bfloat16),
+    "unipc3_f64_f16": (lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), compute_scale=torch.float64), torch.float16),
+    "adams4_f64_bf16": (lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=4), PS.ZSNR(), PM.VelocityModel(), compute_scale=torch.float64), torch.bfloat16),
+    "rku4_f64_bf16": (lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=4, stochasticity=0.5, compute_scale=torch.float64), torch.bfloat16),
+}
+
+
+def replay_fixture(w, fx, dtype, dev, name, exact=False):
+    "teacher-forced replay: every step sees exactly the inputs the reference saw (exact: results must equal the reference's bit for bit)"
     n_calls = len(fx["timesteps"])
     w.set_timesteps(n_calls if not isinstance(w, PD.RKWrapperCore) else 3)
     np.testing.assert_allclose(w.timesteps.numpy(), fx["timesteps"], rtol=0, atol=1e-9)
@@ -151,8 +160,11 @@ def replay_fixture(w, fx, dtype, dev, name):
     for i, t in enumerate(w.timesteps):
         out = from_bits(fx["outs"][i], dtype).to(dev)
         prev, pred = w.step(out, t, x, return_dict=False)
+        pred = torch.as_tensor(pred.materialize() if isinstance(pred, lazy.LazyTensor) else pred)
         assert_close(prev, from_bits(fx["prev"][i], dtype), dtype, f"{name} step {i} prev_sample")
-        assert_close(torch.as_tensor(pred.materialize() if isinstance(pred, lazy.LazyTensor) else pred), from_bits(fx["pred"][i], dtype), dtype, f"{name} step {i} pred_original_sample")
+        assert_close(pred, from_bits(fx["pred"][i], dtype), dtype, f"{name} step {i} pred_original_sample")
+        if exact:
+            assert torch.equal(prev.cpu(), from_bits(fx["prev"][i], dtype)) and torch.equal(pred.cpu(), from_bits(fx["pred"][i], dtype)), (name, i)
         x = from_bits(fx["prev"][i], dtype).to(dev)
     if torch.device(dev).type == "cuda":
         torch.cuda.synchronize()
@@ -179,6 +191,16 @@ def test_extra2_fixtures(name, dev):
     fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
     mk, dt = EXTRA2_WRAPPERS[name]
     replay_fixture(mk(), fx, dt, dev, name)
+
+
+@pytest.mark.parametrize("name", EXTRA4_WRAPPERS)
+def test_float64_compute_scale_on_16_bit_latents(name, dev):
+    """compute_scale=torch.float64 with bf16 / fp16 tensors (reference diffusers.py:575-599): 16-bit operands widened exactly, accumulated in
+    double, rounded once (through fp32, as torch's double -> bf16 / half conversion does) -- the reference's recorded results come back bit for bit."""
+    blob = load_npz("steps_extra4.npz")
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
+    mk, dt = EXTRA4_WRAPPERS[name]
+    replay_fixture(mk(), fx, dt, dev, name, exact=True)
 
 
 @pytest.mark.parametrize("name", EXTRA3_WRAPPERS)

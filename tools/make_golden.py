@@ -12,7 +12,7 @@ Outputs
                         RK all_points, every built-in tableau
   steps_cfg{1..5}.npz   per-step (x_t, model_out, noise) -> (prev_sample, pred_original_sample)
                         through SkrampleWrapperScheduler.step / RKUltraWrapperScheduler.step
-  steps_extra.npz       same for further sampler/model/eta combinations
+  steps_extra.npz       same for further sampler/model/eta combinations (steps_extra2..4: later rounds' additions)
   noise.npz             Offset / Pyramid / Colored outputs with the raw draws they consumed
 """
 
@@ -277,6 +277,24 @@ def steps() -> None:
         for k, v in rec.items():
             blob[f"{name}/{k}"] = v
     np.savez_compressed(os.path.join(OUT, "steps_extra3.npz"), **blob)
+
+    # round 5: compute_scale=float64 over 16-bit latents (diffusers.py:575-599 casts whatever it is handed to compute_scale and the
+    # results back to the model output's dtype)
+    f16, f64 = torch.float16, torch.float64
+    extra4 = {
+        "dpm2_f64_bf16": (lambda: RD.SkrampleWrapperScheduler(structured.DPM(order=2, stochasticity=1), RS.Scaled(), compute_scale=f64), bf16),
+        "unipc3_f64_f16": (lambda: RD.SkrampleWrapperScheduler(structured.UniPC(order=3, stochasticity=1), RS.Linear(), models.FlowModel(), compute_scale=f64), f16),
+        "adams4_f64_bf16": (lambda: RD.SkrampleWrapperScheduler(structured.Adams(order=4), RS.ZSNR(), models.VelocityModel(), compute_scale=f64), bf16),
+        "rku4_f64_bf16": (lambda: RD.RKUltraWrapperScheduler(RS.Scaled(), sampler_order=4, stochasticity=0.5, compute_scale=f64), bf16),
+    }
+    blob = {}
+    for i, (name, (mk, dt)) in enumerate(extra4.items()):
+        rec = run_wrapper(mk(), 2, (4, 8, 8), 7 if "rku" not in name else 3, dt, seed=6000 + i)
+        if dt == torch.float16:
+            rec = {k: (v.view(np.int16) if v.dtype == np.float16 else v) for k, v in rec.items()}
+        for k, v in rec.items():
+            blob[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "steps_extra4.npz"), **blob)
 
 
 # ---------------------------------------------------------------------------------------------------
