@@ -47,6 +47,8 @@ struct ColoredArgs {
   float eps_clip;
   float inv_rmax;
   int32_t raw;               // MODE 1 of the plane kernels: plain inverse transform (no 1/N, no rescale factor) -- colored_planes
+  const float* factors;      // colored_inverse128: [batch] per-sample rescale factors (colored_factors), or null
+  uint32_t* ticket;          // colored_inverse128: the next unclaimed plane (set to 2 x grid by colored_factors), or null = planes dealt out statically
 #ifdef SKR_COLORED_TRACE
   uint64_t* trace;           // tools/tune/tune_colored.hip only: [block][16] phase stamps of the plane kernels (s_memrealtime, 10 ns)
 #endif
@@ -713,6 +715,291 @@ __global__ __launch_bounds__(PLANE_THREADS) void colored_plane(const ColoredArgs
   plane_body<MODE, T, CH, CW>(a, logH_rt, logW_rt, (int64_t)blockIdx.y, (int)blockIdx.x, smem);
 }
 
+// ---- inverse planes of 128 x 128 (BASELINE config 3's unit): persistent blocks, the next plane's spectrum prefetched into registers ----
+// Round 5.  colored_plane<1, T, 7, 7> spent 4.7 of a block's 12.8 us waiting for its spectrum (two 67 KiB blocks per CU cannot cover it),
+// a third of its LDS cycles in bank conflicts, and ran the 65th frequency column as a second trip of the radix-16 pass for 8 lanes.
+// This kernel keeps the arithmetic (8-point pass in registers + one radix-16 pass per axis) and changes the structure around it:
+//   * a block loops over planes (grid = 2 blocks per CU) and issues the NEXT plane's 16 loads per thread right after the current
+//     plane's registers are free, so a plane's HBM latency lies under the previous plane's transforms.  The barriers are raw
+//     `s_waitcnt lgkmcnt(0); s_barrier` -- __syncthreads() would drain the loads in flight (its fence waits for vmcnt(0)) -- and the
+//     result stores are compiler-visible non-temporal stores, so that the wait for the prefetched registers is a counted vmcnt(N) that
+//     does not wait for the stores issued after them;
+//   * the DC and Nyquist frequency columns (both Hermitian along the rows, so both transform to REAL sequences) travel as ONE complex
+//     column, Z = X[:,0] + i X[:,64]: 64 columns, i.e. one radix-16 trip for every wave and no 65th line.  The imaginary parts the
+//     reference's irfftn drops there (rounding residue of the forward transform) land on the other column at that same size;
+//   * the sixteen twiddles of the radix-16 pass depend on k1 = the wave's index only: SGPRs, computed once per block, instead of
+//     fifteen LDS reads per thread and pass;
+//   * Hermitian packing: a thread takes the row pairs' frequencies k0 + 16 n AND 16 - k0 + 16 n, which mirror into each other, so
+//     every column-tile element is read once (was twice); lanes are laid out (8 pairs x 2 neighbouring frequencies per 16 lanes) so
+//     that those reads are conflict-free;
+//   * the row tile keeps element k1 + 8 k2 of a line at slot k2 + 16 (k1 >> 2) + 32 (k1 & 3): packing writes, the radix-16 pass and
+//     the final reads (4 consecutive elements per lane for 8-byte stores) are all conflict-free in that layout.
+// LDS: 64 x 129 complex + the Nyquist staging line = 67 KiB, two blocks per CU.  (Reference: skrample/pytorch/noise.py:380-403.)
+// per-sample rescale factors for colored_inverse128: factors[smp] from the white sums of the forward kernel (one slot per plane) and the
+// Parseval sums of the outer-axis kernel (one slot per block); one wave per sample, fixed summation order
+__global__ __launch_bounds__(64) void colored_factors(const ColoredArgs a, float* factors, uint32_t first_ticket) {
+  const int64_t smp = blockIdx.x;
+  if (smp == 0 && threadIdx.x == 0 && a.ticket) *a.ticket = first_ticket;
+  double fa[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* pw = a.partials + smp * a.n_slots * 2;
+  for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += pw[2 * sl]; fa[1] += pw[2 * sl + 1]; }
+  const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
+  for (int sl = threadIdx.x; sl < a.n_slots_c; sl += 64) { fa[2] += pc[2 * sl]; fa[3] += pc[2 * sl + 1]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
+  if (threadIdx.x == 0) {
+    const double n = (double)a.d1 * (double)a.d2 * (double)a.d3;
+    factors[smp] = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
+  }
+}
+
+// phase stamps of the persistent kernel (tools/tune/tune_inverse128.hip; compiled out of the library): [block][plane trip < 16][16]: eight of s_memrealtime,
+// the shader clock (s_memtime) and the hardware ids (HW_ID, XCC_ID) at the trip's start
+#ifdef SKR_COLORED_TRACE
+#define SKR_STAMP_P(i) do { if (threadIdx.x == 0 && a.trace && trip < 16) { uint64_t* t_ = a.trace + ((int64_t)blockIdx.x * 16 + trip) * 16; t_[(i)] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 0) { t_[8] = __builtin_amdgcn_s_memtime(); t_[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } } while (0)
+#else
+#define SKR_STAMP_P(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void colored_inverse128(const ColoredArgs a, const int64_t n_planes) {
+  extern __shared__ float2 smem[];
+  constexpr int H = 128, W = 128, WH = 65, LD = 129;
+  float2* tile = smem;             // 64 lines x 129: frequency columns (natural order), then row pairs (slot layout above)
+  float2* stage = smem + 64 * LD;  // [128] Nyquist column of the plane whose registers are in flight
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = k1 of both radix-16 passes
+  float twc[16], tws[16];  // exp(+2 pi i n2 k1 / 128): wave-uniform
+  {
+    // the circle once per block (one sincospif per thread instead of fifteen), through the staging line, which is free until the first plane
+    if (tid < H) {
+      float sn, cs;
+      sincospif(2.0f * (float)tid / 128.0f, &sn, &cs);
+      stage[tid] = make_float2(cs, sn);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int n2 = 1; n2 < 16; ++n2) {
+      const float2 w = stage[n2 * wave];  // n2 k1 <= 105
+      twc[n2] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.x)));
+      tws[n2] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.y)));
+    }
+    lds_barrier();
+  }
+  const int r0a = (int)brev((unsigned)wave, 4), r0b = (int)brev((unsigned)wave + 8u, 4);  // first row of this thread's two 8-row groups
+
+  float2 lv[2][8];
+  float2 nyq = make_float2(0.f, 0.f);
+  // Every address below is a wave-uniform base plus a 32-bit lane offset (the saddr form of the load), recomputed where it is used: a 64-bit
+  // pointer per load kept across the four phases under the prefetch would push the kernel past its 128 registers.
+  const uint32_t lane8 = (uint32_t)lane * 8u;
+  // Planes are taken from the LAST one down: the outer-axis kernel in front of this one wrote the spectrum first sample first, so the last
+  // planes are the ones still in the Infinity Cache (r05 timeline: 83.9 us against 92.5 first plane first, same static deal otherwise).
+#ifdef SKR_INV_FORWARD_ORDER  // experiment (tools/tune/tune_inverse128.hip)
+  auto pl = [&](int64_t x) { return x; };
+#else
+  auto pl = [&](int64_t x) { return n_planes - 1 - x; };
+#endif
+  auto prefetch = [&](int64_t q) {
+#ifdef SKR_INV_NOLOAD  // experiment: no spectrum traffic (results are garbage) -- what the transforms alone cost
+    if (a.n_slots >= 0) return;
+#endif
+    const char* plane = reinterpret_cast<const char*>(a.spec) + pl(q) * (int64_t)(H * WH * 8);
+    // (first, so that its use waits for nothing younger; every thread loads -- row tid & 127 -- to keep the loop free of divergent branches,
+    //  behind which the compiler's vmcnt bookkeeping falls back to "wait for everything")
+    nyq = *reinterpret_cast<const float2*>(plane + ((uint32_t)(tid & (H - 1)) * (uint32_t)(WH * 8) + (uint32_t)(W / 2 * 8)));
+    const char* pa = plane + r0a * (WH * 8);
+    const char* pb = plane + r0b * (WH * 8);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) lv[0][n] = *reinterpret_cast<const float2*>(pa + (lane8 + (uint32_t)(n * 16 * WH * 8)));
+#pragma unroll
+    for (int n = 0; n < 8; ++n) lv[1][n] = *reinterpret_cast<const float2*>(pb + (lane8 + (uint32_t)(n * 16 * WH * 8)));
+  };
+
+  // Planes are claimed two trips ahead from a device counter (a.ticket; the first two trips of every block are fixed, the counter starts behind
+  // them): of the two blocks a CU holds, the older one wins the issue arbitration and runs ~2x as fast as the younger while both are there --
+  // dealt out statically, the older block ran out of planes after 60 % of the kernel and left its half of the CU idle (r05 timeline).
+  __shared__ int32_t next_sh;
+  const int64_t stride = gridDim.x;
+  int64_t p = blockIdx.x, pn = p + stride;
+  if (p >= n_planes) return;
+  prefetch(p);
+  {
+    // Eight placeholder stores (zeros, to the very addresses this thread's first plane goes to: same thread, same address, program order -- the
+    // results overwrite them).  Why: inside the loop the prefetched registers are consumed with the eight result stores of the previous plane
+    // behind them in the queue, and the wait should be vmcnt(8), not vmcnt(0) -- which would hold every plane until the previous plane's
+    // stores have completed.  The compiler emits ONE wait for both ways into the loop, so the way in from here must look like the back edge.
+    char* dst = reinterpret_cast<char*>(a.out) + pl(p) * (int64_t)(H * W * sizeof(T));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      T* da = reinterpret_cast<T*>(dst + (uint32_t)((2 * ((tid >> 5) + 16 * it) * W + 4 * (tid & 31)) * (int)sizeof(T)));
+      if constexpr (sizeof(T) == 2) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(u32x2{0u, 0u}, reinterpret_cast<u32x2*>(da));
+        __builtin_nontemporal_store(u32x2{0u, 0u}, reinterpret_cast<u32x2*>(da + W));
+      } else {
+        __builtin_nontemporal_store(pk_f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<pk_f32x4*>(da));
+        __builtin_nontemporal_store(pk_f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<pk_f32x4*>(da + W));
+      }
+    }
+  }
+  stage[tid & (H - 1)] = nyq;
+  lds_barrier();
+  const float scale = a.raw ? 1.0f : 1.0f / ((float)a.d1 * (float)H * (float)W);
+  // packing items: k0 = the frequency residue mod 16 (0..7; its partner is 16 - k0, or 8 for k0 = 0), pr = the row pair
+  const int k0 = ((tid >> 3) & 1) | (((tid >> 7) & 3) << 1);
+  const int pr = (tid & 7) | (((tid >> 4) & 7) << 3);
+  const int gA = (int)brev((unsigned)k0, 4), gB = (int)brev(k0 ? 16u - (unsigned)k0 : 8u, 4);
+
+  [[maybe_unused]] int trip = 0;
+  for (;;) {
+    const int64_t smp = pl(p) / a.d1;
+    SKR_STAMP_P(0);
+
+    // ---- A: stages 0-2 of the column transform on the prefetched registers; column 0 becomes X[:,0] + i X[:,64]
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const float2 ba = stage[r0a + 16 * n], bb = stage[r0b + 16 * n];
+        lv[0][n] = make_float2(lv[0][n].x - ba.y, lv[0][n].y + ba.x);
+        lv[1][n] = make_float2(lv[1][n].x - bb.y, lv[1][n].y + bb.x);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      dft8<true>(lv[r]);
+      float2* col = tile + lane * LD + 8 * (wave + 8 * r);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) col[m] = lv[r][m];
+    }
+    // the sample's rescale factor (colored_factors), loaded BEFORE the prefetch goes out: loads return in order, so anything issued behind
+    // the prefetch and needed before the next plane would wait for all of it
+    // the plane of the trip after next: one returning atomic by one lane, as inline assembly -- the compiler does not know it is in flight, so
+    // it adds no wait of its own; ours, below, counts the (at most) 18 loads issued behind it
+    uint32_t claimed = 0;
+    if (a.ticket != nullptr && tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(claimed) : "v"(0u), "v"(1u), "s"(a.ticket) : "memory");
+    const float factor = a.raw ? 1.0f : a.factors[smp];
+    const bool more = pn < n_planes;
+    prefetch(more ? pn : p);  // lands under the four phases below (last plane of the block: itself again, unused)
+    SKR_STAMP_P(1);
+    lds_barrier();
+    SKR_STAMP_P(2);
+    if (tid == 0) {
+      if (a.ticket != nullptr) {
+        asm volatile("s_waitcnt vmcnt(17)" : "+v"(claimed) : : "memory");
+        next_sh = (int32_t)claimed;
+      } else {
+        next_sh = (int32_t)(pn + stride < n_planes ? pn + stride : n_planes);
+      }
+    }
+    // ---- B: radix-16 pass of the columns (item = (line = lane, k1 = wave)): X[k1 + 8 k2] -> position k1 + 8 k2
+    {
+      float2* q = tile + lane * LD + wave;
+      float2 v[16];
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) v[n2] = q[8 * (int)(__builtin_bitreverse32((unsigned)n2) >> 28)];
+#pragma unroll
+      for (int n2 = 1; n2 < 16; ++n2) v[n2] = make_float2(v[n2].x * twc[n2] - v[n2].y * tws[n2], v[n2].x * tws[n2] + v[n2].y * twc[n2]);
+      dft16<true>(v);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) q[8 * k2] = v[k2];
+    }
+    SKR_STAMP_P(3);
+    lds_barrier();
+    // ---- C: Hermitian packing of the row pairs + stages 0-2 of the row transform
+    float2 A[8], B[8];
+    {
+      float2 xa[8], xb[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float2* sa = tile + (k0 + 16 * j) * LD + 2 * pr;
+        xa[j] = sa[0]; xb[j] = sa[1];
+        const float2* sb = tile + (k0 ? 16 * (j + 1) - k0 : 8 + 16 * j) * LD + 2 * pr;
+        xa[4 + j] = sb[0]; xb[4 + j] = sb[1];
+      }
+      auto direct = [&](int i) { return make_float2(xa[i].x - xb[i].y, xa[i].y + xb[i].x); };  // X_a + i X_b
+      auto mirror = [&](int i) { return make_float2(xa[i].x + xb[i].y, xb[i].x - xa[i].y); };  // conj X_a + i conj X_b
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { A[j] = direct(j); B[j] = direct(4 + j); }
+      if (k0 != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { A[4 + i] = mirror(7 - i); B[4 + i] = mirror(3 - i); }
+      } else {  // residue 0: DC and Nyquist are the real and imaginary parts of the packed column; its partner residue 8 mirrors into itself
+        A[0] = make_float2(xa[0].x, xb[0].x);
+        A[4] = make_float2(xa[0].y, xb[0].y);
+#pragma unroll
+        for (int i = 1; i < 4; ++i) A[4 + i] = mirror(4 - i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) B[4 + i] = mirror(7 - i);
+      }
+    }
+    dft8<true>(A);
+    dft8<true>(B);
+    SKR_STAMP_P(4);
+    lds_barrier();  // every thread has read the column tile: the row tile may overwrite it
+    {
+      float2* la = tile + pr * LD + gA;
+      float2* lb = tile + pr * LD + gB;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int slot = 16 * (m >> 2) + 32 * (m & 3);
+        la[slot] = A[m];
+        lb[slot] = B[m];
+      }
+    }
+    lds_barrier();
+    SKR_STAMP_P(5);
+    // ---- D: radix-16 pass of the row pairs, in the slot layout
+    {
+      float2* q = tile + lane * LD + 16 * (wave >> 2) + 32 * (wave & 3);
+      float2 v[16];
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) v[n2] = q[(int)(__builtin_bitreverse32((unsigned)n2) >> 28)];
+#pragma unroll
+      for (int n2 = 1; n2 < 16; ++n2) v[n2] = make_float2(v[n2].x * twc[n2] - v[n2].y * tws[n2], v[n2].x * tws[n2] + v[n2].y * twc[n2]);
+      dft16<true>(v);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) q[k2] = v[k2];
+    }
+    lds_barrier();
+    SKR_STAMP_P(6);
+    // ---- E: the next plane's Nyquist column goes to its staging line; scale and store (row 2 pr from the real, 2 pr + 1 from the imaginary parts)
+    stage[tid & (H - 1)] = nyq;
+    const float f = scale * factor;
+    char* dst = reinterpret_cast<char*>(a.out) + pl(p) * (int64_t)(H * W * sizeof(T));
+    const int j = tid & 31;
+    const float2* src = tile + (j >> 1) + 16 * (j & 1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int line = (tid >> 5) + 16 * it;
+      const float2* z = src + line * LD;
+      const float2 z0 = z[0], z1 = z[32], z2 = z[64], z3 = z[96];
+      T* da = reinterpret_cast<T*>(dst + (uint32_t)((2 * line * W + 4 * j) * (int)sizeof(T)));
+#ifdef SKR_INV_NOSTORE  // experiment: results stay on the chip (one store per block keeps the arithmetic alive)
+      if (z0.x != 12345.678f) continue;
+#endif
+      if constexpr (sizeof(T) == 2) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(u32x2{pack_pair<T>(z0.x * f, z1.x * f), pack_pair<T>(z2.x * f, z3.x * f)}, reinterpret_cast<u32x2*>(da));
+        __builtin_nontemporal_store(u32x2{pack_pair<T>(z0.y * f, z1.y * f), pack_pair<T>(z2.y * f, z3.y * f)}, reinterpret_cast<u32x2*>(da + W));
+      } else {
+        __builtin_nontemporal_store(pk_f32x4{z0.x * f, z1.x * f, z2.x * f, z3.x * f}, reinterpret_cast<pk_f32x4*>(da));
+        __builtin_nontemporal_store(pk_f32x4{z0.y * f, z1.y * f, z2.y * f, z3.y * f}, reinterpret_cast<pk_f32x4*>(da + W));
+      }
+    }
+    SKR_STAMP_P(7);
+    ++trip;
+    lds_barrier();  // the tile and the staging line are free for the next plane
+    p = pn;
+    pn = __builtin_amdgcn_readfirstlane(next_sh);
+    if (p >= n_planes) break;  // (the prefetch of a block's last trip re-read its own plane)
+  }
+}
+
 // ---- planes whose sides are 2^a * r, r odd <= 63 (96, 112, 144, 152, 160, 168, 192 ... : latents of 768 / 896 / 1152 / 1216 / 1280 /
 // 1344 / 1536-pixel images) ----
 // Round 3.  Cooley-Tukey with ONE odd factor per axis: n = r * m (r odd, 1 ... 63, m = 2^a >= 2).  A line is kept as r sub-lines of m
@@ -1189,6 +1476,37 @@ static int ilog2_exact(int64_t v) {
 
 namespace skr {
 
+// persistent inverse kernel of 128 x 128 planes (colored_inverse128); -1: not taken (the caller launches colored_plane<1, ...>)
+static int launch_inverse128(ColoredArgs a, int32_t out_dtype, int64_t n_planes, float* factors /* [batch] workspace, unused when a.raw */, hipStream_t s) {
+  static const bool off = getenv("SKR_COLORED_OLD_INVERSE") != nullptr;
+  if (off || a.d2 != 128 || a.d3 != 128 || n_planes < 1 || (!a.raw && factors == nullptr) || (out_dtype != SKR_BF16 && out_dtype != SKR_F16 && out_dtype != SKR_F32)) return -1;
+  static int cus[64] = {};  // compute units per device (grid = two resident blocks per CU)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return -1; }
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 256; }
+    cus[dev] = n;
+  }
+  static const int per_cu = [] { const char* e = getenv("SKR_COLORED_INV_BLOCKS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }();
+  int64_t blocks = (int64_t)per_cu * cus[dev];
+  if (blocks > n_planes) blocks = n_planes;
+  const size_t lds = sizeof(float2) * (64 * 129 + 128);
+  a.factors = factors;
+  static const bool static_deal = getenv("SKR_COLORED_INV_STATIC") != nullptr;
+  a.ticket = (a.raw || static_deal) ? nullptr : reinterpret_cast<uint32_t*>(factors + a.batch);  // (the workspace tail holds 4 floats per sample)
+#ifdef SKR_COLORED_TRACE
+  if (a.trace) a.trace += 65536;  // behind the forward kernel's stamps (4096 blocks x 16 words)
+#endif
+  if (!a.raw) hipLaunchKernelGGL(colored_factors, dim3((unsigned)a.batch), dim3(64), 0, s, a, factors, (uint32_t)(2 * blocks));
+#define SKR_INV128(T) do { SKR_ALLOW_LDS((colored_inverse128<T>), lds); hipLaunchKernelGGL((colored_inverse128<T>), dim3((unsigned)blocks), dim3(512), lds, s, a, n_planes); } while (0)
+  if (out_dtype == SKR_BF16) SKR_INV128(__bf16);
+  else if (out_dtype == SKR_F16) SKR_INV128(_Float16);
+  else SKR_INV128(float);
+#undef SKR_INV128
+  return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}
+
 static bool mixed_factor_axis(int d, MixedAxis& x) {
   int v = d;
   while (v % 2 == 0) v /= 2;
@@ -1232,7 +1550,7 @@ int colored_planes(int mode, float2* spec, double* plane_partials, float* real_o
   a.spec = spec; a.real_out = nullptr; a.partials = plane_partials; a.seeds = seeds; a.stream = stream_id;
   a.batch = batch; a.d1 = (int32_t)planes; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
   a.n_slots = (int32_t)planes; a.n_slots_c = 0; a.has_energy = 0; a.energy = 0.0; a.out = real_out;
-  a.exponent_half_neg = 0.f; a.eps_clip = 1.f; a.inv_rmax = 1.f; a.raw = 1;
+  a.exponent_half_neg = 0.f; a.eps_clip = 1.f; a.inv_rmax = 1.f; a.raw = 1; a.factors = nullptr; a.ticket = nullptr;
 #ifdef SKR_COLORED_TRACE
   a.trace = nullptr;
 #endif
@@ -1249,7 +1567,12 @@ int colored_planes(int mode, float2* spec, double* plane_partials, float* real_o
     if (l2 == 7 && l3 == 7) SKR_PLANES_T(MODE, 7, 7);   \
     else if (l2 == 6 && l3 == 6) SKR_PLANES_T(MODE, 6, 6); \
     else SKR_PLANES_T(MODE, 0, 0)
-    if (mode == 0) { SKR_PLANES(0); } else { SKR_PLANES(1); }
+    if (mode == 0) { SKR_PLANES(0); }
+    else {
+      const int rc = launch_inverse128(a, SKR_F32, batch * planes, nullptr, s);
+      if (rc >= 0) return rc;
+      SKR_PLANES(1);
+    }
 #undef SKR_PLANES
 #undef SKR_PLANES_T
     SKR_CHECK_LAUNCH();
@@ -1328,7 +1651,7 @@ static int colored_batch(void* out, int32_t out_dtype, void* spec_c64, float* sc
   a.spec = reinterpret_cast<float2*>(spec_c64); a.real_out = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
   a.stream = stream_id; a.batch = batch; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
   a.exponent_half_neg = (float)(-exponent / 2.0);
-  a.out = out; a.has_energy = has_energy; a.energy = energy; a.n_slots_c = 0; a.raw = 0;
+  a.out = out; a.has_energy = has_energy; a.energy = energy; a.n_slots_c = 0; a.raw = 0; a.factors = nullptr; a.ticket = nullptr;
 #ifdef SKR_COLORED_TRACE
   a.trace = g_colored_trace;
 #endif
@@ -1425,9 +1748,13 @@ static int colored_batch(void* out, int32_t out_dtype, void* spec_c64, float* sc
     } else {
       SKR_PLANE_SZ(0, float);
       SKR_CHECK_LAUNCH();
-      a.n_slots_c = (int32_t)(2 * partial_slots - d1 < 4096 ? 2 * partial_slots - d1 : 4096);  // room left in the partials buffer
+      // room left in the partials buffer, less one slot per sample: the last 2 * batch doubles hold the per-sample factors of colored_inverse128
+      a.n_slots_c = (int32_t)(2 * partial_slots - d1 - 1 < 4096 ? 2 * partial_slots - d1 - 1 : 4096);
+      if (a.n_slots_c < 1) return SKR_ERR_SHAPE;
       const int rc = outer_axis();  // d1 <= 16: register kernel, with the Parseval partials of the weighted spectrum
       if (rc != SKR_OK) return rc;
+      const int inv = launch_inverse128(a, out_dtype, batch * (int64_t)d1, reinterpret_cast<float*>(partials_f64 + 4 * batch * partial_slots - 2 * batch), s);  // 128 x 128 planes: the persistent kernel
+      if (inv >= 0) return inv;
       SKR_PLANE(1);
     }
 #undef SKR_PLANE

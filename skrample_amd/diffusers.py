@@ -596,7 +596,7 @@ class SkrampleWrapperCore(abc.ABC):
     def _finish(prev, pred, like: Tensor, return_dict: bool):
         def conv(v):
             if isinstance(v, LazyTensor):
-                return v if v.dtype == like.dtype else LazyTensor(v.form, like.dtype)
+                return v if v.dtype == like.dtype else LazyTensor(v.form, like.dtype, acc_f64=v._acc_f64)
             return lazy.cast(v, like.dtype) if isinstance(v, Tensor) else v
 
         prev, pred = conv(prev), conv(pred)

@@ -590,8 +590,10 @@ class LazyTensor:
     then: every leaf is stamped (data_ptr, _version) at creation and `materialize()` refuses to run once one of them
     has been modified in place -- read the value before reusing the buffers, as with any view."""
 
-    def __init__(self, form: Lin | None, dtype: torch.dtype, form_fn=None, shape=None, device=None, leaves=None):
+    def __init__(self, form: Lin | None, dtype: torch.dtype, form_fn=None, shape=None, device=None, leaves=None, acc_f64: bool | None = None):
         self._form, self._form_fn, self.dtype, self._value = form, form_fn, dtype, None
+        # the accumulator of the step that made this tensor (compute_scale=float64): it is read later, outside that step's context
+        self._acc_f64 = (_compute_dtype.get() == torch.float64) if acc_f64 is None else bool(acc_f64)
         self._shape, self._device = shape, device
         if leaves is None and form is not None and isinstance(form, Lin):
             leaves = [leaf for leaf, _ in form.terms.values() if isinstance(leaf, torch.Tensor)]
@@ -616,7 +618,7 @@ class LazyTensor:
             for t, ptr, version in self._stamps:
                 if t._version != version or t.data_ptr() != ptr:
                     raise SkrampleHipError("an operand of this lazily evaluated tensor was modified in place before it was read; materialize() it (or use it) before reusing the buffers it was computed from")
-            self._value = evaluate([self.form], [self.dtype])[0]
+            self._value = evaluate([self.form], [self.dtype], acc_f64=True if self._acc_f64 else None)[0]
             self._stamps = []
         return self._value
 

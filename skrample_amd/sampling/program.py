@@ -181,4 +181,4 @@ class StepProgram:
                 form = piece if form is None else form + piece
             return form
 
-        return LazyTensor(None, dtype, form_fn=make_form, shape=tuple(shape), device=device, leaves=[leaf for leaf, _ in bound])
+        return LazyTensor(None, dtype, form_fn=make_form, shape=tuple(shape), device=device, leaves=[leaf for leaf, _ in bound], acc_f64=bool(self.plan.acc_f64))
