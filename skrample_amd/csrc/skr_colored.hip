@@ -48,7 +48,10 @@ struct ColoredArgs {
   float inv_rmax;
   int32_t raw;               // MODE 1 of the plane kernels: plain inverse transform (no 1/N, no rescale factor) -- colored_planes
   const float* factors;      // colored_inverse128: [batch] per-sample rescale factors (colored_factors), or null
-  uint32_t* ticket;          // colored_inverse128: the next unclaimed plane (set to 2 x grid by colored_factors), or null = planes dealt out statically
+  uint32_t* ticket;          // colored_inverse128: the next unclaimed plane, or null = planes dealt out statically
+  uint32_t first_ticket;     // its starting value (2 x the inverse kernel's grid: every block's first two planes are fixed)
+  uint32_t* done_count;      // [batch] blocks of the outer-axis kernel that have stored their Parseval slot; the last one of a sample computes factors[smp]
+  float* factors_out;        // where (null: the factors come from the colored_factors launch)
 #ifdef SKR_COLORED_TRACE
   uint64_t* trace;           // tools/tune/tune_colored.hip only: [block][16] phase stamps of the plane kernels (s_memrealtime, 10 ns)
 #endif
@@ -510,6 +513,10 @@ __device__ __forceinline__ void plane_body(const ColoredArgs& a, int logH_rt, in
     }
     SKR_STAMP(3);
     if (MODE == 0) block_sums<COH>(s1, s2, a.partials + ((0 * a.batch + smp) * a.n_slots + i1) * 2);
+    if (MODE == 0 && a.done_count != nullptr && i1 == 0 && threadIdx.x == 0) {  // bookkeeping of the two kernels behind this one (visible at the kernel boundary)
+      a.done_count[smp] = 0u;
+      if (smp == 0 && a.ticket != nullptr) *a.ticket = a.first_ticket;
+    }
     if (MODE == 0) {
       if constexpr (CH < 2) {  // (runtime-size instantiation: the transform's last pass may be the 2-point one, which writes the tile)
         for (int q = threadIdx.x; q < H * WH; q += PLANE_THREADS) {
@@ -836,7 +843,7 @@ __global__ __launch_bounds__(512, 4) void colored_inverse128(const ColoredArgs a
     char* dst = reinterpret_cast<char*>(a.out) + pl(p) * (int64_t)(H * W * sizeof(T));
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      T* da = reinterpret_cast<T*>(dst + (uint32_t)((2 * ((tid >> 5) + 16 * it) * W + 4 * (tid & 31)) * (int)sizeof(T)));
+      T* da = reinterpret_cast<T*>(dst + (uint32_t)((2 * ((tid >> 5) + 16 * it) * W + 4 * (2 * (tid & 15) + ((tid >> 4) & 1))) * (int)sizeof(T)));
       if constexpr (sizeof(T) == 2) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         __builtin_nontemporal_store(u32x2{0u, 0u}, reinterpret_cast<u32x2*>(da));
@@ -971,7 +978,9 @@ __global__ __launch_bounds__(512, 4) void colored_inverse128(const ColoredArgs a
     stage[tid & (H - 1)] = nyq;
     const float f = scale * factor;
     char* dst = reinterpret_cast<char*>(a.out) + pl(p) * (int64_t)(H * W * sizeof(T));
-    const int j = tid & 31;
+    // lane -> the four elements 4 j .. 4 j + 3 of a row, j = 2 (lane & 15) + ((lane >> 4) & 1): sixteen consecutive lanes then read sixteen
+    // consecutive slots (the compiler pairs the reads into ds_read2_b64, whose bank groups are 16 lanes wide), a half wave still covers its row
+    const int j = 2 * (tid & 15) + ((tid >> 4) & 1);
     const float2* src = tile + (j >> 1) + 16 * (j & 1);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -1423,7 +1432,34 @@ __global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs
 #pragma unroll
     for (int n = 0; n < N; ++n) base[q + (int64_t)n * cols] = v[n];
   }
-  if (a.n_slots_c > 0) block_sums(p1, p2, a.partials + (int64_t)a.batch * a.n_slots * 2 + (smp * a.n_slots_c + blockIdx.x) * 2);
+  if (a.n_slots_c <= 0) return;
+  double* slot = a.partials + (int64_t)a.batch * a.n_slots * 2 + (smp * a.n_slots_c + blockIdx.x) * 2;
+  if (a.done_count == nullptr) { block_sums(p1, p2, slot); return; }
+  // The sample's rescale factor, by whichever block of the sample stores its Parseval slot last (round 5: this was a launch of its own in
+  // front of the persistent inverse kernel, 5 us).  Hand-over as guides/MI355X_MICROARCH.md prescribes for small records: the slot goes out
+  // with agent-scope (sc1, write-through) stores by ONE lane, that lane drains them (vmcnt(0)) and then adds to the sample's counter; the block
+  // whose add returns gridDim.x - 1 reads every slot with agent-scope loads.  The summation order is fixed (lane l takes slots l, l + 64, ...;
+  // shuffle tree), so the factor does not depend on which block comes last.
+  block_sums<true>(p1, p2, slot);
+  __shared__ uint32_t last_sh;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last_sh = __hip_atomic_fetch_add(a.done_count + smp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last_sh == 0u || threadIdx.x >= 64) return;
+  double fa[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* pw = a.partials + smp * a.n_slots * 2;  // (the forward kernel's: a launch ago)
+  for (int sl = threadIdx.x; sl < a.n_slots; sl += 64) { fa[0] += pw[2 * sl]; fa[1] += pw[2 * sl + 1]; }
+  const double* pc = a.partials + (int64_t)a.batch * a.n_slots * 2 + smp * a.n_slots_c * 2;
+  for (int sl = threadIdx.x; sl < a.n_slots_c; sl += 64) { fa[2] += gload<true>(pc + 2 * sl); fa[3] += gload<true>(pc + 2 * sl + 1); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    for (int o = 32; o > 0; o >>= 1) fa[i] += __shfl_down(fa[i], o);
+  if (threadIdx.x == 0) {
+    const double n = (double)a.d1 * (double)a.d2 * (double)a.d3;
+    a.factors_out[smp] = rescale_factor(fa[0], fa[1], fa[2], fa[3] / n, n, a.has_energy, a.energy);
+  }
 }
 
 
@@ -1477,28 +1513,33 @@ static int ilog2_exact(int64_t v) {
 namespace skr {
 
 // persistent inverse kernel of 128 x 128 planes (colored_inverse128); -1: not taken (the caller launches colored_plane<1, ...>)
-static int launch_inverse128(ColoredArgs a, int32_t out_dtype, int64_t n_planes, float* factors /* [batch] workspace, unused when a.raw */, hipStream_t s) {
+// grid of the persistent inverse kernel (two resident blocks per CU), 0 when the kernel does not apply
+static int64_t inverse128_blocks(int32_t d2, int32_t d3, int32_t out_dtype, int64_t n_planes) {
   static const bool off = getenv("SKR_COLORED_OLD_INVERSE") != nullptr;
-  if (off || a.d2 != 128 || a.d3 != 128 || n_planes < 1 || (!a.raw && factors == nullptr) || (out_dtype != SKR_BF16 && out_dtype != SKR_F16 && out_dtype != SKR_F32)) return -1;
-  static int cus[64] = {};  // compute units per device (grid = two resident blocks per CU)
+  if (off || d2 != 128 || d3 != 128 || n_planes < 1 || (out_dtype != SKR_BF16 && out_dtype != SKR_F16 && out_dtype != SKR_F32)) return 0;
+  static int cus[64] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return -1; }
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
   if (cus[dev] == 0) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 256; }
     cus[dev] = n;
   }
   static const int per_cu = [] { const char* e = getenv("SKR_COLORED_INV_BLOCKS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }();
-  int64_t blocks = (int64_t)per_cu * cus[dev];
-  if (blocks > n_planes) blocks = n_planes;
+  const int64_t blocks = (int64_t)per_cu * cus[dev];
+  return blocks > n_planes ? n_planes : blocks;
+}
+
+static int launch_inverse128(ColoredArgs a, int32_t out_dtype, int64_t n_planes, float* factors /* [batch] workspace, unused when a.raw */, hipStream_t s) {
+  if (a.d2 != 128 || a.d3 != 128 || n_planes < 1 || (!a.raw && factors == nullptr) || (out_dtype != SKR_BF16 && out_dtype != SKR_F16 && out_dtype != SKR_F32)) return -1;
+  const int64_t blocks = inverse128_blocks(a.d2, a.d3, out_dtype, n_planes);
+  if (blocks < 1) return -1;
   const size_t lds = sizeof(float2) * (64 * 129 + 128);
   a.factors = factors;
-  static const bool static_deal = getenv("SKR_COLORED_INV_STATIC") != nullptr;
-  a.ticket = (a.raw || static_deal) ? nullptr : reinterpret_cast<uint32_t*>(factors + a.batch);  // (the workspace tail holds 4 floats per sample)
 #ifdef SKR_COLORED_TRACE
   if (a.trace) a.trace += 65536;  // behind the forward kernel's stamps (4096 blocks x 16 words)
 #endif
-  if (!a.raw) hipLaunchKernelGGL(colored_factors, dim3((unsigned)a.batch), dim3(64), 0, s, a, factors, (uint32_t)(2 * blocks));
+  if (!a.raw && a.factors_out == nullptr) hipLaunchKernelGGL(colored_factors, dim3((unsigned)a.batch), dim3(64), 0, s, a, factors, a.first_ticket);  // (not fused: SKR_COLORED_FACTORS_KERNEL)
 #define SKR_INV128(T) do { SKR_ALLOW_LDS((colored_inverse128<T>), lds); hipLaunchKernelGGL((colored_inverse128<T>), dim3((unsigned)blocks), dim3(512), lds, s, a, n_planes); } while (0)
   if (out_dtype == SKR_BF16) SKR_INV128(__bf16);
   else if (out_dtype == SKR_F16) SKR_INV128(_Float16);
@@ -1550,7 +1591,7 @@ int colored_planes(int mode, float2* spec, double* plane_partials, float* real_o
   a.spec = spec; a.real_out = nullptr; a.partials = plane_partials; a.seeds = seeds; a.stream = stream_id;
   a.batch = batch; a.d1 = (int32_t)planes; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
   a.n_slots = (int32_t)planes; a.n_slots_c = 0; a.has_energy = 0; a.energy = 0.0; a.out = real_out;
-  a.exponent_half_neg = 0.f; a.eps_clip = 1.f; a.inv_rmax = 1.f; a.raw = 1; a.factors = nullptr; a.ticket = nullptr;
+  a.exponent_half_neg = 0.f; a.eps_clip = 1.f; a.inv_rmax = 1.f; a.raw = 1; a.factors = nullptr; a.ticket = nullptr; a.first_ticket = 0; a.done_count = nullptr; a.factors_out = nullptr;
 #ifdef SKR_COLORED_TRACE
   a.trace = nullptr;
 #endif
@@ -1651,7 +1692,7 @@ static int colored_batch(void* out, int32_t out_dtype, void* spec_c64, float* sc
   a.spec = reinterpret_cast<float2*>(spec_c64); a.real_out = scratch_f32; a.partials = partials_f64; a.seeds = seeds_dev;
   a.stream = stream_id; a.batch = batch; a.d1 = d1; a.d2 = d2; a.d3 = d3; a.d3h = d3 / 2 + 1;
   a.exponent_half_neg = (float)(-exponent / 2.0);
-  a.out = out; a.has_energy = has_energy; a.energy = energy; a.n_slots_c = 0; a.raw = 0; a.factors = nullptr; a.ticket = nullptr;
+  a.out = out; a.has_energy = has_energy; a.energy = energy; a.n_slots_c = 0; a.raw = 0; a.factors = nullptr; a.ticket = nullptr; a.first_ticket = 0; a.done_count = nullptr; a.factors_out = nullptr;
 #ifdef SKR_COLORED_TRACE
   a.trace = g_colored_trace;
 #endif
@@ -1746,14 +1787,24 @@ static int colored_batch(void* out, int32_t out_dtype, void* spec_c64, float* sc
     if (nd == 2) {
       SKR_PLANE(2);
     } else {
+      // room left in the partials buffer, less one slot per sample: the last 2 * batch doubles (4 floats per sample) are the bookkeeping of
+      // colored_inverse128 -- [batch] rescale factors, the plane ticket, [batch] arrival counters of the outer-axis kernel
+      const int32_t slots_c = (int32_t)(2 * partial_slots - d1 - 1 < 4096 ? 2 * partial_slots - d1 - 1 : 4096);
+      if (slots_c < 1) return SKR_ERR_SHAPE;
+      float* tail = reinterpret_cast<float*>(partials_f64 + 4 * batch * partial_slots - 2 * batch);
+      const int64_t inv_blocks = inverse128_blocks(d2, d3, out_dtype, batch * (int64_t)d1);
+      if (inv_blocks > 0) {
+        static const bool static_deal = getenv("SKR_COLORED_INV_STATIC") != nullptr, factors_kernel = getenv("SKR_COLORED_FACTORS_KERNEL") != nullptr;
+        a.first_ticket = (uint32_t)(2 * inv_blocks);
+        a.ticket = static_deal ? nullptr : reinterpret_cast<uint32_t*>(tail + batch);
+        if (!factors_kernel) { a.done_count = reinterpret_cast<uint32_t*>(tail + 2 * batch); a.factors_out = tail; }
+      }
       SKR_PLANE_SZ(0, float);
       SKR_CHECK_LAUNCH();
-      // room left in the partials buffer, less one slot per sample: the last 2 * batch doubles hold the per-sample factors of colored_inverse128
-      a.n_slots_c = (int32_t)(2 * partial_slots - d1 - 1 < 4096 ? 2 * partial_slots - d1 - 1 : 4096);
-      if (a.n_slots_c < 1) return SKR_ERR_SHAPE;
+      a.n_slots_c = slots_c;
       const int rc = outer_axis();  // d1 <= 16: register kernel, with the Parseval partials of the weighted spectrum
       if (rc != SKR_OK) return rc;
-      const int inv = launch_inverse128(a, out_dtype, batch * (int64_t)d1, reinterpret_cast<float*>(partials_f64 + 4 * batch * partial_slots - 2 * batch), s);  // 128 x 128 planes: the persistent kernel
+      const int inv = launch_inverse128(a, out_dtype, batch * (int64_t)d1, tail, s);  // 128 x 128 planes: the persistent kernel
       if (inv >= 0) return inv;
       SKR_PLANE(1);
     }
