@@ -160,6 +160,7 @@ struct PyramidArgs {
   // noise.py:162-165 draws `randn(running_shape)` before permuting), so level l, element (i0..i3) is normal number
   // sum_j i_j * stride_l[j] of that level's stream.
   int32_t nd, dim[4], axis_a, axis_b;
+  int32_t ytab_off;  // UNI kernels: float offset of the vertical tap table inside the dynamic LDS (behind the level planes)
 };
 
 // level geometry (reference noise.py:157-162,195-196): level i shrinks the RUNNING size by r_i**i,
@@ -233,7 +234,13 @@ constexpr int PYR_THREADS = 512;  // 8 waves per block (the strip kernel's 165 r
 // horizontally interpolated level rows (top / bottom) stay in registers while the coarse source row does not change
 // and slide (bottom -> top) when it advances by one.
 // THREADS: 512 for large planes; 256 for small ones, where it doubles the rows of a run.
-template <bool STRIP, int THREADS>
+// UNI (round 5; strips whose rows are a whole number of waves wide, w % 256 == 0): the row a wave works on, and with it every vertical tap
+// (source rows y0 / y1 and the blend weight ly of each level), is the same in all 64 lanes.  Those taps come from a table in LDS, filled once
+// per block (one src_index per thread), as one broadcast read per level and row, and live in SGPRs from there: the row-cache tests are scalar
+// compares, ly is a scalar operand.  The cached source rows are kept as T = wl top and D = wl (bottom - top), so a pixel costs an add and
+// an FMA per level (was three FMA-class operations after nine VALU operations of tap arithmetic per level and row), and the per-row sums
+// stay in fp32 for eight rows before they are widened.  Measured on 64 x (4, 256, 256): see profiles/r05_prof_pyramid.txt.
+template <bool STRIP, int THREADS, bool UNI = false>
 __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP && THREADS > 256 ? 2 : 4)) void pyramid_pass1(const PyramidArgs a) {
   extern __shared__ float lds[];  // levels >= 1, back to back
   __shared__ double red[2][THREADS / 64];
@@ -312,6 +319,16 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP && THREADS > 
       for (int j = 0; j < 4; ++j) if (at + j >= 0 && at + j < n) g[at + j] = z[j];
     }
   }
+  if constexpr (UNI) {  // vertical taps of the cached levels for every row: (ly, y0 | (y1 - y0) << 16)
+    float2* ytab = reinterpret_cast<float2*>(lds + a.ytab_off);
+    for (int idx = threadIdx.x; idx < (PYR_UNROLLED - 1) * a.h; idx += THREADS) {
+      const int l = 1 + idx / a.h, y = idx - (l - 1) * a.h;
+      int y0 = 0, y1 = 0;
+      float ly = 0.f;
+      if (l < nl) src_index(y, s_sy[l], s_lh[l], y0, y1, ly);
+      ytab[idx] = make_float2(ly, __int_as_float(y0 | ((y1 - y0) << 16)));
+    }
+  }
   __syncthreads();
 
   const int w4 = a.w >> 2;  // w % 4 == 0 (host-checked): 4 consecutive pixels never straddle a row
@@ -363,7 +380,128 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 1 : (STRIP && THREADS > 
     *reinterpret_cast<float4*>(dst + (int64_t)q * 4) = make_float4(v[0], v[1], v[2], v[3]);
   };
 
-  if constexpr (STRIP) {
+  if constexpr (STRIP && UNI) {
+    constexpr int NC = PYR_UNROLLED;  // levels 1 .. NC - 1 are cached
+    const int xg = threadIdx.x % w4, x0 = xg * 4, groups = THREADS / w4;
+    const int run = (a.h + groups - 1) / groups;
+    const int ya = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / w4) * run), yz = ya + run < a.h ? ya + run : a.h;
+    const float2* ytab = reinterpret_cast<const float2*>(lds + a.ytab_off);
+    int tap_idx[NC][4];
+    float tap_lx[NC][4], T[NC][4], D[NC][4];
+    int cy0[NC], cy1[NC];
+#pragma unroll
+    for (int l = 1; l < NC; ++l) {
+      cy0[l] = -1; cy1[l] = -1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int xa = 0, xb = 0;
+        float lx = 0.f;
+        if (l < nl) src_index(x0 + j, s_sx[l], s_lw[l], xa, xb, lx);
+        tap_idx[l][j] = xa | (xb << 16);
+        tap_lx[l][j] = lx;
+        T[l][j] = 0.f; D[l][j] = 0.f;
+      }
+    }
+    float f1 = 0.f, f2 = 0.f;
+    auto row = [&](const int y, const float* drawn_v, const float* drawn_z) {
+      const int64_t e0 = ((int64_t)c * a.h + y) * a.w + x0;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (drawn_v) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = drawn_v[j];
+      } else if (a.with_base) normal4(seed, a.stream_base, (uint64_t)e0 >> 2, v);
+      if (w0 != 0.f) {
+        float z[4];
+        if (drawn_z) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) z[j] = drawn_z[j];
+        } else normal4(seed, a.stream_levels + 1, (uint64_t)e0 >> 2, z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(z[j], w0, v[j]);
+      }
+#pragma unroll
+      for (int l = 1; l < NC; ++l) {
+        if (l >= nl) break;
+        const float wl = s_wgt[l];
+        if (wl == 0.f) continue;
+        const float2 e = ytab[(l - 1) * a.h + y];  // one address for the whole wave: a broadcast
+        const float ly = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e.x)));
+        const int pk = __builtin_amdgcn_readfirstlane(__float_as_int(e.y));
+        const int y0 = pk & 0xFFFF, y1 = y0 + (pk >> 16);
+        const float* g = lds + s_off[l];
+        const int lw = s_lw[l];
+        auto row_taps = [&](int r_, float* dstv) {
+          const float* r = g + r_ * lw;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lx = tap_lx[l][j];
+            dstv[j] = (1.f - lx) * r[tap_idx[l][j] & 0xFFFF] + lx * r[tap_idx[l][j] >> 16];
+          }
+        };
+        bool fresh = false;
+        if (y0 != cy0[l]) {
+          if (y0 == cy1[l]) {  // the bottom row becomes the top row: wl top' = wl top + wl (bottom - top), one rounding away from wl * bottom
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[l][j] += D[l][j];
+          } else {
+            float t[4];
+            row_taps(y0, t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[l][j] = wl * t[j];
+          }
+          cy0[l] = y0;
+          fresh = true;
+        }
+        if (fresh || y1 != cy1[l]) {
+          if (y1 == y0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) D[l][j] = 0.f;
+          } else {
+            float b[4];
+            row_taps(y1, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) D[l][j] = fmaf(wl, b[j], -T[l][j]);
+          }
+          cy1[l] = y1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(ly, D[l][j], v[j] + T[l][j]);
+      }
+#pragma unroll 1
+      for (int l = NC; l < nl; ++l) {  // deeper levels: rare and tiny, sampled directly
+        const float wl = s_wgt[l];
+        if (wl == 0.f) continue;
+        const int lh = s_lh[l], lw = s_lw[l];
+        const float* g = lds + s_off[l];
+        int y0, y1;
+        float ly;
+        src_index(y, s_sy[l], lh, y0, y1, ly);
+        const float* r0 = g + y0 * lw;
+        const float* r1 = g + y1 * lw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int xa, xb;
+          float lx;
+          src_index(x0 + j, s_sx[l], lw, xa, xb, lx);
+          const float tp = (1.f - lx) * r0[xa] + lx * r0[xb];
+          const float bt = (1.f - lx) * r1[xa] + lx * r1[xb];
+          v[j] += wl * ((1.f - ly) * tp + ly * bt);
+        }
+      }
+      f1 += (v[0] + v[1]) + (v[2] + v[3]);
+      f2 += fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+      *reinterpret_cast<float4*>(dst + ((int64_t)y * w4 + xg) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    };
+    int y = ya;
+#pragma unroll
+    for (int r = 0; r < PYR_AHEAD; ++r, ++y)
+      if (y < yz) row(y, ahead_v[r], ahead_z[r]);
+    for (; y < yz; ++y) {
+      row(y, nullptr, nullptr);
+      if (((y - ya) & 7) == 7) { s1 += (double)f1; s2 += (double)f2; f1 = 0.f; f2 = 0.f; }  // 32 values per fp32 partial sum
+    }
+    s1 += (double)f1; s2 += (double)f2;
+  } else if constexpr (STRIP) {
     // column strips over a run of consecutive rows: the horizontal taps of the first PYR_CACHED levels (packed
     // xa | xb << 16 and the blend weight) are computed once per thread, and the horizontally interpolated source rows
     // (top / bottom) once per coarse row instead of once per pixel
@@ -685,11 +823,18 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   a.stream_base = stream_base; a.stream_levels = stream_levels; a.batch = batch; a.lead = (int32_t)lead; a.h = (int32_t)h; a.w = (int32_t)w;
   a.resize_h = resize_h; a.depth = depth; a.with_base = with_base; a.strength = (float)strength;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t lds_bytes = sizeof(float) * (size_t)bound;  // (the level geometry is worked out inside pass 1)
+  size_t lds_bytes = sizeof(float) * (size_t)bound;  // (the level geometry is worked out inside pass 1)
+  // rows a whole number of waves wide (w % 256 == 0) under 1024-lane strips: the vertical taps of the cached levels in a table behind the level planes
+  static const bool no_uni = getenv("SKR_PYR_NO_UNI") != nullptr;
+  const size_t ytab_bytes = sizeof(float2) * (size_t)(skr::PYR_UNROLLED - 1) * (size_t)h;
+  const bool uni = !no_uni && resize_h && (w / 4) % 64 == 0 && 1024 % (w / 4) == 0 && h / (1024 / (w / 4)) >= 12 && lds_bytes + ytab_bytes <= 156 * 1024;
+  a.ytab_off = uni ? (int32_t)((bound + 1) & ~(int64_t)1) : -1;  // (8-byte entries)
+  if (uni) lds_bytes = sizeof(float) * (size_t)a.ytab_off + ytab_bytes;
   if (lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(skr::pyramid_pass1<true, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return SKR_ERR_UNSUPPORTED;
   }
   const int64_t w4 = w / 4;
   const dim3 grid1((unsigned)(batch * lead));
@@ -702,7 +847,8 @@ extern "C" int skr_noise_pyramid(void* out, int32_t out_dtype, float* scratch_f3
   // dependency chains -- 72.9 against 75.9 us per draw at 64 x (4, 256, 256)
   const bool strip1024 = 1024 % w4 == 0 && h / (1024 / w4) >= 12;
   const int mode = forced ? forced : (strip1024 ? 4 : (strip512 ? 2 : (strip256 ? 3 : 1)));
-  if (mode == 4 && strip1024) hipLaunchKernelGGL((skr::pyramid_pass1<true, 1024>), grid1, dim3(1024), lds_bytes, s, a);
+  if (mode == 4 && strip1024 && uni) hipLaunchKernelGGL((skr::pyramid_pass1<true, 1024, true>), grid1, dim3(1024), lds_bytes, s, a);
+  else if (mode == 4 && strip1024) hipLaunchKernelGGL((skr::pyramid_pass1<true, 1024>), grid1, dim3(1024), lds_bytes, s, a);
   else if (mode == 2 && strip512) hipLaunchKernelGGL((skr::pyramid_pass1<true, 512>), grid1, dim3(512), lds_bytes, s, a);
   else if (mode == 3 && strip256) hipLaunchKernelGGL((skr::pyramid_pass1<true, 256>), grid1, dim3(256), lds_bytes, s, a);
   else hipLaunchKernelGGL((skr::pyramid_pass1<false, 512>), grid1, dim3(512), lds_bytes, s, a);
@@ -735,7 +881,7 @@ static int pyramid_nd_impl(void* out, int32_t out_dtype, float* scratch_f32, flo
   // right-align the axes in the 4-slot descriptor
   const int pad = 4 - nd;
   for (int i = 0; i < 4; ++i) a.dim[i] = i < pad ? 1 : (int32_t)shape[i - pad];
-  a.nd = nd; a.axis_a = axis_a < 0 ? -1 : axis_a + pad; a.axis_b = axis_b + pad;
+  a.nd = nd; a.axis_a = axis_a < 0 ? -1 : axis_a + pad; a.axis_b = axis_b + pad; a.ytab_off = -1;
   const int64_t h = axis_a < 0 ? 1 : shape[axis_a], w = shape[axis_b];
   int64_t unit = 1;
   for (int i = 0; i < nd; ++i) unit *= shape[i];
