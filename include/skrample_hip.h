@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 11
+#define SKR_ABI_VERSION 12
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 /* Devices and streams: every entry point launches on the device that owns its output buffer (queried from the pointer when
@@ -138,6 +138,41 @@ int skr_program_create(const skr_step_plan* plan, int64_t numel, skr_program** o
 int skr_program_launch(const skr_program* prog, const void* const* inputs, void* out0, void* out1,
                        const uint64_t* seeds_dev, uint64_t stream0, uint64_t stream1, void* stream);
 void skr_program_destroy(skr_program* prog);
+
+/*
+ * A solver step replayed one rounded tensor operation at a time -- the reference's arithmetic when its samplers are called on tensors
+ * directly (StructuredSampler.sample, skrample/sampling/structured.py:70-86 with :167-497 and models.py:53-224; no scheduler wrapper,
+ * or a wrapper with compute_scale=None): every `*`, `+`, `-`, `/` is a torch op of its own in the TENSOR dtype -- operands widened to the
+ * op-math type (fp32 for bf16 / fp16 / fp32 tensors, fp64 for fp64; a Python scalar is converted to it first), one operation, the result
+ * rounded to the tensor dtype.  skr_step_launch evaluates the collapsed form in fp32 and rounds once (closer to the exact value, not
+ * the reference's bits); skr_tape_launch runs the recorded sequence itself, values in registers, one pass over HBM:
+ *
+ *     LOAD   r[dst] = inputs[a][e]                        STORE  outputs[b][e] = r[a]
+ *     MUL_S  r[dst] = rnd(r[a] * k)    DIV_S  rnd(r[a] / k)    ADD_S  rnd(r[a] + k)    RSUB_S  rnd(k - r[a])    RDIV_S  rnd(k / r[a])
+ *     ADD    r[dst] = rnd(r[a] + r[b]) SUB    rnd(r[a] - r[b]) MUL    rnd(r[a] * r[b]) DIV     rnd(r[a] / r[b]) NEG     -r[a]
+ *
+ * (IEEE operations, no contraction; rnd = round-to-nearest-even to `dtype`.)  Every tensor has `dtype` and `numel` elements; register
+ * numbers are < SKR_TAPE_REGS (the host allocates them); SKR_ERR_TERMS for a malformed tape.
+ */
+#define SKR_TAPE_MAX_OPS 96
+#define SKR_TAPE_REGS 16
+#define SKR_TAPE_MAX_INPUTS 24
+#define SKR_TAPE_MAX_OUTPUTS 4
+enum skr_tape_code {
+  SKR_TAPE_LOAD = 0, SKR_TAPE_STORE = 1, SKR_TAPE_MUL_S = 2, SKR_TAPE_DIV_S = 3, SKR_TAPE_ADD_S = 4, SKR_TAPE_RSUB_S = 5, SKR_TAPE_RDIV_S = 6,
+  SKR_TAPE_ADD = 7, SKR_TAPE_SUB = 8, SKR_TAPE_MUL = 9, SKR_TAPE_DIV = 10, SKR_TAPE_NEG = 11
+};
+typedef struct skr_tape_op {
+  int32_t code; /* skr_tape_code */
+  int32_t dst, a, b;
+  double k;
+} skr_tape_op;
+typedef struct skr_tape {
+  int32_t n_ops, n_inputs, n_outputs;
+  int32_t dtype; /* skr_dtype of every tensor */
+  skr_tape_op ops[SKR_TAPE_MAX_OPS];
+} skr_tape;
+int skr_tape_launch(const skr_tape* tape, const void* const* inputs, void* const* outputs, int64_t numel, void* stream);
 
 /*
  * Noise generators -- replace skrample/pytorch/noise.py behind BatchTensorNoise.generate

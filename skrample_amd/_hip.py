@@ -14,7 +14,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 11
+ABI_VERSION = 12
 SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
@@ -31,6 +31,7 @@ EXPORTS = (
     "skr_program_create",
     "skr_program_launch",
     "skr_program_destroy",
+    "skr_tape_launch",
     "skr_noise_random",
     "skr_noise_offset",
     "skr_noise_brownian",
@@ -80,6 +81,22 @@ class StepPlanC(ctypes.Structure):
         ("convert_from", ctypes.c_int32),
         ("convert_k", ctypes.c_double * 4),
     ]
+
+
+TAPE_MAX_OPS, TAPE_REGS, TAPE_MAX_INPUTS, TAPE_MAX_OUTPUTS = 96, 16, 24, 4  # include/skrample_hip.h SKR_TAPE_*
+(TAPE_LOAD, TAPE_STORE, TAPE_MUL_S, TAPE_DIV_S, TAPE_ADD_S, TAPE_RSUB_S, TAPE_RDIV_S, TAPE_ADD, TAPE_SUB, TAPE_MUL, TAPE_DIV, TAPE_NEG) = range(12)
+
+
+class TapeOpC(ctypes.Structure):
+    "mirror of `skr_tape_op`"
+
+    _fields_ = [("code", ctypes.c_int32), ("dst", ctypes.c_int32), ("a", ctypes.c_int32), ("b", ctypes.c_int32), ("k", ctypes.c_double)]
+
+
+class TapeC(ctypes.Structure):
+    "mirror of `skr_tape`"
+
+    _fields_ = [("n_ops", ctypes.c_int32), ("n_inputs", ctypes.c_int32), ("n_outputs", ctypes.c_int32), ("dtype", ctypes.c_int32), ("ops", TapeOpC * TAPE_MAX_OPS)]
 
 
 ROW_TERMS = 16  # include/skrample_hip.h SKR_ROW_TERMS
@@ -250,6 +267,8 @@ def load() -> ctypes.CDLL:
         lib.skr_program_launch.restype = ctypes.c_int
         lib.skr_program_destroy.argtypes = [vp]
         lib.skr_program_destroy.restype = None
+        lib.skr_tape_launch.argtypes = [ctypes.POINTER(TapeC), ctypes.POINTER(vp), ctypes.POINTER(vp), i64, vp]
+        lib.skr_tape_launch.restype = ctypes.c_int
         lib.skr_noise_random.argtypes = [vp, i32, vp, u64, i64, i64, vp]
         lib.skr_noise_random.restype = ctypes.c_int
         lib.skr_noise_offset.argtypes = [vp, i32, vp, u64, u64, i64, ctypes.POINTER(i64), i32, ctypes.c_uint32, ctypes.c_double, vp]

@@ -1,0 +1,476 @@
+"""The reference's own arithmetic for samplers called on tensors directly: one rounded tensor operation at a time.
+
+`StructuredSampler.sample(bf16_tensor, ...)` without a scheduler wrapper (or behind a wrapper with `compute_scale=None`) runs the
+reference's generic code on torch tensors, so every `*`, `+`, `-`, `/` of the step is a torch op in the TENSOR dtype and rounds
+(reference structured.py:70-86, 167-497; models.py:53-224).  The fused kernel (sampling/lazy.py -> skr_step_launch) collapses the
+step into one linear form, accumulates it in fp32 and rounds once: closer to the exact answer, but 4-47 last-place units away from what
+the reference returns on 16-bit tensors (tests/golden/native16.npz).
+
+This module gives that entry point the reference's bits.  The step is *recorded*: the functions below perform the reference's
+operations, in the reference's order, on `Val` handles whose operators append to a `Tape` instead of computing; the tape then runs as
+ONE kernel (csrc/skr_tape.hip, `skr_tape_launch`) that keeps every intermediate in registers and rounds after each operation exactly as
+the separate torch ops would -- one pass over HBM instead of the reference's ~16, same bits.
+
+Which calls take this path (`mode`):
+    "auto"    (default) tensors of ONE 16-bit dtype, outside any compute_scale context  -> tape (device tensors: one launch of
+              skr_tape_launch; host tensors: the tape one torch op per entry, which is the reference itself); everything else -> fused form
+    "always"  also fp32 / fp64 tensors (their fused result differs from the reference by fp32 / fp64 rounding only)
+    "never"   always the fused kernel
+The scheduler wrappers cast to `compute_scale` first (fp32 by default), as the reference's do (diffusers.py:575-599), and are not
+affected unless compute_scale is None.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from .. import _hip, common
+from ..common import DeltaPoint, Point, divf, ln
+from . import lazy, models
+
+mode = "auto"
+launches = 0  # tapes launched so far (tests assert that a call did / did not take this path)
+
+
+class _Refused(Exception):
+    "this step is outside what the tape covers: the caller takes the fused path"
+
+
+class Tape:
+    "operations of one step over `Val` handles; leaves are device tensors"
+
+    def __init__(self, dtype: torch.dtype, shape, device, require_device: bool = True):
+        self.dtype, self.shape, self.device, self.require_device = dtype, tuple(shape), device, require_device
+        self.ops: list[tuple[int, int, int, float]] = []  # (code, a, b, k); the value an op defines is its position
+        self.leaves: list[torch.Tensor] = []
+        self._leaf_of: dict[int, Val] = {}
+
+    def leaf(self, t) -> "Val":
+        if isinstance(t, Val):
+            return t
+        if isinstance(t, lazy.PhiloxNoise):
+            t = t.realize(self.dtype)
+        if isinstance(t, lazy.LazyTensor):
+            t = t.materialize()
+        if not isinstance(t, torch.Tensor) or (self.require_device and not t.is_cuda) or t.dtype != self.dtype or tuple(t.shape) != self.shape or t.device != self.device or not t.is_contiguous():
+            raise _Refused
+        hit = self._leaf_of.get(id(t))
+        if hit is None:
+            if len(self.leaves) >= _hip.TAPE_MAX_INPUTS:
+                raise _Refused
+            self.leaves.append(t)
+            hit = self._leaf_of[id(t)] = self._emit(_hip.TAPE_LOAD, len(self.leaves) - 1, 0, 0.0)
+        return hit
+
+    def _emit(self, code: int, a: int, b: int, k: float) -> "Val":
+        self.ops.append((code, a, b, float(k)))
+        return Val(self, len(self.ops) - 1)
+
+
+class Val:
+    "a tensor-valued intermediate of the recorded step; arithmetic appends to the tape (torch's operator semantics on a tensor of one dtype)"
+
+    __slots__ = ("tape", "n")
+    __array_ufunc__ = None  # numpy scalars defer to the reflected operators below
+
+    def __init__(self, tape: Tape, n: int):
+        self.tape, self.n = tape, n
+
+    def _bin(self, other, tensor_code: int, scalar_code: int, scalar_k=lambda k: k):
+        if isinstance(other, Val):
+            return self.tape._emit(tensor_code, self.n, other.n, 0.0)
+        if isinstance(other, (int, float, np.floating, np.integer)):
+            return self.tape._emit(scalar_code, self.n, 0, scalar_k(float(other)))
+        if isinstance(other, (torch.Tensor, lazy.LazyTensor, lazy.PhiloxNoise)):
+            return self.tape._emit(tensor_code, self.n, self.tape.leaf(other).n, 0.0)
+        return NotImplemented
+
+    def __add__(self, o):
+        return self._bin(o, _hip.TAPE_ADD, _hip.TAPE_ADD_S)
+
+    __radd__ = __add__  # a + k == k + a, one rounding either way
+
+    def __sub__(self, o):
+        return self._bin(o, _hip.TAPE_SUB, _hip.TAPE_ADD_S, lambda k: -k)  # a - k == a + (-k) exactly
+
+    def __rsub__(self, o):
+        if isinstance(o, (int, float, np.floating, np.integer)):
+            return self.tape._emit(_hip.TAPE_RSUB_S, self.n, 0, float(o))
+        return self.tape.leaf(o) - self
+
+    def __mul__(self, o):
+        return self._bin(o, _hip.TAPE_MUL, _hip.TAPE_MUL_S)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        return self._bin(o, _hip.TAPE_DIV, _hip.TAPE_DIV_S)
+
+    def __rtruediv__(self, o):
+        if isinstance(o, (int, float, np.floating, np.integer)):  # torch: Tensor.__rtruediv__ = reciprocal() * other, two rounded ops
+            return self.tape._emit(_hip.TAPE_RDIV_S, self.n, 0, 1.0) * float(o)
+        return self.tape.leaf(o) / self
+
+    def __neg__(self):
+        return self.tape._emit(_hip.TAPE_NEG, self.n, 0, 0.0)
+
+
+def _sumprod(ps, qs):
+    "math.sumprod on non-float operands (CPython 3.12): total = 0; total = total + p * q, left to right -- reference models.py:65-67"
+    total = 0
+    for p, q in zip(ps, qs):
+        total = total + p * q
+    return total
+
+
+# ---- prediction spaces: reference models.py:86-212 (to_x / from_x, op for op) -------------------------------------------------------
+def _to_x(model, sample, output, point: Point):
+    _t, sigma, alpha = point
+    kind = type(model)
+    if kind is models.DataModel:
+        return output
+    if kind is models.NoiseModel:
+        return (sample - sigma * output) / alpha
+    if kind is models.FlowModel:
+        return (sample - sigma * output) / (alpha + sigma)
+    if kind is models.VelocityModel:
+        return alpha * sample - sigma * output
+    if kind is models.ScaleX:
+        return output * model.x_scale(point)
+    raise _Refused
+
+
+def _from_x(model, sample, x, point: Point):
+    _t, sigma, alpha = point
+    kind = type(model)
+    if kind is models.DataModel:
+        return x
+    if kind is models.NoiseModel:
+        return (sample - alpha * x) / sigma
+    if kind is models.FlowModel:
+        return (sample - (alpha + sigma) * x) / sigma
+    if kind is models.VelocityModel:
+        return (alpha * sample - x) / sigma
+    if kind is models.ScaleX:
+        return x / model.x_scale(point)
+    raise _Refused
+
+
+def _output_to(src, dst, sample, output, point: Point):
+    "ModelConvert.output_to (reference models.py:220-224): identity only for the SAME object"
+    return output if dst is src else _from_x(dst, sample, _to_x(src, sample, output, point), point)
+
+
+def _forward(model, sample, output, delta: DeltaPoint, noise, eta: float):
+    "DiffusionModel.forward (reference models.py:53-67)"
+    gamma, dlt = model.gamma(delta, eta), model.delta(delta, eta)
+    if noise is not None:
+        zeta = model.zeta(delta, eta)
+        if zeta != 0:
+            return _sumprod((sample, output, noise), (gamma, dlt, zeta))
+    return _sumprod((sample, output), (gamma, dlt))
+
+
+class _Rec:
+    "a step's inputs as the recorder sees them (SampleInput with Val / tensor fields)"
+
+    __slots__ = ("sample", "prediction", "step", "noise")
+
+    def __init__(self, sample, prediction, step, noise):
+        self.sample, self.prediction, self.step, self.noise = sample, prediction, step, noise
+
+    def delta_point(self, schedule) -> DeltaPoint:
+        from .structured import _ipoint
+
+        return DeltaPoint(_ipoint(schedule, self.step[0]), _ipoint(schedule, self.step[1]))
+
+
+def _derivative_history(sampler, packed: _Rec, model, schedule, previous: Sequence, order: int, delta: DeltaPoint):
+    "the `predictions` list of DPM / Adams / UniP and the space they live in (reference structured.py:209-225, 304-317, 360-377)"
+    # (the reference slices previous[-effective_order + 1:], which at order 1 is the whole history: entries past `order` are converted
+    #  there too, but nothing reads them -- they are not recorded here)
+    older = list(previous[len(previous) - (order - 1) :]) if order > 1 else []
+    if sampler.derivative_transform:
+        dst = sampler.derivative_transform
+        preds = [_output_to(model, dst, packed.sample, packed.prediction, delta.point_from)]
+        preds += reversed([_output_to(model, dst, p.sample, p.prediction, p.delta_point(schedule).point_from) for p in older])
+        return preds, dst
+    return [packed.prediction, *reversed([p.prediction for p in older])], model
+
+
+def _euler(sampler, packed: _Rec, model, schedule, previous):
+    return _forward(model, packed.sample, packed.prediction, packed.delta_point(schedule), packed.noise, sampler.stochasticity)  # structured.py:174-180
+
+
+def _dpm(sampler, packed: _Rec, model, schedule, previous):
+    "reference structured.py:195-283"
+    from .structured import _ipoint
+
+    delta = packed.delta_point(schedule)
+    order = sampler.effective_order(packed.step, previous)
+    predictions, model = _derivative_history(sampler, packed, model, schedule, previous, order, delta)
+    prediction = predictions.pop(0)
+    if order >= 2:
+        (_t0, sigma_u, sigma_v), (_t1, sigma_u_next, sigma_v_next) = delta
+        lam, lam_next = ln(divf(sigma_v, sigma_u)), ln(divf(sigma_v_next, sigma_u_next))
+        h = abs(lam_next - lam)
+        _tp, su_prev, sv_prev = _ipoint(schedule, previous[-1].step[0])
+        lam_prev = ln(divf(sv_prev, su_prev))
+        r = (lam - lam_prev) / h
+        prediction_prev = predictions.pop(0)
+        d1_0 = (1.0 / r) * (prediction - prediction_prev)
+        if order >= 3:
+            _tp2, su_prev2, sv_prev2 = _ipoint(schedule, previous[-2].step[0])
+            r2 = (lam_prev - ln(divf(sv_prev2, su_prev2))) / h
+            prediction_p2 = predictions.pop(0)
+            d1_1 = (1.0 / r2) * (prediction_prev - prediction_p2)
+            d1 = d1_0 + (r / (r + r2)) * (d1_0 - d1_1)
+            d2 = (1.0 / (r + r2)) * (d1_0 - d1_1)
+            hh = -h
+            e = math.expm1(hh)
+            c1 = (e / hh - 1.0) / e if e != 0 else 0
+            c2 = ((e - hh) / hh**2 - 0.5) / e if e != 0 else 0
+            prediction = prediction + c1 * d1 + c2 * d2
+        else:
+            prediction = prediction + 0.5 * d1_0
+    return _forward(model, packed.sample, prediction, delta, packed.noise, sampler.stochasticity)
+
+
+def _adams(sampler, packed: _Rec, model, schedule, previous):
+    "reference structured.py:294-330"
+    order = sampler.effective_order(packed.step, previous)
+    delta = packed.delta_point(schedule)
+    predictions, model = _derivative_history(sampler, packed, model, schedule, previous, order, delta)
+    weighted = _sumprod(predictions[:order], common.bashforth(order))
+    return _forward(model, packed.sample, weighted, delta, packed.noise, sampler.stochasticity)
+
+
+def _unisolve(sampler, packed: _Rec, model, schedule, previous, prediction_next=None):
+    "UniP.unisolve (reference structured.py:344-436); with `prediction_next` it is the corrector"
+    delta = packed.delta_point(schedule)
+    order = sampler.effective_order(packed.step, previous)
+    src_model = model
+    predictions, model = _derivative_history(sampler, packed, model, schedule, previous, order, delta)
+    if sampler.derivative_transform and prediction_next is not None:
+        prediction_next = _output_to(src_model, model, packed.sample, prediction_next, delta.point_from)
+    prediction = predictions.pop(0)
+    (_t0, sigma_u, sigma_v), (_t1, sigma_u_next, sigma_v_next) = delta
+    lam, lam_next = ln(divf(sigma_v, sigma_u)), ln(divf(sigma_v_next, sigma_u_next))
+    h = abs(lam_next - lam)
+    hh = -h
+    phi_1 = math.expm1(hh)
+    rks: list[float] = []
+    d1s = []
+    for n in range(1, order):
+        prediction_prev = predictions.pop(0)
+        _tn, su_n, sv_n = previous[-n].delta_point(schedule).point_from
+        rk = (ln(divf(sv_n, su_n)) - lam) / h
+        rks.append(rk if math.isfinite(rk) else 0)
+        d1s.append((prediction_prev - prediction) / rk)
+    if prediction_next is not None:
+        rks.append(1.0)
+        order_check = 1
+        d1s.append(prediction_next - prediction)
+    else:
+        order_check = 2
+    if not rks or (order == order_check and sampler.fast_solve):
+        rhos = [0.5]
+    else:
+        phi_k = phi_1 / hh - 1
+        rows, rhs = [], []
+        for n in range(1, len(rks) + 1):
+            rows.append([math.pow(v, n - 1) for v in rks])
+            rhs.append(phi_k * math.factorial(n) / phi_1)
+            phi_k = phi_k / hh - 1 / math.factorial(n + 1)
+        rhos = np.linalg.solve(rows, rhs).tolist()
+    result = _sumprod(rhos[: len(d1s)], d1s)
+    prediction = prediction + result
+    return _forward(model, packed.sample, prediction, delta, packed.noise, sampler.stochasticity)
+
+
+def _stated(sampler):
+    "the recorder of a sampler whose record is (inputs, final): exact types only -- a subclass may compute something else"
+    from . import structured as S
+
+    return {S.Euler: _euler, S.DPM: _dpm, S.Adams: _adams, S.UniP: _unisolve}.get(type(sampler))
+
+
+def _wrap(tape: Tape, rec) -> _Rec:
+    "a history record (SKSamples) with its tensors as leaves"
+    return _Rec(tape.leaf(rec.sample), tape.leaf(rec.prediction), rec.step, None if rec.noise is None else rec.noise)
+
+
+def _noise_leaf(tape: Tape, noise):
+    return None if noise is None else tape.leaf(noise)
+
+
+# ---- execution ----------------------------------------------------------------------------------------------------------------------
+def _run(tape: Tape, results: list) -> list[torch.Tensor]:
+    """Allocate registers (one pass over the straight-line tape: a value holds its register from its definition to its last read),
+    fill a skr_tape and launch it.  `results` are the values to return: a leaf comes back as the caller's own tensor, anything else
+    is stored by the launch right behind its definition."""
+    n = len(tape.ops)
+    two = (_hip.TAPE_ADD, _hip.TAPE_SUB, _hip.TAPE_MUL, _hip.TAPE_DIV)
+    reads = [() if code == _hip.TAPE_LOAD else ((a, b) if code in two else (a,)) for code, a, b, _k in tape.ops]
+    last_read = [-1] * n
+    for i, rd in enumerate(reads):
+        for r in rd:
+            last_read[r] = i
+    stores: dict[int, int] = {}  # value -> output slot
+    for v in results:
+        if tape.ops[v.n][0] != _hip.TAPE_LOAD and v.n not in stores:
+            stores[v.n] = len(stores)
+    if not stores or len(stores) > _hip.TAPE_MAX_OUTPUTS:
+        raise _Refused
+    # (a value nothing reads -- e.g. a difference the reference computes for a term of weight zero -- stays on the tape: it costs no
+    #  memory traffic; only the LOAD of a leaf nothing reads is dropped)
+    free = list(range(_hip.TAPE_REGS - 1, -1, -1))
+    reg_of: dict[int, int] = {}
+    out_ops: list[tuple[int, int, int, int, float]] = []
+    used_leaves: list[int] = []
+    for i, (code, a, b, k) in enumerate(tape.ops):
+        if code == _hip.TAPE_LOAD and last_read[i] < 0:
+            continue
+        srcs = [reg_of[r] for r in reads[i]]
+        for r in set(reads[i]):  # an operand read here for the last time hands its register on (the kernel reads before it writes)
+            if last_read[r] == i:
+                free.append(reg_of.pop(r))
+        if not free:
+            raise _Refused
+        dst = free.pop()
+        if code == _hip.TAPE_LOAD:
+            if a not in used_leaves:
+                used_leaves.append(a)
+            out_ops.append((code, dst, used_leaves.index(a), 0, 0.0))
+        else:
+            out_ops.append((code, dst, srcs[0], srcs[1] if len(srcs) > 1 else 0, k))
+        if i in stores:
+            out_ops.append((_hip.TAPE_STORE, 0, dst, stores[i], 0.0))
+        if last_read[i] < 0:
+            free.append(dst)
+        else:
+            reg_of[i] = dst
+    if len(out_ops) > _hip.TAPE_MAX_OPS or not used_leaves:
+        raise _Refused
+    c = _hip.TapeC()
+    for j, (code, dst, a, b, k) in enumerate(out_ops):
+        c.ops[j].code, c.ops[j].dst, c.ops[j].a, c.ops[j].b, c.ops[j].k = code, dst, a, b, k
+    c.n_ops, c.n_inputs, c.n_outputs, c.dtype = len(out_ops), len(used_leaves), len(stores), _hip.DTYPE_CODE[tape.dtype]
+    leaves = [tape.leaves[i] for i in used_leaves]
+    outs = [lazy.empty_output(tape.shape, tape.dtype, tape.device) for _ in stores]
+    ins = (ctypes.c_void_p * len(leaves))(*[t.data_ptr() for t in leaves])
+    ous = (ctypes.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+    _hip.check(_hip.load().skr_tape_launch(ctypes.byref(c), ins, ous, leaves[0].numel(), _hip.current_stream_ptr(tape.device)), "skr_tape_launch")
+    global launches
+    launches += 1
+    return [tape.leaves[tape.ops[v.n][1]] if tape.ops[v.n][0] == _hip.TAPE_LOAD else outs[stores[v.n]] for v in results]
+
+
+def _run_host(tape: Tape, results: list) -> list[torch.Tensor]:
+    "host-resident tensors (the reference's own habitat): the tape one torch op per entry -- which IS the reference's sequence of aten calls"
+    vals: list[torch.Tensor] = []
+    for code, a, b, k in tape.ops:
+        x = tape.leaves[a] if code == _hip.TAPE_LOAD else vals[a]
+        if code == _hip.TAPE_LOAD:
+            y = x
+        elif code == _hip.TAPE_MUL_S:
+            y = x * k
+        elif code == _hip.TAPE_DIV_S:
+            y = x / k
+        elif code == _hip.TAPE_ADD_S:
+            y = x + k
+        elif code == _hip.TAPE_RSUB_S:
+            y = k - x
+        elif code == _hip.TAPE_RDIV_S:
+            y = x.reciprocal() if k == 1.0 else (torch.tensor(k, dtype=x.dtype if x.dtype == torch.float64 else torch.float32) / x.to(x.dtype if x.dtype == torch.float64 else torch.float32)).to(x.dtype)
+        elif code == _hip.TAPE_ADD:
+            y = x + vals[b]
+        elif code == _hip.TAPE_SUB:
+            y = x - vals[b]
+        elif code == _hip.TAPE_MUL:
+            y = x * vals[b]
+        elif code == _hip.TAPE_DIV:
+            y = x / vals[b]
+        else:
+            y = -x
+        vals.append(y)
+    return [vals[v.n] for v in results]
+
+
+def _execute(tape: Tape, results: list) -> list[torch.Tensor]:
+    return _run(tape, results) if tape.device.type == "cuda" else _run_host(tape, results)
+
+
+def _eligible(sample, prediction) -> bool:
+    if mode == "never" or lazy._compute_dtype.get() is not None:
+        return False
+    if not (isinstance(sample, torch.Tensor) and isinstance(prediction, torch.Tensor) and sample.device == prediction.device):
+        return False
+    if sample.dtype != prediction.dtype or sample.shape != prediction.shape:
+        return False
+    if sample.dtype in (torch.bfloat16, torch.float16):
+        return True
+    return mode == "always" and sample.dtype in (torch.float32, torch.float64)
+
+
+def record_stated(sampler, packed, model, schedule, previous, require_device: bool = True):
+    "(tape, [final]) of a StatedSampler step in the reference's arithmetic; raises _Refused outside the tape's coverage"
+    recorder = _stated(sampler)
+    if recorder is None:
+        raise _Refused
+    tape = Tape(packed.sample.dtype, packed.sample.shape, packed.sample.device, require_device)
+    me = _Rec(tape.leaf(packed.sample), tape.leaf(packed.prediction), packed.step, _noise_leaf(tape, packed.noise))
+    hist = [_wrap(tape, p) for p in previous]
+    return tape, [recorder(sampler, me, model, schedule, hist)]
+
+
+def record_unipc(sampler, packed, model, schedule, previous, require_device: bool = True):
+    "(tape, [record sample, record prediction, final]) of UniPC.sample_packed (reference structured.py:469-497): conversion, corrector on the previous record, predictor"
+    predictor = sampler.predictor
+    if predictor is not None and _stated(predictor) is None:
+        raise _Refused
+    tape = Tape(packed.sample.dtype, packed.sample.shape, packed.sample.device, require_device)
+    delta = _Rec(None, None, packed.step, None).delta_point(schedule)
+    sample, prediction = tape.leaf(packed.sample), tape.leaf(packed.prediction)
+    noise = _noise_leaf(tape, packed.noise)
+    if sampler.derivative_transform:
+        prediction = _output_to(model, sampler.derivative_transform, sample, prediction, delta.point_from)
+        model = sampler.derivative_transform
+    hist = [_wrap(tape, p) for p in previous]
+    if hist:
+        hist[-1].noise = _noise_leaf(tape, previous[-1].noise)  # the corrector re-applies the noise of the step it corrects
+        sample = _unisolve(sampler, hist[-1], model, schedule, hist[:-1], prediction_next=prediction)
+    me = _Rec(sample, prediction, packed.step, noise)
+    final = _unisolve(sampler, me, model, schedule, hist) if predictor is None else _stated(predictor)(predictor, me, model, schedule, hist)
+    return tape, [sample, prediction, final]
+
+
+def try_stated(sampler, packed, model, schedule, previous):
+    "StatedSampler.sample_packed in the reference's arithmetic, or None (the caller runs the fused form)"
+    if _stated(sampler) is None or not _eligible(packed.sample, packed.prediction):
+        return None
+    from .structured import SKSamples
+
+    try:
+        (final,) = _execute(*record_stated(sampler, packed, model, schedule, previous, require_device=False))
+    except _Refused:
+        return None
+    return SKSamples(packed.sample, packed.prediction, packed.step, packed.noise, final)
+
+
+def try_unipc(sampler, packed, model, schedule, previous):
+    "UniPC.sample_packed in the reference's arithmetic (one tape: corrected sample, converted prediction and step result), or None"
+    from . import structured as S
+
+    if type(sampler) is not S.UniPC or not _eligible(packed.sample, packed.prediction):
+        return None
+    try:
+        sample, prediction, final = _execute(*record_unipc(sampler, packed, model, schedule, previous, require_device=False))
+    except _Refused:
+        return None
+    return S.SKSamples(sample, prediction, packed.step, packed.noise, final)

@@ -30,7 +30,7 @@ import torch
 from .. import common
 from ..common import DeltaPoint, Point, Step, divf, ln, softmax, spowf  # noqa: F401  (spowf re-exported, as in the reference)
 from ..scheduling import SkrampleSchedule, ipoint_lru
-from . import lazy, models, traits
+from . import lazy, models, native, traits
 from .lazy import LazyTensor, Lin, lift
 
 
@@ -108,6 +108,10 @@ class StatedSampler(StructuredSampler):
         "the step result as a number or lazy form (no kernel launch)"
 
     def sample_packed(self, packed, model_transform, schedule, previous=()):
+        # called on 16-bit device tensors directly (no compute_scale context): the reference's op-by-op arithmetic, replayed in one launch
+        record = native.try_stated(self, packed, model_transform, schedule, previous)
+        if record is not None:
+            return record
         form = self._form(packed, model_transform, schedule, previous)
         final = lazy.settle(form, dtype=_result_dtype(packed.sample))
         return SKSamples(packed.sample, packed.prediction, packed.step, packed.noise, final)
@@ -318,6 +322,9 @@ class UniPC(UniP):
         return max(super().require_previous + 1, self.predictor.require_previous if self.predictor else 0)
 
     def sample_packed(self, packed, model_transform, schedule, previous=()):
+        record = native.try_unipc(self, packed, model_transform, schedule, previous)  # (see StatedSampler.sample_packed)
+        if record is not None:
+            return record
         result_dtype = _result_dtype(packed.sample)
         if self.derivative_transform:
             conv = models.ModelConvert(model_transform, self.derivative_transform)

@@ -1,0 +1,144 @@
+"""The sampler-level API in the reference's own arithmetic (skrample_amd/sampling/native.py + csrc/skr_tape.hip).
+
+Called on tensors directly, the reference's samplers run one rounded torch op per arithmetic operation in the TENSOR dtype
+(structured.py:70-86, 167-497).  native.py records that sequence; skr_tape_launch replays it in one launch.  Checked here:
+  * no GPU: the RECORDER -- the tape of every step of the twelve reference-recorded 16-bit runs (tests/golden/native16.npz), interpreted
+    with plain torch ops on CPU (one op = one torch call, as the reference), returns the reference's bits; so do tapes of random
+    sampler / model / schedule combinations against the oracle's native-dtype chain, in bf16, fp16 and fp32;
+  * GPU (test_step_gpu.py / below): the KERNEL -- StructuredSampler.sample on device tensors equals the same fixtures bit for bit."""
+
+import zlib
+
+import pytest
+import torch
+from cases import MODELS, NATIVE16_ORACLE, NATIVE16_TAGS, SAMPLERS, SCHEDULES, native16_case
+from conftest import load_npz
+
+from skr_oracle import samplers as OA
+from skrample_amd import _hip
+from skrample_amd.common import Step
+from skrample_amd.sampling import native
+from skrample_amd.sampling import structured as PT
+
+
+def interpret(tape: native.Tape, results):
+    "the tape, one torch op per entry, on the tape's own (CPU) leaves: what separate aten kernels in the tensor dtype compute"
+    vals = []
+    for code, a, b, k in tape.ops:
+        if code == _hip.TAPE_LOAD:
+            vals.append(tape.leaves[a])
+        elif code == _hip.TAPE_MUL_S:
+            vals.append(vals[a] * k)
+        elif code == _hip.TAPE_DIV_S:
+            vals.append(vals[a] / k)
+        elif code == _hip.TAPE_ADD_S:
+            vals.append(vals[a] + k)
+        elif code == _hip.TAPE_RSUB_S:
+            vals.append(k - vals[a])
+        elif code == _hip.TAPE_RDIV_S:
+            vals.append(vals[a].reciprocal() if k == 1.0 else (torch.tensor(k, dtype=torch.float64 if tape.dtype == torch.float64 else torch.float32) / vals[a].to(torch.float64 if tape.dtype == torch.float64 else torch.float32)).to(tape.dtype))
+        elif code == _hip.TAPE_ADD:
+            vals.append(vals[a] + vals[b])
+        elif code == _hip.TAPE_SUB:
+            vals.append(vals[a] - vals[b])
+        elif code == _hip.TAPE_MUL:
+            vals.append(vals[a] * vals[b])
+        elif code == _hip.TAPE_DIV:
+            vals.append(vals[a] / vals[b])
+        elif code == _hip.TAPE_NEG:
+            vals.append(-vals[a])
+        else:
+            raise AssertionError(code)
+        assert vals[-1].dtype == tape.dtype
+    return [vals[v.n] for v in results]
+
+
+def record(sampler, x, out, step, model, sched, noise, previous):
+    packed = PT.SampleInput(x, out, step, noise)
+    if type(sampler) is PT.UniPC:
+        tape, res = native.record_unipc(sampler, packed, model, sched, previous, require_device=False)
+        s, p, f = interpret(tape, res)
+        return PT.SKSamples(s, p, step, noise, f), tape
+    tape, res = native.record_stated(sampler, packed, model, sched, previous, require_device=False)
+    return PT.SKSamples(x, out, step, noise, interpret(tape, res)[0]), tape
+
+
+@pytest.mark.parametrize("tag", NATIVE16_TAGS)
+def test_recorded_steps_return_the_reference_bits(tag):
+    dt, steps, mname, sname, expr, t = native16_case(load_npz("native16.npz"), tag)
+    sampler, sched, model = eval(expr, {"S": PT}), SCHEDULES[sname][1](), MODELS[mname][1]
+    previous = []
+    longest = 0
+    for i in range(steps):
+        x, out, nz = t["x"][i], t["out"][i], t["noise"][i]
+        rec, tape = record(sampler, x, out, Step.from_int(i, steps), model, sched, nz if sampler.require_noise else None, tuple(previous))
+        assert rec.final.dtype == dt and torch.equal(rec.final, t["final"][i]), (tag, i)
+        assert torch.equal(torch.as_tensor(rec.prediction), t["prediction"][i]), (tag, i)
+        longest = max(longest, len(tape.ops))
+        previous.append(rec)
+        keep = sampler.require_previous
+        previous = previous[max(len(previous) - keep, 0) :] if keep else []
+    assert longest <= _hip.TAPE_MAX_OPS
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("name", ["euler_sde", "dpm1_sde", "dpm2_sde", "dpm3_sde", "adams4_sde", "adams9", "unip2_fast", "unip4_sde", "unipc1", "unipc2_fast", "unipc3_sde",
+                                  "unipc2_adams3", "dpm2_deriv_v", "unipc3_deriv_flow_sde", "adams3_noderiv", "unipc3_noderiv"])
+def test_recorded_steps_equal_the_oracles_native_chain(name, dtype):
+    "every sampler family x model x schedule: the recorded tape == the oracle's reference-order chain run in the tensor dtype, bit for bit"
+    mk_o, mk_p = SAMPLERS[name]
+    steps, shape = 9, (2, 3, 8, 8)
+    for sname, mname in (("karras_scaled", "eps"), ("linear", "flow"), ("zsnr", "v"), ("scaled", "scalex"), ("scaled", "data")):
+        g = torch.Generator().manual_seed(zlib.crc32(f"{name}/{sname}/{mname}".encode()))
+        cfg, sampler = mk_o(), mk_p()
+        sched, osched, (omodel, model) = SCHEDULES[sname][1](), SCHEDULES[sname][0](), MODELS[mname]
+        x = torch.randn(shape, generator=g).to(dtype)
+        previous, oprevious = [], []
+        for i in range(steps - (1 if sname == "zsnr" else 0)):
+            out = torch.randn(shape, generator=g).to(dtype)
+            nz = torch.randn(shape, generator=g).to(dtype)
+            noise = nz if sampler.require_noise else None
+            rec, tape = record(sampler, x, out, Step.from_int(i, steps), model, sched, noise, tuple(previous))
+            ref = OA.sample(cfg, x, out, (i / steps, (i + 1) / steps), omodel, osched, noise, oprevious)
+            assert ref.final.dtype == dtype
+            same = torch.equal(rec.final, ref.final) or (torch.isnan(ref.final).any() and torch.equal(torch.isnan(rec.final), torch.isnan(ref.final)))
+            assert same, (name, sname, mname, i, (rec.final.float() - ref.final.float()).abs().max())
+            previous.append(rec)
+            oprevious.append(ref)
+            keep = sampler.require_previous
+            previous = previous[max(len(previous) - keep, 0) :] if keep else []
+            oprevious = oprevious[max(len(oprevious) - keep, 0) :] if keep else []
+            x = ref.final
+
+
+@pytest.mark.parametrize("tag", NATIVE16_TAGS)
+def test_host_tensors_take_the_same_path(tag):
+    "StructuredSampler.sample on host-resident bf16 / fp16 tensors == the reference-recorded runs, bit for bit (same dispatch as on the device)"
+    dt, steps, mname, sname, expr, t = native16_case(load_npz("native16.npz"), tag)
+    sampler, sched, model = eval(expr, {"S": PT}), SCHEDULES[sname][1](), MODELS[mname][1]
+    previous = []
+    for i in range(steps):
+        rec = sampler.sample(t["x"][i], t["out"][i], Step.from_int(i, steps), model, sched, t["noise"][i] if sampler.require_noise else None, tuple(previous))
+        assert torch.equal(rec.final, t["final"][i]) and torch.equal(torch.as_tensor(rec.prediction), t["prediction"][i]), (tag, i)
+        previous.append(rec)
+        keep = sampler.require_previous
+        previous = previous[max(len(previous) - keep, 0) :] if keep else []
+
+
+def test_register_allocation_and_refusals():
+    "the launch form of a tape: registers below SKR_TAPE_REGS, every read of a live value, results stored once; CPU tensors never launch"
+    sampler, sched, model = PT.DPM(order=3, stochasticity=1), SCHEDULES["scaled"][1](), MODELS["eps"][1]
+    g = torch.Generator().manual_seed(3)
+    shape, steps = (2, 4, 8, 8), 9
+    mk = lambda: torch.randn(shape, generator=g).bfloat16()  # noqa: E731
+    previous = [PT.SKSamples(mk(), mk(), Step.from_int(i, steps), None, mk()) for i in (2, 3)]
+    packed = PT.SampleInput(mk(), mk(), Step.from_int(4, steps), mk())
+    tape, res = native.record_stated(sampler, packed, model, sched, previous, require_device=False)
+    assert sum(1 for op in tape.ops if op[0] == _hip.TAPE_LOAD) == 7  # x, out, noise, two history pairs
+    launched = native.launches
+    rec = native.try_stated(sampler, packed, model, sched, previous)  # host tensors: the tape op by op in torch, never a launch
+    assert rec is not None and native.launches == launched and torch.equal(rec.final, interpret(tape, res)[0])
+    with pytest.raises(native._Refused):
+        native.record_stated(sampler, PT.SampleInput(packed.sample, packed.prediction.float(), packed.step, None), model, sched, previous, require_device=False)
+    with pytest.raises(native._Refused):
+        native.record_stated(PT.SPC(), packed, model, sched, previous, require_device=False)

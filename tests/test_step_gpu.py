@@ -366,13 +366,24 @@ def test_inner_boundary_sample_packed(dev):
     assert_close(sched.ipoint(0.3).add_noise(xd, od), x * p.alpha + out * p.sigma, torch.float32, "add_noise")
 
 
+@pytest.fixture
+def fused_mode():
+    "sampler-level calls on 16-bit tensors through the fused kernel (native.mode = 'never'), as every call was before round 5"
+    from skrample_amd.sampling import native
+
+    before, native.mode = native.mode, "never"
+    yield
+    native.mode = before
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kind", ["dpm2_sde", "adams3", "euler"])
-def test_sampler_level_api_on_16_bit_tensors(dtype, kind, dev):
+def test_sampler_level_api_on_16_bit_tensors(dtype, kind, dev, fused_mode):
     """Called directly (no wrapper), the reference's samplers compute in the TENSOR dtype, rounding after every op
-    (structured.py:209-283 -- only its wrappers widen to compute_scale); this engine accumulates the collapsed form in fp32 and
-    rounds once.  Stated difference, pinned here: the results differ by a few last-place units of the 16-bit type, and the
-    engine's is never farther from the exact (fp64) answer than the reference's native-dtype chain is."""
+    (structured.py:209-283 -- only its wrappers widen to compute_scale).  Since round 5 that call replays the reference's own
+    sequence (sampling/native.py, tests below); with native.mode = "never" it takes the fused kernel, which accumulates the collapsed
+    form in fp32 and rounds once.  Pinned here for that mode: the results differ by a few last-place units of the 16-bit type, and the
+    fused result is never farther from the exact (fp64) answer than the reference's native-dtype chain is."""
     mk_o, mk_p = {"dpm2_sde": (OA.make("dpm", 2, eta=1), PT.DPM(order=2, stochasticity=1)), "adams3": (OA.make("adams", 3), PT.Adams(order=3)),
                   "euler": (OA.make("euler"), PT.Euler())}[kind]  # fmt: skip
     sched, model, osched = PS.Scaled(), PM.NoiseModel(), OS.scaled()
@@ -428,8 +439,128 @@ def native16_engine_vs_reference(tag, device):
 
 
 @pytest.mark.parametrize("tag", NATIVE16_TAGS)
-def test_sampler_level_api_vs_reference_recorded_16_bit_runs(tag, dev):
+def test_sampler_level_api_vs_reference_recorded_16_bit_runs(tag, dev, fused_mode):
     native16_engine_vs_reference(tag, dev)
+
+
+@pytest.mark.parametrize("tag", NATIVE16_TAGS)
+def test_sampler_level_api_returns_the_reference_bits(tag, dev):
+    """StructuredSampler.sample on bf16 / fp16 device tensors (default mode): the reference-recorded runs of tests/golden/native16.npz --
+    Euler ODE / SDE, DPM-2 SDE, DPM-3 flow, Adams-3, UniPC-3, seven steps each, every step on the reference's own inputs and its own
+    history records -- come back BIT FOR BIT, `final` and the record's `prediction`, each step in one launch of skr_tape_launch."""
+    from skrample_amd.sampling import native
+
+    dt, steps, mname, sname, expr, t = native16_case(load_npz("native16.npz"), tag)
+    sampler, sched, model = eval(expr, {"S": PT}), SCHEDULES[sname][1](), MODELS[mname][1]
+    previous = []
+    for i in range(steps):
+        x, out, nz = t["x"][i].to(dev), t["out"][i].to(dev), t["noise"][i].to(dev)
+        before = native.launches
+        rec = sampler.sample(x, out, PT.Step.from_int(i, steps), model, sched, nz if sampler.require_noise else None, tuple(previous))
+        assert native.launches == before + 1, (tag, i)
+        assert rec.final.dtype == dt and torch.equal(rec.final.cpu(), t["final"][i]), (tag, i, "final")
+        assert torch.equal(torch.as_tensor(rec.prediction).cpu(), t["prediction"][i]), (tag, i, "prediction")
+        previous.append(rec)
+        keep = sampler.require_previous
+        previous = previous[max(len(previous) - keep, 0) :] if keep else []
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, torch.float64])
+@pytest.mark.parametrize("name", ["euler_sde", "dpm3_sde", "adams9", "unip4_sde", "unipc3_sde", "unipc2_adams3", "unipc3_deriv_flow_sde", "unipc3_noderiv"])
+def test_tape_kernel_equals_the_oracles_native_chain(name, dtype, dev):
+    """Every op of the tape kernel on ragged sizes: sampler families x models x schedules on device tensors whose element count is not
+    a multiple of the lane width, against the oracle's reference-order chain in the tensor dtype (fp32 / fp64: native.mode = 'always')."""
+    from skrample_amd.sampling import native
+
+    mk_o, mk_p = SAMPLERS[name]
+    steps, shape = 8, (3, 5, 7, 3)  # 315 elements: a ragged tail
+    before, native.mode = native.mode, "always"
+    try:
+        for sname, mname in (("karras_scaled", "eps"), ("linear", "flow"), ("scaled", "scalex")):
+            g = torch.Generator().manual_seed(zlib.crc32(f"{name}/{sname}/{mname}/{dtype}".encode()))
+            cfg, sampler = mk_o(), mk_p()
+            sched, osched, (omodel, model) = SCHEDULES[sname][1](), SCHEDULES[sname][0](), MODELS[mname]
+            x = torch.randn(shape, generator=g).to(dtype)
+            previous, oprevious = [], []
+            for i in range(steps):
+                out = torch.randn(shape, generator=g).to(dtype)
+                nz = torch.randn(shape, generator=g).to(dtype)
+                launched = native.launches
+                rec = sampler.sample(x.to(dev), out.to(dev), PT.Step.from_int(i, steps), model, sched, nz.to(dev) if sampler.require_noise else None, tuple(previous))
+                assert native.launches == launched + 1
+                ref = OA.sample(cfg, x, out, (i / steps, (i + 1) / steps), omodel, osched, nz if sampler.require_noise else None, oprevious)
+                assert rec.final.dtype == dtype and torch.equal(rec.final.cpu(), ref.final), (name, sname, mname, i, (rec.final.cpu().double() - ref.final.double()).abs().max())
+                previous.append(rec)
+                oprevious.append(ref)
+                keep = sampler.require_previous
+                previous = previous[max(len(previous) - keep, 0) :] if keep else []
+                oprevious = oprevious[max(len(oprevious) - keep, 0) :] if keep else []
+                x = ref.final
+    finally:
+        native.mode = before
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, torch.float64])
+def test_tape_ops_through_the_c_abi(dtype, dev):
+    "every op code of skr_tape_launch against the same torch op on CPU tensors of that dtype (one rounding per op), whole vectors and a ragged tail"
+    lib = _hip.load()
+    for numel in (4096, 1023, 3):
+        g = torch.Generator().manual_seed(numel)
+        a, b = torch.randn(numel, generator=g).to(dtype), (torch.randn(numel, generator=g) + 3.0).to(dtype)
+        wide = torch.float64 if dtype == torch.float64 else torch.float32  # the op-math type
+        T = _hip
+        programs = [
+            ([(T.TAPE_LOAD, 0, 0, 0, 0.0), (T.TAPE_LOAD, 1, 1, 0, 0.0), (T.TAPE_RSUB_S, 2, 0, 0, 1.5), (T.TAPE_STORE, 0, 2, 0, 0.0), (T.TAPE_RDIV_S, 2, 1, 0, 2.25), (T.TAPE_STORE, 0, 2, 1, 0.0),
+              (T.TAPE_MUL, 2, 0, 1, 0.0), (T.TAPE_STORE, 0, 2, 2, 0.0), (T.TAPE_DIV, 3, 0, 1, 0.0), (T.TAPE_STORE, 0, 3, 3, 0.0)],
+             lambda: [1.5 - a, (torch.tensor(2.25, dtype=wide) / b.to(wide)).to(dtype), a * b, a / b]),  # (k / x: ONE correctly rounded division; torch's own `k / tensor` is reciprocal() * k)
+            ([(T.TAPE_LOAD, 5, 0, 0, 0.0), (T.TAPE_LOAD, 15, 1, 0, 0.0), (T.TAPE_NEG, 0, 5, 0, 0.0), (T.TAPE_STORE, 0, 0, 0, 0.0), (T.TAPE_MUL_S, 1, 5, 0, 0.3), (T.TAPE_ADD, 1, 1, 15, 0.0),
+              (T.TAPE_DIV_S, 1, 1, 0, 0.7), (T.TAPE_ADD_S, 1, 1, 0, -0.125), (T.TAPE_SUB, 1, 1, 5, 0.0), (T.TAPE_STORE, 0, 1, 1, 0.0)],
+             lambda: [-a, ((a * 0.3 + b) / 0.7 + -0.125) - a]),
+        ]
+        for ops, ref in programs:
+            want = ref()
+            tape = _hip.TapeC()
+            for j, (code, dst, ra, rb, k) in enumerate(ops):
+                tape.ops[j].code, tape.ops[j].dst, tape.ops[j].a, tape.ops[j].b, tape.ops[j].k = code, dst, ra, rb, k
+            tape.n_ops, tape.n_inputs, tape.n_outputs, tape.dtype = len(ops), 2, len(want), _hip.DTYPE_CODE[dtype]
+            ad, bd = a.to(dev), b.to(dev)
+            outs = [torch.empty(numel, dtype=dtype, device=dev) for _ in want]
+            ins = (ctypes.c_void_p * 2)(ad.data_ptr(), bd.data_ptr())
+            ous = (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+            assert lib.skr_tape_launch(ctypes.byref(tape), ins, ous, numel, _hip.current_stream_ptr(dev)) == 0
+            for got, w in zip(outs, want):
+                assert torch.equal(got.cpu(), w), (dtype, numel, (got.cpu().double() - w.double()).abs().max())
+    bad = _hip.TapeC()
+    bad.n_ops, bad.n_inputs, bad.n_outputs, bad.dtype = 1, 1, 1, _hip.BF16
+    bad.ops[0].code, bad.ops[0].dst, bad.ops[0].a = _hip.TAPE_MUL_S, 16, 0  # register out of range
+    x = torch.zeros(8, dtype=torch.bfloat16, device=dev)
+    one = (ctypes.c_void_p * 1)(x.data_ptr())
+    assert lib.skr_tape_launch(ctypes.byref(bad), one, one, 8, _hip.current_stream_ptr(dev)) == 3  # SKR_ERR_TERMS
+
+
+def test_wrappers_keep_their_compute_scale(dev):
+    "the scheduler wrappers widen to compute_scale before the sampler runs (reference diffusers.py:575-599): fused kernel; compute_scale=None: the tape"
+    from skrample_amd.sampling import native
+
+    shape, steps = (2, 4, 16, 16), 6
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(shape, generator=g).bfloat16().to(dev)
+    outs = [torch.randn(shape, generator=g).bfloat16().to(dev) for _ in range(steps)]
+
+    def run(w):
+        w.set_timesteps(steps)
+        x = x0
+        for t, o in zip(w.timesteps.tolist(), outs):
+            x = w.step(o, t, x, return_dict=False)[0]
+        return x
+
+    launched = native.launches
+    wide = run(PD.SkrampleWrapperScheduler(PT.DPM(order=2), PS.Scaled()))
+    assert native.launches == launched  # fp32 compute scale: one fused launch per step, as ever
+    narrow = run(PD.SkrampleWrapperScheduler(PT.DPM(order=2), PS.Scaled(), compute_scale=None))
+    assert native.launches == launched + steps  # no widening asked for: the reference computes in bf16, and so does the tape
+    assert narrow.dtype == wide.dtype == torch.bfloat16 and not torch.equal(narrow, wide)
+    assert ((narrow.float() - wide.float()).abs().max() / wide.float().abs().max()).item() < 0.05  # (a 6-step bf16 chain drifts by a few last places)
 
 
 @pytest.mark.parametrize("shape", [(3, 4, 32, 32), (2, 3, 16, 16), (2, 6, 16, 16), (3, 1, 8, 8)])
