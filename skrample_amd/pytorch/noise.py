@@ -24,6 +24,8 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
+import threading
 from abc import ABC, abstractmethod
 from dataclasses import dataclass, field
 from functools import lru_cache
@@ -62,7 +64,19 @@ def seed_device(seed) -> torch.device:
 _seed_vectors: dict = {}  # (device, seed values) -> device int64 vector: read-only by convention, so runs with the same seeds share one upload
 
 
-_private_vectors = [0]  # > 0: seed vectors are neither looked up nor kept (skrample_amd.graphs captures loops that overwrite theirs in place)
+class _PrivateVectors(threading.local):
+    "per THREAD: > 0 means seed vectors are neither looked up nor kept (skrample_amd.graphs captures loops that overwrite theirs in place)"
+
+    depth = 0
+
+    def __getitem__(self, _i):  # (kept subscriptable: graphs.py counts it up and down as `_private_vectors[0] += 1`)
+        return self.depth
+
+    def __setitem__(self, _i, value):
+        self.depth = value
+
+
+_private_vectors = _PrivateVectors()
 
 
 def forget_seed_vector(vector: torch.Tensor | None) -> None:
@@ -73,13 +87,16 @@ def forget_seed_vector(vector: torch.Tensor | None) -> None:
 
 def seeds_tensor(values: Sequence[int], device: torch.device) -> torch.Tensor:
     key = (device, tuple(values))
-    private = _private_vectors[0] > 0
+    # (a caller's own stream capture takes a vector of its own too: the graph would keep reading a shared one after the cache let it go)
+    private = _private_vectors[0] > 0 or (device.type == "cuda" and torch.cuda.is_current_stream_capturing())
     hit = None if private else _seed_vectors.get(key)
     if hit is not None:
+        if device.type == "cuda":  # shared across wrappers and streams: tell the allocator this stream reads it too, so that the block is
+            hit.record_stream(torch.cuda.current_stream(device))  # not recycled under a kernel still reading it once every holder let go
         return hit
     signed = [v - (1 << 64) if v >= (1 << 63) else v for v in values]
     out = torch.tensor(signed, dtype=torch.int64, device=device)
-    if device.type == "cuda" and not private and not torch.cuda.is_current_stream_capturing():
+    if device.type == "cuda" and not private:
         if len(_seed_vectors) >= 8:
             _seed_vectors.pop(next(iter(_seed_vectors)))
         _seed_vectors[key] = out
@@ -560,6 +577,7 @@ def brownian_path(t: float, depth: int) -> dict[int, float]:
 BROWNIAN_GRID_NODE = 1 << 61  # stream namespace of index-bisection nodes (| heap index)
 BROWNIAN_CELL_NODE = 1 << 60  # stream namespace of in-cell bridge nodes (| cell << 24 | heap index inside the cell)
 BROWNIAN_MAX_GRID = 1 << 20
+BROWNIAN_SCHEDULE_PARTITION = os.environ.get("SKR_BROWNIAN_PARTITION", "") not in ("", "0")  # see Brownian._batch
 
 
 def brownian_grid_index(t: float, n: int) -> int | None:
@@ -673,8 +691,13 @@ class Brownian(TensorNoiseCommon):
         if cache is None or tuple(cache.shape) != shape or cache.device != seeds.device:
             cache = state["brownian_cache"] = torch.empty(shape, dtype=torch.float32, device=seeds.device)
             state["brownian_cache_time"] = None
-        if "brownian_grid" not in state:  # the first query decides which path this generator draws from (see "the schedule's own partition")
-            state["brownian_grid"] = brownian_grid_of(t0, t1)
+        if "brownian_grid" not in state:
+            # Default: the dyadic tree -- W(t) is a function of (seed, t) alone, so the same seed walks the same path whatever the step count
+            # or the order of the queries, as torchsde's BrownianInterval does for the reference.  Opt-in
+            # (BROWNIAN_SCHEDULE_PARTITION / SKR_BROWNIAN_PARTITION=1): the path is built over the N-cell partition the FIRST query
+            # belongs to -- 6x cheaper per step (0.21 against 1.33 ms at 256 x (16,128,128)), but a 20-step and a 30-step run of one seed
+            # then see different paths.
+            state["brownian_grid"] = brownian_grid_of(t0, t1) if BROWNIAN_SCHEDULE_PARTITION else None
         hit = state.get("brownian_cache_time") == t0
         nodes, w_to, w_from = brownian_endpoints(None if hit else t0, t1, depth, state["brownian_grid"])
         if len(nodes) > 64:

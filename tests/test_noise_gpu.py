@@ -111,9 +111,18 @@ def test_offset(unit, props, dev):
 
 
 @pytest.mark.parametrize("unit", [(4, 16, 16), (3, 5, 7)])
-def test_brownian(unit, dev):
+def test_brownian(unit, dev, monkeypatch):
     "increments of one fixed Brownian path per seed: oracle parity, additivity over adjacent steps, determinism"
     seeds = [31, 32]
+    # default: ONE path per seed whatever the discretisation (the dyadic tree): a 20-step and a 40-step walk over [0.25, 0.5] add up to the
+    # same W(0.5) - W(0.25), and a generator asked the coarse step first agrees with one asked the fine steps first
+    mk = lambda: PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, props=PN.BrownianProps(), dtype=torch.float32)  # noqa: E731
+    coarse, fine, whole = mk(), mk(), mk()
+    w20 = sum(coarse.generate(Step.from_int(k, 20)).cpu().double() for k in range(5, 10)) * math.sqrt(1 / 20)
+    w40 = sum(fine.generate(Step.from_int(k, 40)).cpu().double() for k in range(10, 20)) * math.sqrt(1 / 40)
+    assert coarse._state["brownian_grid"] is None and fine._state["brownian_grid"] is None
+    assert rel(w20, w40) < 1e-5 and rel(w20, whole.generate(Step(0.25, 0.5)).cpu().double() * 0.5) < 1e-5
+    monkeypatch.setattr(PN, "BROWNIAN_SCHEDULE_PARTITION", True)  # the opt-in: the path over the schedule's own partition (one run, one step count)
     g = PN.BatchTensorNoise.from_batch_inputs(PN.Brownian, unit, seeds, props=PN.BrownianProps(), dtype=torch.float32)
     steps = [Step(0.35, 0.4), Step(0.4, 0.45), Step(0.35, 0.45), Step(0.0, 0.05), Step(0.95, 1.0), Step(0.5, 0.75)]
     got = {s: g.generate(s).cpu().double() for s in steps}
