@@ -77,6 +77,7 @@ class _PrivateVectors(threading.local):
 
 
 _private_vectors = _PrivateVectors()
+_captured_vectors: list = []  # shared vectors a caller's stream capture picked up (kept for the life of the process: a few hundred bytes each)
 
 
 def forget_seed_vector(vector: torch.Tensor | None) -> None:
@@ -87,16 +88,18 @@ def forget_seed_vector(vector: torch.Tensor | None) -> None:
 
 def seeds_tensor(values: Sequence[int], device: torch.device) -> torch.Tensor:
     key = (device, tuple(values))
-    # (a caller's own stream capture takes a vector of its own too: the graph would keep reading a shared one after the cache let it go)
-    private = _private_vectors[0] > 0 or (device.type == "cuda" and torch.cuda.is_current_stream_capturing())
+    private = _private_vectors[0] > 0
     hit = None if private else _seed_vectors.get(key)
     if hit is not None:
-        if device.type == "cuda":  # shared across wrappers and streams: tell the allocator this stream reads it too, so that the block is
-            hit.record_stream(torch.cuda.current_stream(device))  # not recycled under a kernel still reading it once every holder let go
+        if device.type == "cuda":
+            if torch.cuda.is_current_stream_capturing():
+                _captured_vectors.append(hit)  # a caller's own graph will read it at every replay: it must outlive the cache's interest in it
+            else:  # shared across wrappers and streams: tell the allocator this stream reads it too, so that the block is not recycled
+                hit.record_stream(torch.cuda.current_stream(device))  # under a kernel still reading it once every holder let go
         return hit
     signed = [v - (1 << 64) if v >= (1 << 63) else v for v in values]
     out = torch.tensor(signed, dtype=torch.int64, device=device)
-    if device.type == "cuda" and not private:
+    if device.type == "cuda" and not private and not torch.cuda.is_current_stream_capturing():
         if len(_seed_vectors) >= 8:
             _seed_vectors.pop(next(iter(_seed_vectors)))
         _seed_vectors[key] = out
