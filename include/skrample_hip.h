@@ -255,16 +255,16 @@ int skr_noise_colored(void* out, int32_t out_dtype, void* spec_c64, float* scrat
                       int32_t d1, int32_t d2, int32_t d3, double exponent, int32_t has_energy, double energy,
                       void* stream);
 
-/* Same generator for per-sample shapes that are not powers of two (rank 1-6 after dropping size-1 dims, any
+/* Same generator for per-sample shapes that are not powers of two (rank 1-12 after dropping size-1 dims, any
  * sizes >= 2): identical pipeline; the real N-D transform of the inner (up to three) axes runs on the library's own
- * any-length kernels (skr_fft_own.hip: powers of two and 2^a 3^b 5^c lengths (b + c <= 3) directly, up to 4096; every other
- * length <= 2048 through Bluestein's chirp-z on
- * the same LDS tile transform; its per-length tables are allocated on first use, outside stream capture).  hipFFT
- * (dlopen'ed on first use) serves only axes longer than that, or everything when asked for (skr_set_tuning "hipfft" /
- * SKR_FFT_HIPFFT); SKR_ERR_UNSUPPORTED when it is needed and libhipfft.so is absent.  Rank 4-6 (e.g. channels x frames x
- * height x width): every outer axis (<= 128 long) is a direct DFT kernel, the outermost one fused with the radial
- * weights.  Workspaces: spec_c64 = batch*prod(dims[:-1])*(dims[-1]/2+1)
- * complex64, scratch_f32 = batch*prod(dims), partials_f64 = 4*batch*256 doubles. */
+ * any-length kernels (skr_fft_own.hip): lengths 2^a r with r a product of at most three factors out of 3, 5, 7, 11, 13 directly
+ * (up to 4096), every other length <= 2048 through Bluestein's chirp-z on the same LDS tile transform (its per-length tables are
+ * allocated on first use, outside stream capture: SKR_ERR_CAPTURE), and a LAST axis of any even length n = 2 A B with A, B such
+ * lengths (8192, 65536, 5000, 10010 ...) as a half-length complex transform in four steps over the same kernels.
+ * hipFFT (dlopen'ed on first use) runs only when asked for (skr_set_tuning "hipfft" 1 / SKR_FFT_HIPFFT): a shape outside the above
+ * is SKR_ERR_UNSUPPORTED otherwise.  More than three axes (e.g. channels x frames x height x width): every outer axis
+ * (<= 128 long, at most nine of them) is a direct DFT kernel, the outermost one fused with the radial weights.
+ * Workspaces: spec_c64 = batch*prod(dims[:-1])*(dims[-1]/2+1) complex64, scratch_f32 = batch*prod(dims), partials_f64 = 4*batch*256 doubles. */
 int skr_noise_colored_any(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
                           const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank,
                           const int32_t* dims, double exponent, int32_t has_energy, double energy, void* stream);
@@ -317,8 +317,8 @@ const char* skr_build_info(void);
  *                   128 for 4-6 operands, 256 otherwise)
  *   "fft_rank" 0|1|2  skr_noise_colored_any / skr_colorize: trailing axes handed to the N-D transform (0 = up to three, the
  *                   default); the other axes run on the direct-DFT kernels (results agree to rounding, not bit for bit)
- *   "hipfft"   -1|0|1  the N-D transform of those axes: 0 the library's own kernels (any axis length up to 2048, powers of two and
- *                   2^a 3^b 5^c lengths up to 4096), 1 hipFFT (dlopen'ed; also what longer axes take), -1 = by the environment, the default: own
+ *   "hipfft"   -1|0|1  the N-D transform of those axes: 0 the library's own kernels (skr_noise_colored_any's comment lists the lengths;
+ *                   anything else is SKR_ERR_UNSUPPORTED), 1 hipFFT (dlopen'ed; any length), -1 = by the environment, the default: own
  *                   kernels unless SKR_FFT_HIPFFT is set
  *   "reset"    (value ignored) back to the defaults
  * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_NO_TWO_OUT, SKR_RK_UV=n, SKR_RK_BLK=n. */

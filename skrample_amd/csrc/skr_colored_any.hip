@@ -24,6 +24,7 @@ int g_fft_rank = 0;
 int g_use_hipfft = -1;  // skr_set_tuning("hipfft"): 1 = the inner axes on hipFFT, 0 = on skr_fft_own.hip, -1 = by the environment (SKR_FFT_HIPFFT set: hipFFT)
 // (skr_fft_own.hip) rfftn / irfftn of any axis lengths on the LDS tile transform
 int own_prepare(int dev, int n0, int n1, int n2, hipStream_t s);
+bool own_length_ok(int n, bool last);
 int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s, bool skip_outer);
 int own_outer_weighted(int dev, float2* spec, int64_t entries, int n0, int n1, int n2, float inv_rmax, float eps_clip, float exponent_half_neg, hipStream_t s);
 }
@@ -78,6 +79,8 @@ std::atomic<int64_t> g_hipfft_plans{0}, g_hipfft_execs{0}, g_own_execs{0};  // s
 
 constexpr int SLOTS = 256;  // partial-sum slots per sample (one per block of the stats kernels)
 
+constexpr int SKR_ANY_MAX_OUTER = 9;  // leading axes on the direct-DFT kernels: units of up to 12 transform axes (reference noise.py:373-403 takes any)
+
 struct AnyArgs {
   float* real;          // [batch][unit]
   float2* spec;         // [batch][d1][d2][d3h]
@@ -86,7 +89,7 @@ struct AnyArgs {
   uint64_t stream;
   int64_t batch, unit;
   int32_t n_outer;      // axes outside the hipFFT axes (0..5), outermost first; each is a direct DFT (any_outer_axis)
-  int32_t outer[5];
+  int32_t outer[SKR_ANY_MAX_OUTER];
   int32_t d1, d2, d3, d3h;
   float exponent_half_neg, eps_clip, inv_rmax;
 };
@@ -478,26 +481,19 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
   static const bool env_hipfft = getenv("SKR_FFT_HIPFFT") != nullptr;
   const bool prefer_hipfft = skr::g_use_hipfft < 0 ? env_hipfft : skr::g_use_hipfft != 0;
   bool own = !planes && !prefer_hipfft;
-  for (int i = (rank > fft_rank ? rank - fft_rank : 0); own && i < rank; ++i) {
-    const int d = dims[i];
-    own = d <= 2048;  // Bluestein's limit
-    if (!own && d <= 4096) {  // a direct length of skr_fft_own.hip: 2^a, or 2^a 3^b 5^c with a >= 1 and b + c <= 3
-      int rest = d, odd = 0;
-      while (rest % 5 == 0 && odd < 3) { rest /= 5; ++odd; }
-      while (rest % 3 == 0 && odd < 3) { rest /= 3; ++odd; }
-      own = (rest & (rest - 1)) == 0 && (odd == 0 || rest >= 2);
-    }
-  }
-  if (!planes && !own && !api().ok) return SKR_ERR_UNSUPPORTED;  // hipFFT not present on this machine
+  for (int i = (rank > fft_rank ? rank - fft_rank : 0); own && i < rank; ++i) own = skr::own_length_ok(dims[i], i == rank - 1);  // (skr_fft_own.hip)
+  // hipFFT only when it is asked for (skr_set_tuning "hipfft" 1 / SKR_FFT_HIPFFT): a shape the own transforms do not take -- an axis that is
+  // neither a tile length nor, as the last axis, an even product of two -- is refused, not handed to the vendor library behind the caller's back
+  if (!planes && !own && (!prefer_hipfft || !api().ok)) return SKR_ERR_UNSUPPORTED;
   const int full_rank = rank;
   const int32_t* full_dims = dims;
   AnyArgs a;
   a.n_outer = 0;
-  for (int j = 0; j < 5; ++j) a.outer[j] = 1;
+  for (int j = 0; j < SKR_ANY_MAX_OUTER; ++j) a.outer[j] = 1;
   int64_t d0 = 1;  // product of the outer axes
   if (rank > fft_rank) {  // outer axes by direct DFT (any_outer_axis), the inner ones by hipFFT batched over batch * prod(outer)
     a.n_outer = rank - fft_rank;
-    if (a.n_outer > 5) return SKR_ERR_UNSUPPORTED;
+    if (a.n_outer > SKR_ANY_MAX_OUTER) return SKR_ERR_UNSUPPORTED;
     for (int j = 0; j < a.n_outer; ++j) {
       if (dims[j] > 128) return SKR_ERR_UNSUPPORTED;  // (d + 2*d*64) float2 of LDS: 132 KiB at 128
       a.outer[j] = dims[j];
@@ -684,7 +680,7 @@ static int colored_any_attempt(void* out, int32_t out_dtype, void* spec_c64, flo
 static int colored_any_impl(void* out, int32_t out_dtype, void* spec_c64, float* scratch_f32, double* partials_f64,
                             const uint64_t* seeds_dev, uint64_t stream_id, int64_t batch, int32_t rank, const int32_t* dims,
                             double exponent, int32_t has_energy, double energy, void* stream, bool white_given) {
-  if (batch < 0 || rank < 1 || rank > 6 || !dims) return SKR_ERR_SHAPE;
+  if (batch < 0 || rank < 1 || rank > 3 + SKR_ANY_MAX_OUTER || !dims) return SKR_ERR_SHAPE;
   for (int i = 0; i < rank; ++i) if (dims[i] < 2) return SKR_ERR_SHAPE;
   if (batch == 0) return SKR_OK;
   if (!out || !spec_c64 || !scratch_f32 || !partials_f64 || (!white_given && !seeds_dev)) return SKR_ERR_NULL;

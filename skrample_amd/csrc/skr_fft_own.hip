@@ -4,9 +4,9 @@
 // latents, odd heights, 13 frames ...).  The plane kernels of skr_colored.hip take powers of two and 2^a x (odd <= 63); everything else
 // went to a vendor library.  Here an axis of length n is transformed
 //   * directly by fft_tile when n is a power of two (<= 4096);
-//   * directly when n = 2^a 3^b 5^c (a >= 1, b + c <= 3, n <= 4096: 6, 10, 12, 20, 30, 60, 90, 120, 250, 720, 1280 ...): the
-//     r = 3^b 5^c interleaved sub-sequences of 2^a points each go through fft_tile and are joined by b + c radix-3 / radix-5 passes
-//     (own_radix), innermost decimation first;
+//   * directly when n = 2^a r, a >= 1, r a product of at most three factors out of 3, 5, 7, 11, 13 (n <= 4096: 6, 10, 12, 14, 20, 22, 26,
+//     30, 60, 66, 90, 120, 130, 250, 720, 1280 ...): the r interleaved sub-sequences of 2^a points each go through fft_tile and are joined
+//     by one radix-3 / 5 / 7 / 11 / 13 pass per factor (own_radix), innermost decimation first;
 //   * otherwise
 //   * by Bluestein's chirp-z identity  n k = (n^2 + k^2 - (k - n)^2) / 2 :
 //       X[k] = w[k] * sum_j (x[j] w[j]) conj(w[k - j]),   w[k] = exp(-i pi k^2 / n),
@@ -152,6 +152,52 @@ template <bool INV> __device__ __forceinline__ void dft5(float2 v[5]) {
   v[0] = cadd(v[0], cadd(t1, t2));
   v[1] = cadd(a1, b1); v[4] = csub(a1, b1); v[2] = cadd(a2, b2); v[3] = csub(a2, b2);
 }
+// 7, 11 and 13 points (round 5: lengths such as 66 = 2 3 11 and 130 = 2 5 13 went through Bluestein, 1.5x slower than the vendor library):
+// the direct sum over the (R - 1) / 2 conjugate pairs,  X[k], X[R - k] = x0 + sum_j (x_j + x_(R-j)) cos(2 pi j k / R) -+ i sum_j (x_j - x_(R-j)) sin(2 pi j k / R)
+// -- (R - 1)^2 / 2 real-by-complex multiply-adds, every index a compile-time constant.
+template <int R> struct PrimeTable;
+template <> struct PrimeTable<7> {
+  static constexpr float c[3] = {0.62348980185873359f, -0.22252093395631434f, -0.90096886790241903f};
+  static constexpr float s[3] = {0.7818314824680298f, 0.97492791218182362f, 0.43388373911755823f};
+};
+template <> struct PrimeTable<11> {
+  static constexpr float c[5] = {0.84125353283118121f, 0.41541501300188644f, -0.142314838273285f, -0.65486073394528499f, -0.95949297361449737f};
+  static constexpr float s[5] = {0.54064081745559756f, 0.90963199535451833f, 0.9898214418809328f, 0.75574957435425827f, 0.28173255684142967f};
+};
+template <> struct PrimeTable<13> {
+  static constexpr float c[6] = {0.88545602565320991f, 0.56806474673115592f, 0.12053668025532301f, -0.35460488704253545f, -0.74851074817110119f, -0.97094181742605201f};
+  static constexpr float s[6] = {0.46472317204376851f, 0.82298386589365635f, 0.99270887409805397f, 0.93501624268541483f, 0.66312265824079519f, 0.23931566428755768f};
+};
+template <int R, bool INV> __device__ __forceinline__ void dft_prime(float2 v[R]) {
+  constexpr int H = (R - 1) / 2;
+  float2 t[H], d[H];
+#pragma unroll
+  for (int j = 0; j < H; ++j) { t[j] = cadd(v[j + 1], v[R - 1 - j]); d[j] = csub(v[j + 1], v[R - 1 - j]); }
+  float2 sum = v[0];
+#pragma unroll
+  for (int j = 0; j < H; ++j) sum = cadd(sum, t[j]);
+  const float2 x0 = v[0];
+#pragma unroll
+  for (int k = 1; k <= H; ++k) {
+    float2 a = x0, b = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+      const int m = (j * k) % R;  // cos(2 pi m / R) = c[min(m, R - m) - 1], sin: s[..] with the sign of the half m falls in
+      const float cs = PrimeTable<R>::c[(m <= H ? m : R - m) - 1], sn = (m <= H ? 1.f : -1.f) * PrimeTable<R>::s[(m <= H ? m : R - m) - 1];
+      a = make_float2(__builtin_fmaf(cs, t[j - 1].x, a.x), __builtin_fmaf(cs, t[j - 1].y, a.y));
+      b = make_float2(__builtin_fmaf(sn, d[j - 1].x, b.x), __builtin_fmaf(sn, d[j - 1].y, b.y));
+    }
+    const float2 ib = INV ? make_float2(-b.y, b.x) : make_float2(b.y, -b.x);  // -+ i b
+    v[k] = cadd(a, ib);
+    v[R - k] = csub(a, ib);
+  }
+  v[0] = sum;
+}
+template <int R, bool INV> __device__ __forceinline__ void dft_odd(float2 v[R]) {
+  if constexpr (R == 3) dft3<INV>(v);
+  else if constexpr (R == 5) dft5<INV>(v);
+  else dft_prime<R, INV>(v);
+}
 // FWD_JOIN: the joining pass with the forward sign -- a step of a DIRECT transform whose R decimated sub-sequences x[R i + s] were
 // transformed in the segments:  X[t q + j] = sum_s W_R^(t s) W_(R q)^(j s) Z_s[j],  q = the segments' length.
 // Levels: a logical line is `lines` tile lines; at this level it splits into `groups` independent joins of R segments, each segment
@@ -175,7 +221,7 @@ __device__ __forceinline__ void own_radix(float2* tile, const float2* twl, int p
 #pragma unroll
       for (int i = 1; i < R; ++i) { v[i] = cmul(v[i], ws); ws = cmul(ws, w); }
     }
-    if constexpr (R == 3) dft3<JOIN && !FWD_JOIN>(v); else dft5<JOIN && !FWD_JOIN>(v);
+    dft_odd<R, JOIN && !FWD_JOIN>(v);
     if (!JOIN) {
       float2 ws = w;
 #pragma unroll
@@ -185,10 +231,22 @@ __device__ __forceinline__ void own_radix(float2* tile, const float2* twl, int p
     for (int i = 0; i < R; ++i) at[i * hop] = v[i];
   }
 }
-template <bool JOIN, bool FWD_JOIN>
+// BIG: the instantiation that also holds the 7 / 11 / 13-point passes (their 13 complex values in flight cost every kernel 20 registers and two
+// waves per SIMD: lengths without those factors run the lean one)
+template <bool JOIN, bool FWD_JOIN, bool BIG>
 __device__ __forceinline__ void own_radix_any(int R, float2* tile, const float2* twl, int p, int logp, int L, int logL, int lines, int seg, int groups) {
-  if (R == 3) own_radix<3, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups);
-  else own_radix<5, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups);
+  if constexpr (!BIG) {
+    if (R == 3) own_radix<3, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups);
+    else own_radix<5, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups);
+    return;
+  }
+  switch (R) {
+    case 3: own_radix<3, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups); break;
+    case 5: own_radix<5, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups); break;
+    case 7: own_radix<7, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups); break;
+    case 11: own_radix<11, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups); break;
+    default: own_radix<13, JOIN, FWD_JOIN>(tile, twl, p, logp, L, logL, lines, seg, groups); break;
+  }
 }
 
 // The tile: L logical lines, each r segments of p points, every segment p + 1 apart.  own_put fills it: x[k] at the bit-reversed
@@ -196,6 +254,7 @@ __device__ __forceinline__ void own_radix_any(int R, float2* tile, const float2*
 // After own_transform position k < n holds the forward DFT -- for Bluestein short of the factor w[k] / m, which own_get applies.
 __device__ __forceinline__ int own_at(const OwnAxis& ax, int k) { return (k >> ax.logp) * (ax.p + 1) + (k & (ax.p - 1)); }
 __device__ __forceinline__ float2* own_line(float2* tile, const OwnAxis& ax, int l) { return tile + l * ax.r * (ax.p + 1); }
+template <bool BIG>
 __device__ __forceinline__ void own_transform(float2* tile, const float2* tw, const float2* twm, const OwnAxis& ax, int L, int logL) {
   if (!ax.chirp) {  // direct: the r decimated sub-sequences through fft_tile, then the joins from the innermost level outwards
     fft_tile<false>(tile, tw, ax.p, ax.logp, L * ax.r, nullptr, 0, true);
@@ -203,17 +262,17 @@ __device__ __forceinline__ void own_transform(float2* tile, const float2* tw, co
     const float2* twl = twm;
     for (int lev = ax.nlev - 1; lev >= 0; --lev) {
       groups /= ax.rad[lev];
-      own_radix_any<true, true>(ax.rad[lev], tile, twl, ax.p, ax.logp, L, logL, ax.r, seg, groups);
+      own_radix_any<true, true, BIG>(ax.rad[lev], tile, twl, ax.p, ax.logp, L, logL, ax.r, seg, groups);
       twl += seg << ax.logp;
       seg *= ax.rad[lev];
     }
     if (ax.nlev) __syncthreads();
     return;
   }
-  if (ax.nlev) own_radix_any<false, false>(ax.rad[0], tile, twm, ax.p, ax.logp, L, logL, ax.r, 1, 1);
+  if (ax.nlev) own_radix_any<false, false, BIG>(ax.rad[0], tile, twm, ax.p, ax.logp, L, logL, ax.r, 1, 1);
   fft_tile_dif(tile, tw, ax.p, ax.logp, L * ax.r, ax.kernel, ax.r);
   fft_tile<true>(tile, tw, ax.p, ax.logp, L * ax.r, nullptr, 0, true);  // (every pass opens with a barrier, and the transform ends with one)
-  if (ax.nlev) { own_radix_any<true, false>(ax.rad[0], tile, twm, ax.p, ax.logp, L, logL, ax.r, 1, 1); __syncthreads(); }
+  if (ax.nlev) { own_radix_any<true, false, BIG>(ax.rad[0], tile, twm, ax.p, ax.logp, L, logL, ax.r, 1, 1); __syncthreads(); }
 }
 template <bool INVERSE>
 __device__ __forceinline__ void own_put(float2* line, const OwnAxis& ax, int k, float2 v) {
@@ -222,7 +281,9 @@ __device__ __forceinline__ void own_put(float2* line, const OwnAxis& ax, int k, 
   else {  // direct: x[k] to the tile line of its residues (outermost decimation first), bit-reversed position of what is left of k
     int rest = k, tl = 0;
     for (int lev = 0; lev < ax.nlev; ++lev) {
-      const int q = ax.rad[lev] == 3 ? (int)__umulhi((uint32_t)rest, 0x55555556u) : (int)__umulhi((uint32_t)rest, 0x33333334u);
+      const int rd = ax.rad[lev];  // rest / rd by the rounded-up reciprocal (exact far beyond 4096)
+      const uint32_t magic = rd == 3 ? 0x55555556u : (rd == 5 ? 0x33333334u : (rd == 7 ? 0x24924925u : (rd == 11 ? 0x1745d175u : 0x13b13b14u)));
+      const int q = (int)__umulhi((uint32_t)rest, magic);
       tl = tl * ax.rad[lev] + (rest - q * ax.rad[lev]);
       rest = q;
     }
@@ -275,6 +336,7 @@ __device__ __forceinline__ void own_setup(float2* smem, const OwnAxis& ax, float
 
 // ---- last axis: real lines <-> half spectra, two lines per transform --------------------------------------------------------------
 // A wave takes a pair of lines at a time and walks it 64 values per step: runs of 4-byte / 8-byte accesses along the line, no division.
+template <bool BIG>
 __global__ __launch_bounds__(FFT_THREADS) void own_last_forward(const float* real, float2* spec, int64_t lines, OwnAxis ax, int L, int logL) {
   extern __shared__ float2 smem[];
   float2 *tw, *twm, *tile;
@@ -291,7 +353,7 @@ __global__ __launch_bounds__(FFT_THREADS) void own_last_forward(const float* rea
     const float* rb = lb < lines ? real + lb * n : nullptr;
     for (int k = lane; k < n; k += 64) own_put<false>(own_line(tile, ax, pl), ax, k, make_float2(ra[k], rb ? rb[k] : 0.f));
   }
-  own_transform(tile, tw, twm, ax, L, logL);
+  own_transform<BIG>(tile, tw, twm, ax, L, logL);
   for (int pl = wave; pl < here; pl += waves) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
     float2* sa = spec + la * nh;
@@ -304,6 +366,7 @@ __global__ __launch_bounds__(FFT_THREADS) void own_last_forward(const float* rea
   }
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* spec, float* real, int64_t lines, OwnAxis ax, int L, int logL) {
   extern __shared__ float2 smem[];
   float2 *tw, *twm, *tile;
@@ -326,7 +389,7 @@ __global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* sp
       own_put<true>(own_line(tile, ax, pl), ax, k, make_float2(xa.x - xb.y, xa.y + xb.x));
     }
   }
-  own_transform(tile, tw, twm, ax, L, logL);
+  own_transform<BIG>(tile, tw, twm, ax, L, logL);
   for (int pl = wave; pl < here; pl += waves) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
     float* ra = real + la * n;
@@ -342,7 +405,7 @@ __global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* sp
 // ---- any other axis: complex, in place; line l = (o, i), element k at (o n + k) inner + i ------------------------------------------
 // L is a power of two <= FFT_THREADS: a thread keeps ONE line (consecutive lanes = consecutive i: runs of 8-byte accesses along the
 // fastest axis, LDS lines an odd pitch apart) and walks its elements FFT_THREADS / L apart; one 64-bit division per thread.
-template <bool INVERSE>
+template <bool INVERSE, bool BIG>
 __global__ __launch_bounds__(FFT_THREADS) void own_strided(float2* spec, int64_t lines, int64_t inner, OwnAxis ax, int L, int logL) {
   extern __shared__ float2 smem[];
   float2 *tw, *twm, *tile;
@@ -359,7 +422,7 @@ __global__ __launch_bounds__(FFT_THREADS) void own_strided(float2* spec, int64_t
     base = spec + o * n * inner + i;
     for (int k = k0; k < n; k += kstep) own_put<INVERSE>(own_line(tile, ax, pl), ax, k, base[(int64_t)k * inner]);
   }
-  own_transform(tile, tw, twm, ax, L, logL);
+  own_transform<BIG>(tile, tw, twm, ax, L, logL);
   if (pl < here)
     for (int k = k0; k < n; k += kstep) base[(int64_t)k * inner] = own_get<INVERSE>(own_line(tile, ax, pl), ax, k, inv_m);
 }
@@ -374,6 +437,7 @@ struct OwnWeights {
 };
 __device__ __forceinline__ float own_axis_freq(int k, int d) { const int m = k < d - k ? k : d - k; return (float)m / (float)d; }
 
+template <bool BIG>
 __global__ __launch_bounds__(FFT_THREADS) void own_strided_weighted(float2* spec, int64_t lines, int64_t inner, OwnAxis ax, int L, int logL, OwnWeights wp) {
   extern __shared__ float2 smem[];
   float2 *tw, *twm, *tile;
@@ -400,7 +464,7 @@ __global__ __launch_bounds__(FFT_THREADS) void own_strided_weighted(float2* spec
     }
     for (int k = k0; k < n; k += kstep) own_put<false>(own_line(tile, ax, pl), ax, k, base[(int64_t)k * inner]);
   }
-  own_transform(tile, tw, twm, ax, L, logL);
+  own_transform<BIG>(tile, tw, twm, ax, L, logL);
   float2 hold[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -421,9 +485,57 @@ __global__ __launch_bounds__(FFT_THREADS) void own_strided_weighted(float2* spec
     const int k = k0 + j * kstep;
     if (pl < here && k < n) own_put<true>(own_line(tile, ax, pl), ax, k, hold[j]);
   }
-  own_transform(tile, tw, twm, ax, L, logL);
+  own_transform<BIG>(tile, tw, twm, ax, L, logL);
   if (pl < here)
     for (int k = k0; k < n; k += kstep) base[(int64_t)k * inner] = own_get<true>(own_line(tile, ax, pl), ax, k, inv_m);
+}
+
+// ---- a LAST axis too long for one tile (round 5): the half-length complex transform in four steps ------------------------------------
+// A real line of n = 2 h points, read as h complex values z[j] = x[2 j] + i x[2 j + 1] (no copy: that IS its memory image), is transformed
+// by Z = FFT_h(z) and untangled:  E = (Z[k] + conj Z[h - k]) / 2,  O = (Z[k] - conj Z[h - k]) / (2 i),  X[k] = E + W_n^k O,  k = 0 .. h.
+// FFT_h with h = A B runs on the strided kernels above, in place: B-point transforms over b of z[a + A b] (stride A), a twiddle
+// W_h^(a f_b), A-point transforms over a (contiguous) -- after which Z[f_b + B f_a] sits at position f_a + A f_b.  Only the two small
+// kernels below know about that order: own_long_post gathers Z[k], Z[h - k] from their positions and writes X in natural order to the
+// spectrum buffer; own_long_pre is its transpose for the way back (unnormalised, like every transform here: it hands FFT_h^-1 the
+// values 2 Z, so that the result is n x).  Angles are reduced in integers and evaluated in float64 (h can reach millions of points).
+__global__ __launch_bounds__(256) void own_long_twiddle(float2* z, int64_t total, int h, int A, int inverse) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int pos = (int)(e % h), a = pos % A, fb = pos / A;
+    if (a == 0 || fb == 0) continue;
+    double sn, cs;
+    sincospi(2.0 * (double)(((int64_t)a * fb) % h) / (double)h, &sn, &cs);
+    const float2 w = make_float2((float)cs, inverse ? (float)sn : (float)-sn);
+    z[e] = cmul(z[e], w);
+  }
+}
+__device__ __forceinline__ int64_t own_long_pos(int k, int A, int B) { return (int64_t)(k / B) + (int64_t)A * (k % B); }  // where Z[k] sits
+__global__ __launch_bounds__(256) void own_long_post(const float2* z, float2* spec, int64_t lines, int h, int A, int B) {
+  const int64_t total = lines * (h + 1);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t line = e / (h + 1);
+    const int k = (int)(e - line * (h + 1));
+    const float2* zl = z + line * h;
+    const float2 zk = zl[own_long_pos(k == h ? 0 : k, A, B)], zn = zl[own_long_pos(k == 0 || k == h ? 0 : h - k, A, B)];
+    const float2 ev = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)), od = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    double sn, cs;
+    sincospi((double)k / (double)h, &sn, &cs);  // W_n^k = exp(-i pi k / h)
+    spec[e] = cadd(ev, cmul(od, make_float2((float)cs, (float)-sn)));
+  }
+}
+__global__ __launch_bounds__(256) void own_long_pre(const float2* spec, float2* z, int64_t lines, int h, int A, int B) {
+  const int64_t total = lines * h;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t line = e / h;
+    const int k = (int)(e - line * h);
+    const float2* xl = spec + line * (h + 1);
+    float2 xk = xl[k], xn = xl[h - k];
+    if (k == 0) { xk.y = 0.f; xn.y = 0.f; }  // (the imaginary parts of the DC and Nyquist bins are ignored, as a C2R transform does)
+    const float2 sm = make_float2(xk.x + xn.x, xk.y - xn.y), df = make_float2(xk.x - xn.x, xk.y + xn.y);
+    double sn, cs;
+    sincospi((double)k / (double)h, &sn, &cs);
+    const float2 t = cmul(df, make_float2((float)cs, (float)sn));  // W_n^-k (X[k] - conj X[h - k])
+    z[line * h + own_long_pos(k, A, B)] = make_float2(sm.x - t.y, sm.y + t.x);
+  }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
@@ -451,10 +563,10 @@ int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
     ax = OwnAxis{n, n, n, ilog2(n), 1, 0, {1, 1, 1}, nullptr, nullptr};
     return SKR_OK;
   }
-  {  // n = 2^a 3^b 5^c with a >= 1 and b + c <= 3: interleaved power-of-two sub-sequences, no chirp, no padding
+  {  // n = 2^a x (at most three factors out of 3, 5, 7, 11, 13), a >= 1: interleaved power-of-two sub-sequences, no chirp, no padding
     int rest = n, nlev = 0, rad[3] = {1, 1, 1}, r = 1;
-    while (rest % 5 == 0 && nlev < 3) { rad[nlev++] = 5; rest /= 5; r *= 5; }
-    while (rest % 3 == 0 && nlev < 3) { rad[nlev++] = 3; rest /= 3; r *= 3; }
+    for (int f : {13, 11, 7, 5, 3})
+      while (rest % f == 0 && nlev < 3) { rad[nlev++] = f; rest /= f; r *= f; }
     if (nlev > 0 && rest >= 2 && (rest & (rest - 1)) == 0 && n <= OWN_MAX_M) {
       ax = OwnAxis{n, n, rest, ilog2(rest), r, nlev, {rad[0], rad[1], rad[2]}, nullptr, nullptr};
       return SKR_OK;
@@ -491,6 +603,7 @@ int tile_lines(const OwnAxis& ax) {
 }
 size_t tile_bytes(const OwnAxis& ax, int L) { return sizeof(float2) * ((size_t)ax.p / 2 + (size_t)own_join_entries(ax) + (size_t)L * ax.r * (ax.p + 1)); }
 
+bool own_big(const OwnAxis& ax) { return ax.rad[0] > 5 || ax.rad[1] > 5 || ax.rad[2] > 5; }
 template <typename K, typename... A>
 int own_launch(K kernel, int64_t blocks, const OwnAxis& ax, int L, hipStream_t s, A... args) {
   if (blocks < 1) return SKR_OK;
@@ -501,12 +614,91 @@ int own_launch(K kernel, int64_t blocks, const OwnAxis& ax, int L, hipStream_t s
   return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
 }
 
+// each kernel in its lean or its BIG instantiation (the one with the 7 / 11 / 13-point passes), by the axis's factors
+template <typename... A> int launch_last_forward(int64_t blocks, const OwnAxis& ax, int L, hipStream_t s, A... args) {
+  return own_big(ax) ? own_launch(own_last_forward<true>, blocks, ax, L, s, args...) : own_launch(own_last_forward<false>, blocks, ax, L, s, args...);
+}
+template <typename... A> int launch_last_inverse(int64_t blocks, const OwnAxis& ax, int L, hipStream_t s, A... args) {
+  return own_big(ax) ? own_launch(own_last_inverse<true>, blocks, ax, L, s, args...) : own_launch(own_last_inverse<false>, blocks, ax, L, s, args...);
+}
+template <bool INVERSE, typename... A> int launch_strided(int64_t blocks, const OwnAxis& ax, int L, hipStream_t s, A... args) {
+  return own_big(ax) ? own_launch(own_strided<INVERSE, true>, blocks, ax, L, s, args...) : own_launch(own_strided<INVERSE, false>, blocks, ax, L, s, args...);
+}
+template <typename... A> int launch_strided_weighted(int64_t blocks, const OwnAxis& ax, int L, hipStream_t s, A... args) {
+  return own_big(ax) ? own_launch(own_strided_weighted<true>, blocks, ax, L, s, args...) : own_launch(own_strided_weighted<false>, blocks, ax, L, s, args...);
+}
+
+// a length the tile transforms take: the direct forms up to 4096, anything up to 2048 through Bluestein
+bool own_short(int n) {
+  if (n < 2) return false;
+  if (n <= (OWN_MAX_M + 1) / 2) return true;
+  if (n > OWN_MAX_M) return false;
+  int rest = n, odd = 0;
+  for (int f : {13, 11, 7, 5, 3})
+    while (rest % f == 0 && odd < 3) { rest /= f; ++odd; }
+  return (rest & (rest - 1)) == 0 && (odd == 0 || rest >= 2);
+}
+// n = 2 A B for a long last axis: both factors short lengths, as close to each other as they come, direct forms preferred over Bluestein
+bool own_long_split(int n, int& A, int& B) {
+  if (n < 4 || (n & 1)) return false;
+  const int h = n / 2;
+  long best = -1;
+  for (int a = 2; (long)a * a <= h; ++a) {
+    if (h % a) continue;
+    const int b = h / a;
+    if (!own_short(a) || !own_short(b)) continue;
+    OwnAxis xa{}, xb{};
+    auto direct = [](int m) { int r = m; for (int f : {13, 11, 7, 5, 3}) for (int c = 0; c < 3 && r % f == 0; ++c) r /= f; return (r & (r - 1)) == 0; };
+    const long score = (direct(a) ? 1000000 : 0) + (direct(b) ? 1000000 : 0) + a;  // (a <= sqrt(h): the larger, the squarer)
+    if (score > best) { best = score; A = a; B = b; }
+  }
+  return best >= 0;
+}
+
+int own_long_last(int dev, bool inverse, float* real, float2* spec, int64_t lines, int n, hipStream_t s) {
+  int A = 0, B = 0;
+  if (!own_long_split(n, A, B)) return SKR_ERR_UNSUPPORTED;
+  const int h = n / 2;
+  OwnAxis xa{}, xb{};
+  int rc;
+  if ((rc = own_axis(dev, A, s, xa)) != SKR_OK || (rc = own_axis(dev, B, s, xb)) != SKR_OK) return rc;
+  float2* z = reinterpret_cast<float2*>(real);  // [lines][h]: the real lines, two values per complex
+  const int La = tile_lines(xa), Lb = tile_lines(xb);
+  const int64_t lines_b = lines * A, lines_a = lines * B, total = lines * h;
+  if (total > 0x7fffffffffffll) return SKR_ERR_UNSUPPORTED;
+  int64_t blocks = (total + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
+  if (!inverse) {
+    if ((rc = launch_strided<false>((lines_b + Lb - 1) / Lb, xb, Lb, s, z, lines_b, (int64_t)A, xb, Lb, ilog2(Lb))) != SKR_OK) return rc;  // over b, stride A
+    hipLaunchKernelGGL(own_long_twiddle, dim3((unsigned)blocks), dim3(256), 0, s, z, total, h, A, 0);
+    if ((rc = launch_strided<false>((lines_a + La - 1) / La, xa, La, s, z, lines_a, (int64_t)1, xa, La, ilog2(La))) != SKR_OK) return rc;  // over a, contiguous
+    hipLaunchKernelGGL(own_long_post, dim3((unsigned)blocks), dim3(256), 0, s, (const float2*)z, spec, lines, h, A, B);
+  } else {
+    hipLaunchKernelGGL(own_long_pre, dim3((unsigned)blocks), dim3(256), 0, s, (const float2*)spec, z, lines, h, A, B);
+    if ((rc = launch_strided<true>((lines_a + La - 1) / La, xa, La, s, z, lines_a, (int64_t)1, xa, La, ilog2(La))) != SKR_OK) return rc;
+    hipLaunchKernelGGL(own_long_twiddle, dim3((unsigned)blocks), dim3(256), 0, s, z, total, h, A, 1);
+    if ((rc = launch_strided<true>((lines_b + Lb - 1) / Lb, xb, Lb, s, z, lines_b, (int64_t)A, xb, Lb, ilog2(Lb))) != SKR_OK) return rc;
+  }
+  return hipGetLastError() == hipSuccess ? SKR_OK : SKR_ERR_LAUNCH;
+}
+
 }  // namespace
+
+// can the own transforms take this axis?  `last`: the innermost (real) axis, which may be long (own_long_split)
+bool own_length_ok(int n, bool last) {
+  int A, B;
+  return own_short(n) || (last && own_long_split(n, A, B));
+}
 
 // the per-length tables of every axis, built now (own_rfftn / own_outer_weighted then only look them up); SKR_ERR_CAPTURE when a
 // table is missing and `s` is capturing
 int own_prepare(int dev, int n0, int n1, int n2, hipStream_t s) {
   OwnAxis ax{};
+  int A = 0, B = 0;
+  if (!own_short(n2) && own_long_split(n2, A, B)) {  // a long last axis: its two factors
+    int rc;
+    if ((rc = own_axis(dev, A, s, ax)) != SKR_OK || (rc = own_axis(dev, B, s, ax)) != SKR_OK) return rc;
+    n2 = 1;
+  }
   for (int n : {n2, n1, n0}) {
     if (n <= 1) continue;
     const int rc = own_axis(dev, n, s, ax);
@@ -517,25 +709,28 @@ int own_prepare(int dev, int n0, int n1, int n2, hipStream_t s) {
 
 // rfftn / irfftn over the last three axes n0 x n1 x n2 (leading ones may be 1) of `entries` independent units:
 // real [entries][n0][n1][n2] fp32  <->  spec [entries][n0][n1][n2/2 + 1] complex64.  SKR_ERR_UNSUPPORTED: an axis beyond the tile
-// (a power of two > 4096, any other length > 2048), or tables needed during stream capture.
+// (see own_short) other than an even last axis that splits into two tile lengths (own_long_last); SKR_ERR_CAPTURE: tables needed during stream capture.
 // skip_outer: leave out the outermost transformed axis (n0, or n1 when n0 == 1) -- own_outer_weighted does it both ways in one pass.
 int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries, int n0, int n1, int n2, hipStream_t s, bool skip_outer) {
   OwnAxis a0{}, a1{}, a2{};
   int rc;
-  if ((rc = own_axis(dev, n2, s, a2)) != SKR_OK) return rc;
+  const bool long2 = !own_short(n2);
+  if (!long2 && (rc = own_axis(dev, n2, s, a2)) != SKR_OK) return rc;
   if (n1 > 1 && (rc = own_axis(dev, n1, s, a1)) != SKR_OK) return rc;
   if (n0 > 1 && (rc = own_axis(dev, n0, s, a0)) != SKR_OK) return rc;
   const int64_t n2h = n2 / 2 + 1, lines2 = entries * n0 * n1, lines1 = entries * n0 * n2h, lines0 = entries * n1 * n2h;
-  const int L2 = tile_lines(a2), L1 = n1 > 1 ? tile_lines(a1) : 1, L0 = n0 > 1 ? tile_lines(a0) : 1;
+  const int L2 = long2 ? 1 : tile_lines(a2), L1 = n1 > 1 ? tile_lines(a1) : 1, L0 = n0 > 1 ? tile_lines(a0) : 1;
   const bool do0 = n0 > 1 && !skip_outer, do1 = n1 > 1 && !(skip_outer && n0 == 1);
   if (!inverse) {
-    if ((rc = own_launch(own_last_forward, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float*)real, spec, lines2, a2, L2, ilog2(L2))) != SKR_OK) return rc;
-    if (do1 && (rc = own_launch(own_strided<false>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
-    if (do0 && (rc = own_launch(own_strided<false>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
+    if (long2) { if ((rc = own_long_last(dev, false, real, spec, lines2, n2, s)) != SKR_OK) return rc; }
+    else if ((rc = launch_last_forward(((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float*)real, spec, lines2, a2, L2, ilog2(L2))) != SKR_OK) return rc;
+    if (do1 && (rc = launch_strided<false>((lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
+    if (do0 && (rc = launch_strided<false>((lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
   } else {
-    if (do0 && (rc = own_launch(own_strided<true>, (lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
-    if (do1 && (rc = own_launch(own_strided<true>, (lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
-    if ((rc = own_launch(own_last_inverse, ((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float2*)spec, real, lines2, a2, L2, ilog2(L2))) != SKR_OK) return rc;
+    if (do0 && (rc = launch_strided<true>((lines0 + L0 - 1) / L0, a0, L0, s, spec, lines0, (int64_t)n1 * n2h, a0, L0, ilog2(L0))) != SKR_OK) return rc;
+    if (do1 && (rc = launch_strided<true>((lines1 + L1 - 1) / L1, a1, L1, s, spec, lines1, n2h, a1, L1, ilog2(L1))) != SKR_OK) return rc;
+    if (long2) { if ((rc = own_long_last(dev, true, real, spec, lines2, n2, s)) != SKR_OK) return rc; }
+    else if ((rc = launch_last_inverse(((lines2 + 1) / 2 + L2 - 1) / L2, a2, L2, s, (const float2*)spec, real, lines2, a2, L2, ilog2(L2))) != SKR_OK) return rc;
   }
   return SKR_OK;
 }
@@ -551,7 +746,7 @@ int own_outer_weighted(int dev, float2* spec, int64_t entries, int n0, int n1, i
   const int64_t n2h = n2 / 2 + 1, inner = n0 > 1 ? (int64_t)n1 * n2h : n2h, lines = n0 > 1 ? entries * n1 * n2h : entries * n0 * n2h;
   const int L = tile_lines(ax);
   const OwnWeights wp{n0, n1, n2, inv_rmax, eps_clip, exponent_half_neg};
-  return own_launch(own_strided_weighted, (lines + L - 1) / L, ax, L, s, spec, lines, inner, ax, L, ilog2(L), wp);
+  return launch_strided_weighted((lines + L - 1) / L, ax, L, s, spec, lines, inner, ax, L, ilog2(L), wp);
 }
 
 }  // namespace skr

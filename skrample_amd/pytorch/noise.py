@@ -442,8 +442,8 @@ class Colored(TensorNoiseCommon):
     def _axes(unit_shape) -> tuple[list[int], bool]:
         "(transform dims after dropping size-1 axes, whether the hand-written power-of-two path applies)"
         dims = [d for d in unit_shape if d != 1]
-        if not 1 <= len(dims) <= 6 or any(d > 128 for d in dims[:-3]):
-            raise SkrampleHipError(f"Colored noise needs 1 to 6 transform axes per sample (those outside the last three at most 128 long), got shape {tuple(unit_shape)}")
+        if not 1 <= len(dims) <= 12 or any(d > 128 for d in dims[:-3]):
+            raise SkrampleHipError(f"Colored noise needs 1 to 12 transform axes per sample (those outside the last three at most 128 long), got shape {tuple(unit_shape)}")
         pow2 = 2 <= len(dims) <= 3 and all(d & (d - 1) == 0 for d in dims) and dims[-1] >= 4 and max(dims) <= 4096
         return dims, pow2
 

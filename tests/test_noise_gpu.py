@@ -818,19 +818,28 @@ def test_colored_with_two_axes_on_the_transform_and_the_rest_direct(unit, hipfft
         assert lib.skr_set_tuning(b"fft_rank", 0) == 0 and lib.skr_set_tuning(b"hipfft", -1) == 0
 
 
-def _own_length(d: int) -> bool:
-    "an axis length skr_fft_own.hip takes: anything up to 2048 (Bluestein), and up to 4096 the direct ones -- 2^a 3^b 5^c, a >= 1, b + c <= 3"
+def _short_length(d: int) -> bool:
+    "an axis length the tile transforms of skr_fft_own.hip take: anything up to 2048 (Bluestein), and up to 4096 the direct ones -- 2^a (a >= 1) times at most three factors out of 3, 5, 7, 11, 13"
     if d <= 2048:
         return True
     odd = 0
-    for f in (5, 3):
+    for f in (13, 11, 7, 5, 3):
         while d % f == 0 and odd < 3:
             d, odd = d // f, odd + 1
     return d <= 4096 and d & (d - 1) == 0 and (odd == 0 or d >= 2)
 
 
+def _own_length(d: int, last: bool = False) -> bool:
+    "... or, as the LAST axis, an even length 2 A B with A, B such lengths (the half-length transform in four steps)"
+    if _short_length(d):
+        return True
+    h = d // 2
+    return last and d % 2 == 0 and any(h % a == 0 and _short_length(a) and _short_length(h // a) for a in range(2, int(h**0.5) + 1))
+
+
 @pytest.mark.parametrize("unit", [(4, 97, 97), (4, 30, 90), (3, 250, 250), (2, 66, 130), (1, 45, 96), (2, 134, 64), (3, 7, 11, 13), (2, 1025), (1, 3, 2050), (4, 720, 1280), (2, 3, 5), (5, 1300),
-                                  (2, 250, 60), (3, 3072), (3, 2560), (2, 90, 18), (1, 720, 30), (2, 3000), (2, 1500), (1, 6, 10), (3, 1080), (3, 3840)])
+                                  (2, 250, 60), (3, 3072), (3, 2560), (2, 90, 18), (1, 720, 30), (2, 3000), (2, 1500), (1, 6, 10), (3, 1080), (3, 3840),
+                                  (2, 154, 182), (3, 2002), (2, 28, 44), (1, 4004), (2, 14, 22, 26), (16, 66, 130)])
 def test_awkward_shapes_run_on_the_own_transforms(unit, dev):
     """odd sides, widths that are not multiples of 4, odd parts beyond 63, primes, lengths next to a power of two, a 720 x 1280 plane, one-,
     two- and three-level 2^a 3^b 5^c lengths (30, 60, 90, 250, 720, 3072 ...) and ones with four odd factors (1080, 1500: Bluestein again): every
@@ -847,7 +856,73 @@ def test_awkward_shapes_run_on_the_own_transforms(unit, dev):
         err = rel(got, ref, "colored (own any-length transforms)", COLORED_TOL, exact)
         assert err < TOL and no_further_from_exact(got, ref, exact, slack=3.0), (unit, st, err)
     after = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_plans"), lib.skr_stat(b"hipfft_execs")
-    if all(_own_length(d) for d in unit):  # (0 own transforms: a shape the LDS plane kernels take after all -- still no vendor transform)
-        assert after[0] - before[0] in (0, 2) and after[1:] == before[1:], (unit, before, after)
-    else:
-        assert after[0] == before[0] and after[2] - before[2] == 2, (unit, before, after)
+    assert all(_own_length(d, i == len(unit) - 1) for i, d in enumerate(unit))
+    # (0 own transforms: a shape the LDS plane kernels take after all -- still no vendor transform)
+    assert after[0] - before[0] in (0, 2) and after[1:] == before[1:], (unit, before, after)
+
+
+@pytest.mark.parametrize("unit", [(65536,), (2, 8192), (3, 5000), (2, 3, 6000), (1, 10010), (2, 4100), (4, 12, 4098)])
+def test_long_last_axes_run_on_the_own_transforms(unit, dev):
+    """(Round 5.)  A last axis beyond one LDS tile -- 8192, 65536 samples of a waveform, 5000, 10010 ... -- is a half-length complex transform
+    in four steps over the same tile kernels (n = 2 A B): no hipFFT plan, no hipFFT transform, the oracle bar as everywhere."""
+    lib = _hip.load()
+    seeds = [71, 72]
+    before = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_plans"), lib.skr_stat(b"hipfft_execs")
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
+    for n, st in enumerate((None, Step(0.45, 0.5))):
+        got = g.generate(st).cpu()
+        ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
+        exact = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape).double(), st) for s in seeds])
+        err = rel(got, ref, "colored (long last axis, four-step)", COLORED_TOL, exact)
+        assert err < TOL and no_further_from_exact(got, ref, exact, slack=3.0), (unit, st, err)
+    after = lib.skr_stat(b"own_fft_execs"), lib.skr_stat(b"hipfft_plans"), lib.skr_stat(b"hipfft_execs")
+    assert after[0] - before[0] == 2 and after[1:] == before[1:], (unit, before, after)
+
+
+def test_the_vendor_fft_runs_only_when_asked_for(dev):
+    "a shape the own transforms do not take (a long axis that is not the last one; a last axis 2 x prime): refused -- and served once hipFFT is asked for"
+    lib = _hip.load()
+    for unit in ((4100, 6), (2, 2 * 4099)):
+        g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, [5, 6], props=PN.ColoredProps(), dtype=torch.float32)
+        plans = lib.skr_stat(b"hipfft_plans")
+        with pytest.raises(_hip.SkrampleHipError):
+            g.generate(Step(0.45, 0.5))
+        assert lib.skr_stat(b"hipfft_plans") == plans
+        assert lib.skr_set_tuning(b"hipfft", 1) == 0
+        try:
+            got = g.generate(Step(0.45, 0.5)).cpu()
+        finally:
+            assert lib.skr_set_tuning(b"hipfft", -1) == 0
+        assert lib.skr_stat(b"hipfft_plans") > plans
+        ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, 256, shape), Step(0.45, 0.5)) for s in (5, 6)])
+        assert rel(got, ref, "colored (hipFFT on request)", COLORED_TOL) < TOL
+
+
+@pytest.mark.parametrize("unit", [(2, 3, 2, 2, 3, 4, 6), (2, 2, 3, 2, 2, 2, 4, 4), (2, 1, 2, 2, 2, 2, 2, 2, 2, 2, 3, 4)])
+def test_colored_with_seven_and_more_transform_axes(unit, dev, monkeypatch):
+    """reference noise.py:373-403 transforms over every non-singleton axis, however many: the leading ones (up to nine) are direct-DFT kernels.
+    (The reference's own torch.fft.rfftn stops at seven axes on the host -- MKL refuses more -- so for eight and twelve axes the oracle's
+    two library calls are served axis by axis here: the same transform, composed.)"""
+    if sum(d != 1 for d in unit) > 7:
+        def rfftn(x):
+            y = torch.fft.rfft(x, dim=-1)
+            for d in range(x.dim() - 2, -1, -1):
+                y = torch.fft.fft(y, dim=d)
+            return y
+
+        def irfftn(y, s):
+            for d in range(y.dim() - 1):
+                y = torch.fft.ifft(y, dim=d)
+            return torch.fft.irfft(y, n=s[-1], dim=-1)
+
+        monkeypatch.setattr(torch.fft, "rfftn", rfftn)
+        monkeypatch.setattr(torch.fft, "irfftn", irfftn)
+    seeds = [81, 82]
+    g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, seeds, props=PN.ColoredProps(), dtype=torch.float32)
+    for n, st in enumerate((None, Step(0.45, 0.5))):
+        got = g.generate(st).cpu()
+        ref = torch.stack([ON.colored_noise(unit, lambda shape, s=s: spec_normal(s, n * 256, shape), st) for s in seeds])
+        assert rel(got, ref, "colored (7+ axes)", COLORED_TOL) < TOL, (unit, st)
+
+
+

@@ -9,7 +9,7 @@ from skrample_amd.pytorch import noise as PN
 from skrample_amd.common import Step
 
 lib = _hip.load()
-shapes = [((16, 60, 104), 64), ((16, 90, 160), 32), ((4, 152, 104), 64), ((4, 97, 97), 64), ((4, 30, 90), 256), ((16, 13, 60, 104), 8), ((3, 250, 250), 16), ((4, 720, 1280), 2), ((4, 100), 1024), ((16, 66, 130), 64)]
+shapes = [((16, 60, 104), 64), ((16, 90, 160), 32), ((4, 152, 104), 64), ((4, 97, 97), 64), ((4, 30, 90), 256), ((16, 13, 60, 104), 8), ((3, 250, 250), 16), ((4, 720, 1280), 2), ((4, 100), 1024), ((16, 66, 130), 64), ((4, 154, 182), 64), ((2, 2002), 256)]
 print(f"{'unit':>22s} {'B':>5s} {'own us':>10s} {'hipFFT us':>10s} {'ratio':>6s}  rel. difference of the two results")
 for unit, B in shapes:
     res, t = {}, {}
