@@ -505,9 +505,9 @@ def wrapper_rate(wl: Workload, batch: int, dev: torch.device, shard, nbuf: int =
 # HBM traffic from the PMC counters
 # ---------------------------------------------------------------------------------------------------------------------------
 def load_traffic(wl: Workload) -> tuple[float | None, str]:
-    """HBM bytes per solver step from the committed PMC passes of this same command (profiles/r04_pmc_traffic_<config>.json, else the
+    """HBM bytes per solver step from the committed PMC passes of this same command (profiles/r05_pmc_traffic_<config>.json, else the
     headline's earlier rounds): the fallback when the live passes below cannot run"""
-    names = [f"r04_pmc_traffic_{wl.name}.json"] + (["r03_pmc_traffic.json", "r02_pmc_traffic.json"] if wl.name == "headline" else [])
+    names = [f"r05_pmc_traffic_{wl.name}.json", f"r04_pmc_traffic_{wl.name}.json"] + (["r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"] if wl.name == "headline" else [])
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.isfile(path):

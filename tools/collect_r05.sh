@@ -4,7 +4,7 @@
 #          pmc      (headline PMC / SQ passes -> r05_pmc_traffic.json, r05_sq_counters.json)
 #          plans    (cold-buffer plan launches: kernel trace + counters)
 #          micro    (bench_plan / bench_graph), noise, colored / pyramid (SQ counters of those generators' kernels), fftown (awkward Colored shapes: own transforms vs hipFFT),
-#          margins (measured parity maxima)
+#          margins (measured parity maxima), rehearsal (two torchrun ranks on the one card at the driver's K = 20 / W = 5)
 # The raw rocprofv3 output stays in /tmp on the box (hundreds of MB); only the condensed files come back, under
 # gpurun_out/r5c/profiles/ -- copy what is to be judged from there into profiles/.
 set -e
@@ -97,5 +97,19 @@ if has margins; then
   tail -3 $O/margins_pytest.log
   (cd $R && python3 tools/summarize_margins.py /tmp/r5_margins.jsonl $O/profiles/r05_parity_margins.txt > /dev/null) || echo "summarize_margins failed"
   echo "margins part done"
+fi
+if has rehearsal; then
+  # the N > 1 path on ONE card (both ranks on device 0, gloo instead of RCCL, which refuses two ranks on one device), at the driver's K = 20 / W = 5
+  { echo "# bench.py under python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py --gpus 2 --steps 20 --warmup 5 [--config cfg4] on ONE MI355X"
+    echo "# (SKR_BENCH_DEVICE=0 SKR_BENCH_BACKEND=gloo).  A rehearsal of the N > 1 code path -- shards through BatchShard.from_env, opening barrier, every rank's wall read after ITS OWN"
+    echo "# synchronise and before the closing barrier (sharding.TimedRegion), MAX over ranks, per-rank clocks in roofline.ranks -- NOT a scaling number: the two ranks share one GPU."
+    for c in headline cfg4; do
+      (cd $R && SKR_BENCH_DEVICE=0 SKR_BENCH_BACKEND=gloo $T 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --config $c --no-traffic 2>/dev/null | python3 -c "
+import json, sys
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+r = d['roofline']
+print(json.dumps({k: d[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling')} | {'config': {k: d['config'][k] for k in ('name', 'global_batch', 'per_gpu_batch', 'parallelism')}, 'roofline.us_per_step': r['us_per_step'], 'roofline.ranks': r['ranks'], 'cpu_baseline': d.get('cpu_baseline')}))")
+    done; } > $O/profiles/r05_two_rank_rehearsal.txt
+  echo "rehearsal part done"
 fi
 du -sh $R/gpurun_out || true

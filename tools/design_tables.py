@@ -2,8 +2,8 @@
 """Generate the measured-number tables of DESIGN.md / README.md from the COMMITTED evidence files, so that no quoted figure can
 drift from the file it cites ("DESIGN quotes numbers the committed profile does not contain").
 
-  inputs : profiles/r04_bench_line[_k20|_<config>].json   (one JSON line per `python bench.py [--config <c>]`)
-           profiles/r04_kernel_stats_<config>.csv          (tools/kernel_stats.py over `rocprofv3 --kernel-trace --stats -- python3 bench.py --config <c> ...`)
+  inputs : profiles/r05_bench_line[_k20|_<config>].json   (one JSON line per `python bench.py [--config <c>]`)
+           profiles/r05_kernel_stats_<config>.csv          (tools/kernel_stats.py over `rocprofv3 --kernel-trace --stats -- python3 bench.py --config <c> ...`)
   output : the text between  <!-- GENERATED:<name> BEGIN ... -->  and  <!-- GENERATED:<name> END -->  in DESIGN.md and README.md
 
 usage:  python tools/design_tables.py            rewrite the blocks in place
@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROFILES = os.path.join(ROOT, "profiles")
-ROUND = "r04"
+ROUND = "r05"
 CONFIGS = ("headline", "cfg2", "cfg3", "cfg3c", "cfg4", "cfg5")
 
 
@@ -70,8 +70,8 @@ def fmt(v: float, digits: int = 1) -> str:
 def table_lines() -> str:
     "one row per committed bench line"
     rows = [
-        "| config (`bench.py --config`) | `value` steps/s | µs per step (wall) | step kernels µs (HIP events) | `roofline.frac` (of 8 TB/s) | by wall clock | PMC traffic ÷ algorithmic | eager wrapper steps/s | CPU baseline steps/s (threads) | file |",
-        "|---|---|---|---|---|---|---|---|---|---|",
+        "| config (`bench.py --config`) | `value` steps/s | µs per step (wall) | step kernels µs (HIP events) | `roofline.frac` (8(d) bytes ÷ 8 TB/s) | `frac_on_measured_traffic` (PMC bytes ÷ 8 TB/s) | whole step incl. generator (8(d) bytes ÷ 8 TB/s) | by wall clock | PMC traffic ÷ algorithmic | eager wrapper steps/s | CPU baseline steps/s (threads) | file |",
+        "|---|---|---|---|---|---|---|---|---|---|---|---|",
     ]
     files = [("headline", f"{ROUND}_bench_line.json"), ("headline, driver's K=20 / W=5", f"{ROUND}_bench_line_k20.json")] + [(c, f"{ROUND}_bench_line_{c}.json") for c in CONFIGS[1:]]
     for label, name in files:
@@ -84,8 +84,10 @@ def table_lines() -> str:
         wrap = d.get("wrapper_steps_per_s")
         whole = r.get("whole_step")
         extra = f" (whole step with generator: {fmt(whole['us_per_step'])} µs, generator {fmt(whole['generator_us_per_step'])} µs)" if whole else ""
+        measured = r.get("frac_on_measured_traffic")
         rows.append(
-            f"| {label} | {fmt(d['value'])} | {fmt(d['ms_per_step'] * 1e3, 2)} | {fmt(r['us_per_step'], 2)}{extra} | {fmt(r['frac'], 3)} | {fmt(r['wall_clock']['frac'], 3)} | {ratio} | "
+            f"| {label} | {fmt(d['value'])} | {fmt(d['ms_per_step'] * 1e3, 2)} | {fmt(r['us_per_step'], 2)}{extra} | {fmt(r['frac'], 3)} | {'—' if measured is None else fmt(measured, 3)} | "
+            f"{'—' if not whole else fmt(whole['frac_of_step_bytes'], 3)} | {fmt(r['wall_clock']['frac'], 3)} | {ratio} | "
             f"{'—' if wrap is None else fmt(wrap)} | {'—' if not cpu else fmt(cpu['value'], 2) + ' (' + str(cpu['cores']) + ')'} | `profiles/{name}` |"
         )
     return "\n".join(rows)
@@ -120,11 +122,11 @@ def table_kernels() -> str:
 
 
 def table_noise() -> str:
-    "generator kernels of tools/prof_noise.py (256 x (16,128,128) bf16 draws of every generator), rows of profiles/r04_noise_kernel_stats.csv"
+    "generator kernels of tools/prof_noise.py (256 x (16,128,128) bf16 draws of every generator), rows of profiles/r05_noise_kernel_stats.csv"
     path = os.path.join(PROFILES, f"{ROUND}_noise_kernel_stats.csv")
     if not os.path.isfile(path):
         return "(no committed noise kernel stats yet)"
-    rows = ["| kernel (row of `profiles/r04_noise_kernel_stats.csv`) | workgroups × threads | calls | avg µs | min – max µs |", "|---|---|---|---|---|"]
+    rows = [f"| kernel (row of `profiles/{ROUND}_noise_kernel_stats.csv`) | workgroups × threads | calls | avg µs | min – max µs |", "|---|---|---|---|---|"]
     for r in csv.DictReader(open(path)):
         short = short_kernel(r["Name"])
         if short.startswith(("at::", "__amd", "void at::")) or "at::native" in r["Name"]:
@@ -151,8 +153,8 @@ def table_readme() -> str:
     return "\n".join(out)
 
 
-BLOCKS = {"r04_bench_lines": table_lines, "r04_kernel_rows": table_kernels, "r04_noise_rows": table_noise, "r04_readme": table_readme}
-TARGETS = {"DESIGN.md": ("r04_bench_lines", "r04_kernel_rows", "r04_noise_rows"), "README.md": ("r04_readme",)}
+BLOCKS = {"bench_lines": table_lines, "kernel_rows": table_kernels, "noise_rows": table_noise, "readme": table_readme}
+TARGETS = {"DESIGN.md": ("bench_lines", "kernel_rows", "noise_rows"), "README.md": ("readme",)}
 
 
 def render(text: str, names) -> str:
