@@ -1795,7 +1795,7 @@ def test_two_streams_do_not_interfere(dev):
     assert torch.equal(ya, want_a) and torch.equal(yb, want_b)
 
 
-def test_more_than_two_to_the_31_elements_in_one_launch(dev):
+def test_more_than_two_to_the_31_elements_in_one_launch(dev, fused_mode):
     """Maximum sizes: a single launch over 2^31 + 6144 bf16 elements (4.3 GB per tensor), deterministic and with in-kernel Philox
     noise; every index in the kernels is 64-bit.  Checked on device against torch in fp32, chunk by chunk, around the 2^31 boundary
     and at both ends, plus a whole-tensor checksum; the noise prefix equals the noise of a small launch with the same seed."""
@@ -1811,6 +1811,19 @@ def test_more_than_two_to_the_31_elements_in_one_launch(dev):
             hi = min(lo + 2**28, n)
             t[0, lo:hi] = torch.randn(hi - lo, device=dev, generator=g)
     step = (0.2, 0.3)
+    # the op-tape kernel (the default for a direct call on bf16 tensors) over the same tensors: elementwise, so windows at both ends and
+    # across 2^31 must equal small launches on copies of those windows, bit for bit
+    from skrample_amd.sampling import native
+
+    native.mode = "auto"
+    try:
+        whole = PT.DPM(order=1, stochasticity=0).sample(x, out, step, model, sched).final
+        for lo in (0, 2**31 - 4096, n - 8192):
+            part = PT.DPM(order=1, stochasticity=0).sample(x[:, lo : lo + 8192].contiguous(), out[:, lo : lo + 8192].contiguous(), step, model, sched).final
+            assert torch.equal(whole[:, lo : lo + 8192], part), lo
+        del whole
+    finally:
+        native.mode = "never"
     rec = PT.Euler().sample(x, out, step, model, sched)
     got = rec.final
     assert tuple(got.shape) == (1, n) and got.dtype == torch.bfloat16
