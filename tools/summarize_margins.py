@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Condense the measured parity margins of one GPU test run into profiles/r04_parity_margins.txt.
+"""Condense the measured parity margins of one GPU test run into profiles/r05_parity_margins.txt.
 
     SKR_PARITY_MARGINS=/tmp/margins.jsonl python -m pytest tests -m gpu -q      (every parity comparison appends what it measured)
-    python tools/summarize_margins.py /tmp/margins.jsonl profiles/r04_parity_margins.txt
+    python tools/summarize_margins.py /tmp/margins.jsonl profiles/r05_parity_margins.txt
 
 One line per (family, measure): how many comparisons, the median, the 99th percentile and the maximum that was MEASURED, the bar the
 test asserts, and the test that produced the maximum -- the record the tolerances written in tests/ are justified against."""
@@ -17,7 +17,7 @@ def main(src: str, dst: str) -> None:
         r = json.loads(line)
         groups[(r["family"], r["measure"], r["bar"])].append((r["value"], r["test"]))
     lines = [
-        "# measured parity margins of `SKR_PARITY_MARGINS=... pytest tests -m gpu` on one MI355X (tools/collect_r04.sh margins; tools/summarize_margins.py)",
+        "# measured parity margins of `SKR_PARITY_MARGINS=... pytest tests -m gpu` on one MI355X (tools/collect_r05.sh margins; tools/summarize_margins.py)",
         "# family | measure | comparisons | median | p99 | MAX | bar asserted | share of the bar used by the max | test of the max",
     ]
     for (family, measure, bar), vals in sorted(groups.items(), key=lambda kv: (kv[0][0], kv[0][1])):
