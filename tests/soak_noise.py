@@ -170,4 +170,6 @@ for i in range(n_cases):
             rng.setstate(after)
             if fn in (case_colored, case_colored_mixed, case_colored_extreme, case_colored_awkward):
                 diag_colored(e.args[0][0] if e.args and isinstance(e.args[0], tuple) else None)
-print("done, failures:", bad)
+lib = _hip.load()
+print("done, failures:", bad, "| hipFFT plans made:", lib.skr_stat(b"hipfft_plans"), "hipFFT transforms run:", lib.skr_stat(b"hipfft_execs"), "own N-D transforms run:", lib.skr_stat(b"own_fft_execs"))
+assert lib.skr_stat(b"hipfft_plans") == 0 and lib.skr_stat(b"hipfft_execs") == 0  # the vendor FFT runs only when asked for (skr_set_tuning "hipfft" 1)
