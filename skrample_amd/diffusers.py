@@ -1517,11 +1517,16 @@ class DynasauRKWrapperScheduler(RKWrapperCore):
         return fs.tableau(Step.from_int(self._index // stages, self._steps))
 
     def _schedule_full(self, steps: int) -> Sequence[Point]:
-        fs = self.functional_sampler()
+        """The points the functional sampler itself calls the network at (reference diffusers.py:1029-1042): a scalar run over
+        `functional_interface()`'s schedule -- the PRISTINE one, so a Karras / Exponential sub-schedule keeps its constructor's `steps`
+        here while RKUltra's table reads the re-targeted one -- with the sampler's own rule of not calling the network at t = 0 or
+        sigma = 0, which makes the count fall short and the assertion fire for schedules whose last stage lands there."""
         seen: list[Point] = []
-        for n in range(steps):
-            step = Step.from_int(n, steps)
-            t0, t1 = step
-            seen.extend(self.schedule.ipoints([t0 + c * (t1 - t0) for c, _ in fs.tableau(step).stages]))
+
+        def record(x: float, t: float, s: float, a: float) -> float:
+            seen.append(Point(t, s, a))
+            return x
+
+        self.functional_sample_model(1, record, steps)
         assert len(seen) == self.order * steps
         return seen

@@ -10,7 +10,20 @@ import pytest
 import torch
 from cases import MODELS, NATIVE16_TAGS, SAMPLERS, SCHEDULES, oracle_schedule
 from conftest import load_npz
-from test_step_gpu import EXTRA2_WRAPPERS, EXTRA3_WRAPPERS, EXTRA4_WRAPPERS, EXTRA_WRAPPERS, FIXTURE_WRAPPERS, Injected, assert_close, native16_engine_vs_reference, replay_fixture
+from test_step_gpu import (
+    EXTRA2_WRAPPERS,
+    EXTRA3_WRAPPERS,
+    EXTRA4_WRAPPERS,
+    EXTRA_WRAPPERS,
+    FIXTURE_WRAPPERS,
+    SWEEP_COUNT,
+    SWEEP_NAMES,
+    Injected,
+    assert_close,
+    native16_engine_vs_reference,
+    replay_fixture,
+    sweep_case,
+)
 
 import skrample_amd.diffusers as PD
 import skrample_amd.scheduling as PS
@@ -62,6 +75,32 @@ def test_float64_compute_scale_on_16_bit_latents_on_cpu(name):
     fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
     mk, dt = EXTRA4_WRAPPERS[name]
     replay_fixture(mk(), fx, dt, CPU, name)
+
+
+@pytest.mark.parametrize("index", range(SWEEP_COUNT))
+def test_reference_recorded_random_sweep_on_cpu(index):
+    "64 seeded random wrapper configurations recorded from the reference itself, replayed on host tensors"
+    m, fx, dt = sweep_case(index)
+    replay_fixture(eval(m["text"], SWEEP_NAMES), fx, dt, CPU, m["text"], steps=m["steps"])
+
+
+def test_configurations_the_reference_refuses_are_refused_here_too():
+    "the sweep's rejects: set_timesteps / step raised in the reference -- the same configuration raises here (never a silent result)"
+    import json
+
+    from conftest import load_npz as load
+
+    refused = json.loads(str(load("steps_sweep.npz")["refused"]))
+    assert refused
+    for r in refused:
+        dt = getattr(torch, r["dtype"])
+        with pytest.raises((ZeroDivisionError, ValueError, AssertionError, IndexError, AttributeError, TypeError, _hip.SkrampleHipError)):
+            w = eval(r["text"], SWEEP_NAMES)
+            w.set_timesteps(r["steps"])
+            x = torch.zeros(r["shape"], dtype=dt)
+            for t in w.timesteps:
+                x = torch.as_tensor(w.step(torch.ones_like(x), t, x, return_dict=False)[0])
+            assert torch.isfinite(x.float()).all()
 
 
 @pytest.mark.parametrize("tag", NATIVE16_TAGS)

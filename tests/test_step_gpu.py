@@ -149,10 +149,10 @@ EXTRA4_WRAPPERS = {
 }
 
 
-def replay_fixture(w, fx, dtype, dev, name, exact=False):
+def replay_fixture(w, fx, dtype, dev, name, exact=False, steps=None):
     "teacher-forced replay: every step sees exactly the inputs the reference saw (exact: results must equal the reference's bit for bit)"
     n_calls = len(fx["timesteps"])
-    w.set_timesteps(n_calls if not isinstance(w, PD.RKWrapperCore) else 3)
+    w.set_timesteps(steps if steps is not None else n_calls if not isinstance(w, PD.RKWrapperCore) else 3)
     np.testing.assert_allclose(w.timesteps.numpy(), fx["timesteps"], rtol=0, atol=1e-9)
     used = int(fx["noise_used"])
     w._noise_generator = Injected([torch.from_numpy(v) for v in fx["noises"][:used]], dev) if used else None
@@ -201,6 +201,31 @@ def test_float64_compute_scale_on_16_bit_latents(name, dev):
     fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(name + "/")}
     mk, dt = EXTRA4_WRAPPERS[name]
     replay_fixture(mk(), fx, dt, dev, name, exact=True)
+
+
+# round 5 (tests/golden/steps_sweep.npz): 64 seeded random configurations stepped through the imported reference, each stored with the
+# text of its constructor (W = diffusers module, T = samplers, S = schedules, M = models)
+SWEEP_NAMES = {"W": PD, "T": PT, "S": PS, "M": PM, "torch": torch}
+SWEEP_COUNT = 64
+
+
+def sweep_case(index):
+    import json
+
+    blob = load_npz("steps_sweep.npz")
+    meta = json.loads(str(blob["meta"]))
+    assert len(meta) == SWEEP_COUNT
+    m = meta[index]
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(m["tag"] + "/")}
+    return m, fx, getattr(torch, m["dtype"])
+
+
+@pytest.mark.parametrize("index", range(SWEEP_COUNT))
+def test_reference_recorded_random_sweep(index, dev):
+    """sampler x nesting x schedule x modifier x predictor x eta x dtype x compute_scale x ragged shape x run length, drawn from a seeded
+    generator and stepped through the reference itself (tools/make_golden.py::sweep): the wrapper on the device, teacher-forced"""
+    m, fx, dt = sweep_case(index)
+    replay_fixture(eval(m["text"], SWEEP_NAMES), fx, dt, dev, m["text"], steps=m["steps"])
 
 
 @pytest.mark.parametrize("name", EXTRA3_WRAPPERS)
