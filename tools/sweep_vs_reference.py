@@ -3,7 +3,7 @@ step each through the imported reference and through skrample_amd on host tensor
 every difference -- results beyond the parity bar, different timesteps, or one side raising where the other does not.
 tests/golden/steps_sweep.npz holds the first 64 accepted cases of the same generator; this runs as many as asked.
 
-    python tools/sweep_vs_reference.py [count] [first_seed]
+    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise]
 """
 
 import os
@@ -112,14 +112,153 @@ def one(seed: int) -> str | None:
     return None
 
 
+# ---- the functional samplers (RKUltra, DynasauRK, adaptive RKMoire, the structured adapter) on float64 host tensors ----------
+def _functional_spec(rng):
+    eta = lambda: rng.choice(("0", "0", "0.5", "1", "-1.5"))  # noqa: E731
+    deriv = lambda: rng.choice(("", "", ", derivative_transform=None", ", derivative_transform=M.VelocityModel()", ", derivative_transform=M.FlowModel()"))  # noqa: E731
+    roll = rng.random()
+    if roll < 0.3:
+        text = f"F.RKUltra(order={rng.randint(1, 9)}, stochasticity={eta()}{deriv()})"
+    elif roll < 0.5:
+        opts = rng.choice(("", ", invert=True", ", per_step_decay=0.1, total_step_decay=-0.02", ", per_step_decay=0.0", ", total_step_decay=0.3"))
+        text = f"F.DynasauRK(order={rng.randint(2, 4)}, stochasticity={eta()}{opts}{deriv()})"
+    elif roll < 0.8:
+        opts = "".join(
+            rng.sample(
+                (", threshold=1e-3", ", initial=1 / 20", ", maximum=1 / 3", ", adaption=0.5", ", discard=2.0", ", rescale_init=False", ", rescale_max=True", ", evaluator=F.FunctionalAdaptive.mae"),
+                rng.randint(0, 3),
+            )
+        )
+        text = f"F.RKMoire(order={rng.randint(2, 7)}{opts}{deriv()})"
+    else:
+        kind = rng.choice(("T.Euler(stochasticity={e})", "T.DPM(order={o3}, stochasticity={e})", "T.Adams(order={o9})", "T.UniP(order={o9})", "T.UniPC(order={o6}, stochasticity={e})", "T.SPC()"))
+        text = "I.StructuredFunctionalAdapter(" + kind.format(e=eta(), o3=rng.randint(1, 3), o9=rng.randint(1, 9), o6=rng.randint(1, 6)) + ")"
+    if rng.random() < 0.4:
+        schedule = rng.choice(("S.Linear()", "S.FlowShift(S.Linear())", "S.Sinner(S.Linear())", "S.Beta(S.Linear())"))
+        model = rng.choice(("M.FlowModel()", "M.DataModel()", "M.VelocityModel()"))
+    else:
+        schedule = rng.choice(("S.Scaled()", "S.ZSNR()", "S.Karras(S.Scaled())", "S.Exponential(S.Scaled())", "S.Hyper(S.Scaled())", "S.Scaled(beta_scale=1)"))
+        model = rng.choice(("M.DataModel()", "M.VelocityModel()") if "ZSNR" in schedule else ("M.NoiseModel()", "M.DataModel()", "M.VelocityModel()", "M.ScaleX()"))
+    steps_n = rng.randint(1, 9)
+    lo = rng.choice((None, None, 0, 1, 2))
+    hi = rng.choice((None, None, steps_n, max(steps_n - 1, 1), 5))
+    return text, schedule, model, steps_n, (lo, hi)
+
+
+def one_functional(seed: int) -> str | None:
+    import skrample.sampling.functional as RF
+    import skrample.sampling.interface as RI
+
+    import skrample_amd.sampling.functional as OF
+    import skrample_amd.sampling.interface as OI
+
+    text, schedule, model, steps_n, (lo, hi) = _functional_spec(random.Random(seed))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn([2, 3, 4], generator=g, dtype=torch.float64)
+    draws = [torch.randn([2, 3, 4], generator=g, dtype=torch.float64) for _ in range(400)]
+    sides = []
+    for names, F, I in ((REF, RF, RI), (OWN, OF, OI)):
+        env = {**names, "F": F, "I": I}
+        seen, trace, pool = [], [], list(draws)
+
+        def toy(xx, t, s, a):
+            seen.append((float(t), float(s), float(a)))
+            return xx * 0.3 - 0.1 * s + 0.05 * a + 0.01 * torch.sin(xx * 3.0)
+
+        def cb(sample, n, dp):
+            trace.append((int(n), *[float(v) for v in dp.point_from], *[float(v) for v in dp.point_to], float(torch.as_tensor(sample).sum())))
+
+        try:
+            sampler = eval(text, env)
+            res = sampler.sample_model(x.clone(), toy, eval(model, env), eval(schedule, env), steps_n, slice(lo, hi), lambda *_: pool.pop(0), cb)
+            sides.append((None, torch.as_tensor(res), list(seen), list(trace), len(draws) - len(pool), sampler.adjust_steps(steps_n) if hasattr(sampler, "adjust_steps") else None))
+        except Exception as err:  # noqa: BLE001
+            sides.append((err, None, None, None, None, None))
+    (re_, rres, rseen, rtrace, rused, radj), (pe, pres, pseen, ptrace, pused, padj) = sides
+    if re_ or pe:
+        return None if type(re_) is type(pe) else f"reference {re_!r}, here {pe!r}"
+    if not torch.isfinite(rres).all():
+        return None if not torch.isfinite(pres).all() else "reference non-finite, here finite"
+    if radj != padj or rused != pused or len(rseen) != len(pseen) or len(rtrace) != len(ptrace):
+        return f"adjust_steps {radj}/{padj}, draws {rused}/{pused}, model calls {len(rseen)}/{len(pseen)}, callbacks {len(rtrace)}/{len(ptrace)}"
+    close = lambda a, b: np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=1e-9, atol=1e-9)  # noqa: E731
+    if rseen and not close(rseen, pseen):
+        return "the (t, sigma, alpha) the model was called at differ"
+    if rtrace and not close(rtrace, ptrace):
+        return "callback traces differ"
+    err = ((pres - rres).abs().max() / rres.abs().max().clamp_min(1e-30)).item()
+    return None if err <= 1e-9 else f"result differs: rel inf-norm {err:.3g}"
+
+
+# ---- structured noise on host tensors: the reference's generators vs pytorch/host_noise.py, same CPU generator seeds -> same bits -------
+def _noise_spec(rng):
+    rank = rng.choice((2, 3, 3, 3, 4))
+    unit = tuple(rng.choice((1, 2, 3, 4, 6, 8, 9, 12, 16, 17, 24, 32)) for _ in range(rank))
+    kind = rng.choice(("Random", "Offset", "Pyramid", "Colored"))
+    if kind == "Offset":
+        dims = tuple(sorted(rng.sample(range(rank), rng.randint(1, rank))))
+        props = rng.choice(("None", f"N.OffsetProps(dims={dims}, strength={rng.choice((0.2, 0.5, 1.3))}, static={rng.choice((True, False))})"))
+    elif kind == "Pyramid":
+        dims = tuple(rng.sample(range(-rank, rank), rng.randint(1, min(rank, 3))))
+        props = rng.choice(("None", f"N.PyramidProps(dims={dims}, strength={rng.choice((0.3, 0.6, 1.0))}, depth={rng.choice((1, 2, 3, 99))}, static={rng.choice((True, False))})"))
+    elif kind == "Colored":
+        props = rng.choice(("None", f"N.ColoredProps(energy={rng.choice((None, 2.5, 0.5))}, color_start={rng.choice((0.25, 1.5, 0, -1))}, color_end={rng.choice((-2, -3, 0, 1))}, color_curve={rng.choice((2, 0, 1, 0.5))})"))
+    else:
+        props = "None"
+    step = rng.choice(("None", "Step(0.0, 0.05)", "Step(0.45, 0.5)", "Step(0.95, 1.0)", "Step(0.3, 0.9)"))
+    dtype = rng.choice(("float32", "float32", "float64", "bfloat16"))
+    return kind, unit, props, step, dtype, rng.randint(1, 3)
+
+
+def one_noise(seed: int) -> str | None:
+    from skrample.common import Step as RStep
+
+    from skrample_amd.common import Step as OStep
+    from skrample_amd.pytorch import noise as ON
+
+    kind, unit, props, step, dtype, draws = _noise_spec(random.Random(seed))
+    dt = getattr(torch, dtype)
+    from skrample_amd.pytorch import host_noise as HN
+
+    sides = []
+    for N, StepT in ((MG.RN, RStep), (ON, OStep)):
+        env = {"N": N, "Step": StepT}
+        gens = [torch.Generator().manual_seed(seed + k) for k in range(2)]
+        try:
+            pr = eval(props, env)
+            if N is MG.RN:
+                gen = N.BatchTensorNoise.from_batch_inputs(getattr(N, kind), unit, gens, *(() if pr is None else (pr,)), dtype=dt) if pr is not None else N.BatchTensorNoise.from_batch_inputs(getattr(N, kind), unit, gens, dtype=dt)
+            else:  # (what the wrapper builds for host-resident latents, diffusers.py::_make_noise_generator)
+                gen = ON.HostRandomBatch(unit, gens, dt) if kind == "Random" else HN.HostStructuredBatch(getattr(N, kind), unit, gens, pr, dt)
+            outs = [torch.as_tensor(gen.generate(eval(step, env))) for _ in range(draws)]
+            sides.append((None, outs))
+        except Exception as err:  # noqa: BLE001
+            sides.append((err, None))
+    (re_, r), (pe, p) = sides
+    if re_ or pe:
+        return None if type(re_) is type(pe) else f"reference {re_!r}, here {pe!r}"
+    for i, (a, b) in enumerate(zip(p, r)):
+        if a.dtype != b.dtype or a.shape != b.shape:
+            return f"draw {i}: {a.dtype}{tuple(a.shape)} vs {b.dtype}{tuple(b.shape)}"
+        if not torch.equal(a.cpu(), b) and not (torch.isnan(a.cpu()) == torch.isnan(b)).all():
+            return f"draw {i}: NaN pattern differs"
+        same = torch.equal(torch.nan_to_num(a.cpu().double(), nan=7.0), torch.nan_to_num(b.double(), nan=7.0))
+        if not same:
+            d = (a.cpu().double() - b.double()).abs().max().item()
+            return f"draw {i}: bits differ (max diff {d:.3g})"
+    return None
+
+
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     found = 0
+    which = sys.argv[3] if len(sys.argv) > 3 else "wrapper"
     for seed in range(first, first + count):
-        text = MG._sweep_spec(random.Random(seed))
+        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise)}[which]
+        text = spec(random.Random(seed))
         try:
-            why = one(seed)
+            why = run(seed)
         except Exception as err:  # noqa: BLE001
             why = f"harness error {err!r}"
         if why:
