@@ -20,6 +20,7 @@ the captured network.  The reference redoes this work on the host every step, wi
 
 from __future__ import annotations
 
+from collections import OrderedDict
 from typing import Callable, Sequence
 
 import torch
@@ -89,6 +90,49 @@ class CapturedLoop:
             self.seeds_dev.copy_(seeds_tensor([int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds], self.seeds_dev.device))
         self.graph.replay()
         return self.static_out.clone()
+
+
+class CapturedLoops:
+    """Captured sampling loops for ANY run length: `out = loops(latents, steps, seeds=None)`.
+
+    A run's length shapes the loop itself (number of launches, the multistep ramp-up, the operands of every step), so a graph
+    serves one length; the reference's loop takes `steps` per call (skrample/sampling/interface.py:34-59).  This keeps one
+    `CapturedLoop` per length, recorded the first time that length is asked for (one eager warm-up + one capture, tens of
+    milliseconds) and replayed afterwards; the `keep` most recently used lengths stay resident, the oldest graph and its static
+    buffers are dropped beyond that.  `make_wrapper()` returns a fresh scheduler wrapper per capture (a graph reads its wrapper's
+    device buffers, so lengths cannot share one); the other arguments are `capture_sampling_loop`'s."""
+
+    def __init__(self, make_wrapper: Callable[[], object], model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], example: torch.Tensor, seeds: Sequence[int] | None = None,
+                 keep: int = 8, **capture_options):
+        if keep < 1:
+            raise ValueError("keep at least one captured length")
+        self._make, self._model, self._example, self._seeds, self._options = make_wrapper, model, example, seeds, capture_options
+        self.keep = keep
+        self._loops: OrderedDict[int, CapturedLoop] = OrderedDict()
+        self.captures = 0  # how many graphs were recorded so far (a replay of a resident length adds none)
+
+    def loop(self, steps: int) -> CapturedLoop:
+        "the captured loop of this run length (recorded now if it is not resident)"
+        steps = int(steps)
+        if steps < 1:
+            raise ValueError(f"a sampling loop has at least one step, not {steps}")
+        found = self._loops.get(steps)
+        if found is None:
+            found = capture_sampling_loop(self._make(), self._model, self._example, steps, seeds=self._seeds, **self._options)
+            self.captures += 1
+            self._loops[steps] = found
+            while len(self._loops) > self.keep:
+                self._loops.popitem(last=False)
+        self._loops.move_to_end(steps)
+        return found
+
+    @property
+    def resident(self) -> tuple[int, ...]:
+        "run lengths whose graphs are resident, least recently used first"
+        return tuple(self._loops)
+
+    def __call__(self, latents: torch.Tensor, steps: int, seeds: Sequence[int] | None = None, slot: int | None = None) -> torch.Tensor:
+        return self.loop(steps)(latents, seeds, slot)
 
 
 def capture_sampling_loop(wrapper, model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], example: torch.Tensor, steps: int, seeds: Sequence[int] | None = None, warmup: int = 2,

@@ -1462,6 +1462,34 @@ def test_whole_loop_graph_capture_vs_oracle(indexed, dev):
     assert rel_err(got, ref) < 5e-5, rel_err(got, ref)  # 9 chained steps of <= 1e-5 each (Philox normals within 2e-6)
 
 
+def test_captured_loops_serve_any_run_length(dev):
+    """the reference's loop takes `steps` per call (interface.py:34-59): CapturedLoops records one graph per run length on first use,
+    replays it afterwards, keeps the most recently used lengths -- every length equals the eager run of that length bit for bit, with the
+    seeds given at the call"""
+    from skrample_amd.graphs import CapturedLoops
+
+    shape = (3, 4, 16, 16)
+    g = torch.Generator().manual_seed(77)
+    net = lambda x, t: x * 0.75 - (t / 2000) * x.abs()  # noqa: E731
+    x0 = torch.randn(shape, generator=g).to(dev)
+    mk = lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Karras(PS.Scaled()))  # noqa: E731
+
+    def eager(steps, seeds, x):
+        w = mk()
+        w.set_timesteps(steps)
+        for t in w.timesteps.tolist():
+            x = w.step(net(x, t), t, x, generator=list(seeds), return_dict=False)[0]
+        return x
+
+    loops = CapturedLoops(mk, net, x0, seeds=[1, 2, 3], keep=2)
+    for steps, seeds in ((5, [1, 2, 3]), (9, [4, 5, 6]), (5, [7, 8, 9]), (1, [1, 2, 3]), (9, [1, 2, 3])):
+        x = torch.randn(shape, generator=g).to(dev)
+        assert torch.equal(loops(x, steps, seeds=seeds), eager(steps, seeds, x)), steps
+    assert loops.captures == 4 and loops.resident == (1, 9)  # 5, 9 recorded; 5 replayed; 1 recorded (9, the least recently used, dropped); 9 recorded again (5 dropped)
+    with pytest.raises(ValueError):
+        loops(x0, 0)
+
+
 @pytest.mark.parametrize("kind", ["dpm2_sde", "unipc3_sde", "adams4", "rk4_sde", "adams7", "unipc5_sde"])
 def test_indexed_graph_serves_other_schedules(kind, dev):
     """skr_step_launch_indexed: one captured loop, step scalars resident on the device.  Re-targeting it to other schedules of
