@@ -69,9 +69,9 @@ def _wl() -> dict[str, Workload]:
     from skrample_amd.sampling import models as PM
     from skrample_amd.sampling import structured as PT
 
-    # alias_history=True: the synthetic "network" hands over fresh tensors, which the default ("auto") would find out by its second
-    # call -- stated here so that the traced plans name the caller's own tensors from the first step on (capture maps pointers)
-    dpm2 = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), alias_history=True)  # noqa: E731
+    # Default-constructed wrappers (alias_history="auto"): a run's first call snapshots its two tensors, the second call sees the
+    # synthetic "network" hand over a fresh tensor and aliases from then on -- the traced steady-state steps (5-14) are the aliased ones
+    dpm2 = lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()))  # noqa: E731
     steady = tuple(range(5, 15))
     return {
         w.name: w
@@ -101,7 +101,7 @@ def _wl() -> dict[str, Workload]:
                 "in-kernel Philox noise (two draws per element), one two-output launch per step (fp32 corrected state + bf16 result)",
                 "sampler steps/sec (fused UniPC-3 SDE step, flow-pred, Linear schedule, Bx16x128x128 bf16, Philox noise) + achieved HBM GB/s",
                 256, (16, 128, 128), 26, 1, 20, steady,
-                lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), alias_history=True),
+                lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel()),
                 "skr::step_kernel_k2<bf16_t, 8 + 1 operands, NOISE=true> (two outputs: fp32 state + bf16 result)",
                 (("step_kernel_k2<skr::bf16_t, 8, 1, true", 1),),
                 oracle=lambda: _step_oracle("unipc", 3, 1.0, "linear", "flow", "random"), cpu_sample=16,
@@ -111,7 +111,7 @@ def _wl() -> dict[str, Workload]:
                 "per step one Colored draw (3 launches: plane FFTs, channel axis + radial weights, inverse planes) and one two-output step launch",
                 "sampler steps/sec (UniPC-3 SDE step + Colored noise, flow-pred, Linear schedule, 256x16x128x128 bf16) + achieved HBM GB/s",
                 256, (16, 128, 128), 30, 1, 20, steady,
-                lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), noise_type=PN.Colored, noise_props=PN.ColoredProps(), alias_history=True),
+                lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), noise_type=PN.Colored, noise_props=PN.ColoredProps()),
                 "skr::step_kernel_k2<bf16_t, 10 + 1 operands> (two outputs); generator: colored_plane<0> + colored_outer_axis_regs<16> + colored_plane<1>",
                 (("step_kernel_k2<skr::bf16_t, 10, 1, false", 1), ("colored_plane", 2), ("colored_outer_axis", 1)),
                 generator_bytes_note="Colored generator, unavoidable HBM traffic per draw: half spectrum (complex64) written, read + written by the channel-axis pass, read by the inverse, + bf16 result = 18.2 B/element",
@@ -122,7 +122,7 @@ def _wl() -> dict[str, Workload]:
                 "= {batch} samples per GPU (the shard a rank owns; no collective), one fused launch per step",
                 "sampler steps/sec (fused Adams-4 step, v-pred, ZSNR, 2048x4x128x128 bf16 sharded by sample over 8 GPUs: 256 per GPU) + achieved HBM GB/s",
                 256, (4, 128, 128), 18, 1, 20, steady,
-                lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=4), PS.ZSNR(), PM.VelocityModel(), alias_history=True),
+                lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=4), PS.ZSNR(), PM.VelocityModel()),
                 "skr::step_kernel_k1<bf16_t, K=8> (x, out and three verbatim (x, out) history pairs)",
                 (("step_kernel_k1<skr::bf16_t, 8, false", 1),),
                 oracle=lambda: _step_oracle("adams", 4, 0.0, "zsnr", "v", "random"),
@@ -133,7 +133,7 @@ def _wl() -> dict[str, Workload]:
                 "+ one Pyramid draw (2 launches)",
                 "sampler steps/sec (RKUltra-6 SDE step = 6 fused stage launches + Pyramid noise, 512x4x256x256 bf16 sharded by sample over 8 GPUs: 64 per GPU) + achieved HBM GB/s",
                 64, (4, 256, 256), 100, 6, 6, (1, 2, 3, 4),
-                lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=6, stochasticity=1, noise_type=PN.Pyramid, noise_props=PN.PyramidProps(), alias_history=True),
+                lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=6, stochasticity=1, noise_type=PN.Pyramid, noise_props=PN.PyramidProps()),
                 "skr::step_kernel_rk1<bf16_t, K=2..7> x 6 stages (derivative + next stage input per launch); generator: pyramid_pass1 + normalise_pass2",
                 (("step_kernel_rk1", 6), ("pyramid_pass1", 1), ("normalise_pass2", 1)),
                 generator_bytes_note="Pyramid generator: fp32 scratch written and re-read by the normalising pass + bf16 result = 10 B/element per draw",

@@ -30,14 +30,20 @@ class Point(NamedTuple):
 
     def add_noise(self, sample, noise):
         "alpha*sample + sigma*noise (reference common.py:32-33).  Tensors go through the HIP engine."
+        from .sampling import native
         from .sampling.lazy import lift, settle
 
-        return settle(lift(sample) * self.alpha + lift(noise) * self.sigma, like=sample)
+        done = native.try_point("add", self, sample, noise)  # 16-bit tensors: the reference's three rounded ops, one launch
+        return done if done is not None else settle(lift(sample) * self.alpha + lift(noise) * self.sigma, like=sample)
 
     def remove_noise(self, sample, noise):
         "(sample - sigma*noise)/alpha; alpha == 0 returns the scaled noise (reference common.py:35-40)"
+        from .sampling import native
         from .sampling.lazy import lift, settle
 
+        done = native.try_point("remove", self, sample, noise)  # 16-bit tensors, and any tensor at alpha = 0 (inf / nan, as the reference's)
+        if done is not None:
+            return done
         if self.alpha == 0:
             return settle(lift(noise) * self.sigma, like=sample)
         return settle((lift(sample) - lift(noise) * self.sigma) / self.alpha, like=sample)

@@ -425,6 +425,8 @@ def evaluate(forms: Sequence[Lin], dtypes: Sequence[torch.dtype | None], acc_f64
             raise SkrampleHipError(f"operand shape {tuple(t.shape)} does not match {shape}")
     narrow_types = [t.dtype for t in prepared.values() if t.dtype != wide]
     group_a = max(dict.fromkeys(narrow_types), key=narrow_types.count) if narrow_types else wide  # (first seen wins a tie: no dependence on hash order)
+    if conv is not None and conv.dtype == wide:
+        group_a = wide  # the rounded conversion's operands lead group A: whatever is narrower (fp32 noise beside fp64 latents) is widened, exactly, below
     # outputs must be group_a or wide
     for k, od in enumerate(out_dtypes):
         if od not in (group_a, wide):

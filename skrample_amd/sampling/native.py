@@ -474,3 +474,26 @@ def try_unipc(sampler, packed, model, schedule, previous):
     except _Refused:
         return None
     return S.SKSamples(sample, prediction, packed.step, packed.noise, final)
+
+
+def try_point(kind: str, point: Point, sample, noise):
+    """`Point.add_noise` / `Point.remove_noise` on tensors in the reference's arithmetic (common.py:32-40: `sample * alpha + noise * sigma`,
+    `(sample - noise * sigma) / alpha`, each operator a rounded tensor op), or None (the caller runs the fused form).  What a diffusers
+    pipeline reaches through `scheduler.add_noise` / `scale_noise` on 16-bit latents.  A tensor divided by alpha = 0 is not an exception in
+    the reference (only its float path catches ZeroDivisionError): the quotient is inf / nan, and so it is here, whatever `mode` says."""
+    singular = kind == "remove" and point.alpha == 0
+    if not (isinstance(sample, torch.Tensor) and isinstance(noise, torch.Tensor)):
+        return None
+    if singular:
+        if sample.dtype != noise.dtype or sample.shape != noise.shape or sample.device != noise.device or sample.dtype not in (torch.bfloat16, torch.float16, torch.float32, torch.float64):
+            return None
+    elif not _eligible(sample, noise):
+        return None
+    try:
+        tape = Tape(sample.dtype, sample.shape, sample.device, require_device=False)
+        s, n = tape.leaf(sample), tape.leaf(noise)
+        out = s * point.alpha + n * point.sigma if kind == "add" else (s - n * point.sigma) / point.alpha
+        (done,) = _execute(tape, [out])
+    except _Refused:
+        return None
+    return done

@@ -142,3 +142,55 @@ def test_register_allocation_and_refusals():
         native.record_stated(sampler, PT.SampleInput(packed.sample, packed.prediction.float(), packed.step, None), model, sched, previous, require_device=False)
     with pytest.raises(native._Refused):
         native.record_stated(PT.SPC(), packed, model, sched, previous, require_device=False)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_add_noise_and_remove_noise_round_as_the_reference_does(dtype):
+    """Point.add_noise / remove_noise (reference common.py:32-40) are tensor expressions too: `sample * alpha + noise * sigma` is three
+    rounded ops on 16-bit tensors.  What scheduler.add_noise / scale_noise hand a pipeline (img2img start) equals those ops bit for bit."""
+    import skrample_amd.diffusers as PD
+    import skrample_amd.scheduling as PS
+    from skrample_amd.common import Point
+    from skrample_amd.sampling import structured as PT
+
+    g = torch.Generator().manual_seed(9)
+    x, n = torch.randn(3, 4, 9, 7, generator=g).to(dtype), torch.randn(3, 4, 9, 7, generator=g).to(dtype)
+    pt = Point(613.0, 0.7391, 0.6733)
+    before = native.launches
+    assert torch.equal(pt.add_noise(x, n), x * pt.alpha + n * pt.sigma)
+    assert torch.equal(pt.remove_noise(x, n), (x - n * pt.sigma) / pt.alpha)
+    assert native.launches == before  # (host tensors: the tape runs one torch op per entry)
+    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2), PS.Karras(PS.Scaled()))
+    w.set_timesteps(7)
+    t, _, sigma, alpha = w.timesteps[3], *w.schedule_np[3]
+    want = x * float(alpha) + n * float(sigma)
+    assert torch.equal(w.scale_noise(x, t, n), want) and torch.equal(w.add_noise(x, n, w.timesteps[3:4]), want)
+    rk = PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=3)
+    rk.set_timesteps(4)
+    _, sigma, alpha = rk.schedule_np[5]
+    assert torch.equal(rk.scale_noise(x, rk.timesteps[5], n), x * float(alpha) + n * float(sigma))
+    # "never": the fused form, one rounding -- within half a unit of the exact value, not the reference's bits
+    keep, native.mode = native.mode, "never"
+    try:
+        fused = pt.add_noise(x, n)
+    finally:
+        native.mode = keep
+    exact = x.double() * pt.alpha + n.double() * pt.sigma
+    assert (fused.double() - exact).abs().max() <= (pt.add_noise(x, n).double() - exact).abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float64])
+def test_remove_noise_at_alpha_zero_divides_as_the_reference_does(dtype):
+    "a tensor over alpha = 0 is inf / nan in the reference (only its float path catches ZeroDivisionError, common.py:37-40): the same tensor here"
+    from skrample_amd.common import Point
+
+    g = torch.Generator().manual_seed(10)
+    x, n = torch.randn(2, 5, generator=g).to(dtype), torch.randn(2, 5, generator=g).to(dtype)
+    x[0, 0] = 0.0
+    n[0, 0] = 0.0
+    pt = Point(1000.0, 1.0, 0.0)
+    want = (x - n * pt.sigma) / pt.alpha
+    got = pt.remove_noise(x, n)
+    assert got.dtype == dtype and torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+    assert torch.isnan(got[0, 0]) and torch.isinf(got[0, 1])
+    assert pt.remove_noise(0.5, 2.0) == 2.0  # the float path: the scaled noise

@@ -563,6 +563,27 @@ def test_tape_ops_through_the_c_abi(dtype, dev):
     assert lib.skr_tape_launch(ctypes.byref(bad), one, one, 8, _hip.current_stream_ptr(dev)) == 3  # SKR_ERR_TERMS
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_add_noise_on_the_device_returns_the_reference_bits(dtype, dev):
+    "scheduler.add_noise / scale_noise / Point.remove_noise on 16-bit device tensors: one tape launch each, the reference's three rounded ops (common.py:32-40)"
+    from skrample_amd.common import Point
+    from skrample_amd.sampling import native
+
+    g = torch.Generator().manual_seed(19)
+    x, n = torch.randn(3, 4, 33, 17, generator=g).to(dtype), torch.randn(3, 4, 33, 17, generator=g).to(dtype)
+    w = PD.SkrampleWrapperScheduler(PT.DPM(order=2), PS.Karras(PS.Scaled()))
+    w.set_timesteps(7)
+    _, sigma, alpha = w.schedule_np[3]
+    before = native.launches
+    got = w.add_noise(x.to(dev), n.to(dev), w.timesteps[3:4])
+    assert native.launches == before + 1 and got.is_cuda and torch.equal(got.cpu(), x * float(alpha) + n * float(sigma))
+    pt = Point(613.0, 0.7391, 0.6733)
+    assert torch.equal(pt.remove_noise(x.to(dev), n.to(dev)).cpu(), (x - n * pt.sigma) / pt.alpha)
+    zero = Point(1000.0, 1.0, 0.0)
+    a, b = zero.remove_noise(x.float().to(dev), n.float().to(dev)).cpu(), (x.float() - n.float() * 1.0) / 0.0
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
 def test_wrappers_keep_their_compute_scale(dev):
     "the scheduler wrappers widen to compute_scale before the sampler runs (reference diffusers.py:575-599): fused kernel; compute_scale=None: the tape"
     from skrample_amd.sampling import native

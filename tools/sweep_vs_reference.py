@@ -3,7 +3,7 @@ step each through the imported reference and through skrample_amd on host tensor
 every difference -- results beyond the parity bar, different timesteps, or one side raising where the other does not.
 tests/golden/steps_sweep.npz holds the first 64 accepted cases of the same generator; this runs as many as asked.
 
-    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise]
+    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config]
 """
 
 import os
@@ -74,8 +74,35 @@ def one(seed: int) -> str | None:
     n = len(r_times)
     outs = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]
     noises = [torch.randn(shape, generator=g) for _ in range(n)]
-    r._noise_generator, p._noise_generator = MG._Injected(noises), _Replay(noises)
+    # the helper entry points a diffusers pipeline calls around the loop (img2img start: add_noise / scale_noise at a later timestep,
+    # set_begin_index, scale_model_input, init_noise_sigma), then the steps from that start with an empty history
+    extras = random.Random(seed ^ 0x5EED)
+    stride = max(int(getattr(r, "order", 1)), 1)
+    start = extras.randrange(0, n, stride) if extras.random() < 0.4 else 0
+    probes = []
+    for w, times in ((r, r_times), (p, p_times)):
+        try:
+            if start:
+                w.set_begin_index(start)
+            probe = [float(w.init_noise_sigma)]
+            probe.append(torch.as_tensor(w.add_noise(x, noises[0].to(dt), times[start : start + 1])).double())
+            probe.append(torch.as_tensor(w.scale_noise(x, times[start], noises[0].to(dt))).double())
+            probe.append(torch.as_tensor(w.scale_model_input(x, times[start])).double())
+            probes.append(probe)
+        except Exception as err:  # noqa: BLE001
+            probes.append(err)
+    if isinstance(probes[0], Exception) or isinstance(probes[1], Exception):
+        return None if type(probes[0]) is type(probes[1]) else f"helper entry points: reference {probes[0]!r}, here {probes[1]!r}"
+    if abs(probes[0][0] - probes[1][0]) > 1e-12 * max(abs(probes[0][0]), 1.0):
+        return f"init_noise_sigma {probes[0][0]} vs {probes[1][0]}"
+    for name, a, b in zip(("add_noise", "scale_noise", "scale_model_input"), probes[1][1:], probes[0][1:]):
+        exact = dt in (torch.bfloat16, torch.float16)  # (16-bit: the reference's own rounded ops, bit for bit)
+        if a.shape != b.shape or not (torch.equal(a, b) if exact else torch.allclose(a, b, rtol=1e-5, atol=1e-6, equal_nan=True)):
+            return f"{name} at timestep index {start} differs: max diff {(a - b).abs().max().item():.3g}"
+    r._noise_generator, p._noise_generator = MG._Injected(noises[start:]), _Replay(noises[start:])
     for i, (tr, tp) in enumerate(zip(r_times, p_times)):
+        if i < start:
+            continue
         try:
             ref = r.step(outs[i], tr, x, return_dict=False)
             r_err = None
@@ -249,13 +276,75 @@ def one_noise(seed: int) -> str | None:
     return None
 
 
+# ---- diffusers configs: from_diffusers_config over random config dicts, then set_timesteps with random arguments ----------------------------------
+def _config_spec(rng):
+    cfg: dict = {}
+    if rng.random() < 0.85:
+        cfg["_class_name"] = rng.choice(
+            ("DDIMScheduler", "DDPMScheduler", "DPMSolverMultistepScheduler", "DPMSolverSDEScheduler", "EulerAncestralDiscreteScheduler", "EulerDiscreteScheduler",
+             "FlowMatchEulerDiscreteScheduler", "IPNDMScheduler", "MiniMaxH3Scheduler", "UniPCMultistepScheduler", "PNDMScheduler")
+        )  # fmt: skip
+    for key, values in (
+        ("prediction_type", ("epsilon", "flow", "sample", "v_prediction", "other")),
+        ("beta_schedule", ("linear", "scaled_linear", "squaredcos_cap_v2")),
+        ("algorithm_type", ("dpmsolver", "dpmsolver++", "sde-dpmsolver", "sde-dpmsolver++")),
+        ("use_flow_sigmas", (True, False)),
+        ("use_beta_sigmas", (True, False)),
+        ("use_exponential_sigmas", (True, False)),
+        ("use_karras_sigmas", (True, False)),
+        ("rescale_betas_zero_snr", (True, False)),
+        ("shift", (1.0, 3.0, 1.7)),
+        ("flow_shift", (2.0, 5.0)),
+        ("solver_order", (1, 2, 3)),
+        ("num_train_timesteps", (1000, 500)),
+        ("beta_start", (0.00085, 0.0001)),
+        ("beta_end", (0.012, 0.02)),
+        ("timestep_spacing", ("leading", "trailing")),
+    ):
+        if rng.random() < 0.3:
+            cfg[key] = rng.choice(values)
+    extra = rng.choice(("", "", "", ", sampler=T.Adams", ", schedule=S.Linear", ", schedule=S.ZSNR", ", subschedule=S.Karras", ", subschedule=S.Beta, subschedule_props={'alpha': 0.8}",
+                        ", schedule_modifiers=[(S.Hyper, {})]", ", schedule_modifiers=[(S.FlowShift, {'shift': 2.0})], modifier_merge_strategy=W.MergeStrategy.Ours", ", model=M.VelocityModel()",
+                        ", sampler_props={'order': 2}", ", schedule_props={'base_timesteps': 800}", ", invert_prediction=True", ", allow_dynamic=False"))  # fmt: skip
+    kind = rng.choice(("W.SkrampleWrapperScheduler", "W.SkrampleWrapperScheduler", "W.RKUltraWrapperScheduler", "W.DynasauRKWrapperScheduler"))
+    if kind != "W.SkrampleWrapperScheduler" and ("sampler" in extra):
+        extra = ""
+    call = rng.choice(("set_timesteps({n})", "set_timesteps({n})", "set_timesteps({n}, mu=0.8)", "set_timesteps(num_inference_steps={n}, device='cpu')", "set_timesteps(timesteps=[900.0, 500.0, 100.0])", "set_timesteps(sigmas=[1.0, 0.5, 0.25, 0.1])"))
+    return cfg, kind, extra, call.format(n=rng.randint(1, 12))
+
+
+def one_config(seed: int) -> str | None:
+    cfg, kind, extra, call = _config_spec(random.Random(seed))
+    sides = []
+    for names in (REF, OWN):
+        try:
+            w = eval(f"{kind}.from_diffusers_config(cfg{extra})", {**names, "cfg": dict(cfg)})
+            made = (repr(getattr(w, "sampler", None)), repr(w.schedule), repr(w.model), w.invert_prediction, sorted((k, repr(v)) for k, v in w.config.items()))
+            eval(f"w.{call}", {"w": w})
+            after = (repr(w.schedule), w.timesteps.tolist(), np.asarray(w.schedule_np).tolist(), sorted((k, repr(v)) for k, v in w.config.items()), w.order, w.init_noise_sigma if hasattr(w, "init_noise_sigma") else None)
+            sides.append((None, made, after))
+        except Exception as err:  # noqa: BLE001
+            sides.append((err, None, None))
+    (re_, rmade, rafter), (pe, pmade, pafter) = sides
+    if re_ or pe:
+        return None if type(re_) is type(pe) else f"reference {re_!r}, here {pe!r}"
+    strip = lambda text: text.replace("skrample_amd.", "skrample.")  # noqa: E731
+    if strip(repr(rmade)) != strip(repr(pmade)):
+        return f"constructed objects differ:\n      {rmade}\n      {pmade}"
+    if strip(repr(rafter[0])) != strip(repr(pafter[0])) or rafter[4:] != pafter[4:] or strip(repr(rafter[3])) != strip(repr(pafter[3])):
+        return f"after {call}: {rafter[0]} order {rafter[4:]} vs {pafter[0]} order {pafter[4:]} / config {rafter[3]} vs {pafter[3]}"
+    if not np.allclose(rafter[1], pafter[1], rtol=0, atol=1e-9, equal_nan=True) or not np.allclose(rafter[2], pafter[2], rtol=1e-12, atol=1e-12, equal_nan=True):
+        return f"after {call}: timesteps / points differ"
+    return None
+
+
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     found = 0
     which = sys.argv[3] if len(sys.argv) > 3 else "wrapper"
     for seed in range(first, first + count):
-        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise)}[which]
+        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config)}[which]
         text = spec(random.Random(seed))
         try:
             why = run(seed)
