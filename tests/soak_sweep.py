@@ -1,0 +1,80 @@
+"""GPU box: the device path against the package's own host executor over the sweep grammar (tests/sweep_grammar.py) -- usage:
+python tests/soak_sweep.py [first_seed last_seed].  The host side of every case is what tools/sweep_vs_reference.py compares with the imported
+reference in the build container (1500 configurations, 0 differences), so device == host here carries the reference's answer to seeds
+the fixture (tests/golden/steps_sweep.npz, 64 cases) does not hold.  Teacher-forced: each step sees the host run's inputs."""
+import os
+import random
+import sys
+import traceback
+
+root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
+import torch  # noqa: E402
+import test_step_gpu as T  # noqa: E402
+from sweep_grammar import sweep_spec  # noqa: E402
+
+from skrample_amd import _hip  # noqa: E402
+from skrample_amd.sampling import lazy  # noqa: E402
+
+_hip.load()
+dev = torch.device("cuda:0")
+
+
+def settle(v):
+    return torch.as_tensor(v.materialize() if isinstance(v, lazy.LazyTensor) else v)
+
+
+def one(seed: int) -> str:
+    text, dtype, shape, steps_n = sweep_spec(random.Random(seed))
+    dt = getattr(torch, dtype)
+    g = torch.Generator().manual_seed(seed)
+    try:
+        host, card = eval(text, T.SWEEP_NAMES), eval(text, T.SWEEP_NAMES)
+        host.set_timesteps(steps_n)
+        card.set_timesteps(steps_n)
+        times = host.timesteps
+    except (ZeroDivisionError, ValueError, AssertionError, IndexError, AttributeError, TypeError):
+        return "refused"
+    assert torch.equal(times, card.timesteps.cpu())
+    n = len(times)
+    x = torch.randn(shape, generator=g).to(dt)
+    outs = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]
+    noises = [torch.randn(shape, generator=g) for _ in range(n)]
+    host._noise_generator, card._noise_generator = T.Injected(noises, "cpu"), T.Injected(noises, dev)
+    for i, t in enumerate(times):
+        try:
+            ref = [settle(v) for v in host.step(outs[i], t, x, return_dict=False)]
+        except ZeroDivisionError:
+            try:
+                card.step(outs[i].to(dev), t, x.to(dev), return_dict=False)
+            except ZeroDivisionError:
+                return "singular"
+            raise AssertionError(f"step {i}: the host path refuses a zero denominator, the device path does not")
+        got = [settle(v) for v in card.step(outs[i].to(dev), t, x.to(dev), return_dict=False)]
+        if not all(torch.isfinite(v.float()).all() for v in ref):
+            return "non-finite"
+        for name, a, b in zip(("prev_sample", "pred_original_sample"), got, ref):
+            assert a.is_cuda, name
+            T.assert_close(a, b, dt, f"step {i} {name}", flips=0.2)
+        x = ref[0]
+    return "ok"
+
+
+if __name__ == "__main__":
+    first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (800000, 800400)
+    tally: dict = {}
+    bad = 0
+    for seed in range(first, last):
+        try:
+            kind = one(seed)
+        except Exception:  # noqa: BLE001
+            bad += 1
+            kind = "FAILED"
+            print(f"seed {seed}: {sweep_spec(random.Random(seed))}", flush=True)
+            traceback.print_exc(limit=3)
+        tally[kind] = tally.get(kind, 0) + 1
+        if (seed - first) % 100 == 99:
+            print(f"... {seed - first + 1} cases: {tally}", flush=True)
+    torch.cuda.synchronize()
+    print(f"sweep soak over seeds {first}..{last - 1}: {tally}; {bad} failures")
+    sys.exit(1 if bad else 0)

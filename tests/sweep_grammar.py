@@ -1,0 +1,53 @@
+"""The seeded grammar of wrapper configurations behind tests/golden/steps_sweep.npz (tools/make_golden.py::sweep), the live sweeps of
+tools/sweep_vs_reference.py and the GPU box's device-vs-host soak (tests/soak_sweep.py).  A case is the TEXT of its constructor in a neutral
+vocabulary -- W = diffusers module, T = structured samplers, S = schedules, M = models -- so that the reference, the package and the
+tests build their objects from the same words.  Changing a line here changes the fixture: regenerate it."""
+
+
+def sweep_spec(rng) -> tuple[str, str, tuple[int, ...], int]:
+    eta = lambda: rng.choice(("0", "0", "0.5", "1", "-1.5", "0.3"))  # noqa: E731
+
+    def deriv():
+        return rng.choice(("", "", "", ", derivative_transform=None", ", derivative_transform=M.VelocityModel()", ", derivative_transform=M.FlowModel()"))
+
+    def single(allow_unipc=True):
+        kind = rng.choice(("Euler", "DPM", "DPM", "Adams", "Adams", "UniP", "UniPC", "UniPC") if allow_unipc else ("Euler", "DPM", "Adams", "UniP"))
+        if kind == "Euler":
+            return f"T.Euler(stochasticity={eta()})"
+        if kind == "DPM":
+            return f"T.DPM(order={rng.randint(1, 3)}, stochasticity={eta()}{deriv()})"
+        if kind == "Adams":
+            return f"T.Adams(order={rng.randint(1, 9)}, stochasticity={eta()}{deriv()})"
+        fast = rng.choice(("", "", ", fast_solve=True"))
+        if kind == "UniP":
+            return f"T.UniP(order={rng.randint(1, 9)}, stochasticity={eta()}{fast}{deriv()})"
+        pred = rng.choice(("", "", f", predictor={single(False)}"))
+        return f"T.UniPC(order={rng.randint(1, 6)}, stochasticity={eta()}{fast}{pred}{deriv()})"
+
+    flow = rng.random() < 0.4
+    if flow:
+        base = rng.choice(("S.Linear()", "S.Linear()", "S.Linear(sigma_start=0.9)"))
+        mod = rng.choice(("{}", "{}", "S.FlowShift({})", "S.FlowShift({}, shift=1.7)", "S.Sinner({})", "S.Probit({})", "S.Beta({})", "S.Hyper({})", "S.FlowShift(S.Beta({}))"))
+        model = rng.choice(("M.FlowModel()", "M.FlowModel()", "M.DataModel()", "M.VelocityModel()"))
+    else:
+        base = rng.choice(("S.Scaled()", "S.Scaled()", "S.ZSNR()", "S.Scaled(beta_scale=1)", "S.Scaled(beta_start=0.0001, beta_end=0.02, beta_scale=1)", "S.Scaled(base_timesteps=-1000, beta_scale=1)"))
+        mod = rng.choice(("{}", "{}", "S.Karras({})", "S.Karras({}, rho=5.0)", "S.Exponential({})", "S.Beta({})", "S.Hyper({})", "S.Hyper({}, scale=3, tail=False)", "S.Sinner({})", "S.Hyper(S.Karras({}))"))
+        model = rng.choice(("M.DataModel()", "M.VelocityModel()") if "ZSNR" in base else ("M.NoiseModel()", "M.NoiseModel()", "M.DataModel()", "M.VelocityModel()", "M.ScaleX()"))
+    schedule = mod.format(base)
+    opts = rng.choice(("", "", "", ", invert_prediction=True", ", compute_scale=torch.float64"))
+    roll = rng.random()
+    if roll < 0.12:
+        text = f"W.RKUltraWrapperScheduler({schedule}, sampler_order={rng.randint(1, 6)}, stochasticity={eta()}, model={model}{opts})"
+    elif roll < 0.2:
+        text = f"W.DynasauRKWrapperScheduler({schedule}, sampler_order={rng.randint(2, 4)}, stochasticity={eta()}, model={model}{opts})"
+    elif roll < 0.32:
+        spc = f"T.SPC(predictor={single(False)}, corrector={single(False)}, bias={rng.choice(('0', '0.3', '-0.2'))}, power={rng.choice(('1', '2', '0.5'))}, adaptive={rng.choice(('True', 'False'))}, invert={rng.choice(('True', 'False'))})"
+        text = f"W.SkrampleWrapperScheduler({spc}, {schedule}, {model}{opts})"
+    else:
+        text = f"W.SkrampleWrapperScheduler({single()}, {schedule}, {model}{opts})"
+    dtype = rng.choice(("float32", "float32", "bfloat16", "float16"))
+    if "float64" in opts and rng.random() < 0.5:
+        dtype = "float64"
+    shape = (rng.randint(1, 3), rng.randint(1, 4), rng.choice((4, 7, 8)), rng.choice((5, 8, 6)))
+    steps_n = rng.randint(2, 9) if "RK" not in text else rng.randint(1, 3)
+    return text, dtype, shape, steps_n

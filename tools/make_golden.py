@@ -32,6 +32,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.environ.get("SKR_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 
 import ref_loader  # noqa: E402
 
@@ -302,53 +303,7 @@ def steps() -> None:
 # eta x dtype x compute_scale x ragged shape x run length), each case stepped through the imported reference.  A case is stored as
 # the TEXT of its constructor in a neutral vocabulary (W = diffusers module, T = structured samplers, S = schedules, M = models), so
 # the test builds the product's object from the same words.
-def _sweep_spec(rng) -> tuple[str, str, tuple[int, ...], int]:
-    eta = lambda: rng.choice(("0", "0", "0.5", "1", "-1.5", "0.3"))  # noqa: E731
-
-    def deriv():
-        return rng.choice(("", "", "", ", derivative_transform=None", ", derivative_transform=M.VelocityModel()", ", derivative_transform=M.FlowModel()"))
-
-    def single(allow_unipc=True):
-        kind = rng.choice(("Euler", "DPM", "DPM", "Adams", "Adams", "UniP", "UniPC", "UniPC") if allow_unipc else ("Euler", "DPM", "Adams", "UniP"))
-        if kind == "Euler":
-            return f"T.Euler(stochasticity={eta()})"
-        if kind == "DPM":
-            return f"T.DPM(order={rng.randint(1, 3)}, stochasticity={eta()}{deriv()})"
-        if kind == "Adams":
-            return f"T.Adams(order={rng.randint(1, 9)}, stochasticity={eta()}{deriv()})"
-        fast = rng.choice(("", "", ", fast_solve=True"))
-        if kind == "UniP":
-            return f"T.UniP(order={rng.randint(1, 9)}, stochasticity={eta()}{fast}{deriv()})"
-        pred = rng.choice(("", "", f", predictor={single(False)}"))
-        return f"T.UniPC(order={rng.randint(1, 6)}, stochasticity={eta()}{fast}{pred}{deriv()})"
-
-    flow = rng.random() < 0.4
-    if flow:
-        base = rng.choice(("S.Linear()", "S.Linear()", "S.Linear(sigma_start=0.9)"))
-        mod = rng.choice(("{}", "{}", "S.FlowShift({})", "S.FlowShift({}, shift=1.7)", "S.Sinner({})", "S.Probit({})", "S.Beta({})", "S.Hyper({})", "S.FlowShift(S.Beta({}))"))
-        model = rng.choice(("M.FlowModel()", "M.FlowModel()", "M.DataModel()", "M.VelocityModel()"))
-    else:
-        base = rng.choice(("S.Scaled()", "S.Scaled()", "S.ZSNR()", "S.Scaled(beta_scale=1)", "S.Scaled(beta_start=0.0001, beta_end=0.02, beta_scale=1)", "S.Scaled(base_timesteps=-1000, beta_scale=1)"))
-        mod = rng.choice(("{}", "{}", "S.Karras({})", "S.Karras({}, rho=5.0)", "S.Exponential({})", "S.Beta({})", "S.Hyper({})", "S.Hyper({}, scale=3, tail=False)", "S.Sinner({})", "S.Hyper(S.Karras({}))"))
-        model = rng.choice(("M.DataModel()", "M.VelocityModel()") if "ZSNR" in base else ("M.NoiseModel()", "M.NoiseModel()", "M.DataModel()", "M.VelocityModel()", "M.ScaleX()"))
-    schedule = mod.format(base)
-    opts = rng.choice(("", "", "", ", invert_prediction=True", ", compute_scale=torch.float64"))
-    roll = rng.random()
-    if roll < 0.12:
-        text = f"W.RKUltraWrapperScheduler({schedule}, sampler_order={rng.randint(1, 6)}, stochasticity={eta()}, model={model}{opts})"
-    elif roll < 0.2:
-        text = f"W.DynasauRKWrapperScheduler({schedule}, sampler_order={rng.randint(2, 4)}, stochasticity={eta()}, model={model}{opts})"
-    elif roll < 0.32:
-        spc = f"T.SPC(predictor={single(False)}, corrector={single(False)}, bias={rng.choice(('0', '0.3', '-0.2'))}, power={rng.choice(('1', '2', '0.5'))}, adaptive={rng.choice(('True', 'False'))}, invert={rng.choice(('True', 'False'))})"
-        text = f"W.SkrampleWrapperScheduler({spc}, {schedule}, {model}{opts})"
-    else:
-        text = f"W.SkrampleWrapperScheduler({single()}, {schedule}, {model}{opts})"
-    dtype = rng.choice(("float32", "float32", "bfloat16", "float16"))
-    if "float64" in opts and rng.random() < 0.5:
-        dtype = "float64"
-    shape = (rng.randint(1, 3), rng.randint(1, 4), rng.choice((4, 7, 8)), rng.choice((5, 8, 6)))
-    steps_n = rng.randint(2, 9) if "RK" not in text else rng.randint(1, 3)
-    return text, dtype, shape, steps_n
+from sweep_grammar import sweep_spec as _sweep_spec  # noqa: E402  (tests/sweep_grammar.py: shared with the GPU box's device-vs-host soak)
 
 
 def sweep(count: int = 64) -> None:

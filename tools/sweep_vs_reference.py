@@ -3,7 +3,7 @@ step each through the imported reference and through skrample_amd on host tensor
 every difference -- results beyond the parity bar, different timesteps, or one side raising where the other does not.
 tests/golden/steps_sweep.npz holds the first 64 accepted cases of the same generator; this runs as many as asked.
 
-    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config]
+    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule]
 """
 
 import os
@@ -338,13 +338,126 @@ def one_config(seed: int) -> str | None:
     return None
 
 
+# ---- the sampler-level API on host tensors (no wrapper): sampler.sample(...) free-running with its own history; 16-bit results bit for bit -------
+def _sampler_spec(rng):
+    text, dtype, shape, steps_n = MG._sweep_spec(rng)
+    while not text.startswith("W.SkrampleWrapperScheduler("):
+        text, dtype, shape, steps_n = MG._sweep_spec(rng)
+    inner = text[len("W.SkrampleWrapperScheduler(") : -1]
+    for opt in (", invert_prediction=True", ", compute_scale=torch.float64"):
+        inner = inner.replace(opt, "")
+    return f"({inner})", dtype, shape, steps_n
+
+
+def one_sampler(seed: int) -> str | None:
+    from skrample.common import Step as RStep
+
+    from skrample_amd.common import Step as OStep
+
+    text, dtype, shape, steps_n = _sampler_spec(random.Random(seed))
+    dt = getattr(torch, dtype)
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(shape, generator=g).to(dt)
+    outs = [torch.randn(shape, generator=g).to(dt) for _ in range(steps_n)]
+    nzs = [torch.randn(shape, generator=g).to(dt) for _ in range(steps_n)]
+    sides = []
+    for names, StepT in ((REF, RStep), (OWN, OStep)):
+        try:
+            sampler, schedule, model = eval(text, names)
+            x, prev, got = x0, [], []
+            for i in range(steps_n):
+                rec = sampler.sample(x, outs[i], StepT.from_int(i, steps_n), model, schedule, nzs[i] if sampler.require_noise else None, tuple(prev))
+                final, pred = torch.as_tensor(rec.final), rec.prediction
+                pred = torch.as_tensor(pred.materialize() if hasattr(pred, "materialize") else pred)
+                got.append((final, pred))
+                prev.append(rec)
+                x = final
+            sides.append((None, got))
+        except Exception as err:  # noqa: BLE001
+            sides.append((err, None))
+    (re_, r), (pe, p) = sides
+    if re_ or pe:
+        if re_ is None and isinstance(pe, ZeroDivisionError):
+            return None if not all(torch.isfinite(a.float()).all() and torch.isfinite(b.float()).all() for a, b in r) else f"here {pe!r}, reference finite"
+        return None if type(re_) is type(pe) else f"reference {re_!r}, here {pe!r}"
+    exact = dt in (torch.bfloat16, torch.float16) and "SPC" not in text
+    for i, ((fa, pa), (fb, pb)) in enumerate(zip(p, r)):
+        for name, a, b in (("final", fa, fb), ("prediction", pa, pb)):
+            if a.dtype != b.dtype or a.shape != b.shape:
+                return f"step {i} {name}: {a.dtype}{tuple(a.shape)} vs {b.dtype}{tuple(b.shape)}"
+            if not torch.isfinite(b.float()).all():
+                return None
+            if exact:
+                if not torch.equal(a, b):
+                    return f"step {i} {name}: {(a != b).sum().item()} elements differ from the reference's bits (max {(a.double() - b.double()).abs().max().item():.3g})"
+            else:
+                scale = b.double().abs().max().clamp_min(1e-30)
+                err = ((a.double() - b.double()).abs().max() / scale).item()
+                bar = 1e-5 if dt in (torch.float32, torch.float64) else 0.05  # (SPC on 16-bit: fused form vs the reference's 16-bit chain; a free-running chain diverges)
+                if err > bar:
+                    return f"step {i} {name}: rel inf-norm {err:.3g}"
+    return None
+
+
+# ---- schedules: random compositions and parameters, every public evaluation ------------------------------------------------------------------------
+def _schedule_spec(rng):
+    num = lambda lo, hi: repr(round(rng.uniform(lo, hi), 4))  # noqa: E731
+    if rng.random() < 0.45:
+        base = rng.choice(("S.Linear()", f"S.Linear(sigma_start={num(0.5, 20)})", f"S.Linear(base_timesteps={rng.choice((1000, 1, -1000, 500))})", "S.Linear(custom_space=S.VariancePreserving())"))
+    else:
+        base = rng.choice(("S.Scaled()", "S.ZSNR()", f"S.Scaled(beta_start={num(0.0001, 0.001)}, beta_end={num(0.01, 0.03)}, beta_scale={rng.choice((1, 2, 3))})",
+                           f"S.Scaled(base_timesteps={rng.choice((1000, -1000, 250))})", f"S.ZSNR(beta_scale={rng.choice((1, 2))})"))  # fmt: skip
+    text = base
+    if rng.random() < 0.5:
+        text = rng.choice((f"S.Karras({text}, rho={num(1, 9)}, steps={rng.randint(2, 40)})", f"S.Exponential({text}, rho={num(0.5, 3)}, steps={rng.randint(2, 40)})",
+                           f"S.Beta({text}, alpha={num(0.3, 1.5)}, beta={num(0.3, 1.5)})", f"S.Probit({text}, scale={num(1, 5)})", f"S.Karras({text})", f"S.Beta({text})"))  # fmt: skip
+    for _ in range(rng.choice((0, 0, 1, 1, 2))):
+        text = rng.choice((f"S.FlowShift({text}, shift={num(0.5, 6)})", f"S.Hyper({text}, scale={num(-3, 4)}, tail={rng.choice((True, False))})",
+                           f"S.Sinner({text}, count={num(-4, 4)}, scale={num(0.5, 3)})", f"S.Hyper({text})", f"S.Sinner({text})"))  # fmt: skip
+    return text, rng.randint(1, 30), [round(rng.random(), 6) for _ in range(5)] + [0.0, 1.0]
+
+
+def one_schedule(seed: int) -> str | None:
+    text, steps_n, ts = _schedule_spec(random.Random(seed))
+    sides = []
+    for names in (REF, OWN):
+        got = {}
+        try:
+            sch = eval(text, names)
+        except Exception as err:  # noqa: BLE001
+            sides.append({"construct": err})
+            continue
+        for name, fn in (
+            ("schedule_np", lambda: np.asarray(sch.schedule_np(steps_n))), ("points", lambda: np.asarray(sch.points(ts))), ("ipoints", lambda: np.asarray(sch.ipoints(ts))),
+            ("ipoint", lambda: np.asarray([sch.ipoint(t) for t in ts])), ("point", lambda: np.asarray([sch.point(t) for t in ts])), ("ends", lambda: np.asarray([sch.point_0, sch.point_1])),
+            ("space", lambda: np.asarray([sch.space.regularize(0.37), sch.space.alpha(0.37), *sch.space.regularize(np.asarray([0.1, 2.0]))], dtype=np.float64)),
+            ("schedule", lambda: np.asarray(sch.schedule(steps_n))), ("sigmas", lambda: np.asarray(sch.sigmas(steps_n))), ("timesteps", lambda: np.asarray(sch.timesteps(steps_n))),
+            ("repr", lambda: np.asarray([0.0]) if repr(sch) else None),
+        ):  # fmt: skip
+            try:
+                got[name] = fn()
+            except Exception as err:  # noqa: BLE001
+                got[name] = err
+        sides.append(got)
+    r, p = sides
+    for name in r:
+        a, b = p.get(name), r[name]
+        if isinstance(a, Exception) or isinstance(b, Exception):
+            if type(a) is not type(b):
+                return f"{name}: reference {b!r}, here {a!r}"
+            continue
+        if a is None or a.shape != b.shape or not np.allclose(a, b, rtol=1e-10, atol=1e-10, equal_nan=True):
+            return f"{name}: differs\n      {b.tolist()}\n      {None if a is None else a.tolist()}"
+    return None
+
+
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     found = 0
     which = sys.argv[3] if len(sys.argv) > 3 else "wrapper"
     for seed in range(first, first + count):
-        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config)}[which]
+        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule)}[which]
         text = spec(random.Random(seed))
         try:
             why = run(seed)
