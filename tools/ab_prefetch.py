@@ -45,3 +45,5 @@ ab("cfg5 RKUltra-6 SDE + Pyramid 64x4x256x256", lambda **kw: PD.RKUltraWrapperSc
 ab("DPM-2 SDE + Pyramid 256x4x128x128", lambda **kw: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=PN.Pyramid, noise_props=PN.PyramidProps(), **kw), (256, 4, 128, 128), 1)
 ab("DPM-2 SDE + Offset 256x4x128x128", lambda **kw: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=PN.Offset, noise_props=PN.OffsetProps(), **kw), (256, 4, 128, 128), 1)
 ab("UniPC-3 SDE + Pyramid 256x16x128x128", lambda **kw: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), noise_type=PN.Pyramid, noise_props=PN.PyramidProps(), **kw), (256, 16, 128, 128), 1)
+ab("cfg3c UniPC-3 SDE + Colored 256x16x128x128", lambda **kw: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), noise_type=PN.Colored, noise_props=PN.ColoredProps(), **kw), (256, 16, 128, 128), 1)
+ab("DPM-2 SDE + Colored 256x4x128x128", lambda **kw: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=PN.Colored, noise_props=PN.ColoredProps(), **kw), (256, 4, 128, 128), 1)

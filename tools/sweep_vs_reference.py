@@ -3,7 +3,7 @@ step each through the imported reference and through skrample_amd on host tensor
 every difference -- results beyond the parity bar, different timesteps, or one side raising where the other does not.
 tests/golden/steps_sweep.npz holds the first 64 accepted cases of the same generator; this runs as many as asked.
 
-    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule]
+    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule|generator]
 """
 
 import os
@@ -451,13 +451,55 @@ def one_schedule(seed: int) -> str | None:
     return None
 
 
+# ---- the wrapper's own noise: generator=None (seeds from the sample), one generator, a list, a list of the wrong length; every noise type; host tensors ----
+def _generator_spec(rng):
+    batch = rng.choice((1, 1, 2, 3))
+    shape = (batch, rng.randint(1, 4), rng.choice((4, 8)), rng.choice((5, 8)))
+    noise = rng.choice(("Random", "Random", "Offset", "Pyramid", "Colored"))
+    if rng.random() < 0.7:
+        text = f"W.SkrampleWrapperScheduler({rng.choice(('T.DPM(order=2, stochasticity=1)', 'T.Euler(stochasticity=0.5)', 'T.UniPC(order=2, stochasticity=1)'))}, S.Scaled(), noise_type=N.{noise})"
+    else:
+        text = f"W.RKUltraWrapperScheduler(S.Scaled(), sampler_order={rng.randint(1, 4)}, stochasticity=1, noise_type=N.{noise})"
+    return text, shape, rng.choice(("none", "single", "list", "shortlist")), rng.choice(("float32", "bfloat16"))
+
+
+def one_generator(seed: int) -> str | None:
+    from skrample_amd.pytorch import noise as ON
+
+    text, shape, mode, dtype = _generator_spec(random.Random(seed))
+    dt = getattr(torch, dtype)
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(shape, generator=g).to(dt)
+    outs = [torch.randn(shape, generator=g).to(dt) for _ in range(16)]
+    sides = []
+    for names, N in ((REF, MG.RN), (OWN, ON)):
+        gens = {"none": None, "single": torch.Generator().manual_seed(5), "list": [torch.Generator().manual_seed(7 + i) for i in range(shape[0])], "shortlist": [torch.Generator().manual_seed(9)]}[mode]
+        try:
+            w = eval(text, {**names, "N": N})
+            w.set_timesteps(3)
+            x, got = x0, []
+            for i, t in enumerate(w.timesteps):
+                x = torch.as_tensor(w.step(outs[i], t, x, generator=gens, return_dict=False)[0])
+                got.append(x)
+            sides.append(got)
+        except Exception as err:  # noqa: BLE001
+            sides.append(err)
+    r, p = sides
+    if isinstance(r, Exception) or isinstance(p, Exception):
+        return None if type(r) is type(p) else f"reference {r!r}, here {p!r}"
+    for i, (a, b) in enumerate(zip(p, r)):
+        if a.dtype != b.dtype or not torch.allclose(a.double(), b.double(), rtol=1e-5 if dt == torch.float32 else 2.0**-7, atol=1e-5):
+            return f"step {i}: max diff {(a.double() - b.double()).abs().max().item():.3g} (the draws differ, or the step)"
+    return None
+
+
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     found = 0
     which = sys.argv[3] if len(sys.argv) > 3 else "wrapper"
     for seed in range(first, first + count):
-        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule)}[which]
+        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule), "generator": (_generator_spec, one_generator)}[which]
         text = spec(random.Random(seed))
         try:
             why = run(seed)
