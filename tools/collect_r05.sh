@@ -109,7 +109,14 @@ import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
 print(json.dumps({k: d[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling')} | {'config': {k: d['config'][k] for k in ('name', 'global_batch', 'per_gpu_batch', 'parallelism')}, 'roofline.us_per_step': r['us_per_step'], 'roofline.ranks': r['ranks'], 'cpu_baseline': d.get('cpu_baseline')}))")
-    done; } > $O/profiles/r05_two_rank_rehearsal.txt
+    done
+    echo "# the RCCL code path itself (backend nccl: communicator, barriers, the per-rank all_gather) with ONE rank under torch.distributed.run:"
+    (cd $R && $T 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --steps 20 --warmup 5 --no-traffic 2>/dev/null | python3 -c "
+import json, sys
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+r = d['roofline']
+print(json.dumps({k: d[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling')} | {'backend': 'nccl (RCCL), world 1', 'roofline.us_per_step': r['us_per_step'], 'roofline.ranks': r['ranks']}))")
+  } > $O/profiles/r05_two_rank_rehearsal.txt
   echo "rehearsal part done"
 fi
 du -sh $R/gpurun_out || true
