@@ -81,7 +81,9 @@ def test_round5_lines_of_every_config_follow_the_contract():
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     # the two-rank rehearsal at the driver's K = 20 / W = 5: both ranks seen, value from the slower rank's own wall clock
     rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r05_two_rank_rehearsal.txt")) if l.startswith("{")]
-    assert len(rows) == 2
+    assert len(rows) == 3
+    single = rows.pop()  # the RCCL path itself (backend nccl) with one rank under torch.distributed.run
+    assert single["backend"].startswith("nccl") and single["n_gpus"] == 1 and single["roofline.ranks"]["n_ranks_seen"] == 1 and single["steps"] == 20
     for d in rows:
         ranks = d["roofline.ranks"]
         assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and ranks["n_ranks_seen"] == 2 and len(ranks["wall_us_per_step"]["per_rank"]) == 2
