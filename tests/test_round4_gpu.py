@@ -295,3 +295,56 @@ def test_bench_line_of_a_config_on_the_device(config):
     assert ("whole_step" in r) == (config != "headline")
     if config != "headline":
         assert r["whole_step"]["us_per_step"] > r["us_per_step"] and r["whole_step"]["generator_us_per_step"] > 0
+
+
+def test_two_threads_on_two_streams_do_not_disturb_each_other(dev):
+    """serving: two Python threads, each with its own stream, scheduler and noise generators (Colored / Pyramid / in-kernel Philox), stepping
+    at the same time -- every thread's trajectory equals the one it produces alone, bit for bit (workspaces, tickets, plan caches and the
+    seed-vector cache are per generator / per thread; the library's tables are built once)"""
+    import threading
+
+    from skrample_amd.pytorch import noise as PN
+
+    shape, steps = (4, 4, 64, 64), 6
+    makers = [
+        lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled()), noise_type=PN.Colored, noise_props=PN.ColoredProps()),
+        lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3, stochasticity=1), PS.Linear(), PM.FlowModel(), noise_type=PN.Pyramid, noise_props=PN.PyramidProps()),
+        lambda: PD.RKUltraWrapperScheduler(PS.Scaled(), sampler_order=3, stochasticity=1),
+        lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), noise_type=PN.Colored, noise_props=PN.ColoredProps()),
+    ]
+    g = torch.Generator().manual_seed(31)
+    x0 = torch.randn(shape, generator=g).to(torch.bfloat16).to(dev)
+    outs = [torch.randn(shape, generator=g).to(torch.bfloat16).to(dev) for _ in range(steps * 3)]
+
+    def run(k, rounds, sink, stream=None):
+        try:
+            with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream(dev)):
+                res = []
+                for _ in range(rounds):
+                    w = makers[k]()
+                    w.set_timesteps(steps)
+                    x = x0
+                    for i, t in enumerate(w.timesteps):
+                        x = w.step(outs[i], t, x, generator=[torch.Generator().manual_seed(100 + k * 10 + b) for b in range(shape[0])], return_dict=False)[0]
+                    res.append(x.clone())
+                torch.cuda.current_stream(dev).synchronize()
+                sink[k] = res
+        except BaseException as exc:  # noqa: BLE001
+            sink[k] = exc
+
+    alone: dict = {}
+    for k in range(len(makers)):
+        run(k, 1, alone)
+        assert not isinstance(alone[k], BaseException), alone[k]
+    torch.cuda.synchronize(dev)
+    together: dict = {}
+    threads = [threading.Thread(target=run, args=(k, 4, together, torch.cuda.Stream(device=dev))) for k in range(len(makers))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    for k in range(len(makers)):
+        assert not isinstance(together[k], BaseException), together[k]
+        for res in together[k]:
+            assert torch.equal(res, alone[k][0]), k
