@@ -595,10 +595,13 @@ int own_axis(int dev, int n, hipStream_t s, OwnAxis& ax) {
   return SKR_OK;
 }
 
-// logical lines per block: a power of two, about FFT_MAX_TILE points
-int tile_lines(const OwnAxis& ax) {
+// logical lines per block: a power of two, about FFT_MAX_TILE points -- fewer when the launch would otherwise leave CUs without a block
+// (256 transforms of 2002 points in tiles of two filled half the chip with one wave per SIMD: 28 us for 4 MB): halve the tile while
+// there are fewer than two blocks per CU and a tile still gives every thread two points
+int tile_lines(const OwnAxis& ax, int64_t logical_lines) {
   int L = 1;
   while (2 * L * ax.m <= FFT_MAX_TILE && 2 * L <= FFT_THREADS) L *= 2;
+  while (L > 1 && (logical_lines + L - 1) / L < 2 * 256 && (L / 2) * ax.m >= 2 * FFT_THREADS) L /= 2;
   return L;
 }
 size_t tile_bytes(const OwnAxis& ax, int L) { return sizeof(float2) * ((size_t)ax.p / 2 + (size_t)own_join_entries(ax) + (size_t)L * ax.r * (ax.p + 1)); }
@@ -663,8 +666,8 @@ int own_long_last(int dev, bool inverse, float* real, float2* spec, int64_t line
   int rc;
   if ((rc = own_axis(dev, A, s, xa)) != SKR_OK || (rc = own_axis(dev, B, s, xb)) != SKR_OK) return rc;
   float2* z = reinterpret_cast<float2*>(real);  // [lines][h]: the real lines, two values per complex
-  const int La = tile_lines(xa), Lb = tile_lines(xb);
   const int64_t lines_b = lines * A, lines_a = lines * B, total = lines * h;
+  const int La = tile_lines(xa, lines_a), Lb = tile_lines(xb, lines_b);
   if (total > 0x7fffffffffffll) return SKR_ERR_UNSUPPORTED;
   int64_t blocks = (total + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
   if (!inverse) {
@@ -719,7 +722,7 @@ int own_rfftn(int dev, bool inverse, float* real, float2* spec, int64_t entries,
   if (n1 > 1 && (rc = own_axis(dev, n1, s, a1)) != SKR_OK) return rc;
   if (n0 > 1 && (rc = own_axis(dev, n0, s, a0)) != SKR_OK) return rc;
   const int64_t n2h = n2 / 2 + 1, lines2 = entries * n0 * n1, lines1 = entries * n0 * n2h, lines0 = entries * n1 * n2h;
-  const int L2 = long2 ? 1 : tile_lines(a2), L1 = n1 > 1 ? tile_lines(a1) : 1, L0 = n0 > 1 ? tile_lines(a0) : 1;
+  const int L2 = long2 ? 1 : tile_lines(a2, (lines2 + 1) / 2), L1 = n1 > 1 ? tile_lines(a1, lines1) : 1, L0 = n0 > 1 ? tile_lines(a0, lines0) : 1;
   const bool do0 = n0 > 1 && !skip_outer, do1 = n1 > 1 && !(skip_outer && n0 == 1);
   if (!inverse) {
     if (long2) { if ((rc = own_long_last(dev, false, real, spec, lines2, n2, s)) != SKR_OK) return rc; }
@@ -744,7 +747,7 @@ int own_outer_weighted(int dev, float2* spec, int64_t entries, int n0, int n1, i
   int rc;
   if ((rc = own_axis(dev, n, s, ax)) != SKR_OK) return rc;
   const int64_t n2h = n2 / 2 + 1, inner = n0 > 1 ? (int64_t)n1 * n2h : n2h, lines = n0 > 1 ? entries * n1 * n2h : entries * n0 * n2h;
-  const int L = tile_lines(ax);
+  const int L = tile_lines(ax, lines);
   const OwnWeights wp{n0, n1, n2, inv_rmax, eps_clip, exponent_half_neg};
   return launch_strided_weighted((lines + L - 1) / L, ax, L, s, spec, lines, inner, ax, L, ilog2(L), wp);
 }
