@@ -335,7 +335,23 @@ __device__ __forceinline__ void own_setup(float2* smem, const OwnAxis& ax, float
 }
 
 // ---- last axis: real lines <-> half spectra, two lines per transform --------------------------------------------------------------
-// A wave takes a pair of lines at a time and walks it 64 values per step: runs of 4-byte / 8-byte accesses along the line, no division.
+// The block's pairs of lines are walked in chunks of 64 values (one wave, one chunk: runs of 4-byte / 8-byte accesses along the line), the
+// a wave per pair -- unless the tile holds fewer pairs than the block has waves (one or two long lines: 2002 points), where the chunks of all
+// pairs are dealt round-robin to the waves instead: a wave per pair left three of four idle and one wave walking 32 dependent steps
+// ((2, 2002) x 256: 90 -> 66 us per draw, profiles/r05_bench_fft_own.txt).
+template <typename F> __device__ __forceinline__ void own_walk(int pairs_here, int n, F&& f) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+  if (pairs_here >= waves) {  // the usual tile: a wave per pair, the pair's addresses hoisted out of its walk
+    for (int pl = wave; pl < pairs_here; pl += waves)
+      for (int k = lane; k < n; k += 64) f(pl, k);
+    return;
+  }
+  const int chunks = (n + 63) >> 6;
+  for (int it = wave; it < pairs_here * chunks; it += waves) {
+    const int pl = it / chunks, k = ((it - pl * chunks) << 6) + lane;  // (wave-uniform division)
+    if (k < n) f(pl, k);
+  }
+}
 template <bool BIG>
 __global__ __launch_bounds__(FFT_THREADS) void own_last_forward(const float* real, float2* spec, int64_t lines, OwnAxis ax, int L, int logL) {
   extern __shared__ float2 smem[];
@@ -345,25 +361,18 @@ __global__ __launch_bounds__(FFT_THREADS) void own_last_forward(const float* rea
   const float inv_m = 1.0f / (float)ax.m;
   const int64_t pairs = (lines + 1) / 2, p0 = (int64_t)blockIdx.x * L;
   const int here = (int)(pairs - p0 < L ? pairs - p0 : L);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
   own_clear(tile, ax, L);
-  for (int pl = wave; pl < here; pl += waves) {
+  own_walk(here, n, [&](int pl, int k) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
-    const float* ra = real + la * n;
-    const float* rb = lb < lines ? real + lb * n : nullptr;
-    for (int k = lane; k < n; k += 64) own_put<false>(own_line(tile, ax, pl), ax, k, make_float2(ra[k], rb ? rb[k] : 0.f));
-  }
+    own_put<false>(own_line(tile, ax, pl), ax, k, make_float2(real[la * n + k], lb < lines ? real[lb * n + k] : 0.f));
+  });
   own_transform<BIG>(tile, tw, twm, ax, L, logL);
-  for (int pl = wave; pl < here; pl += waves) {
+  own_walk(here, nh, [&](int pl, int k) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
-    float2* sa = spec + la * nh;
-    float2* sb = lb < lines ? spec + lb * nh : nullptr;
-    for (int k = lane; k < nh; k += 64) {
-      const float2 zk = own_get<false>(own_line(tile, ax, pl), ax, k, inv_m), zn = own_get<false>(own_line(tile, ax, pl), ax, k ? n - k : 0, inv_m);
-      sa[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-      if (sb) sb[k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-    }
-  }
+    const float2 zk = own_get<false>(own_line(tile, ax, pl), ax, k, inv_m), zn = own_get<false>(own_line(tile, ax, pl), ax, k ? n - k : 0, inv_m);
+    spec[la * nh + k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    if (lb < lines) spec[lb * nh + k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  });
 }
 
 template <bool BIG>
@@ -375,31 +384,22 @@ __global__ __launch_bounds__(FFT_THREADS) void own_last_inverse(const float2* sp
   const float inv_m = 1.0f / (float)ax.m;
   const int64_t pairs = (lines + 1) / 2, p0 = (int64_t)blockIdx.x * L;
   const int here = (int)(pairs - p0 < L ? pairs - p0 : L);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
   own_clear(tile, ax, L);
-  for (int pl = wave; pl < here; pl += waves) {
+  own_walk(here, n, [&](int pl, int k) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
-    const float2* sa = spec + la * nh;
-    const float2* sb = lb < lines ? spec + lb * nh : nullptr;
-    for (int k = lane; k < n; k += 64) {
-      const int f = k < nh ? k : n - k;
-      float2 xa = sa[f], xb = sb ? sb[f] : make_float2(0.f, 0.f);
-      if (f == 0 || 2 * f == n) { xa.y = 0.f; xb.y = 0.f; }
-      if (k >= nh) { xa.y = -xa.y; xb.y = -xb.y; }
-      own_put<true>(own_line(tile, ax, pl), ax, k, make_float2(xa.x - xb.y, xa.y + xb.x));
-    }
-  }
+    const int f = k < nh ? k : n - k;
+    float2 xa = spec[la * nh + f], xb = lb < lines ? spec[lb * nh + f] : make_float2(0.f, 0.f);
+    if (f == 0 || 2 * f == n) { xa.y = 0.f; xb.y = 0.f; }
+    if (k >= nh) { xa.y = -xa.y; xb.y = -xb.y; }
+    own_put<true>(own_line(tile, ax, pl), ax, k, make_float2(xa.x - xb.y, xa.y + xb.x));
+  });
   own_transform<BIG>(tile, tw, twm, ax, L, logL);
-  for (int pl = wave; pl < here; pl += waves) {
+  own_walk(here, n, [&](int pl, int k) {
     const int64_t la = 2 * (p0 + pl), lb = la + 1;
-    float* ra = real + la * n;
-    float* rb = lb < lines ? real + lb * n : nullptr;
-    for (int k = lane; k < n; k += 64) {
-      const float2 z = own_get<true>(own_line(tile, ax, pl), ax, k, inv_m);
-      ra[k] = z.x;
-      if (rb) rb[k] = z.y;
-    }
-  }
+    const float2 z = own_get<true>(own_line(tile, ax, pl), ax, k, inv_m);
+    real[la * n + k] = z.x;
+    if (lb < lines) real[lb * n + k] = z.y;
+  });
 }
 
 // ---- any other axis: complex, in place; line l = (o, i), element k at (o n + k) inner + i ------------------------------------------
