@@ -297,6 +297,20 @@ def test_config_parsing():
     r = PD.RKUltraWrapperScheduler.from_diffusers_config(flow, sampler_order=6)
     r.set_timesteps(4)
     assert r.order == 6 and isinstance(r.model, PM.FlowModel)
+    # which sub-schedule wins when a diffusers config raises several `use_*_sigmas` flags (reference tests/diffusers_map.py:162-230, the table
+    # itself; their configs come from a hub download, these are the same keys spelled out)
+    vp = {"_class_name": "DPMSolverMultistepScheduler", "beta_schedule": "scaled_linear", "beta_start": 0.00085, "beta_end": 0.012, "num_train_timesteps": 1000, "prediction_type": "epsilon"}
+    fm = {"_class_name": "DPMSolverMultistepScheduler", "num_train_timesteps": 1000, "prediction_type": "flow_prediction", "use_flow_sigmas": True, "flow_shift": 3}
+    table_vp = {(1, 1, 1): PS.Karras, (0, 1, 1): PS.Exponential, (1, 0, 1): PS.Karras, (1, 1, 0): PS.Karras, (1, 0, 0): PS.Karras, (0, 1, 0): PS.Exponential, (0, 0, 1): PS.Beta, (0, 0, 0): None}
+    table_fm = {(1, 1, 1): PS.FlowShift, (0, 1, 1): PS.FlowShift, (1, 0, 1): PS.FlowShift, (1, 1, 0): PS.FlowShift, (1, 0, 0): PS.FlowShift, (0, 1, 0): PS.FlowShift, (0, 0, 1): PS.Beta, (0, 0, 0): PS.FlowShift}
+    for (karras, exp, beta), sub in table_vp.items():
+        flags = {"use_karras_sigmas": bool(karras), "use_exponential_sigmas": bool(exp), "use_beta_sigmas": bool(beta), "use_flow_sigmas": False, "flow_shift": 3}
+        w = PD.SkrampleWrapperScheduler.from_diffusers_config(vp | flags)
+        assert w.sampler == PT.DPM() and w.schedule == (PS.Scaled() if sub is None else sub(PS.Scaled())), (karras, exp, beta, w.schedule)
+    for (karras, exp, beta), sub in table_fm.items():
+        flags = {"use_karras_sigmas": bool(karras), "use_exponential_sigmas": bool(exp), "use_beta_sigmas": bool(beta)}
+        w = PD.SkrampleWrapperScheduler.from_diffusers_config(fm | flags)
+        assert w.schedule == sub(PS.Linear()) and w.model == PM.FlowModel(), (karras, exp, beta, w.schedule)
 
 
 def test_lazy_algebra_is_symbolic():
