@@ -10,8 +10,13 @@
 // over its four elements with the values held in registers -- each input tensor is read once, each result written once, nothing else
 // touches memory, and the bits are the reference's.
 //
-// Registers: SKR_TAPE_REGS values per element, as ext-vector registers indexed by the (wave-uniform) operand numbers of the current op --
-// the compiler turns that into VGPR-indexed moves, not scratch.  The tape itself sits in the kernel argument block (scalar loads).
+// Registers: the tape's SKR_TAPE_REGS values live in LDS, one column per thread ([register][thread]: consecutive lanes, consecutive words --
+// no bank conflict, no barrier: a thread only ever touches its own column), IN THE TENSOR DTYPE.  That is exact, not a shortcut: every value
+// a tape defines is the result of an op rounded to the tensor dtype, so a 16-bit register is two bytes -- a thread's four elements are one
+// 8-byte word, LOAD and STORE are plain copies between memory and the file, and an op is two 8-byte LDS reads, four lane operations, one
+// rounding pack and one LDS write.  (Round 5's first version kept fp32 registers in VGPRs behind s_set_gpr_idx: the compiler copied the
+// 64-register file at every indexed write, 192 v_mov_b64 per trip, and waited for every load on its own -- 414 us for a 40-op DPM-2 tape
+// over 100 MB, see profiles/r05_bench_tape.txt.)  The tape itself sits in the kernel argument block (scalar loads).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,6 +26,7 @@
 namespace skr {
 
 constexpr int TAPE_ELEMS = 4;  // elements per lane and trip: 8-byte accesses on 16-bit tensors, 16-byte on fp32, 32-byte on fp64
+constexpr int TAPE_THREADS = 256;
 
 struct TapeArgs {
   skr_tape tape;
@@ -29,101 +35,143 @@ struct TapeArgs {
   int64_t numel;
 };
 
-template <typename M> struct TapeRegs;
-template <> struct TapeRegs<float> { typedef float type __attribute__((ext_vector_type(SKR_TAPE_REGS))); };
-template <> struct TapeRegs<double> { typedef double type __attribute__((ext_vector_type(SKR_TAPE_REGS))); };
+// what one register holds for a thread's four elements, and its memory image
+template <typename T> struct TapeWord;
+template <> struct TapeWord<bf16_t> { typedef u32x2_t type; };
+template <> struct TapeWord<f16_t> { typedef u32x2_t type; };
+template <> struct TapeWord<float> { typedef f32x4_t type; };
+struct f64x4_pack { f64x2_t lo, hi; };
+template <> struct TapeWord<double> { typedef f64x4_pack type; };
 
-// one value rounded to the tensor dtype, kept in the op-math type
-template <typename T, typename M> __device__ __forceinline__ M tape_round(M v) {
-  if constexpr (std::is_same<M, double>::value) return v;
-  else return rnd<T>(v);
+template <typename T, typename M> __device__ __forceinline__ void tape_unpack(const typename TapeWord<T>::type& w, M (&x)[TAPE_ELEMS]) {
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    x[0] = __uint_as_float(w[0] << 16); x[1] = __uint_as_float(w[0] & 0xFFFF0000u); x[2] = __uint_as_float(w[1] << 16); x[3] = __uint_as_float(w[1] & 0xFFFF0000u);
+  } else if constexpr (std::is_same<T, f16_t>::value) {
+    x[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[0] & 0xFFFFu)); x[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[0] >> 16));
+    x[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[1] & 0xFFFFu)); x[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[1] >> 16));
+  } else if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int i = 0; i < TAPE_ELEMS; ++i) x[i] = w[i];
+  } else {
+    x[0] = w.lo[0]; x[1] = w.lo[1]; x[2] = w.hi[0]; x[3] = w.hi[1];
+  }
+}
+// the op results (op-math type) rounded to the tensor dtype: the register's new contents
+template <typename T, typename M> __device__ __forceinline__ typename TapeWord<T>::type tape_pack(const M (&y)[TAPE_ELEMS]) {
+  typename TapeWord<T>::type w;
+  if constexpr (std::is_same<T, bf16_t>::value) { w[0] = pack_bf16(y[0], y[1]); w[1] = pack_bf16(y[2], y[3]); }
+  else if constexpr (std::is_same<T, f16_t>::value) { w[0] = pack_f16(y[0], y[1]); w[1] = pack_f16(y[2], y[3]); }  // (pack_f16 pins the fp32 result first: two roundings, as torch's)
+  else if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int i = 0; i < TAPE_ELEMS; ++i) w[i] = y[i];
+  } else { w.lo = f64x2_t{y[0], y[1]}; w.hi = f64x2_t{y[2], y[3]}; }
+  return w;
 }
 
-template <typename T, typename M>
-__device__ __forceinline__ M tape_load(const void* base, int64_t e) {
-  if constexpr (std::is_same<M, double>::value) return load_scalar_d<T>(base, e);
-  else return load_scalar<T>(base, e);
-}
-
-// The arithmetic of one op.  Contraction is off inside mul_ / sub_ (skr_step_common.h); additions are spelled through sub_ of the
-// negated operand only where a neighbouring multiply could be contracted into them -- here every op stands alone, so plain operators
-// under `fp contract(off)` are enough.
+// The arithmetic of one op.  Contraction is off inside mul_ / sub_ (skr_step_common.h); every op stands alone here, so a plain `+`
+// under `fp contract(off)` is enough for the additions.
 template <typename M> __device__ __forceinline__ M tape_add(M a, M b) {
 #pragma clang fp contract(off)
   return a + b;
 }
 
 template <typename T, typename M>
-__global__ __launch_bounds__(256) void tape_kernel(const TapeArgs a) {
-  typedef typename TapeRegs<M>::type Regs;
+__global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
+  typedef typename TapeWord<T>::type Word;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tape_lds[];
+  Word* const file = reinterpret_cast<Word*>(tape_lds) + threadIdx.x;  // register g of this thread: file[g * TAPE_THREADS]
   const int n_ops = a.tape.n_ops;
   const int64_t n_vec = (a.numel + TAPE_ELEMS - 1) / TAPE_ELEMS;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * 256) {
+  for (int64_t v = (int64_t)blockIdx.x * TAPE_THREADS + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * TAPE_THREADS) {
     const int64_t e0 = v * TAPE_ELEMS;
     const bool whole = e0 + TAPE_ELEMS <= a.numel;
-    Regs r[TAPE_ELEMS];
-#pragma unroll
-    for (int i = 0; i < TAPE_ELEMS; ++i) r[i] = (M)0;
     for (int o = 0; o < n_ops; ++o) {
       const skr_tape_op op = a.tape.ops[o];  // uniform: scalar loads from the kernel argument block
       const int code = op.code, dst = op.dst, ia = op.a, ib = op.b;
-      const M k = (M)op.k;  // the Python scalar, converted to the op-math type as torch does
       if (code == SKR_TAPE_LOAD) {
-        const void* src = a.in[ia];
+        // A run of consecutive LOADs (the recorder opens a tape with its leaves) is issued as ONE batch: every global load first, the LDS
+        // writes behind them -- one memory latency per run instead of one per input.
+        constexpr int RUN = sizeof(T) == 8 ? 2 : (sizeof(T) == 4 ? 4 : 8);
+        int run = 1;
+        while (run < RUN && o + run < n_ops && a.tape.ops[o + run].code == SKR_TAPE_LOAD) ++run;
+        Word q[RUN];
         if (whole) {
-          if constexpr (sizeof(T) == 2) {
-            const u32x2_t q = *(reinterpret_cast<const u32x2_t*>(src) + v);
-            if constexpr (std::is_same<T, bf16_t>::value) {
-              r[0][dst] = __uint_as_float(q[0] << 16); r[1][dst] = __uint_as_float(q[0] & 0xFFFF0000u);
-              r[2][dst] = __uint_as_float(q[1] << 16); r[3][dst] = __uint_as_float(q[1] & 0xFFFF0000u);
-            } else {
-              r[0][dst] = (float)__builtin_bit_cast(_Float16, (uint16_t)(q[0] & 0xFFFFu)); r[1][dst] = (float)__builtin_bit_cast(_Float16, (uint16_t)(q[0] >> 16));
-              r[2][dst] = (float)__builtin_bit_cast(_Float16, (uint16_t)(q[1] & 0xFFFFu)); r[3][dst] = (float)__builtin_bit_cast(_Float16, (uint16_t)(q[1] >> 16));
+#pragma unroll
+          for (int j = 0; j < RUN; ++j)
+            if (j < run) q[j] = *(reinterpret_cast<const Word*>(a.in[a.tape.ops[o + j].a]) + v);
+        } else {
+          for (int j = 0; j < run; ++j) {
+            const void* src = a.in[a.tape.ops[o + j].a];
+            M x[TAPE_ELEMS];
+#pragma unroll
+            for (int i = 0; i < TAPE_ELEMS; ++i) {
+              if constexpr (std::is_same<M, double>::value) x[i] = e0 + i < a.numel ? load_scalar_d<T>(src, e0 + i) : 0.0;
+              else x[i] = e0 + i < a.numel ? load_scalar<T>(src, e0 + i) : 0.f;
             }
-          } else if constexpr (sizeof(T) == 4) {
-            const f32x4_t q = *(reinterpret_cast<const f32x4_t*>(src) + v);
+            const Word w = tape_pack<T, M>(x);  // (exact: the values come from the tensor dtype)
 #pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) r[i][dst] = q[i];
-          } else {
-            const f64x2_t q0 = *(reinterpret_cast<const f64x2_t*>(src) + 2 * v), q1 = *(reinterpret_cast<const f64x2_t*>(src) + 2 * v + 1);
-            r[0][dst] = q0[0]; r[1][dst] = q0[1]; r[2][dst] = q1[0]; r[3][dst] = q1[1];
+            for (int jj = 0; jj < RUN; ++jj)
+              if (jj == j) q[jj] = w;
           }
-        } else {
-#pragma unroll
-          for (int i = 0; i < TAPE_ELEMS; ++i) r[i][dst] = e0 + i < a.numel ? tape_load<T, M>(src, e0 + i) : (M)0;
         }
-      } else if (code == SKR_TAPE_STORE) {
-        void* dstp = a.out[ib];
-        if (whole && sizeof(T) == 2) {
-          u32x2_t q;
-          if constexpr (std::is_same<T, bf16_t>::value) { q[0] = pack_bf16((float)r[0][ia], (float)r[1][ia]); q[1] = pack_bf16((float)r[2][ia], (float)r[3][ia]); }
-          else { q[0] = pack_f16((float)r[0][ia], (float)r[1][ia]); q[1] = pack_f16((float)r[2][ia], (float)r[3][ia]); }
-          __builtin_nontemporal_store(q, reinterpret_cast<u32x2_t*>(dstp) + v);
-        } else if (whole && sizeof(T) == 4) {
-          __builtin_nontemporal_store(f32x4_t{(float)r[0][ia], (float)r[1][ia], (float)r[2][ia], (float)r[3][ia]}, reinterpret_cast<f32x4_t*>(dstp) + v);
-        } else {
 #pragma unroll
-          for (int i = 0; i < TAPE_ELEMS; ++i) if (e0 + i < a.numel) store_scalar<T, M>(dstp, e0 + i, r[i][ia]);
+        for (int j = 0; j < RUN; ++j)
+          if (j < run) file[a.tape.ops[o + j].dst * TAPE_THREADS] = q[j];
+        o += run - 1;
+      } else if (code == SKR_TAPE_STORE) {
+        const Word w = file[ia * TAPE_THREADS];
+        void* dstp = a.out[ib];
+        if (whole) {
+          if constexpr (sizeof(T) == 8) { f64x2_t* p = reinterpret_cast<f64x2_t*>(dstp) + 2 * v; p[0] = w.lo; p[1] = w.hi; }
+          else __builtin_nontemporal_store(w, reinterpret_cast<Word*>(dstp) + v);
+        } else {
+          M x[TAPE_ELEMS];
+          tape_unpack<T, M>(w, x);
+#pragma unroll
+          for (int i = 0; i < TAPE_ELEMS; ++i) if (e0 + i < a.numel) store_scalar<T, M>(dstp, e0 + i, x[i]);
         }
       } else {
+        // both operand numbers are valid for every code (the host checks them); a scalar op replaces the second operand by the Python
+        // scalar, converted to the op-math type as torch does
+        M x[TAPE_ELEMS], z[TAPE_ELEMS], y[TAPE_ELEMS];
+        tape_unpack<T, M>(file[ia * TAPE_THREADS], x);
+        if (code >= SKR_TAPE_ADD && code != SKR_TAPE_NEG) tape_unpack<T, M>(file[ib * TAPE_THREADS], z);
+        else {
+          const M k = (M)op.k;
 #pragma unroll
-        for (int i = 0; i < TAPE_ELEMS; ++i) {
-          const M x = r[i][ia];
-          M y;
-          switch (code) {
-            case SKR_TAPE_MUL_S: y = mul_(x, k); break;
-            case SKR_TAPE_DIV_S: y = div_(x, k); break;
-            case SKR_TAPE_ADD_S: y = tape_add(x, k); break;
-            case SKR_TAPE_RSUB_S: y = sub_(k, x); break;
-            case SKR_TAPE_RDIV_S: y = div_(k, x); break;
-            case SKR_TAPE_ADD: y = tape_add(x, (M)r[i][ib]); break;
-            case SKR_TAPE_SUB: y = sub_(x, (M)r[i][ib]); break;
-            case SKR_TAPE_MUL: y = mul_(x, (M)r[i][ib]); break;
-            case SKR_TAPE_DIV: y = div_(x, (M)r[i][ib]); break;
-            default: y = -x; break;  // SKR_TAPE_NEG
-          }
-          r[i][dst] = tape_round<T, M>(y);
+          for (int i = 0; i < TAPE_ELEMS; ++i) z[i] = k;
         }
+        switch (code) {
+          case SKR_TAPE_MUL_S: case SKR_TAPE_MUL:
+#pragma unroll
+            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = mul_(x[i], z[i]);
+            break;
+          case SKR_TAPE_DIV_S: case SKR_TAPE_DIV:
+#pragma unroll
+            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = div_(x[i], z[i]);
+            break;
+          case SKR_TAPE_ADD_S: case SKR_TAPE_ADD:
+#pragma unroll
+            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = tape_add(x[i], z[i]);
+            break;
+          case SKR_TAPE_RSUB_S:
+#pragma unroll
+            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = sub_(z[i], x[i]);
+            break;
+          case SKR_TAPE_SUB:
+#pragma unroll
+            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = sub_(x[i], z[i]);
+            break;
+          case SKR_TAPE_RDIV_S:
+#pragma unroll
+            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = div_(z[i], x[i]);
+            break;
+          default:  // SKR_TAPE_NEG
+#pragma unroll
+            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = -x[i];
+            break;
+        }
+        file[dst * TAPE_THREADS] = tape_pack<T, M>(y);
       }
     }
   }
@@ -132,9 +180,14 @@ __global__ __launch_bounds__(256) void tape_kernel(const TapeArgs a) {
 template <typename T, typename M>
 static int launch_tape(const TapeArgs& a, hipStream_t s) {
   const int64_t n_vec = (a.numel + TAPE_ELEMS - 1) / TAPE_ELEMS;
-  int64_t blocks = (n_vec + 255) / 256;
+  int64_t blocks = (n_vec + TAPE_THREADS - 1) / TAPE_THREADS;
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 blocks per CU
-  hipLaunchKernelGGL((tape_kernel<T, M>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  const size_t lds = sizeof(typename TapeWord<T>::type) * SKR_TAPE_REGS * TAPE_THREADS;  // 32 KiB (16-bit), 64 KiB (fp32), 128 KiB (fp64)
+  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(tape_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return SKR_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL((tape_kernel<T, M>), dim3((unsigned)blocks), dim3(TAPE_THREADS), lds, s, a);
   return finish_launch();
 }
 
