@@ -145,7 +145,7 @@ void skr_program_destroy(skr_program* prog);
  * or a wrapper with compute_scale=None): every `*`, `+`, `-`, `/` is a torch op of its own in the TENSOR dtype -- operands widened to the
  * op-math type (fp32 for bf16 / fp16 / fp32 tensors, fp64 for fp64; a Python scalar is converted to it first), one operation, the result
  * rounded to the tensor dtype.  skr_step_launch evaluates the collapsed form in fp32 and rounds once (closer to the exact value, not
- * the reference's bits); skr_tape_launch runs the recorded sequence itself, values in registers, one pass over HBM:
+ * the reference's bits); skr_tape_launch runs the recorded sequence itself, values on chip (a register file in LDS), one pass over HBM:
  *
  *     LOAD   r[dst] = inputs[a][e]                        STORE  outputs[b][e] = r[a]
  *     MUL_S  r[dst] = rnd(r[a] * k)    DIV_S  rnd(r[a] / k)    ADD_S  rnd(r[a] + k)    RSUB_S  rnd(k - r[a])    RDIV_S  rnd(k / r[a])
