@@ -85,8 +85,10 @@ __global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
   for (int64_t v = (int64_t)blockIdx.x * TAPE_THREADS + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * TAPE_THREADS) {
     const int64_t e0 = v * TAPE_ELEMS;
     const bool whole = e0 + TAPE_ELEMS <= a.numel;
-    for (int o = 0; o < n_ops; ++o) {
-      const skr_tape_op op = a.tape.ops[o];  // uniform: scalar loads from the kernel argument block
+    skr_tape_op ahead = a.tape.ops[0];  // uniform: scalar loads from the kernel argument block, one op ahead of its use (the load's latency
+    for (int o = 0; o < n_ops; ++o) {   // then runs under the current op's LDS round trip instead of in front of it)
+      const skr_tape_op op = ahead;
+      ahead = a.tape.ops[o + 1 < SKR_TAPE_MAX_OPS ? o + 1 : o];
       const int code = op.code, dst = op.dst, ia = op.a, ib = op.b;
       if (code == SKR_TAPE_LOAD) {
         // A run of consecutive LOADs (the recorder opens a tape with its leaves) is issued as ONE batch: every global load first, the LDS
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
 #pragma unroll
         for (int j = 0; j < RUN; ++j)
           if (j < run) file[a.tape.ops[o + j].dst * TAPE_THREADS] = q[j];
-        o += run - 1;
+        if (run > 1) { o += run - 1; ahead = a.tape.ops[o + 1 < SKR_TAPE_MAX_OPS ? o + 1 : o]; }
       } else if (code == SKR_TAPE_STORE) {
         const Word w = file[ia * TAPE_THREADS];
         void* dstp = a.out[ib];
@@ -182,7 +184,17 @@ static int launch_tape(const TapeArgs& a, hipStream_t s) {
   const int64_t n_vec = (a.numel + TAPE_ELEMS - 1) / TAPE_ELEMS;
   int64_t blocks = (n_vec + TAPE_THREADS - 1) / TAPE_THREADS;
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 blocks per CU
-  const size_t lds = sizeof(typename TapeWord<T>::type) * SKR_TAPE_REGS * TAPE_THREADS;  // 32 KiB (16-bit), 64 KiB (fp32), 128 KiB (fp64)
+  // the file holds the registers the tape names, not all SKR_TAPE_REGS: the elements in flight on a CU are what its LDS can give a register
+  // file to, and the loads of those elements are the memory parallelism of this kernel (a 4-register Euler tape: 8 KiB per block, 32 waves per CU)
+  int regs = 1;
+  for (int o = 0; o < a.tape.n_ops; ++o) {
+    const skr_tape_op& op = a.tape.ops[o];
+    const bool two = op.code >= SKR_TAPE_ADD && op.code != SKR_TAPE_NEG;  // (the second operand number means a register for the tensor-tensor ops only)
+    int hi = op.code == SKR_TAPE_LOAD ? op.dst : (op.code == SKR_TAPE_STORE ? op.a : (op.dst > op.a ? op.dst : op.a));
+    if (two && op.b > hi) hi = op.b;
+    if (hi + 1 > regs) regs = hi + 1;
+  }
+  const size_t lds = sizeof(typename TapeWord<T>::type) * (size_t)regs * TAPE_THREADS;  // per register: 2 KiB (16-bit), 4 KiB (fp32), 8 KiB (fp64)
   if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(tape_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     (void)hipGetLastError();
     return SKR_ERR_UNSUPPORTED;
