@@ -12,9 +12,9 @@
 //
 // Registers: the tape's SKR_TAPE_REGS values live in LDS, one column per thread ([register][thread]: consecutive lanes, consecutive words --
 // no bank conflict, no barrier: a thread only ever touches its own column), IN THE TENSOR DTYPE.  That is exact, not a shortcut: every value
-// a tape defines is the result of an op rounded to the tensor dtype, so a 16-bit register is two bytes -- a thread's four elements are one
-// 8-byte word, LOAD and STORE are plain copies between memory and the file, and an op is two 8-byte LDS reads, four lane operations, one
-// rounding pack and one LDS write.  (Round 5's first version kept fp32 registers in VGPRs behind s_set_gpr_idx: the compiler copied the
+// a tape defines is the result of an op rounded to the tensor dtype, so a 16-bit register is two bytes -- a thread's eight elements are one
+// 16-byte word, LOAD and STORE are plain copies between memory and the file, and an op is two 16-byte LDS reads, eight lane operations,
+// four rounding packs and one LDS write.  (Round 5's first version kept fp32 registers in VGPRs behind s_set_gpr_idx: the compiler copied the
 // 64-register file at every indexed write, 192 v_mov_b64 per trip, and waited for every load on its own -- 414 us for a 40-op DPM-2 tape
 // over 100 MB, see profiles/r05_bench_tape.txt.)  The tape itself sits in the kernel argument block (scalar loads).
 #include <hip/hip_runtime.h>
@@ -25,7 +25,8 @@
 
 namespace skr {
 
-constexpr int TAPE_ELEMS = 4;  // elements per lane and trip: 8-byte accesses on 16-bit tensors, 16-byte on fp32, 32-byte on fp64
+// elements per lane and trip: eight 16-bit values (16-byte accesses, two independent chains of four per op decode), four fp32 (16 bytes), four fp64 (32)
+template <typename T> struct TapeElems { static constexpr int value = sizeof(T) == 2 ? 8 : 4; };
 constexpr int TAPE_THREADS = 256;
 
 struct TapeArgs {
@@ -37,33 +38,41 @@ struct TapeArgs {
 
 // what one register holds for a thread's four elements, and its memory image
 template <typename T> struct TapeWord;
-template <> struct TapeWord<bf16_t> { typedef u32x2_t type; };
-template <> struct TapeWord<f16_t> { typedef u32x2_t type; };
+template <> struct TapeWord<bf16_t> { typedef u32x4_t type; };
+template <> struct TapeWord<f16_t> { typedef u32x4_t type; };
 template <> struct TapeWord<float> { typedef f32x4_t type; };
 struct f64x4_pack { f64x2_t lo, hi; };
 template <> struct TapeWord<double> { typedef f64x4_pack type; };
 
-template <typename T, typename M> __device__ __forceinline__ void tape_unpack(const typename TapeWord<T>::type& w, M (&x)[TAPE_ELEMS]) {
+template <typename T, typename M> __device__ __forceinline__ void tape_unpack(const typename TapeWord<T>::type& w, M (&x)[TapeElems<T>::value]) {
   if constexpr (std::is_same<T, bf16_t>::value) {
-    x[0] = __uint_as_float(w[0] << 16); x[1] = __uint_as_float(w[0] & 0xFFFF0000u); x[2] = __uint_as_float(w[1] << 16); x[3] = __uint_as_float(w[1] & 0xFFFF0000u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[2 * j] = __uint_as_float(w[j] << 16); x[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
   } else if constexpr (std::is_same<T, f16_t>::value) {
-    x[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[0] & 0xFFFFu)); x[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[0] >> 16));
-    x[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[1] & 0xFFFFu)); x[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[1] >> 16));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[2 * j] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[j] & 0xFFFFu));
+      x[2 * j + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[j] >> 16));
+    }
   } else if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
-    for (int i = 0; i < TAPE_ELEMS; ++i) x[i] = w[i];
+    for (int i = 0; i < 4; ++i) x[i] = w[i];
   } else {
     x[0] = w.lo[0]; x[1] = w.lo[1]; x[2] = w.hi[0]; x[3] = w.hi[1];
   }
 }
 // the op results (op-math type) rounded to the tensor dtype: the register's new contents
-template <typename T, typename M> __device__ __forceinline__ typename TapeWord<T>::type tape_pack(const M (&y)[TAPE_ELEMS]) {
+template <typename T, typename M> __device__ __forceinline__ typename TapeWord<T>::type tape_pack(const M (&y)[TapeElems<T>::value]) {
   typename TapeWord<T>::type w;
-  if constexpr (std::is_same<T, bf16_t>::value) { w[0] = pack_bf16(y[0], y[1]); w[1] = pack_bf16(y[2], y[3]); }
-  else if constexpr (std::is_same<T, f16_t>::value) { w[0] = pack_f16(y[0], y[1]); w[1] = pack_f16(y[2], y[3]); }  // (pack_f16 pins the fp32 result first: two roundings, as torch's)
-  else if constexpr (std::is_same<T, float>::value) {
+  if constexpr (std::is_same<T, bf16_t>::value) {
 #pragma unroll
-    for (int i = 0; i < TAPE_ELEMS; ++i) w[i] = y[i];
+    for (int j = 0; j < 4; ++j) w[j] = pack_bf16(y[2 * j], y[2 * j + 1]);
+  } else if constexpr (std::is_same<T, f16_t>::value) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = pack_f16(y[2 * j], y[2 * j + 1]);  // (pack_f16 pins the fp32 result first: two roundings, as torch's)
+  } else if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = y[i];
   } else { w.lo = f64x2_t{y[0], y[1]}; w.hi = f64x2_t{y[2], y[3]}; }
   return w;
 }
@@ -78,6 +87,7 @@ template <typename M> __device__ __forceinline__ M tape_add(M a, M b) {
 template <typename T, typename M>
 __global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
   typedef typename TapeWord<T>::type Word;
+  constexpr int TAPE_ELEMS = TapeElems<T>::value;
   extern __shared__ __attribute__((aligned(16))) unsigned char tape_lds[];
   Word* const file = reinterpret_cast<Word*>(tape_lds) + threadIdx.x;  // register g of this thread: file[g * TAPE_THREADS]
   const int n_ops = a.tape.n_ops;
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
       if (code == SKR_TAPE_LOAD) {
         // A run of consecutive LOADs (the recorder opens a tape with its leaves) is issued as ONE batch: every global load first, the LDS
         // writes behind them -- one memory latency per run instead of one per input.
-        constexpr int RUN = sizeof(T) == 8 ? 2 : (sizeof(T) == 4 ? 4 : 8);
+        constexpr int RUN = sizeof(T) == 8 ? 2 : (sizeof(T) == 4 ? 4 : 6);  // (batch registers: 8, 16, 24)
         int run = 1;
         while (run < RUN && o + run < n_ops && a.tape.ops[o + run].code == SKR_TAPE_LOAD) ++run;
         Word q[RUN];
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
 
 template <typename T, typename M>
 static int launch_tape(const TapeArgs& a, hipStream_t s) {
+  constexpr int TAPE_ELEMS = TapeElems<T>::value;
   const int64_t n_vec = (a.numel + TAPE_ELEMS - 1) / TAPE_ELEMS;
   int64_t blocks = (n_vec + TAPE_THREADS - 1) / TAPE_THREADS;
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 blocks per CU
@@ -194,7 +205,7 @@ static int launch_tape(const TapeArgs& a, hipStream_t s) {
     if (two && op.b > hi) hi = op.b;
     if (hi + 1 > regs) regs = hi + 1;
   }
-  const size_t lds = sizeof(typename TapeWord<T>::type) * (size_t)regs * TAPE_THREADS;  // per register: 2 KiB (16-bit), 4 KiB (fp32), 8 KiB (fp64)
+  const size_t lds = sizeof(typename TapeWord<T>::type) * (size_t)regs * TAPE_THREADS;  // per register: 4 KiB (16-bit, fp32), 8 KiB (fp64)
   if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(tape_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     (void)hipGetLastError();
     return SKR_ERR_UNSUPPORTED;
