@@ -15,7 +15,7 @@
 // a tape defines is the result of an op rounded to the tensor dtype, so a 16-bit register is two bytes -- a thread's eight elements are one
 // 16-byte word, LOAD and STORE are plain copies between memory and the file, and an op is two 16-byte LDS reads, eight lane operations,
 // four rounding packs and one LDS write.  (Round 5's first version kept fp32 registers in VGPRs behind s_set_gpr_idx: the compiler copied the
-// 64-register file at every indexed write, 192 v_mov_b64 per trip, and waited for every load on its own -- 414 us for a 40-op DPM-2 tape
+// 64-register file at every indexed write, 192 v_mov_b64 per trip, and waited for every load on its own -- 414 us for a 21-op DPM-2 tape
 // over 100 MB, see profiles/r05_bench_tape.txt.)  The tape itself sits in the kernel argument block (scalar loads).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
