@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two and four gloo ranks run the SAME shard arithmetic bench.py runs (skrample_amd.sharding: rank / world
+"""N > 1 path on CPU: two, four and eight gloo ranks (eight = the node the driver measures) run the SAME shard arithmetic bench.py runs (skrample_amd.sharding: rank / world
 from the launcher's environment, contiguous batch slices, seeds by GLOBAL sample index, MAX-over-ranks timing, whole-job
 rate) -- the only things ranks share; there is no data-path collective to test."""
 
@@ -36,7 +36,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_rank_shards_equal_single_process(world, tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -79,7 +79,7 @@ def _timing_worker(rank: int, world: int, port: int, out_dir: str, dawdle_s: flo
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_closing_barrier_is_not_billed_to_the_timed_steps(world, tmp_path):
     """A rank that sits 50 ms in the closing collective changes nobody's wall time and so not `value` (the
     old window read the clock after dist.barrier(), so an 8-rank RCCL barrier was billed to a 0.54 ms K = 20 region)."""
