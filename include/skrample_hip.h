@@ -151,7 +151,9 @@ void skr_program_destroy(skr_program* prog);
  *     MUL_S  r[dst] = rnd(r[a] * k)    DIV_S  rnd(r[a] / k)    ADD_S  rnd(r[a] + k)    RSUB_S  rnd(k - r[a])    RDIV_S  rnd(k / r[a])
  *     ADD    r[dst] = rnd(r[a] + r[b]) SUB    rnd(r[a] - r[b]) MUL    rnd(r[a] * r[b]) DIV     rnd(r[a] / r[b]) NEG     -r[a]
  *
- * (IEEE operations, no contraction; rnd = round-to-nearest-even to `dtype`.)  Every tensor has `dtype` and `numel` elements; register
+ * (IEEE operations, no contraction; rnd = round-to-nearest-even to `dtype`.  The scalar k: converted to the op-math type for MUL_S / DIV_S /
+ * RDIV_S, but rounded to `dtype` FIRST for ADD_S / RSUB_S -- torch's add / sub / rsub of a Python number to a 16-bit CPU tensor do that, its
+ * mul / div do not.)  Every tensor has `dtype` and `numel` elements; register
  * numbers are < SKR_TAPE_REGS (the host allocates them); SKR_ERR_TERMS for a malformed tape.
  */
 #define SKR_TAPE_MAX_OPS 96

@@ -149,7 +149,12 @@ __global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
         tape_unpack<T, M>(file[ia * TAPE_THREADS], x);
         if (code >= SKR_TAPE_ADD && code != SKR_TAPE_NEG) tape_unpack<T, M>(file[ib * TAPE_THREADS], z);
         else {
-          const M k = (M)op.k;
+          // the Python scalar: converted to the op-math type for x k, / k, k / (torch's mul / div keep it there) -- but torch's add / sub /
+          // rsub round it to the TENSOR dtype first (`bf16_tensor + 7.7` adds 7.6875; found by the tape fuzz of tests/test_step_gpu.py)
+          M k = (M)op.k;
+          if constexpr (!std::is_same<M, double>::value) {
+            if (code == SKR_TAPE_ADD_S || code == SKR_TAPE_RSUB_S) k = rnd<T>(k);
+          }
 #pragma unroll
           for (int i = 0; i < TAPE_ELEMS; ++i) z[i] = k;
         }

@@ -541,6 +541,10 @@ def test_tape_ops_through_the_c_abi(dtype, dev):
             ([(T.TAPE_LOAD, 5, 0, 0, 0.0), (T.TAPE_LOAD, 15, 1, 0, 0.0), (T.TAPE_NEG, 0, 5, 0, 0.0), (T.TAPE_STORE, 0, 0, 0, 0.0), (T.TAPE_MUL_S, 1, 5, 0, 0.3), (T.TAPE_ADD, 1, 1, 15, 0.0),
               (T.TAPE_DIV_S, 1, 1, 0, 0.7), (T.TAPE_ADD_S, 1, 1, 0, -0.125), (T.TAPE_SUB, 1, 1, 5, 0.0), (T.TAPE_STORE, 0, 1, 1, 0.0)],
              lambda: [-a, ((a * 0.3 + b) / 0.7 + -0.125) - a]),
+            # scalars a 16-bit dtype cannot hold: torch's add / rsub round them to the tensor dtype first, its mul / div do not
+            ([(T.TAPE_LOAD, 3, 0, 0, 0.0), (T.TAPE_LOAD, 4, 1, 0, 0.0), (T.TAPE_ADD_S, 0, 3, 0, 7.7), (T.TAPE_STORE, 0, 0, 0, 0.0), (T.TAPE_RSUB_S, 1, 4, 0, 0.001), (T.TAPE_STORE, 0, 1, 1, 0.0),
+              (T.TAPE_MUL_S, 2, 3, 0, 7.7), (T.TAPE_STORE, 0, 2, 2, 0.0), (T.TAPE_ADD_S, 2, 4, 0, -3.3), (T.TAPE_STORE, 0, 2, 3, 0.0)],
+             lambda: [a + 7.7, 0.001 - b, a * 7.7, b - 3.3]),
         ]
         for ops, ref in programs:
             want = ref()
@@ -582,6 +586,57 @@ def test_add_noise_on_the_device_returns_the_reference_bits(dtype, dev):
     zero = Point(1000.0, 1.0, 0.0)
     a, b = zero.remove_noise(x.float().to(dev), n.float().to(dev)).cpu(), (x.float() - n.float() * 1.0) / 0.0
     assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, torch.float64])
+def test_random_tapes_equal_the_host_interpreter(dtype, dev):
+    """fuzz of skr_tape_launch: random straight-line tapes (every op code, scattered register numbers, values read several times and never,
+    up to the register and op limits) through native._run on the device against native._run_host -- one torch op per entry on CPU tensors,
+    which is the reference's own sequence of calls -- bit for bit, non-finite values included; whole vectors and ragged tails"""
+    import random
+
+    from skrample_amd.sampling import native
+
+    T = _hip
+    binary = (T.TAPE_ADD, T.TAPE_SUB, T.TAPE_MUL, T.TAPE_DIV)
+    scalar = (T.TAPE_MUL_S, T.TAPE_DIV_S, T.TAPE_ADD_S, T.TAPE_RSUB_S)
+    for seed in range(24):
+        rng = random.Random(seed * 7 + 1)
+        numel = rng.choice((8192, 4096 + 5, 1023, 37, 8, 3))
+        g = torch.Generator().manual_seed(seed)
+        n_leaves = rng.randint(1, 6)
+        leaves = [(torch.randn(numel, generator=g) * rng.choice((0.1, 1.0, 30.0)) + rng.choice((0.0, 2.0))).to(dtype) for _ in range(n_leaves)]
+        tapes = []
+        for device in ("cpu", dev):
+            tape = native.Tape(dtype, (numel,), torch.device(device), require_device=False)
+            vals = [tape.leaf(t.to(device)) for t in leaves]
+            r2 = random.Random(seed)  # the same program on both sides
+            for _ in range(r2.randint(3, 40)):
+                live = vals[-8:] if r2.random() < 0.7 else vals  # mostly recent values, sometimes an old one (long live ranges)
+                a = r2.choice(live)
+                kind = r2.random()
+                if kind < 0.45:
+                    code, b = r2.choice(binary), r2.choice(live)
+                    v = {T.TAPE_ADD: a + b, T.TAPE_SUB: a - b, T.TAPE_MUL: a * b, T.TAPE_DIV: a / b}[code]
+                elif kind < 0.9:
+                    k = r2.choice((0.5, -1.25, 3.0, 0.1, 1e-3, 7.7, 1.0))
+                    v = {T.TAPE_MUL_S: lambda: a * k, T.TAPE_DIV_S: lambda: a / k, T.TAPE_ADD_S: lambda: a + k, T.TAPE_RSUB_S: lambda: k - a}[r2.choice(scalar)]()
+                elif kind < 0.95:
+                    v = -a
+                else:
+                    v = r2.choice((2.0, -0.5)) / a  # reciprocal() * k, as torch's k / tensor
+                vals.append(v)
+            results = r2.sample(vals[n_leaves:], min(len(vals) - n_leaves, r2.randint(1, 4)))
+            tapes.append((tape, results))
+        try:
+            host = native._run_host(*tapes[0])
+            card = native._run(*tapes[1])
+        except native._Refused:
+            continue  # (more live values than registers, or more ops than a tape holds: the caller would take the fused path)
+        for h, c in zip(host, card):
+            c = c.cpu()
+            assert c.dtype == dtype and torch.equal(torch.isnan(h), torch.isnan(c)), (seed, dtype)
+            assert torch.equal(torch.nan_to_num(h, nan=0.0), torch.nan_to_num(c, nan=0.0)), (seed, dtype, numel, (h.double() - c.double()).abs().max())
 
 
 def test_wrappers_keep_their_compute_scale(dev):
