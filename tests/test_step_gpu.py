@@ -624,7 +624,7 @@ def test_random_tapes_equal_the_host_interpreter(dtype, dev):
                 elif kind < 0.95:
                     v = -a
                 else:
-                    v = r2.choice((2.0, -0.5)) / a  # reciprocal() * k, as torch's k / tensor
+                    v = r2.choice((2.0, -0.5, 7.7)) / a  # reciprocal() * k, as torch's k / tensor
                 vals.append(v)
             results = r2.sample(vals[n_leaves:], min(len(vals) - n_leaves, r2.randint(1, 4)))
             tapes.append((tape, results))
@@ -637,6 +637,71 @@ def test_random_tapes_equal_the_host_interpreter(dtype, dev):
             c = c.cpu()
             assert c.dtype == dtype and torch.equal(torch.isnan(h), torch.isnan(c)), (seed, dtype)
             assert torch.equal(torch.nan_to_num(h, nan=0.0), torch.nan_to_num(c, nan=0.0)), (seed, dtype, numel, (h.double() - c.double()).abs().max())
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_linear_forms_vs_float64(seed, dev):
+    """fuzz of the fused evaluator (lazy.evaluate -> skr_step_launch): one or two random linear forms over 1-18 tensors of mixed dtypes (a narrow
+    group, a wide group, stragglers of a third dtype), zero and negative coefficients, an optional chained second output, ragged sizes -- against
+    the same sums in float64 on the CPU, within the accumulation error of the kernel's accumulator plus one rounding of the output dtype"""
+    import random
+
+    rng = random.Random(9000 + seed)
+    numel = rng.choice((4096, 2048 * 3, 1000, 37, 8 * 511 + 3, 5))
+    narrow = rng.choice((torch.bfloat16, torch.float16, torch.float32))
+    wide = rng.choice((torch.float32, torch.float64)) if narrow != torch.float32 else rng.choice((torch.float32, torch.float64))
+    third = rng.choice((torch.bfloat16, torch.float16, torch.float32))
+    g = torch.Generator().manual_seed(seed)
+    n_terms = rng.randint(1, 18)
+    tensors, coefs0, coefs1 = [], [], []
+    for _ in range(n_terms):
+        dt = rng.choices((narrow, wide, third), weights=(6, 3, 1))[0]
+        tensors.append((torch.randn(numel, generator=g) * rng.choice((0.05, 1.0, 20.0))).to(dt))
+        coefs0.append(rng.choice((0.0, 1.0, -1.0, rng.uniform(-3, 3), rng.uniform(-1e-3, 1e-3))))
+        coefs1.append(rng.choice((0.0, 0.0, 1.0, rng.uniform(-3, 3))))
+    if all(c == 0.0 for c in coefs0):
+        coefs0[0] = 1.0
+    two = rng.random() < 0.5
+    chain = rng.choice((0.0, 1.0, -0.75)) if two else 0.0
+    acc64 = wide == torch.float64
+    out_dtypes = [rng.choice((narrow, wide)), rng.choice((narrow, wide))]
+    on_card = [t.to(dev) for t in tensors]
+    f0 = None
+    for t, c in zip(on_card, coefs0):
+        term = lazy.Lin.leaf(t) * c
+        f0 = term if f0 is None else f0 + term
+    forms = [f0]
+    if two:
+        f1 = f0.node() * chain if chain != 0.0 else None
+        for t, c in zip(on_card, coefs1):
+            if c != 0.0:
+                term = lazy.Lin.leaf(t) * c
+                f1 = term if f1 is None else f1 + term
+        if f1 is None:
+            f1 = lazy.Lin.leaf(on_card[0]) * 1.0
+            coefs1[0] = 1.0
+        forms.append(f1)
+    try:
+        got = lazy.evaluate(forms, out_dtypes[: len(forms)])
+    except _hip.SkrampleHipError as exc:
+        assert "exceed the kernel limit" in str(exc) or "incompatible" in str(exc), exc  # (stated refusals: too many operands, an output dtype outside the two groups)
+        return
+    wide64 = [t.double() for t in tensors]
+    acc0 = sum(c * t for c, t in zip(coefs0, wide64))
+    mag0 = sum(abs(c) * t.abs() for c, t in zip(coefs0, wide64))
+    refs, mags = [acc0], [mag0]
+    if two:
+        refs.append(chain * acc0 + sum(c * t for c, t in zip(coefs1, wide64)))
+        mags.append(abs(chain) * mag0 + sum(abs(c) * t.abs() for c, t in zip(coefs1, wide64)))
+    eps_acc = 2.0**-52 if acc64 else 2.0**-23
+    for out, ref, mag, od in zip(got, refs, mags, out_dtypes):
+        assert out.dtype == od and out.is_cuda
+        eps_out = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11, torch.float32: 2.0**-24, torch.float64: 2.0**-53}[od]
+        allowed = (n_terms + 4) * eps_acc * mag + eps_out * ref.abs() * 1.01 + 1e-30
+        if od == torch.float16:
+            allowed = allowed + 2.0**-25  # (subnormal halves)
+        err = (out.cpu().double() - ref).abs()
+        assert (err <= allowed).all(), (seed, narrow, wide, third, od, n_terms, two, chain, (err / allowed).max().item())
 
 
 def test_wrappers_keep_their_compute_scale(dev):
