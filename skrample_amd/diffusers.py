@@ -781,6 +781,13 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
             self._alias_check(model_output, sample)
 
         prediction = LazyTensor(-Lin.leaf(model_output), model_output.dtype) if self.invert_prediction else model_output
+        if self.invert_prediction and self.compute_scale is None and isinstance(model_output, Tensor) and isinstance(sample, Tensor):
+            # no compute scale: the sampler runs the reference's rounded tensor ops on what it is handed (sampling/native.py), and the
+            # reference hands it the negated TENSOR (diffusers.py:563-564) -- an exact op, one launch
+            from .sampling import native
+
+            if native._eligible(sample, model_output) and model_output.is_contiguous():
+                prediction = native._express(model_output, lambda o: -o, model_output)
         noise = None
         if self.sampler.require_noise:
             noise = self.get_step_noise(step, sample, self.noise_type, self.noise_props, generator, self.compute_scale, lazy_ok=True)
@@ -1246,6 +1253,14 @@ class RKWrapperCore(SkrampleWrapperCore):
         return result
 
     def _step_stage(self, model_output: Tensor, sample: Tensor, generator, return_dict: bool):
+        if self.compute_scale is None and isinstance(sample, Tensor) and isinstance(model_output, Tensor):
+            # 16-bit tensors without a compute scale: the reference's own rounded tensor ops, recorded and replayed (sampling/native.py)
+            from .sampling import native
+
+            done = native.rk_step(self, model_output, sample, generator)
+            if done is not None:
+                return self._finish(done[0], done[1], model_output, return_dict)
+            self._derivatives = [lift(d) if isinstance(d, Tensor) else d for d in self._derivatives]  # (a step begun in that mode goes on fused)
         # stage programs: the same lower-once / replay-by-binding scheme as SkrampleWrapperScheduler.step
         owner = (self.schedule, self._steps, self.sampler_order, self.stochasticity, self.model, self.derivative_transform, self.compute_scale, self.invert_prediction)
         if self._rk_programs_for != owner:

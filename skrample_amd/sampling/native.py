@@ -499,3 +499,83 @@ def try_point(kind: str, point: Point, sample, noise):
     except _Refused:
         return None
     return done
+
+
+# ---- the Runge-Kutta wrappers under compute_scale=None (reference diffusers.py:746-870) -----------------------------------------------
+def _backward(model, sample, result, delta: DeltaPoint):
+    "DiffusionModel.backward without noise (reference models.py:68-82): (result - sample * gamma) / delta"
+    return (result - sample * model.gamma(delta, 0)) / model.delta(delta, 0)
+
+
+def _express(like: torch.Tensor, fn, *tensors):
+    "record fn over the tensors' leaves and run it: one launch (device) / the torch ops themselves (host); a result that IS a leaf comes back as that tensor"
+    tape = Tape(like.dtype, like.shape, like.device, require_device=False)
+    out = fn(*[tape.leaf(t) for t in tensors])
+    (done,) = _execute(tape, [out]) if tape.ops[out.n][0] != _hip.TAPE_LOAD else (tape.leaves[tape.ops[out.n][1]],)
+    return done
+
+
+def rk_step(wrapper, model_output: torch.Tensor, sample: torch.Tensor, generator):
+    """`RKWrapperCore.step` for tensors of one 16-bit dtype under compute_scale=None: the reference's own sequence -- negation, derivative
+    conversion, `forward(sample, sumprod(derivatives, row) / fsum(row))` per stage, `backward` for the stages on the clean end -- each as one
+    recorded expression (one launch).  Returns (stage input or step result, pred_original_sample), or None when the call is outside this
+    mode (the caller then takes the fused path); state (`_derivatives`, `_sample`, `_index`) advances exactly as in the reference."""
+    if wrapper.compute_scale is not None or not _eligible(sample, model_output) or not (sample.is_contiguous() and model_output.is_contiguous()):
+        return None
+    held = list(wrapper._derivatives)
+    if any(not isinstance(d, torch.Tensor) or d.dtype != sample.dtype for d in held) or (wrapper._sample is not None and not isinstance(wrapper._sample, torch.Tensor)):
+        return None
+    nodes, weights = wrapper.tableau()
+    if len(weights) + 3 > _hip.TAPE_MAX_INPUTS or 2 * len(weights) + 12 > _hip.TAPE_MAX_OPS or abs(wrapper.stochasticity) > 1e-8 and wrapper.noise_type.__name__ == "Brownian":
+        return None  # (the 25-35-stage tableaux: more leaves than a tape takes)
+    points = [*wrapper.all_points, Point(0, 0, 1)]
+    eta = wrapper.stochasticity
+
+    def inside_out(output, space, s0: Point, s1: Point, sn: Point):
+        "step_tableau_inside_out (diffusers.py:746-796)"
+        wrapper._derivatives.append(output)
+        if wrapper._sample is None:
+            wrapper._sample = sample
+        base, ds = wrapper._sample, list(wrapper._derivatives)
+        if len(ds) == len(weights):
+            noise = None
+            if abs(eta) > 1e-8:
+                noise = wrapper.get_step_noise(common.Step.from_int(wrapper._index // wrapper.order, wrapper._steps), base, wrapper.noise_type, wrapper.noise_props, generator, None)
+            wrapper._last_noise = noise
+            if noise is not None:
+                final = _express(base, lambda b, n, *d: _forward(space, b, _sumprod(d, weights), DeltaPoint(s0, s1), n, eta), base, noise, *ds)
+            else:
+                final = _express(base, lambda b, *d: _forward(space, b, _sumprod(d, weights), DeltaPoint(s0, s1), None, eta), base, *ds)
+            wrapper._derivatives = []
+            wrapper._sample = None
+            return final
+        row = nodes[len(ds)][1]
+        if not row:
+            raise ValueError
+        return _express(base, lambda b, *d: _forward(space, b, _sumprod(d, row) / math.fsum(row), DeltaPoint(s0, sn), None, 0), base, *ds)
+
+    try:
+        output = model_output
+        if wrapper.invert_prediction:
+            output = _express(sample, lambda o: -o, output)
+        space = wrapper.model
+        if wrapper.derivative_transform:
+            at = points[wrapper._index]
+            output = _express(sample, lambda s_, o: _output_to(wrapper.model, wrapper.derivative_transform, s_, o, at), sample, output)
+            space = wrapper.derivative_transform
+    except _Refused:
+        return None  # (nothing has been touched yet)
+    n_held = len(held)
+    i0, i1, sn = wrapper._index - n_held, wrapper._index + wrapper.order - n_held, wrapper._index + 1
+    sampled = inside_out(output, space, points[i0], points[i1], points[sn])
+    wrapper._index += 1
+    clean = wrapper.schedule.point_0
+    while wrapper._index < len(wrapper.all_points) and (
+        abs(wrapper.all_points[wrapper._index].timestep - clean.timestep) < 1e-8 or abs(wrapper.all_points[wrapper._index].sigma - clean.sigma) < 1e-8
+    ):
+        base = sample if wrapper._sample is None else wrapper._sample
+        delta = DeltaPoint(points[i0], points[i1])
+        synth = _express(base, lambda b, r: _backward(space, b, r, delta), base, sampled)
+        sampled = inside_out(synth, space, points[i0], points[i1], points[sn + 1])
+        wrapper._index += 1
+    return sampled, output

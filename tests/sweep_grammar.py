@@ -51,3 +51,16 @@ def sweep_spec(rng) -> tuple[str, str, tuple[int, ...], int]:
     shape = (rng.randint(1, 3), rng.randint(1, 4), rng.choice((4, 7, 8)), rng.choice((5, 8, 6)))
     steps_n = rng.randint(2, 9) if "RK" not in text else rng.randint(1, 3)
     return text, dtype, shape, steps_n
+
+
+def native_spec(rng) -> tuple[str, str, tuple[int, ...], int]:
+    """the same draw re-targeted at `compute_scale=None` on 16-bit tensors: the reference then computes in the TENSOR dtype, one rounded op at a
+    time (tests/golden/steps_sweep_native.npz; results are compared bit for bit).  SPC is left out: this package evaluates its blend fused."""
+    while True:
+        text, dtype, shape, steps_n = sweep_spec(rng)
+        if "T.SPC(" not in text:
+            break
+    text = text.replace(", compute_scale=torch.float64", "")[:-1] + ", compute_scale=None)"
+    if dtype in ("float32", "float64"):
+        dtype = rng.choice(("bfloat16", "float16"))
+    return text, dtype, shape, steps_n

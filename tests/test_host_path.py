@@ -16,12 +16,14 @@ from test_step_gpu import (
     EXTRA4_WRAPPERS,
     EXTRA_WRAPPERS,
     FIXTURE_WRAPPERS,
+    NATIVE_SWEEP_COUNT,
     SWEEP_COUNT,
     SWEEP_NAMES,
     Injected,
     assert_close,
     native16_engine_vs_reference,
     replay_fixture,
+    replay_native_sweep,
     sweep_case,
 )
 
@@ -82,6 +84,12 @@ def test_reference_recorded_random_sweep_on_cpu(index):
     "64 seeded random wrapper configurations recorded from the reference itself, replayed on host tensors"
     m, fx, dt = sweep_case(index)
     replay_fixture(eval(m["text"], SWEEP_NAMES), fx, dt, CPU, m["text"], steps=m["steps"])
+
+
+@pytest.mark.parametrize("index", range(NATIVE_SWEEP_COUNT))
+def test_reference_recorded_sweep_without_a_compute_scale_on_cpu(index):
+    "compute_scale=None on 16-bit host tensors: the wrappers (Runge-Kutta ones included) return the reference's bits"
+    replay_native_sweep(index, CPU)
 
 
 def test_configurations_the_reference_refuses_are_refused_here_too():

@@ -228,6 +228,39 @@ def test_reference_recorded_random_sweep(index, dev):
     replay_fixture(eval(m["text"], SWEEP_NAMES), fx, dt, dev, m["text"], steps=m["steps"])
 
 
+NATIVE_SWEEP_COUNT = 32
+
+
+def replay_native_sweep(index, dev):
+    """tests/golden/steps_sweep_native.npz: the sweep grammar under compute_scale=None on 16-bit tensors, where the reference computes in the tensor
+    dtype one rounded op at a time (Runge-Kutta wrappers, invert_prediction, nested predictors, derivative transforms) -- bit for bit"""
+    import json
+
+    blob = load_npz("steps_sweep_native.npz")
+    meta = json.loads(str(blob["meta"]))
+    assert len(meta) == NATIVE_SWEEP_COUNT
+    m = meta[index]
+    fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(m["tag"] + "/")}
+    dt = getattr(torch, m["dtype"])
+    w = eval(m["text"], SWEEP_NAMES)
+    w.set_timesteps(m["steps"])
+    np.testing.assert_allclose(w.timesteps.numpy(), fx["timesteps"], rtol=0, atol=1e-9)
+    used = int(fx["noise_used"])
+    w._noise_generator = Injected([from_bits(v, dt) for v in fx["noises"][:used]], dev) if used else None
+    x = from_bits(fx["x0"], dt).to(dev)
+    for i, t in enumerate(w.timesteps):
+        prev, pred = w.step(from_bits(fx["outs"][i], dt).to(dev), t, x, return_dict=False)
+        pred = torch.as_tensor(pred.materialize() if isinstance(pred, lazy.LazyTensor) else pred)
+        for name, got, want in (("prev_sample", prev, fx["prev"][i]), ("pred_original_sample", pred, fx["pred"][i])):
+            assert got.dtype == dt and torch.equal(got.cpu(), from_bits(want, dt)), (m["text"], i, name, (got.cpu().double() - from_bits(want, dt).double()).abs().max())
+        x = prev
+
+
+@pytest.mark.parametrize("index", range(NATIVE_SWEEP_COUNT))
+def test_reference_recorded_sweep_without_a_compute_scale(index, dev):
+    replay_native_sweep(index, dev)
+
+
 @pytest.mark.parametrize("name", EXTRA3_WRAPPERS)
 def test_high_order_fixtures(name, dev):
     """Adams-Bashforth 6 / 9, UniP 7, UniPC 6 / 9 (north_star: "Adams-IPNDM 1-9"): outputs of the reference's own step() replayed

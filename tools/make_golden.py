@@ -184,7 +184,7 @@ def run_wrapper(w, B, unit, steps, dtype, seed, noise_fn=None):
     outs = [torch.randn([B, *unit], generator=g).to(dtype) for _ in range(n_calls)]
     noises = [(noise_fn(i, g) if noise_fn else torch.randn([B, *unit], generator=g)) for i in range(n_calls)]
     w._noise_generator = _Injected(noises)
-    rec = {"x0": bits(x), "outs": np.stack([bits(o) for o in outs]), "noises": np.stack([n.numpy() for n in noises]), "timesteps": w.timesteps.numpy().copy()}
+    rec = {"x0": bits(x), "outs": np.stack([bits(o) for o in outs]), "noises": np.stack([bits(n) for n in noises]), "timesteps": w.timesteps.numpy().copy()}
     prevs, preds = [], []
     for t, o in zip(w.timesteps, outs):
         prev, pred = w.step(o, t, x, return_dict=False)
@@ -303,6 +303,7 @@ def steps() -> None:
 # eta x dtype x compute_scale x ragged shape x run length), each case stepped through the imported reference.  A case is stored as
 # the TEXT of its constructor in a neutral vocabulary (W = diffusers module, T = structured samplers, S = schedules, M = models), so
 # the test builds the product's object from the same words.
+from sweep_grammar import native_spec as _native_spec  # noqa: E402
 from sweep_grammar import sweep_spec as _sweep_spec  # noqa: E402  (tests/sweep_grammar.py: shared with the GPU box's device-vs-host soak)
 
 
@@ -332,6 +333,32 @@ def sweep(count: int = 64) -> None:
     blob["meta"] = np.asarray(json.dumps(meta))
     blob["refused"] = np.asarray(json.dumps(refused))  # configurations the reference itself refuses (an exception out of set_timesteps / step)
     np.savez_compressed(os.path.join(OUT, "steps_sweep.npz"), **blob)
+
+
+def sweep_native(count: int = 32) -> None:
+    "the sweep's grammar under compute_scale=None on 16-bit tensors (noise handed over in the tensor dtype, as get_step_noise does: diffusers.py:346)"
+    import random
+
+    names = {"W": RD, "T": structured, "S": RS, "M": models, "torch": torch}
+    blob, meta, seed = {}, [], 0
+    while len(meta) < count:
+        seed += 1
+        text, dtype, shape, steps_n = _native_spec(random.Random(8000 + seed))
+        dt = getattr(torch, dtype)
+        try:
+            rec = run_wrapper(eval(text, names), shape[0], shape[1:], steps_n, dt, seed=8000 + seed, noise_fn=lambda i, g: torch.randn(shape, generator=g).to(dt))
+        except (ZeroDivisionError, ValueError, AssertionError, IndexError, AttributeError, TypeError):
+            continue
+        as_t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).view(dt)  # noqa: E731
+        if not all(torch.isfinite(as_t(rec[k]).float()).all() for k in ("prev", "pred")):
+            continue
+        rec = {k: (v.view(np.int16) if v.dtype == np.float16 else v) for k, v in rec.items()}
+        tag = f"n{len(meta):02d}"
+        meta.append({"tag": tag, "text": text, "dtype": dtype, "shape": list(shape), "steps": steps_n, "seed": 8000 + seed})
+        for k, v in rec.items():
+            blob[f"{tag}/{k}"] = v
+    blob["meta"] = np.asarray(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "steps_sweep_native.npz"), **blob)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -859,6 +886,7 @@ if __name__ == "__main__":
     tables()
     steps()
     sweep()
+    sweep_native()
     noise()
     wrapper_api()
     functional_api()

@@ -3,7 +3,7 @@ step each through the imported reference and through skrample_amd on host tensor
 every difference -- results beyond the parity bar, different timesteps, or one side raising where the other does not.
 tests/golden/steps_sweep.npz holds the first 64 accepted cases of the same generator; this runs as many as asked.
 
-    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule|generator]
+    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule|generator|native]
 """
 
 import os
@@ -31,6 +31,8 @@ def bf16_ulp(ref: torch.Tensor) -> torch.Tensor:
     mag = ref.float().abs().clamp_min(2.0**-126)
     return torch.exp2(torch.floor(torch.log2(mag)) - 7)
 
+
+NOISE_LIKE_SAMPLE = False  # the "native" mode of __main__ sets it: compute_scale=None wrappers on 16-bit tensors
 
 REF = {"W": MG.RD, "T": MG.structured, "S": MG.RS, "M": MG.models, "torch": torch}
 OWN = {"W": PD, "T": PT, "S": PS, "M": PM, "torch": torch}
@@ -73,7 +75,7 @@ def one(seed: int) -> str | None:
     x = torch.randn(shape, generator=g).to(dt)
     n = len(r_times)
     outs = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]
-    noises = [torch.randn(shape, generator=g) for _ in range(n)]
+    noises = [torch.randn(shape, generator=g).to(dt if NOISE_LIKE_SAMPLE else torch.float32) for _ in range(n)]  # (what get_step_noise hands over is cast to compute_scale, or to the sample's dtype when that is None)
     # the helper entry points a diffusers pipeline calls around the loop (img2img start: add_noise / scale_noise at a later timestep,
     # set_begin_index, scale_model_input, init_noise_sigma), then the steps from that start with an empty history
     extras = random.Random(seed ^ 0x5EED)
@@ -493,13 +495,67 @@ def one_generator(seed: int) -> str | None:
     return None
 
 
+# ---- wrappers without a compute scale on 16-bit host tensors: the reference computes in the tensor dtype, op by op -- results bit for bit ------------------
+def _native_spec(rng):
+    from sweep_grammar import native_spec
+
+    return native_spec(rng)
+
+
+def one_native(seed: int) -> str | None:
+    text, dtype, shape, steps_n = _native_spec(random.Random(seed))
+    dt = getattr(torch, dtype)
+    g = torch.Generator().manual_seed(seed)
+    made = []
+    for names in (REF, OWN):
+        try:
+            w = eval(text, names)
+            w.set_timesteps(steps_n)
+            len(w.timesteps)  # (the Runge-Kutta wrappers build their table here, and refuse some schedules with an assertion)
+            made.append(w)
+        except Exception as err:  # noqa: BLE001
+            made.append(err)
+    if any(isinstance(m, Exception) for m in made):
+        return None if type(made[0]) is type(made[1]) else f"set_timesteps: reference {made[0]!r}, here {made[1]!r}"
+    r, p = made
+    if not torch.isfinite(r.timesteps).all():
+        return None
+    x = torch.randn(shape, generator=g).to(dt)
+    n = len(r.timesteps)
+    outs = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]
+    noises = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]  # (get_step_noise hands the draw over in the sample's dtype: diffusers.py:346)
+    r._noise_generator, p._noise_generator = MG._Injected(list(noises)), _Replay(list(noises))
+    for i, (tr, tp) in enumerate(zip(r.timesteps, p.timesteps)):
+        sides = []
+        for w, t in ((r, tr), (p, tp)):
+            try:
+                got = w.step(outs[i], t, x, return_dict=False)
+                sides.append([torch.as_tensor(v.materialize() if isinstance(v, lazy.LazyTensor) else v) for v in got])
+            except Exception as err:  # noqa: BLE001
+                sides.append(err)
+        a, b = sides
+        if isinstance(a, Exception) or isinstance(b, Exception):
+            if isinstance(a, Exception) and isinstance(b, Exception):
+                return None
+            if isinstance(b, Exception) and not all(torch.isfinite(v.float()).all() for v in a):
+                return None
+            return f"step {i}: reference {a if isinstance(a, Exception) else 'ok'!r}, here {b if isinstance(b, Exception) else 'ok'!r}"
+        if not all(torch.isfinite(v.float()).all() for v in a):
+            return None
+        for name, u, v in zip(("prev", "pred"), a, b):
+            if u.dtype != v.dtype or not torch.equal(u, v):
+                return f"step {i} {name}: {(u != v).sum().item()} elements differ from the reference's bits (max {(u.double() - v.double()).abs().max().item():.3g})"
+        x = a[0]
+    return None
+
+
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     found = 0
     which = sys.argv[3] if len(sys.argv) > 3 else "wrapper"
     for seed in range(first, first + count):
-        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule), "generator": (_generator_spec, one_generator)}[which]
+        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule), "generator": (_generator_spec, one_generator), "native": (_native_spec, one_native)}[which]
         text = spec(random.Random(seed))
         try:
             why = run(seed)
