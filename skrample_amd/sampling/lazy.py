@@ -557,7 +557,10 @@ def error_mean(a, b: torch.Tensor, power: int) -> float:
 
 
 def power_blend(a: torch.Tensor, b: torch.Tensor, wa: float, wb: float, power: float, dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    "spowf(wa * spowf(a, power) + wb * spowf(b, power), 1 / power) as one elementwise launch; fp32 or fp64 result"
+    "spowf(wa * spowf(a, power) + wb * spowf(b, power), 1 / power) as one elementwise launch; fp32 or fp64 result (ndarrays in: ndarray out)"
+    as_numpy = not isinstance(a, torch.Tensor) or not isinstance(b, torch.Tensor)
+    a = a if isinstance(a, torch.Tensor) else _from_numpy(a)
+    b = b if isinstance(b, torch.Tensor) else _from_numpy(b)
     _check_tensor(a)
     _check_tensor(b)
     if a.shape != b.shape:
@@ -566,7 +569,8 @@ def power_blend(a: torch.Tensor, b: torch.Tensor, wa: float, wb: float, power: f
         raise SkrampleHipError("the signed-power blend is evaluated in float32 or float64")
     if not a.is_cuda and not b.is_cuda:  # host-resident operands
         spow = lambda v, f: v.abs().pow(f) * v.sign()  # noqa: E731
-        return spow(wa * spow(a.to(dtype), power) + wb * spow(b.to(dtype), power), 1 / power)
+        blended = spow(wa * spow(a.to(dtype), power) + wb * spow(b.to(dtype), power), 1 / power)
+        return blended.numpy() if as_numpy else blended
     a, b = _prepare_tensor(a), _prepare_tensor(b)
     out = empty_output(a.shape, dtype, a.device)
     status = _hip.load().skr_power_blend(out.data_ptr(), _hip.DTYPE_CODE[dtype], a.data_ptr(), _hip.DTYPE_CODE[a.dtype], b.data_ptr(), _hip.DTYPE_CODE[b.dtype], float(wa), float(wb), float(power), a.numel(), _hip.current_stream_ptr(a.device))

@@ -68,6 +68,8 @@ def _result_dtype(value) -> torch.dtype | None:
         return value.dtype
     if isinstance(value, LazyTensor):
         return value.dtype
+    if type(value).__module__ == "numpy" and hasattr(value, "__array_interface__") and getattr(value, "ndim", 0) > 0:
+        return lazy._from_numpy(value).dtype  # ndarrays keep their width too (float64 state and predictions for float64 arrays)
     return None
 
 
@@ -298,7 +300,16 @@ def _two_output_step(state_form, final_form, packed: SampleInput, prediction, re
 
 
 def _as_prediction(form, dtype):
-    return LazyTensor(form, dtype or torch.float32) if isinstance(form, Lin) else form
+    "the converted prediction as a lazy tensor of the sample's dtype -- or, when its operands differ in dtype, of their promotion (what the reference's tensor ops return)"
+    if not isinstance(form, Lin):
+        return form
+    seen = {leaf.dtype for leaf, c in form.expanded().terms.values() if isinstance(leaf, torch.Tensor) and c != 0.0}
+    if len(seen) > 1 or (len(seen) == 1 and dtype is not None and next(iter(seen)) != dtype and lazy._compute_dtype.get() is None):
+        promoted = None
+        for d in seen:
+            promoted = d if promoted is None else torch.promote_types(promoted, d)
+        dtype = promoted
+    return LazyTensor(form, dtype or torch.float32)
 
 
 @dataclass(frozen=True)
@@ -399,6 +410,10 @@ class SPC(traits.DerivativeTransform, StructuredSampler):
                     # the one non-linear tensor op of the samplers: materialise the corrector's result (one launch), blend
                     # (one elementwise launch), then predict from the blended sample as usual
                     wide = _state_dtype(result_dtype)  # compute_scale: float32, or float64 when asked for
+                    if not isinstance(packed.sample, torch.Tensor):
+                        # ndarrays: the reference's spowf multiplies by an int64 sign array (common.py:187-190), which makes numpy promote a
+                        # float32 array to float64 -- the blended sample and everything computed from it are float64 there
+                        wide = result_dtype = torch.float64
                     sample_t = packed.sample if isinstance(packed.sample, torch.Tensor) else lazy.settle(lift(packed.sample), dtype=wide)
                     blended = lazy.power_blend(sample_t, lazy.settle(corrected, dtype=wide), wp, wc, self.power, wide)
                     inner = replace(inner, sample=blended)

@@ -166,6 +166,31 @@ def test_numpy_arrays_through_the_sampler_protocol():
     assert np.isfinite(xa).all()
 
 
+def test_numpy_arrays_keep_the_dtypes_the_reference_returns():
+    """found by tools/sweep_vs_reference.py `array`: UniPC kept its state and prediction in float32 for float64 arrays; SPC's signed-power blend took
+    no ndarrays at all -- and the reference's spowf (common.py:187-190) multiplies by an int64 sign array, so numpy promotes a float32 array to
+    float64 from the blended sample on, while the converted prediction of a DataModel stays what the network output was"""
+    rng = np.random.default_rng(0)
+    for dt in (np.float64, np.float32):
+        x, out = rng.standard_normal((2, 3, 4)).astype(dt), rng.standard_normal((2, 3, 4)).astype(dt)
+        for sampler in (PT.UniPC(order=2), PT.UniPC(order=3, stochasticity=1), PT.SPC()):
+            prev, xx = [], x
+            for i in range(4):
+                rec = sampler.sample(xx, out, Step.from_int(i, 6), PM.NoiseModel(), PS.Scaled(), rng.standard_normal((2, 3, 4)).astype(dt) if sampler.require_noise else None, tuple(prev))
+                pred = rec.prediction.materialize() if isinstance(rec.prediction, lazy.LazyTensor) else rec.prediction
+                assert isinstance(rec.final, np.ndarray) and rec.final.dtype == dt and np.asarray(pred).dtype == dt and np.asarray(rec.sample).dtype == dt, (sampler, i)
+                prev.append(rec)
+                xx = rec.final
+    x, out = rng.standard_normal((2, 3, 4)).astype(np.float32), rng.standard_normal((2, 3, 4)).astype(np.float32)
+    sampler, prev, xx = PT.SPC(power=0.5), [], x
+    for i in range(3):
+        rec = sampler.sample(xx, out, Step.from_int(i, 6), PM.DataModel(), PS.Scaled(), None, tuple(prev))
+        pred = rec.prediction.materialize() if isinstance(rec.prediction, lazy.LazyTensor) else rec.prediction
+        assert rec.final.dtype == (np.float32 if i == 0 else np.float64) and np.asarray(pred).dtype == np.float32, i
+        prev.append(rec)
+        xx = rec.final
+
+
 def test_wrapper_random_noise_on_cpu_uses_the_callers_generators():
     "host-resident latents draw white noise as the reference does: torch.randn from one CPU generator per sample"
     shape, steps = (2, 4, 8, 8), 4

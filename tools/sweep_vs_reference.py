@@ -3,7 +3,7 @@ step each through the imported reference and through skrample_amd on host tensor
 every difference -- results beyond the parity bar, different timesteps, or one side raising where the other does not.
 tests/golden/steps_sweep.npz holds the first 64 accepted cases of the same generator; this runs as many as asked.
 
-    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule|generator|native]
+    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule|generator|native|array]
 """
 
 import os
@@ -549,13 +549,64 @@ def one_native(seed: int) -> str | None:
     return None
 
 
+# ---- the sampler-level API on what else the reference's generic `T` covers: Python floats and numpy arrays (float32 / float64) -----------------------------
+def _array_spec(rng):
+    text, _dtype, shape, steps_n = _sampler_spec(rng)
+    return text, rng.choice(("float", "f64", "f32", "f64")), shape, steps_n
+
+
+def one_array(seed: int) -> str | None:
+    from skrample.common import Step as RStep
+
+    from skrample_amd.common import Step as OStep
+
+    text, kind, shape, steps_n = _array_spec(random.Random(seed))
+    g = np.random.default_rng(seed)
+    mk = (lambda: float(g.standard_normal())) if kind == "float" else (lambda: g.standard_normal(shape).astype(np.float64 if kind == "f64" else np.float32))
+    x0, outs, nzs = mk(), [mk() for _ in range(steps_n)], [mk() for _ in range(steps_n)]
+    sides = []
+    for names, StepT in ((REF, RStep), (OWN, OStep)):
+        try:
+            sampler, schedule, model = eval(text, names)
+            x, prev, got = x0, [], []
+            for i in range(steps_n):
+                rec = sampler.sample(x, outs[i], StepT.from_int(i, steps_n), model, schedule, nzs[i] if sampler.require_noise else None, tuple(prev))
+                pred = rec.prediction.materialize() if hasattr(rec.prediction, "materialize") else rec.prediction
+                got.append((rec.final, pred))
+                prev.append(rec)
+                x = rec.final
+            sides.append(got)
+        except Exception as err:  # noqa: BLE001
+            sides.append(err)
+    r, p = sides
+    if isinstance(r, Exception) or isinstance(p, Exception):
+        if isinstance(r, Exception) and isinstance(p, Exception):
+            return None
+        if isinstance(p, ZeroDivisionError) and not all(np.isfinite(np.asarray(v)).all() for pair in r for v in pair):
+            return None  # (singular point: the reference's arrays fill with inf / nan, the engine raises)
+        return f"reference {r if isinstance(r, Exception) else 'ok'!r}, here {p if isinstance(p, Exception) else 'ok'!r}"
+    for i, ((fa, pa), (fb, pb)) in enumerate(zip(p, r)):
+        if type(fa) is not type(fb):
+            return f"step {i}: result is a {type(fa).__name__}, the reference's a {type(fb).__name__}"
+        for name, a, b in (("final", fa, fb), ("prediction", pa, pb)):
+            a, b = np.asarray(a), np.asarray(b)
+            if a.shape != b.shape or a.dtype != b.dtype:
+                return f"step {i} {name}: {a.dtype}{a.shape} vs {b.dtype}{b.shape}"
+            if not np.isfinite(b).all():
+                return None
+            tol = 1e-5 if kind == "f32" else 1e-9  # (float32 inputs: float32 arithmetic somewhere upstream even where numpy promoted the result)
+            if not np.allclose(a, b, rtol=tol, atol=tol * max(1.0, float(np.abs(b).max()))):
+                return f"step {i} {name}: max diff {float(np.abs(a - b).max()):.3g}"
+    return None
+
+
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     found = 0
     which = sys.argv[3] if len(sys.argv) > 3 else "wrapper"
     for seed in range(first, first + count):
-        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule), "generator": (_generator_spec, one_generator), "native": (_native_spec, one_native)}[which]
+        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule), "generator": (_generator_spec, one_generator), "native": (_native_spec, one_native), "array": (_array_spec, one_array)}[which]
         text = spec(random.Random(seed))
         try:
             why = run(seed)
