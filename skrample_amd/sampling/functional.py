@@ -99,7 +99,7 @@ def step_tableau(
             derivs.append(convert.form_to(stage_in, out, point) if convert else lift(out))
     forms = [space.update_form(base, common.sumprod(derivs, row), delta, noise, stochasticity) for row in weight_rows]
     if len(forms) == 2 and all(isinstance(f, Lin) for f in forms):  # embedded pair: both solutions from ONE launch
-        dtype = sample.dtype if hasattr(sample, "dtype") else None
+        dtype = sample.dtype if isinstance(sample, lazy.torch.Tensor) else None  # (ndarrays: the forms' own leaves name the dtype)
         return tuple(lazy.evaluate(forms, [dtype, dtype]))
     return tuple(_materialise(f, sample) for f in forms)
 

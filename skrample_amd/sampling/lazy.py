@@ -534,7 +534,9 @@ _norm_ws: dict = {}
 
 
 def error_mean(a, b: torch.Tensor, power: int) -> float:
-    "mean(|a - b|^power) over a device tensor pair (a may be the number 0); one reduction launch + read-back"
+    "mean(|a - b|^power) over a device tensor pair (a may be the number 0); one reduction launch + read-back (ndarrays: on the host)"
+    a = _from_numpy(a) if type(a).__module__ == "numpy" and hasattr(a, "__array_interface__") and getattr(a, "ndim", 0) > 0 else a
+    b = _from_numpy(b) if type(b).__module__ == "numpy" and hasattr(b, "__array_interface__") else b
     _check_tensor(b)
     if not b.is_cuda:  # host-resident operands: plain torch (fp64 accumulation, as the kernel)
         d = (b.double() if not isinstance(a, torch.Tensor) else a.double() - b.double()).abs()

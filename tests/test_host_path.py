@@ -191,6 +191,21 @@ def test_numpy_arrays_keep_the_dtypes_the_reference_returns():
         xx = rec.final
 
 
+def test_adaptive_runge_kutta_takes_ndarrays():
+    "found by the live sweep: RKMoire's embedded pair asked the evaluator for a numpy dtype, and its error norm refused ndarrays"
+    import skrample_amd.sampling.functional as PF
+
+    rng = np.random.default_rng(3)
+    toy = lambda xx, t, s, a: xx * 0.3 - 0.1 * s + 0.05 * a  # noqa: E731
+    for dt in (np.float64, np.float32):
+        x = rng.standard_normal((2, 3)).astype(dt)
+        for sampler in (PF.RKMoire(order=2), PF.RKMoire(order=3, evaluator=PF.FunctionalAdaptive.mae), PF.RKUltra(order=4), PF.DynasauRK(order=3)):
+            res = sampler.sample_model(x.copy(), toy, PM.FlowModel(), PS.Linear(), 6)
+            assert isinstance(res, np.ndarray) and res.dtype == dt and np.isfinite(res).all(), sampler
+            twin = sampler.sample_model(torch.from_numpy(x.copy()), toy, PM.FlowModel(), PS.Linear(), 6)
+            np.testing.assert_allclose(res, twin.numpy(), rtol=1e-6 if dt == np.float32 else 1e-12, atol=1e-7 if dt == np.float32 else 1e-13)
+
+
 def test_wrapper_random_noise_on_cpu_uses_the_callers_generators():
     "host-resident latents draw white noise as the reference does: torch.randn from one CPU generator per sample"
     shape, steps = (2, 4, 8, 8), 4
