@@ -25,6 +25,12 @@ from ..common import DeltaPoint, Point
 from .lazy import lift, settle
 
 
+def _native():
+    from . import native  # (native imports this module)
+
+    return native
+
+
 @dataclasses.dataclass(frozen=True)
 class DiffusionModel(abc.ABC):
     # ---- linear coefficient tables ------------------------------------------------------------------
@@ -76,6 +82,9 @@ class DiffusionModel(abc.ABC):
     # ---- value-level API (numbers, lazy forms or HIP tensors) ------------------------------------------
     def to_x(self, sample, output, point: Point):
         "output -> x_hat"
+        done = _native().try_expr(lambda s_, o_: _native()._to_x(self, s_, o_, point), sample, output)  # 16-bit tensors: the reference's rounded ops
+        if done is not None:
+            return done
         xs, xo = self.x_weights(point)
         if xs == 0 and xo == 1:
             return output
@@ -83,6 +92,9 @@ class DiffusionModel(abc.ABC):
 
     def from_x(self, sample, x, point: Point):
         "x_hat -> output"
+        done = _native().try_expr(lambda s_, x_: _native()._from_x(self, s_, x_, point), sample, x)
+        if done is not None:
+            return done
         os_, ox = self.out_weights(point)
         if os_ == 0 and ox == 1:
             return x
@@ -99,10 +111,18 @@ class DiffusionModel(abc.ABC):
 
     def forward(self, sample, output, delta_point: DeltaPoint, noise=None, eta: float = 0):
         "sample*Gamma + output*Delta + noise*zeta (reference models.py:53-67), one fused launch"
+        operands = (sample, output) if noise is None else (sample, output, noise)
+        done = _native().try_expr(lambda s_, o_, n_=None: _native()._forward(self, s_, o_, delta_point, n_, eta), *operands)
+        if done is not None:
+            return done
         return settle(self.update_form(sample, output, delta_point, noise, eta), like=sample)
 
     def backward(self, sample, result, delta_point: DeltaPoint, noise=None, eta: float = 0):
         "solve forward() for the output (reference models.py:69-83)"
+        operands = (sample, result) if noise is None else (sample, result, noise)
+        done = _native().try_expr(lambda s_, r_, n_=None: _native()._backward(self, s_, r_, delta_point, n_, eta), *operands)
+        if done is not None:
+            return done
         form = lift(result) - lift(sample) * self.gamma(delta_point, eta)
         if noise is not None:
             z = self.zeta(delta_point, eta)
@@ -249,10 +269,12 @@ class ScaleX(FakeModel):
         return 0.0, 1.0 / self.x_scale(point)
 
     def to_x(self, sample, output, point):
-        return settle(lift(output) * self.x_scale(point), like=output)
+        done = _native().try_expr(lambda o_: _native()._to_x(self, None, o_, point), output)
+        return done if done is not None else settle(lift(output) * self.x_scale(point), like=output)
 
     def from_x(self, sample, x, point):
-        return settle(lift(x) / self.x_scale(point), like=x)
+        done = _native().try_expr(lambda x_: _native()._from_x(self, None, x_, point), x)
+        return done if done is not None else settle(lift(x) / self.x_scale(point), like=x)
 
     def gamma(self, delta_point, eta=0):
         src, dst = self.eta_transform(delta_point, eta)
@@ -313,11 +335,17 @@ class ModelConvert:
     def output_to(self, sample, output_from, point: Point):
         if self.transform_to is self.transform_from:
             return output_from
+        done = _native().try_expr(lambda s_, o_: _native()._output_to(self.transform_from, self.transform_to, s_, o_, point), sample, output_from)
+        if done is not None:
+            return done
         return settle(self.form_to(sample, output_from, point), like=output_from)
 
     def output_from(self, sample, output_to, point: Point):
         if self.transform_from is self.transform_to:
             return output_to
+        done = _native().try_expr(lambda s_, o_: _native()._output_to(self.transform_to, self.transform_from, s_, o_, point), sample, output_to)
+        if done is not None:
+            return done
         ws, wo = self.weights_from(point)
         return settle(lift(sample) * ws + lift(output_to) * wo, like=output_to)
 

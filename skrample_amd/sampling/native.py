@@ -502,9 +502,28 @@ def try_point(kind: str, point: Point, sample, noise):
 
 
 # ---- the Runge-Kutta wrappers under compute_scale=None (reference diffusers.py:746-870) -----------------------------------------------
-def _backward(model, sample, result, delta: DeltaPoint):
-    "DiffusionModel.backward without noise (reference models.py:68-82): (result - sample * gamma) / delta"
-    return (result - sample * model.gamma(delta, 0)) / model.delta(delta, 0)
+def _backward(model, sample, result, delta: DeltaPoint, noise=None, eta: float = 0):
+    "DiffusionModel.backward (reference models.py:68-82): (result - sample * gamma [- noise * zeta]) / delta"
+    gamma, dlt = model.gamma(delta, eta), model.delta(delta, eta)
+    if noise is not None:
+        zeta = model.zeta(delta, eta)
+        if zeta != 0:
+            return (result - sample * gamma - noise * zeta) / dlt
+    return (result - sample * gamma) / dlt
+
+
+def try_expr(fn, *tensors):
+    """a model-transform expression (`to_x`, `from_x`, `forward`, `backward`, `ModelConvert.output_to` called directly) over tensors of one
+    16-bit dtype, in the reference's arithmetic -- one launch -- or None (the caller evaluates the fused form)"""
+    if not tensors or not all(isinstance(t, torch.Tensor) for t in tensors) or not _eligible(tensors[0], tensors[-1]):
+        return None
+    first = tensors[0]
+    if any(t.dtype != first.dtype or t.shape != first.shape or t.device != first.device or not t.is_contiguous() for t in tensors):
+        return None
+    try:
+        return _express(first, fn, *tensors)
+    except _Refused:
+        return None
 
 
 def _express(like: torch.Tensor, fn, *tensors):

@@ -737,6 +737,28 @@ def test_random_linear_forms_vs_float64(seed, dev):
         assert (err <= allowed).all(), (seed, narrow, wide, third, od, n_terms, two, chain, (err / allowed).max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_model_transforms_on_the_device_return_the_reference_bits(dtype, dev):
+    """DiffusionModel.to_x / from_x / forward / backward and ModelConvert.output_to called directly on 16-bit device tensors: one tape launch each, equal
+    to the same call on host tensors -- which runs the reference's own torch ops (tools/sweep_vs_reference.py `model`: 3000 cases against the reference)"""
+    from skrample_amd.common import DeltaPoint, Point
+    from skrample_amd.sampling import native
+
+    g = torch.Generator().manual_seed(23)
+    s_, o_, n_ = (torch.randn(3, 4, 33, 17, generator=g).to(dtype) for _ in range(3))
+    p0, p1 = Point(500.0, 0.6, 0.8), Point(300.0, 0.3, 0.9539392014169456)
+    d = DeltaPoint(p0, p1)
+    for model in (PM.NoiseModel(), PM.FlowModel(), PM.VelocityModel(), PM.ScaleX(bias=-1.5)):
+        calls = {
+            "to_x": lambda a, b, c: model.to_x(a, b, p0), "from_x": lambda a, b, c: model.from_x(a, b, p0), "forward": lambda a, b, c: model.forward(a, b, d, c, 0.5),
+            "backward": lambda a, b, c: model.backward(a, b, d), "convert": lambda a, b, c: PM.ModelConvert(model, PM.VelocityModel()).output_to(a, b, p0),
+        }  # fmt: skip
+        for name, call in calls.items():
+            before = native.launches
+            got = call(s_.to(dev), o_.to(dev), n_.to(dev))
+            assert native.launches == before + 1 and got.is_cuda and torch.equal(got.cpu(), call(s_, o_, n_)), (type(model).__name__, name)
+
+
 def test_wrappers_keep_their_compute_scale(dev):
     "the scheduler wrappers widen to compute_scale before the sampler runs (reference diffusers.py:575-599): fused kernel; compute_scale=None: the tape"
     from skrample_amd.sampling import native

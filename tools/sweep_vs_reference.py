@@ -3,9 +3,10 @@ step each through the imported reference and through skrample_amd on host tensor
 every difference -- results beyond the parity bar, different timesteps, or one side raising where the other does not.
 tests/golden/steps_sweep.npz holds the first 64 accepted cases of the same generator; this runs as many as asked.
 
-    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule|generator|native|array]
+    python tools/sweep_vs_reference.py [count] [first_seed] [wrapper|functional|noise|config|sampler|schedule|generator|native|array|model]
 """
 
+import math
 import os
 import random
 import sys
@@ -606,13 +607,71 @@ def one_array(seed: int) -> str | None:
     return None
 
 
+# ---- the model transforms called directly (to_x / from_x / forward / backward / ModelConvert) over every operand kind; 16-bit tensors bit for bit ---------
+MODEL_TEXTS = ("M.DataModel()", "M.NoiseModel()", "M.FlowModel()", "M.VelocityModel()", "M.ScaleX()", "M.ScaleX(bias=-1.5)")
+
+
+def _model_spec(rng):
+    sig0 = rng.uniform(0.05, 0.95)
+    sig1 = rng.uniform(0.02, sig0)
+    flow = rng.random() < 0.5
+    points = ((500.0, sig0, 1 - sig0), (300.0, sig1, 1 - sig1)) if flow else ((500.0, sig0, math.sqrt(1 - sig0**2)), (300.0, sig1, math.sqrt(1 - sig1**2)))
+    return (rng.choice(MODEL_TEXTS), rng.choice(MODEL_TEXTS), rng.choice(("float", "f64arr", "f32arr", "t64", "t32", "tbf16", "tf16")),
+            rng.choice(("to_x", "from_x", "forward", "forward_noise", "backward", "backward_noise", "output_to", "output_from", "wrap")), points, rng.choice((0, 0.5, 1)))  # fmt: skip
+
+
+def one_model(seed: int) -> str | None:
+    import skrample.sampling.models as RM
+    from skrample.common import DeltaPoint as RDelta
+    from skrample.common import Point as RPoint
+
+    import skrample_amd.sampling.models as OM
+    from skrample_amd.common import DeltaPoint as ODelta
+    from skrample_amd.common import Point as OPoint
+
+    m1, m2, kind, op, points, eta = _model_spec(random.Random(seed))
+    g = torch.Generator().manual_seed(seed)
+
+    def make():
+        t = torch.randn([2, 3], generator=g, dtype=torch.float64)
+        return {"float": lambda: float(t[0, 0]), "f64arr": t.numpy, "f32arr": lambda: t.float().numpy(), "t64": lambda: t, "t32": t.float, "tbf16": t.bfloat16, "tf16": t.half}[kind]()
+
+    s_, o_, n_ = make(), make(), make()
+    sides = []
+    for names, P, D, Mod in ((REF, RPoint, RDelta, RM), (OWN, OPoint, ODelta, OM)):
+        try:
+            a, b, p0, p1 = eval(m1, names), eval(m2, names), P(*points[0]), P(*points[1])
+            d = D(p0, p1)
+            v = {
+                "to_x": lambda: a.to_x(s_, o_, p0), "from_x": lambda: a.from_x(s_, o_, p0), "forward": lambda: a.forward(s_, o_, d), "forward_noise": lambda: a.forward(s_, o_, d, n_, eta),
+                "backward": lambda: a.backward(s_, o_, d), "backward_noise": lambda: a.backward(s_, o_, d, n_, eta), "output_to": lambda: Mod.ModelConvert(a, b).output_to(s_, o_, p0),
+                "output_from": lambda: Mod.ModelConvert(a, b).output_from(s_, o_, p0), "wrap": lambda: Mod.ModelConvert(a, b).wrap_model_call(lambda x, t, sg, al: x * 0.5)(s_, *p0),
+            }[op]()  # fmt: skip
+            sides.append(v.materialize() if isinstance(v, lazy.LazyTensor) else v)
+        except Exception as err:  # noqa: BLE001
+            sides.append(err)
+    r, p = sides
+    if isinstance(r, Exception) or isinstance(p, Exception):
+        return None if type(r) is type(p) else f"reference {r!r}, here {p!r}"
+    if type(r) is not type(p) or getattr(r, "dtype", None) != getattr(p, "dtype", None):
+        return f"a {type(p).__name__} of {getattr(p, 'dtype', None)}, the reference's a {type(r).__name__} of {getattr(r, 'dtype', None)}"
+    if kind in ("tbf16", "tf16"):
+        ok = torch.equal(torch.isnan(r), torch.isnan(p)) and torch.equal(torch.nan_to_num(r), torch.nan_to_num(p))
+        return None if ok else f"{(r != p).sum().item()} elements differ from the reference's bits (max {(r.double() - p.double()).abs().max().item():.3g})"
+    ra, pa = np.asarray(r, dtype=np.float64), np.asarray(p, dtype=np.float64)
+    if not np.isfinite(ra).all():
+        return None
+    tol = 1e-5 if kind in ("f32arr", "t32") else 1e-12
+    return None if np.allclose(pa, ra, rtol=tol, atol=tol * max(1.0, float(np.abs(ra).max()))) else f"max diff {float(np.abs(pa - ra).max()):.3g}"
+
+
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     found = 0
     which = sys.argv[3] if len(sys.argv) > 3 else "wrapper"
     for seed in range(first, first + count):
-        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule), "generator": (_generator_spec, one_generator), "native": (_native_spec, one_native), "array": (_array_spec, one_array)}[which]
+        spec, run = {"wrapper": (MG._sweep_spec, one), "functional": (_functional_spec, one_functional), "noise": (_noise_spec, one_noise), "config": (_config_spec, one_config), "sampler": (_sampler_spec, one_sampler), "schedule": (_schedule_spec, one_schedule), "generator": (_generator_spec, one_generator), "native": (_native_spec, one_native), "array": (_array_spec, one_array), "model": (_model_spec, one_model)}[which]
         text = spec(random.Random(seed))
         try:
             why = run(seed)
