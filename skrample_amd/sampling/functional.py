@@ -75,6 +75,11 @@ def step_tableau(
     epsilon: float = 1e-8,
 ) -> tuple:
     """One explicit Runge-Kutta step in derivative space; returns one result per weight row."""
+    from . import native
+
+    done = native.step_tableau(tableau, sample, model, model_transform, schedule, step, derivative_transform, noise, stochasticity, epsilon)
+    if done is not None:  # a 16-bit tensor sample outside a compute scale: the reference's rounded tensor ops
+        return done
     nodes, weight_rows = tableau[0], tableau[1:]
     convert = models.ModelConvert(model_transform, derivative_transform) if derivative_transform else None
     space = derivative_transform or model_transform

@@ -598,3 +598,46 @@ def rk_step(wrapper, model_output: torch.Tensor, sample: torch.Tensor, generator
         sampled = inside_out(synth, space, points[i0], points[i1], points[sn + 1])
         wrapper._index += 1
     return sampled, output
+
+
+def step_tableau(tableau, sample, model, model_transform, schedule, step, derivative_transform, noise, eta: float, epsilon: float):
+    """`functional.step_tableau` (reference functional.py:55-108) for a tensor sample of one 16-bit dtype outside a compute scale: every stage input,
+    clean-end derivative and weighted result is one recorded expression in the reference's own order (one launch each); a network output that is not a
+    tensor of that dtype sends the rest of the step through plain tensor operators -- the reference's own arithmetic, op by op.  None: not this mode."""
+    if not isinstance(sample, torch.Tensor) or not _eligible(sample, sample) or not sample.is_contiguous():
+        return None
+    if noise is not None and not (isinstance(noise, torch.Tensor) and noise.dtype == sample.dtype and noise.shape == sample.shape and noise.device == sample.device):
+        return None
+    nodes, weight_rows = tableau[0], tableau[1:]
+    if max(len(row) for row in weight_rows) + 3 > _hip.TAPE_MAX_INPUTS or 2 * max(len(row) for row in weight_rows) + 12 > _hip.TAPE_MAX_OPS:
+        return None
+    if derivative_transform:
+        model = models.ModelConvert(model_transform, derivative_transform).wrap_model_call(model)  # (output_to: the tape as well)
+        model_transform = derivative_transform
+    t0, t1 = step
+    s0, s1, *fractions = schedule.ipoints([t0, t1, *(t0 + c * (t1 - t0) for c, _ in nodes)])
+    delta = DeltaPoint(s0, s1)
+    plain = [False]  # set once an operand falls outside the tape's coverage: plain tensor operators from then on
+
+    def run(fn, *operands):
+        if not plain[0] and all(isinstance(t, torch.Tensor) and t.dtype == sample.dtype and t.shape == sample.shape and t.device == sample.device and t.is_contiguous() for t in operands):
+            try:
+                return _express(sample, fn, *operands)
+            except _Refused:
+                pass
+        plain[0] = True
+        return fn(*operands)
+
+    derivatives: list = []
+    for frac, (_c, row) in zip(fractions, nodes):
+        if row:
+            stage_in = run(lambda b, *d: _forward(model_transform, b, _sumprod(d, row) / math.fsum(row), DeltaPoint(delta.point_from, frac), None, 0), sample, *derivatives)
+        else:
+            stage_in = sample
+        if abs(frac.timestep) < epsilon or abs(frac.sigma) < epsilon:  # never call the network at timestep = 0 or sigma = 0
+            derivatives.append(run(lambda b, x: _backward(model_transform, b, x, delta), sample, stage_in))
+        else:
+            derivatives.append(model(stage_in, *frac))
+    if noise is not None:
+        return tuple(run(lambda b, n, *d, w=w: _forward(model_transform, b, _sumprod(d, w), delta, n, eta), sample, noise, *derivatives) for w in weight_rows)
+    return tuple(run(lambda b, *d, w=w: _forward(model_transform, b, _sumprod(d, w), delta, None, eta), sample, *derivatives) for w in weight_rows)

@@ -194,3 +194,53 @@ def test_remove_noise_at_alpha_zero_divides_as_the_reference_does(dtype):
     assert got.dtype == dtype and torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
     assert torch.isnan(got[0, 0]) and torch.isinf(got[0, 1])
     assert pt.remove_noise(0.5, 2.0) == 2.0  # the float path: the scaled noise
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_functional_samplers_on_16_bit_tensors_follow_the_generic_arithmetic(dtype):
+    """functional.step_tableau on a 16-bit tensor sample (reference functional.py:55-108: generic tensor operators, every one rounded): each stage input and
+    each weighted result is one recorded expression; on host tensors the tape runs one torch op per entry, so the result equals the expression written out
+    with tensor operators.  (tools/sweep_vs_reference.py `functional` compares RKUltra / DynasauRK / the adapter with the imported reference bit for bit.)"""
+    import math
+
+    import skrample_amd.scheduling as PS
+    from skrample_amd.common import DeltaPoint
+    from skrample_amd.sampling import functional as PF
+    from skrample_amd.sampling import models as PM
+    from skrample_amd.sampling import tableaux
+
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 5, generator=g).to(dtype)
+    net = lambda xx, t, s, a: xx * 0.3 - 0.1 * s + 0.05 * a  # noqa: E731
+    schedule, model = PS.Scaled(), PM.NoiseModel()
+    tab = PF.RKUltra(order=2).tableau()
+    step = Step(0.25, 0.5)
+    (got,) = PF.step_tableau(tab, x, net, model, schedule, step)
+    nodes, weights = tab
+    s0, s1, *fr = schedule.ipoints([step[0], step[1], *(step[0] + c * (step[1] - step[0]) for c, _ in nodes)])
+    delta = DeltaPoint(s0, s1)
+    ds = []
+    for frac, (_c, row) in zip(fr, nodes):
+        if row:
+            mix = 0
+            for d, q in zip(ds, row):
+                mix = mix + d * q
+            d2 = DeltaPoint(s0, frac)
+            xin = 0 + x * model.gamma(d2, 0) + (mix / math.fsum(row)) * model.delta(d2, 0)
+        else:
+            xin = x
+        ds.append(net(xin, *frac))
+    mix = 0
+    for d, q in zip(ds, weights):
+        mix = mix + d * q
+    want = 0 + x * model.gamma(delta, 0) + mix * model.delta(delta, 0)
+    assert got.dtype == dtype and torch.equal(got, want)
+    assert tableaux  # (imported for the providers' side effects in some builds)
+    # a full loop keeps the dtype, and differs from the fused form (native.mode = "never") by the chain's own rounding only
+    chained = PF.RKUltra(order=4).sample_model(x, net, model, schedule, 5)
+    keep, native.mode = native.mode, "never"
+    try:
+        fused = PF.RKUltra(order=4).sample_model(x, net, model, schedule, 5)
+    finally:
+        native.mode = keep
+    assert chained.dtype == fused.dtype == dtype and (chained.float() - fused.float()).abs().max() <= 0.05 * fused.float().abs().max()

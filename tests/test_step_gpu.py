@@ -759,6 +759,30 @@ def test_model_transforms_on_the_device_return_the_reference_bits(dtype, dev):
             assert native.launches == before + 1 and got.is_cuda and torch.equal(got.cpu(), call(s_, o_, n_)), (type(model).__name__, name)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_functional_samplers_on_16_bit_device_tensors_equal_the_host_run(dtype, dev):
+    "RKUltra / DynasauRK / the structured adapter over a 16-bit device tensor: the recorded expressions of native.step_tableau give the bits of the host run (the reference's own torch ops)"
+    from skrample_amd.sampling import functional as PF
+    from skrample_amd.sampling import interface as PI
+    from skrample_amd.sampling import native
+
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 4, 16, 16, generator=g).to(dtype)
+    draws = [torch.randn(2, 4, 16, 16, generator=g).to(dtype) for _ in range(40)]
+    net = lambda xx, t, s, a: xx * 0.3 - 0.1 * s + 0.05 * a  # noqa: E731
+    for sampler, model, schedule in (
+        (PF.RKUltra(order=4), PM.NoiseModel(), PS.Scaled()),
+        (PF.RKUltra(order=3, stochasticity=1, derivative_transform=PM.VelocityModel()), PM.FlowModel(), PS.Linear()),
+        (PF.DynasauRK(order=3), PM.VelocityModel(), PS.Karras(PS.Scaled())),
+        (PI.StructuredFunctionalAdapter(PT.UniPC(order=3, stochasticity=0.5)), PM.NoiseModel(), PS.Scaled()),
+    ):
+        pools = [list(draws), [d.to(dev) for d in draws]]
+        host = sampler.sample_model(x, net, model, schedule, 5, rng=lambda *_: pools[0].pop(0))
+        before = native.launches
+        card = sampler.sample_model(x.to(dev), net, model, schedule, 5, rng=lambda *_: pools[1].pop(0))
+        assert native.launches > before and card.is_cuda and card.dtype == dtype and torch.equal(card.cpu(), host), sampler
+
+
 def test_wrappers_keep_their_compute_scale(dev):
     "the scheduler wrappers widen to compute_scale before the sampler runs (reference diffusers.py:575-599): fused kernel; compute_scale=None: the tape"
     from skrample_amd.sampling import native

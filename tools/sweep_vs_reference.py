@@ -184,8 +184,9 @@ def one_functional(seed: int) -> str | None:
 
     text, schedule, model, steps_n, (lo, hi) = _functional_spec(random.Random(seed))
     g = torch.Generator().manual_seed(seed)
-    kind = random.Random(seed ^ 0xA11).choice(("tensor", "tensor", "f64", "f32", "float"))  # what the reference's generic `T` covers
+    kind = random.Random(seed ^ 0xA11).choice(("tensor", "tensor", "f64", "f32", "float", "bf16", "f16"))  # what the reference's generic `T` covers
     make = {"tensor": lambda: torch.randn([2, 3, 4], generator=g, dtype=torch.float64), "f64": lambda: torch.randn([2, 3, 4], generator=g, dtype=torch.float64).numpy(),
+            "bf16": lambda: torch.randn([2, 3, 4], generator=g).bfloat16(), "f16": lambda: torch.randn([2, 3, 4], generator=g).half(),
             "f32": lambda: torch.randn([2, 3, 4], generator=g).numpy(), "float": lambda: float(torch.randn([], generator=g, dtype=torch.float64))}[kind]  # fmt: skip
     x = make()
     draws = [make() for _ in range(400)]
@@ -199,7 +200,7 @@ def one_functional(seed: int) -> str | None:
             return xx * 0.3 - 0.1 * s + 0.05 * a + (0.01 * torch.sin(xx * 3.0) if isinstance(xx, torch.Tensor) else 0.01 * np.sin(xx * 3.0))
 
         def cb(sample, n, dp):
-            trace.append((int(n), *[float(v) for v in dp.point_from], *[float(v) for v in dp.point_to], float(np.asarray(sample, dtype=np.float64).sum())))
+            trace.append((int(n), *[float(v) for v in dp.point_from], *[float(v) for v in dp.point_to], float((sample.double() if isinstance(sample, torch.Tensor) else np.asarray(sample, dtype=np.float64)).sum())))
 
         try:
             sampler = eval(text, env)
@@ -210,6 +211,17 @@ def one_functional(seed: int) -> str | None:
     (re_, rres, rseen, rtrace, rused, radj), (pe, pres, pseen, ptrace, pused, padj) = sides
     if re_ or pe:
         return None if type(re_) is type(pe) else f"reference {re_!r}, here {pe!r}"
+    if kind in ("bf16", "f16"):  # 16-bit tensors: the reference computes in the tensor dtype, one rounded op at a time -- bit for bit (adaptive RKMoire and the SPC adapter aside: fused blends / error norms steer them)
+        if type(rres) is not type(pres) or rres.dtype != pres.dtype:
+            return f"result is a {type(pres).__name__} of {getattr(pres, 'dtype', None)}, the reference's of {getattr(rres, 'dtype', None)}"
+        if radj != padj or rused != pused or len(rseen) != len(pseen):
+            return f"adjust_steps {radj}/{padj}, draws {rused}/{pused}, model calls {len(rseen)}/{len(pseen)}"
+        if not torch.isfinite(rres.float()).all():
+            return None
+        if "RKMoire" in text or "SPC" in text:
+            err = ((pres.double() - rres.double()).abs().max() / rres.double().abs().max().clamp_min(1e-30)).item()
+            return None if err <= 0.05 else f"result differs: rel inf-norm {err:.3g}"
+        return None if torch.equal(rres, pres) else f"{(rres != pres).sum().item()} elements differ from the reference's bits (max {(rres.double() - pres.double()).abs().max().item():.3g})"
     if type(rres) is not type(pres) or np.asarray(rres).dtype != np.asarray(pres).dtype:
         return f"result is a {type(pres).__name__} of {np.asarray(pres).dtype}, the reference's a {type(rres).__name__} of {np.asarray(rres).dtype}"
     rres, pres = torch.as_tensor(np.asarray(rres, dtype=np.float64)), torch.as_tensor(np.asarray(pres, dtype=np.float64))
@@ -223,7 +235,7 @@ def one_functional(seed: int) -> str | None:
     if rtrace and not close(rtrace, ptrace):
         return "callback traces differ"
     err = ((pres - rres).abs().max() / rres.abs().max().clamp_min(1e-30)).item()
-    return None if err <= (1e-5 if kind == "f32" else 1e-9) else f"result differs: rel inf-norm {err:.3g}"
+    return None if err <= (5e-5 if kind == "f32" else 1e-9) else f"result differs: rel inf-norm {err:.3g}"  # (float32: a free-running chain of up to nine steps of <= 1e-5 each)
 
 
 # ---- structured noise on host tensors: the reference's generators vs pytorch/host_noise.py, same CPU generator seeds -> same bits -------
