@@ -769,7 +769,9 @@ def test_functional_samplers_on_16_bit_device_tensors_equal_the_host_run(dtype, 
     g = torch.Generator().manual_seed(12)
     x = torch.randn(2, 4, 16, 16, generator=g).to(dtype)
     draws = [torch.randn(2, 4, 16, 16, generator=g).to(dtype) for _ in range(40)]
-    net = lambda xx, t, s, a: xx * 0.3 - 0.1 * s + 0.05 * a  # noqa: E731
+    # (the network is torch's own code on either side: a product with a host-computed factor -- torch adds / subtracts a Python number to a 16-bit tensor
+    #  differently on the CPU, where it rounds the number to the tensor dtype first, and on the device)
+    net = lambda xx, t, s, a: xx * (0.3 - 0.1 * s + 0.05 * a)  # noqa: E731
     for sampler, model, schedule in (
         (PF.RKUltra(order=4), PM.NoiseModel(), PS.Scaled()),
         (PF.RKUltra(order=3, stochasticity=1, derivative_transform=PM.VelocityModel()), PM.FlowModel(), PS.Linear()),
