@@ -385,7 +385,31 @@ class SPC(traits.DerivativeTransform, StructuredSampler):
     def require_previous(self) -> int:
         return max(self.predictor.require_previous, self.corrector.require_previous + 1)
 
+    def _sample_packed_composed(self, packed, model_transform, schedule, previous):
+        """The reference's own composition (structured.py:527-575) for tensors of one 16-bit dtype outside a compute scale and the linear blend: derivative
+        conversion, corrector on the shifted history, `sample * p + corrected * c`, predictor -- every piece takes the tape (the reference's rounded ops), a
+        launch apiece instead of one fused launch."""
+        point_from = _ipoint(schedule, packed.step[0])
+        if self.derivative_transform:
+            convert = models.ModelConvert(model_transform, self.derivative_transform)
+            packed = replace(packed, prediction=convert.output_to(packed.sample, packed.prediction, point_from))
+            model_transform = convert.transform_to
+        if previous:
+            shifted = [replace(rec, prediction=nxt) for rec, nxt in zip(previous, (*(rec.prediction for rec in previous[1:]), packed.prediction))]
+            corrected = self.corrector.sample_packed(shifted.pop(), model_transform, schedule, shifted).final
+            wp, wc = (point_from.sigma, point_from.alpha) if self.adaptive else (0, 0)
+            wp, wc = softmax((wp - self.bias, wc + self.bias))
+            if self.invert:
+                wp, wc = wc, wp
+            blended = native.try_expr(lambda s_, c_: s_ * wp + c_ * wc, packed.sample, corrected)
+            if blended is None:
+                blended = lazy.settle(lift(packed.sample) * wp + lift(corrected) * wc, like=packed.sample)
+            packed = replace(packed, sample=blended)
+        return self.predictor.sample_packed(packed, model_transform, schedule, previous)
+
     def sample_packed(self, packed, model_transform, schedule, previous=()):
+        if abs(self.power - 1) <= 1e-8 and native._eligible(packed.sample, packed.prediction):
+            return self._sample_packed_composed(packed, model_transform, schedule, previous)
         result_dtype = _result_dtype(packed.sample)
         point_from = _ipoint(schedule, packed.step[0])
         if self.derivative_transform:
