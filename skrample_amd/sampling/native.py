@@ -534,6 +534,23 @@ def _express(like: torch.Tensor, fn, *tensors):
     return done
 
 
+def _tensor_expression(like: torch.Tensor):
+    """`run(fn, *operands)`: the expression as ONE recorded launch while every operand is a contiguous tensor of `like`'s dtype / shape / device and the
+    tape takes it; otherwise -- and from then on -- through the operands' own operators, which is the reference's arithmetic op by op"""
+    plain = [False]
+
+    def run(fn, *operands):
+        if not plain[0] and all(isinstance(t, torch.Tensor) and t.dtype == like.dtype and t.shape == like.shape and t.device == like.device and t.is_contiguous() for t in operands):
+            try:
+                return _express(like, fn, *operands)
+            except _Refused:
+                pass
+        plain[0] = True
+        return fn(*operands)
+
+    return run
+
+
 def rk_step(wrapper, model_output: torch.Tensor, sample: torch.Tensor, generator):
     """`RKWrapperCore.step` for tensors of one 16-bit dtype under compute_scale=None: the reference's own sequence -- negation, derivative
     conversion, `forward(sample, sumprod(derivatives, row) / fsum(row))` per stage, `backward` for the stages on the clean end -- each as one
@@ -545,10 +562,11 @@ def rk_step(wrapper, model_output: torch.Tensor, sample: torch.Tensor, generator
     if any(not isinstance(d, torch.Tensor) or d.dtype != sample.dtype for d in held) or (wrapper._sample is not None and not isinstance(wrapper._sample, torch.Tensor)):
         return None
     nodes, weights = wrapper.tableau()
-    if len(weights) + 3 > _hip.TAPE_MAX_INPUTS or 2 * len(weights) + 12 > _hip.TAPE_MAX_OPS or abs(wrapper.stochasticity) > 1e-8 and wrapper.noise_type.__name__ == "Brownian":
+    if len(weights) + 3 > _hip.TAPE_MAX_INPUTS or 2 * len(weights) + 12 > _hip.TAPE_MAX_OPS:
         return None  # (the 25-35-stage tableaux: more leaves than a tape takes)
     points = [*wrapper.all_points, Point(0, 0, 1)]
     eta = wrapper.stochasticity
+    run = _tensor_expression(sample)
 
     def inside_out(output, space, s0: Point, s1: Point, sn: Point):
         "step_tableau_inside_out (diffusers.py:746-796)"
@@ -562,28 +580,25 @@ def rk_step(wrapper, model_output: torch.Tensor, sample: torch.Tensor, generator
                 noise = wrapper.get_step_noise(common.Step.from_int(wrapper._index // wrapper.order, wrapper._steps), base, wrapper.noise_type, wrapper.noise_props, generator, None)
             wrapper._last_noise = noise
             if noise is not None:
-                final = _express(base, lambda b, n, *d: _forward(space, b, _sumprod(d, weights), DeltaPoint(s0, s1), n, eta), base, noise, *ds)
+                final = run(lambda b, n, *d: _forward(space, b, _sumprod(d, weights), DeltaPoint(s0, s1), n, eta), base, noise, *ds)
             else:
-                final = _express(base, lambda b, *d: _forward(space, b, _sumprod(d, weights), DeltaPoint(s0, s1), None, eta), base, *ds)
+                final = run(lambda b, *d: _forward(space, b, _sumprod(d, weights), DeltaPoint(s0, s1), None, eta), base, *ds)
             wrapper._derivatives = []
             wrapper._sample = None
             return final
         row = nodes[len(ds)][1]
         if not row:
             raise ValueError
-        return _express(base, lambda b, *d: _forward(space, b, _sumprod(d, row) / math.fsum(row), DeltaPoint(s0, sn), None, 0), base, *ds)
+        return run(lambda b, *d: _forward(space, b, _sumprod(d, row) / math.fsum(row), DeltaPoint(s0, sn), None, 0), base, *ds)
 
-    try:
-        output = model_output
-        if wrapper.invert_prediction:
-            output = _express(sample, lambda o: -o, output)
-        space = wrapper.model
-        if wrapper.derivative_transform:
-            at = points[wrapper._index]
-            output = _express(sample, lambda s_, o: _output_to(wrapper.model, wrapper.derivative_transform, s_, o, at), sample, output)
-            space = wrapper.derivative_transform
-    except _Refused:
-        return None  # (nothing has been touched yet)
+    output = model_output
+    if wrapper.invert_prediction:
+        output = run(lambda o: -o, output)
+    space = wrapper.model
+    if wrapper.derivative_transform:
+        at = points[wrapper._index]
+        output = run(lambda s_, o: _output_to(wrapper.model, wrapper.derivative_transform, s_, o, at), sample, output)
+        space = wrapper.derivative_transform
     n_held = len(held)
     i0, i1, sn = wrapper._index - n_held, wrapper._index + wrapper.order - n_held, wrapper._index + 1
     sampled = inside_out(output, space, points[i0], points[i1], points[sn])
@@ -594,7 +609,7 @@ def rk_step(wrapper, model_output: torch.Tensor, sample: torch.Tensor, generator
     ):
         base = sample if wrapper._sample is None else wrapper._sample
         delta = DeltaPoint(points[i0], points[i1])
-        synth = _express(base, lambda b, r: _backward(space, b, r, delta), base, sampled)
+        synth = run(lambda b, r: _backward(space, b, r, delta), base, sampled)
         sampled = inside_out(synth, space, points[i0], points[i1], points[sn + 1])
         wrapper._index += 1
     return sampled, output
@@ -617,16 +632,7 @@ def step_tableau(tableau, sample, model, model_transform, schedule, step, deriva
     t0, t1 = step
     s0, s1, *fractions = schedule.ipoints([t0, t1, *(t0 + c * (t1 - t0) for c, _ in nodes)])
     delta = DeltaPoint(s0, s1)
-    plain = [False]  # set once an operand falls outside the tape's coverage: plain tensor operators from then on
-
-    def run(fn, *operands):
-        if not plain[0] and all(isinstance(t, torch.Tensor) and t.dtype == sample.dtype and t.shape == sample.shape and t.device == sample.device and t.is_contiguous() for t in operands):
-            try:
-                return _express(sample, fn, *operands)
-            except _Refused:
-                pass
-        plain[0] = True
-        return fn(*operands)
+    run = _tensor_expression(sample)
 
     derivatives: list = []
     for frac, (_c, row) in zip(fractions, nodes):
