@@ -1,5 +1,5 @@
 """GPU box: the device path against the package's own host executor over the sweep grammar (tests/sweep_grammar.py) -- usage:
-python tests/soak_sweep.py [first_seed last_seed].  The host side of every case is what tools/sweep_vs_reference.py compares with the imported
+python tests/soak_sweep.py [first_seed last_seed [native]].  The host side of every case is what tools/sweep_vs_reference.py compares with the imported
 reference in the build container (1500 configurations, 0 differences), so device == host here carries the reference's answer to seeds
 the fixture (tests/golden/steps_sweep.npz, 64 cases) does not hold.  Teacher-forced: each step sees the host run's inputs."""
 import os
@@ -12,7 +12,7 @@ sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import test_step_gpu as T  # noqa: E402
-from sweep_grammar import sweep_spec  # noqa: E402
+from sweep_grammar import native_spec, sweep_spec  # noqa: E402
 
 from skrample_amd import _hip  # noqa: E402
 from skrample_amd.sampling import lazy  # noqa: E402
@@ -25,8 +25,11 @@ def settle(v):
     return torch.as_tensor(v.materialize() if isinstance(v, lazy.LazyTensor) else v)
 
 
+NATIVE = len(sys.argv) > 3 and sys.argv[3] == "native"  # compute_scale=None on 16-bit tensors: the tape on the device against torch's own ops on the host, bit for bit
+
+
 def one(seed: int) -> str:
-    text, dtype, shape, steps_n = sweep_spec(random.Random(seed))
+    text, dtype, shape, steps_n = (native_spec if NATIVE else sweep_spec)(random.Random(seed))
     dt = getattr(torch, dtype)
     g = torch.Generator().manual_seed(seed)
     try:
@@ -42,7 +45,7 @@ def one(seed: int) -> str:
     n = len(times)
     x = torch.randn(shape, generator=g).to(dt)
     outs = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]
-    noises = [torch.randn(shape, generator=g) for _ in range(n)]
+    noises = [torch.randn(shape, generator=g).to(dt if NATIVE else torch.float32) for _ in range(n)]
     host._noise_generator, card._noise_generator = T.Injected(noises, "cpu"), T.Injected(noises, dev)
     for i, t in enumerate(times):
         try:
@@ -58,7 +61,10 @@ def one(seed: int) -> str:
             return "non-finite"
         for name, a, b in zip(("prev_sample", "pred_original_sample"), got, ref):
             assert a.is_cuda, name
-            T.assert_close(a, b, dt, f"step {i} {name}", flips=0.2)
+            if NATIVE:
+                assert a.dtype == b.dtype and torch.equal(a.cpu(), b), (f"step {i} {name}", int((a.cpu() != b).sum()))
+            else:
+                T.assert_close(a, b, dt, f"step {i} {name}", flips=0.2)
         x = ref[0]
     return "ok"
 
