@@ -254,6 +254,36 @@ class SkrampleWrapperCore(abc.ABC):
         self._alias_stamps: list[tuple[Tensor, int, int]] = []  # (caller tensor aliased by history, data_ptr, _version)
         self._alias_auto = None  # alias_history="auto": None before a run's first call, (model_output, sample) of that call, then "alias" / "snapshot"
 
+    # ---- copies (copy.deepcopy / pickle of a scheduler, also in the middle of a run: a plain dataclass in the reference) ------------------
+    # What a copy must not inherit: pointer-bound replay entries and lowered programs (ctypes structures naming THIS object's buffers), stream
+    # and event handles, weak references -- and the alias stamps, which record the addresses of the ORIGINAL's tensors: the copy's own tensors
+    # are stamped afresh, so its guard keeps guarding.
+    _COPY_RESET = {
+        "_noise_ahead": None, "_noise_done": None, "_noise_side": None, "_noise_wanted": None, "_predrawn_noise": None, "_fast": {}, "_fast_ids": None, "_fast_hits": 0,
+        "_programs": {}, "_programs_for": None, "_rk_programs": {}, "_rk_programs_for": None, "_issued_timesteps": [], "_foreign_timesteps": {},
+    }  # fmt: skip
+
+    def __getstate__(self):
+        self._drain_noise_ahead()
+        if self._noise_ahead is not None and self._noise_generator is not None and self._noise_generator._draws == self._noise_ahead[4]:
+            self._noise_generator._draws = self._noise_ahead[3]  # (a guess drawn ahead is not part of the state: the copy draws it itself)
+            self._noise_ahead = None
+        state = dict(self.__dict__)
+        for key, fresh in self._COPY_RESET.items():
+            if key in state:
+                state[key] = type(fresh)() if isinstance(fresh, (dict, list)) else fresh
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._alias_stamps = [(t, t.data_ptr(), t._version) for t, _ptr, _version in self._alias_stamps]
+        if getattr(self, "_hist_ptrs", None):
+            raws = zip(getattr(self, "_raw_samples", []), getattr(self, "_raw_outputs", []), getattr(self, "_previous", []))
+            self._hist_ptrs = [
+                (smp.data_ptr(), out.data_ptr(), rec.sample.data_ptr() if isinstance(rec.sample, Tensor) else 0) if old is not None else None
+                for old, (smp, out, rec) in zip(self._hist_ptrs, raws)
+            ]
+
     # ---- guard of the aliased history (alias_history=True) -------------------------------------------------------
     # The reference deep-copies every record (structured.py:113-125); this engine keeps the caller's own tensors as
     # history operands instead (0 bytes written, 4 B/element read per entry).  That is only sound while the caller

@@ -206,6 +206,45 @@ def test_adaptive_runge_kutta_takes_ndarrays():
             np.testing.assert_allclose(res, twin.numpy(), rtol=1e-6 if dt == np.float32 else 1e-12, atol=1e-7 if dt == np.float32 else 1e-13)
 
 
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_a_scheduler_copied_in_the_middle_of_a_run_goes_on_like_the_original(device):
+    """copy.deepcopy / pickle of a wrapper after some steps (a plain dataclass in the reference: either works there): the copy's history guard is
+    stamped with the copy's own tensors, pointer-bound replay state is dropped, and copy and original continue to the same result"""
+    import copy
+    import pickle
+
+    from skrample_amd.pytorch import noise as PN
+
+    makers = [
+        lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Karras(PS.Scaled())),
+        lambda: PD.SkrampleWrapperScheduler(PT.UniPC(order=3), PS.Linear(), PM.FlowModel()),
+        lambda: PD.SkrampleWrapperScheduler(PT.Adams(order=4), PS.Scaled(), alias_history=True),
+    ]
+    if device == "cuda":
+        makers.append(lambda: PD.SkrampleWrapperScheduler(PT.DPM(order=2, stochasticity=1), PS.Scaled(), noise_type=PN.Colored, noise_props=PN.ColoredProps()))
+        makers.append(lambda: PD.SkrampleWrapperScheduler(PT.Euler(stochasticity=1), PS.Scaled(), noise_type=PN.Pyramid, noise_props=PN.PyramidProps()))
+    for mk in makers:
+        w = mk()
+        w.set_timesteps(8)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(2, 4, 16, 16, generator=g).to(device)
+        outs = [torch.randn(2, 4, 16, 16, generator=g).to(device) for _ in range(8)]
+        seeds = [11, 12] if device == "cuda" else [torch.Generator().manual_seed(i) for i in range(2)]
+        for i, t in enumerate(w.timesteps[:4]):
+            x = torch.as_tensor(w.step(outs[i], t, x, generator=seeds, return_dict=False)[0])
+        if device == "cuda":
+            torch.cuda.synchronize()
+        copies = [copy.deepcopy(w), pickle.loads(pickle.dumps(w))] if device == "cpu" else [copy.deepcopy(w)]
+        ends = []
+        for runner in (*copies, w):
+            xx = x
+            for i, t in enumerate(runner.timesteps[4:], start=4):
+                xx = torch.as_tensor(runner.step(outs[i], t, xx, return_dict=False)[0])
+            ends.append(xx)
+        for other in ends[:-1]:
+            assert torch.equal(other, ends[-1]), type(w.sampler).__name__
+
+
 def test_wrapper_random_noise_on_cpu_uses_the_callers_generators():
     "host-resident latents draw white noise as the reference does: torch.randn from one CPU generator per sample"
     shape, steps = (2, 4, 8, 8), 4
