@@ -1418,6 +1418,67 @@ __device__ __forceinline__ void outer_column(const ColoredArgs& a, float2 (&v)[N
   dft_n<N, true>(v);
 }
 
+// ---- passes B + C + D in ONE tile residency: a short channel axis over planes too large for the fused plane kernels ------------
+// (4, 256, 256): the separate-axis route sends the half spectrum through HBM five times -- row transform out, column transform in / out,
+// channel axis in / out, inverse columns in / out, rows in: 34 B / element, 220 us for 64 such units.  The three middle passes touch the
+// same (channel, row) lines of a block of T neighbouring frequency columns: with N1 = 2 or 4 channels those N1 T lines of d2 points fit one
+// tile (N1 T d2 <= 8192 points), so the block keeps them for the forward column transform, the channel-axis transform + radial weights +
+// inverse (registers, outer_column: the very code of colored_outer_axis_regs) and the inverse column transform -- one read and one write of
+// the spectrum, 18 B / element over the whole draw.  The arithmetic per line is that of colored_strided_axis / outer_column unchanged.
+template <int N1>
+__global__ __launch_bounds__(FFT_THREADS) void colored_mid_axes(const ColoredArgs a, int N, int logN, int logT) {
+  extern __shared__ float2 smem[];
+  const int T = 1 << logT, ld = N + 1, L = N1 * T;
+  float2* tw = smem;
+  float2* buf = smem + N / 2;
+  const int64_t smp = blockIdx.y;
+  const int k30 = (int)blockIdx.x * T;
+  const int cols_here = (int)a.d3h - k30 < T ? (int)a.d3h - k30 : T;
+  float2* base = a.spec + smp * (int64_t)N1 * a.d2 * a.d3h + k30;
+  make_twiddles(tw, N);
+  // loads: consecutive lanes take consecutive frequency columns (runs of 8 T bytes), a thread walks the (channel, row) pairs FFT_THREADS / T apart
+  const int t = threadIdx.x & (T - 1), r0 = threadIdx.x >> logT, dn = FFT_THREADS >> logT;
+  const bool live = t < cols_here;
+  const int rows = N1 * N;
+  for (int i0 = r0; i0 < rows; i0 += 8 * dn) {
+    float2 r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * dn;
+      r[u] = (live && i < rows) ? base[(int64_t)i * a.d3h + t] : make_float2(0.f, 0.f);  // (row i = c d2 + h: the spectrum's own order)
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * dn;
+      if (i < rows) buf[((i >> logN) * T + t) * ld + (int)brev(i & (N - 1), logN)] = r[u];
+    }
+  }
+  fft_tile<false>(buf, tw, N, logN, L);
+  // the channel axis of every (column, row frequency) of the tile, in registers
+  double p1 = 0.0, p2 = 0.0;
+  for (int q = threadIdx.x; q < T * N; q += FFT_THREADS) {
+    const int tt = q & (T - 1), kh = q >> logT;
+    if (tt >= cols_here) continue;
+    float2 v[N1];
+#pragma unroll
+    for (int c = 0; c < N1; ++c) v[c] = buf[(c * T + tt) * ld + kh];
+    outer_column<N1>(a, v, (int64_t)kh * a.d3h + k30 + tt, p1, p2);
+#pragma unroll
+    for (int c = 0; c < N1; ++c) buf[(c * T + tt) * ld + kh] = v[c];
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < L * N; q += FFT_THREADS) {  // natural order -> bit-reversed, in place (each pair swapped once)
+    const int j = q >> logN, k = q & (N - 1);
+    const int r = (int)brev(k, logN);
+    if (k < r) { const float2 x = buf[j * ld + k]; buf[j * ld + k] = buf[j * ld + r]; buf[j * ld + r] = x; }
+  }
+  fft_tile<true>(buf, tw, N, logN, L);
+  if (live) {
+    for (int i = r0; i < rows; i += dn) base[(int64_t)i * a.d3h + t] = buf[((i >> logN) * T + t) * ld + (i & (N - 1))];
+  }
+  if (a.n_slots_c > 0) block_sums(p1, p2, a.partials + (int64_t)a.batch * a.n_slots * 2 + (smp * a.n_slots_c + blockIdx.x) * 2);
+}
+
 template <int N>
 __global__ __launch_bounds__(256) void colored_outer_axis_regs(const ColoredArgs a) {
   const int64_t cols = (int64_t)a.d2 * a.d3h;  // columns per sample; element n of column q sits at q + n*cols
@@ -1846,7 +1907,32 @@ static int colored_batch(void* out, int32_t out_dtype, void* spec_c64, float* sc
   int rc;
   // 3-D units with a short outer axis: Parseval partials from the outer-axis kernel, so that pass E can write the result itself
   const bool direct_out = nd == 3 && d1 <= 16 && d3 % 4 == 0 && 2 * partial_slots - blocks_a >= 1;
-  if (nd == 3) {
+  // a short channel axis: columns + channels + inverse columns in one tile residency (colored_mid_axes).  Tile width T: N1 T d2 <= 8192 points
+  // (66 KB: two blocks per CU; a 132 KB tile left a CU one block of four waves and ran 20 % SLOWER than the three separate passes), halved
+  // while the launch has fewer than six blocks per CU; measured on 256 x 256 planes (us per draw, separate passes -> fused): 4 channels x 64
+  // 215 -> 188, x 256 755 -> 616, 2 channels x 128 205 -> 159; 8 channels stay on the separate passes (186 vs 211 at T = 4).
+  int mid_logT = -1;
+  if (nd == 3 && direct_out && (d1 == 2 || d1 == 4) && getenv("SKR_COLORED_NO_MID") == nullptr) {
+    int logT = 0;
+    while ((int64_t)d1 * (2 << logT) * d2 <= 8192) ++logT;
+    while (logT > 2 && ((d3h + (1 << logT) - 1) >> logT) * batch < 6 * 256) --logT;
+    if (const char* e = getenv("SKR_COLORED_MID_LOGT")) { const int v = atoi(e); if (v >= 2 && (int64_t)d1 * (1 << v) * d2 <= 16384 && (d1 << v) <= 64) logT = v; }
+    const int64_t tiles = (d3h + (1 << logT) - 1) >> logT;
+    if (logT >= 2 && tiles <= 2 * partial_slots - blocks_a && (int64_t)d1 * (1 << logT) * d2 <= 16384) mid_logT = logT;
+  }
+  if (mid_logT >= 0) {
+    const int T = 1 << mid_logT;
+    const int64_t tiles = (d3h + T - 1) / T;
+    a.n_slots_c = (int32_t)tiles;
+    const size_t lds = sizeof(float2) * ((size_t)d2 / 2 + (size_t)d1 * T * (d2 + 1));
+    dim3 grid((unsigned)tiles, (unsigned)batch);
+    switch (d1) {
+      case 2: SKR_ALLOW_LDS(colored_mid_axes<2>, lds); hipLaunchKernelGGL(colored_mid_axes<2>, grid, dim3(FFT_THREADS), lds, s, a, d2, l2, mid_logT); break;
+      case 4: SKR_ALLOW_LDS(colored_mid_axes<4>, lds); hipLaunchKernelGGL(colored_mid_axes<4>, grid, dim3(FFT_THREADS), lds, s, a, d2, l2, mid_logT); break;
+      default: return SKR_ERR_SHAPE;
+    }
+    SKR_CHECK_LAUNCH();
+  } else if (nd == 3) {
     // axis 2 (length d2, stride d3h): lines = (i1, k3)
     if ((rc = strided(0, d2, l2, (int64_t)d1 * d3h, d3h, (int64_t)d2 * d3h, d3h, 2)) != SKR_OK) return rc;
     if (direct_out) a.n_slots_c = (int32_t)(2 * partial_slots - blocks_a < 4096 ? 2 * partial_slots - blocks_a : 4096);

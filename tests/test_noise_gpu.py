@@ -743,6 +743,25 @@ def test_mixed_radix_planes_run_on_the_lds_kernels_and_agree_with_hipfft(unit, d
         assert lib.skr_noise_colored(out.data_ptr(), _hip.F32, spec.data_ptr(), scratch.data_ptr(), partials.data_ptr(), 256, sd.data_ptr(), 512, 1, 1, d2, d3, 1.0, 0, 0.0, _hip.current_stream_ptr(dev)) == 7
 
 
+@pytest.mark.parametrize("unit", [(4, 256, 256), (2, 256, 256), (4, 512, 512), (4, 256, 512), (2, 512, 256)])
+def test_large_planes_with_few_channels_keep_their_middle_passes_in_one_tile(unit, dev, monkeypatch):
+    """planes too large for the fused plane kernels under 2 or 4 channels: column transform, channel axis + radial weights and inverse column transform run
+    in one tile residency (colored_mid_axes) -- the same per-line arithmetic as the three separate passes (SKR_COLORED_NO_MID=1), so the same bits; and the
+    draw equals the oracle's rfftn route on the same white field as every other shape does"""
+    outs = {}
+    for mode in ("fused", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("SKR_COLORED_NO_MID", "1")
+        for dtype in (torch.float32, torch.bfloat16):
+            g = PN.BatchTensorNoise.from_batch_inputs(PN.Colored, unit, [71, 72, 73], props=PN.ColoredProps(), dtype=dtype)
+            outs[mode, dtype] = [g.generate(st).clone() for st in (None, Step(0.3, 0.4))]
+    monkeypatch.delenv("SKR_COLORED_NO_MID", raising=False)
+    for dtype in (torch.float32, torch.bfloat16):
+        for a, b in zip(outs["fused", dtype], outs["separate", dtype]):
+            assert torch.equal(a, b), (unit, dtype)
+    assert abs(outs["fused", torch.float32][0].std().item() - 1.0) < 0.02
+
+
 @pytest.mark.parametrize("unit", [(4, 96, 96), (16, 96, 96), (96, 96), (2, 160, 160), (160, 160), (2, 192, 192)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_compile_time_geometry_planes_agree_with_the_runtime_kernel(unit, dtype, dev):
