@@ -362,3 +362,40 @@ def test_colorize_with_up_to_six_axes_fixtures():
         exponent, energy = fx[f"{tag}/args"].tolist()
         got = ON.colorize(torch.from_numpy(fx[f"{tag}/white"]), exponent, None if math.isnan(energy) else energy)
         assert torch.equal(got, torch.from_numpy(fx[f"{tag}/out"])), tag
+
+
+# ---- the two reference-recorded sweeps (tests/golden/steps_sweep.npz, steps_sweep_native.npz) through the oracle --------------------------------
+@pytest.mark.parametrize("fname", ["steps_sweep.npz", "steps_sweep_native.npz"])
+def test_oracle_replays_the_reference_recorded_sweeps(fname):
+    """every drawn configuration the oracle models (tests/oracle_sweep.py turns the constructor text into skr_oracle objects; DynasauRK's per-step tableau is
+    not driven) -- teacher-forced, the reference's recorded outputs come back bit for bit: nested predictors, every schedule modifier, invert_prediction,
+    compute_scale fp32 / fp64 / None on bf16 / fp16 / fp32 / fp64 tensors, the Runge-Kutta wrapper stage by stage"""
+    import json
+
+    import oracle_sweep as OSW
+    from cases import from_bits
+
+    blob = load_npz(fname)
+    native = fname.endswith("native.npz")
+    replayed = 0
+    for m in json.loads(str(blob["meta"])):
+        fx = {k.split("/", 1)[1]: v for k, v in blob.items() if k.startswith(m["tag"] + "/")}
+        dt = getattr(torch, m["dtype"])
+        d = OSW.driver(m["text"], m["steps"])
+        if d is None:
+            continue
+        np.testing.assert_allclose(d.timesteps.numpy(), fx["timesteps"], rtol=0, atol=1e-9)
+        used = int(fx["noise_used"])
+        noises = [from_bits(v, dt) if native else torch.from_numpy(v) for v in fx["noises"][:used]]
+        x = from_bits(fx["x0"], dt)
+        for i, t in enumerate(d.timesteps):
+            out = from_bits(fx["outs"][i], dt)
+            if isinstance(d, OSW.OW.StepDriver):
+                prev, pred = d.step(out, t, x, noise=noises.pop(0) if used and OSW.OA.require_noise(d.cfg) else None)
+                assert torch.equal(pred, from_bits(fx["pred"][i], dt)), (m["tag"], i, "pred_original_sample", m["text"])
+            else:  # (what get_step_noise hands the stage is cast to compute_scale, or to the sample's dtype: diffusers.py:346)
+                prev = d.step(out, t, x, noise_fn=lambda st: noises.pop(0).to(d.compute or dt))
+            assert torch.equal(prev, from_bits(fx["prev"][i], dt)), (m["tag"], i, "prev_sample", m["text"])
+            x = from_bits(fx["prev"][i], dt)
+        replayed += 1
+    assert replayed >= (58 if not native else 30)
