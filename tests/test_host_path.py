@@ -23,6 +23,7 @@ from test_step_gpu import (
     assert_close,
     native16_engine_vs_reference,
     replay_fixture,
+    replay_native_api16,
     replay_native_sweep,
     sweep_case,
 )
@@ -90,6 +91,10 @@ def test_reference_recorded_random_sweep_on_cpu(index):
 def test_reference_recorded_sweep_without_a_compute_scale_on_cpu(index):
     "compute_scale=None on 16-bit host tensors: the wrappers (Runge-Kutta ones included) return the reference's bits"
     replay_native_sweep(index, CPU)
+
+
+def test_reference_recorded_functional_loops_and_transforms_on_16_bit_host_tensors():
+    replay_native_api16(CPU)
 
 
 def test_configurations_the_reference_refuses_are_refused_here_too():

@@ -261,6 +261,40 @@ def test_reference_recorded_sweep_without_a_compute_scale(index, dev):
     replay_native_sweep(index, dev)
 
 
+def replay_native_api16(dev):
+    """tests/golden/native_api16.npz: functional sampler loops (RKUltra, DynasauRK, the structured adapter), model transforms called directly and
+    Point.add_noise / remove_noise on bf16 / fp16 tensors, recorded from the reference (generic tensor operators, every one rounded) -- bit for bit"""
+    import json
+
+    from skrample_amd.common import DeltaPoint, Point
+    from skrample_amd.sampling import functional as PF
+    from skrample_amd.sampling import interface as PI
+
+    blob = load_npz("native_api16.npz")
+    names = {"F": PF, "I": PI, "T": PT, "S": PS, "M": PM, "Point": Point, "DeltaPoint": DeltaPoint}
+    net = lambda xx, t, sg, al: xx * (0.3 - 0.1 * sg + 0.05 * al)  # noqa: E731
+    checked = 0
+    for m in json.loads(str(blob["meta"])):
+        dt = torch.bfloat16 if m["dtype"] == "bf16" else torch.float16
+        get = lambda key: torch.from_numpy(blob[f"{m['dtype']}/{key}"].copy()).view(dt)  # noqa: E731
+        s_, o_, n_ = get("s").to(dev), get("o").to(dev), get("n").to(dev)
+        want = torch.from_numpy(blob[m["key"]].copy()).view(dt)
+        if m["kind"] == "loop":
+            pool = [d.to(dev) for d in get("draws")]
+            got = eval(m["sampler"], names).sample_model(s_.clone(), net, eval(m["model"], names), eval(m["schedule"], names), m["steps"], rng=lambda *_: pool.pop(0))
+            assert len(get("draws")) - len(pool) == m["draws_used"], m
+        else:
+            got = eval(m["text"], {**names, "s": s_, "o": o_, "n": n_})
+        got = torch.as_tensor(got.materialize() if isinstance(got, lazy.LazyTensor) else got).cpu()
+        assert got.dtype == dt and torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)), (m, (got.double() - want.double()).abs().max())
+        checked += 1
+    assert checked == 40
+
+
+def test_reference_recorded_functional_loops_and_transforms_on_16_bit_tensors(dev):
+    replay_native_api16(dev)
+
+
 @pytest.mark.parametrize("name", EXTRA3_WRAPPERS)
 def test_high_order_fixtures(name, dev):
     """Adams-Bashforth 6 / 9, UniP 7, UniPC 6 / 9 (north_star: "Adams-IPNDM 1-9"): outputs of the reference's own step() replayed

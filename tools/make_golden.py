@@ -361,6 +361,57 @@ def sweep_native(count: int = 32) -> None:
     np.savez_compressed(os.path.join(OUT, "steps_sweep_native.npz"), **blob)
 
 
+def native_api16() -> None:
+    """The reference's generic tensor arithmetic on 16-bit tensors beyond the samplers: the functional samplers' loops (RKUltra, DynasauRK, the structured
+    adapter) over a network both devices compute alike, the model transforms called directly, Point.add_noise / remove_noise.  Every call stored with the text
+    that makes it (F = functional module, I = interface, T = samplers, S = schedules, M = models; s / o / n = the three recorded operands)."""
+    from skrample.common import DeltaPoint as DP
+    from skrample.common import Point as PT_
+    from skrample.sampling import interface
+
+    names = {"F": functional, "I": interface, "T": structured, "S": RS, "M": models, "Point": PT_, "DeltaPoint": DP}
+    loops = [
+        ("F.RKUltra(order=4)", "M.NoiseModel()", "S.Scaled()", 5),
+        ("F.RKUltra(order=3, stochasticity=1, derivative_transform=M.VelocityModel())", "M.FlowModel()", "S.Linear()", 4),
+        ("F.RKUltra(order=6, stochasticity=0.5)", "M.VelocityModel()", "S.ZSNR()", 3),
+        ("F.DynasauRK(order=3)", "M.VelocityModel()", "S.Karras(S.Scaled())", 5),
+        ("F.DynasauRK(order=2, stochasticity=0.3, invert=True)", "M.NoiseModel()", "S.Scaled()", 4),
+        ("I.StructuredFunctionalAdapter(T.UniPC(order=3, stochasticity=0.5))", "M.NoiseModel()", "S.Scaled()", 6),
+        ("I.StructuredFunctionalAdapter(T.DPM(order=2, stochasticity=1))", "M.FlowModel()", "S.FlowShift(S.Linear())", 5),
+    ]
+    calls = [
+        "M.NoiseModel().to_x(s, o, Point(500.0, 0.6, 0.8))", "M.FlowModel().from_x(s, o, Point(500.0, 0.6, 0.4))", "M.VelocityModel().to_x(s, o, Point(500.0, 0.6, 0.8))",
+        "M.ScaleX(bias=-1.5).from_x(s, o, Point(500.0, 0.6, 0.8))", "M.NoiseModel().forward(s, o, DeltaPoint(Point(500.0, 0.6, 0.8), Point(300.0, 0.3, 0.9539392014169456)), n, 0.5)",
+        "M.FlowModel().forward(s, o, DeltaPoint(Point(500.0, 0.6, 0.4), Point(300.0, 0.3, 0.7)))", "M.VelocityModel().backward(s, o, DeltaPoint(Point(500.0, 0.6, 0.8), Point(300.0, 0.3, 0.9539392014169456)))",
+        "M.ModelConvert(M.NoiseModel(), M.VelocityModel()).output_to(s, o, Point(500.0, 0.6, 0.8))", "M.ModelConvert(M.FlowModel(), M.DataModel()).output_from(s, o, Point(500.0, 0.6, 0.4))",
+        "M.ModelConvert(M.VelocityModel(), M.VelocityModel()).output_to(s, o, Point(500.0, 0.6, 0.8))", "Point(613.0, 0.7391, 0.6733).add_noise(s, n)", "Point(613.0, 0.7391, 0.6733).remove_noise(s, n)",
+        "Point(1000.0, 1.0, 0.0).remove_noise(s, n)",
+    ]  # fmt: skip
+    blob, meta = {}, []
+    for dt in (torch.bfloat16, torch.float16):
+        tag_dt = "bf16" if dt == torch.bfloat16 else "f16"
+        g = torch.Generator().manual_seed(9000 + (dt == torch.float16))
+        s_, o_, n_ = (torch.randn(2, 3, 8, 6, generator=g).to(dt) for _ in range(3))
+        draws = [torch.randn(2, 3, 8, 6, generator=g).to(dt) for _ in range(40)]
+        view = (lambda t: t.view(torch.int16).numpy().copy())
+        blob[f"{tag_dt}/s"], blob[f"{tag_dt}/o"], blob[f"{tag_dt}/n"] = view(s_), view(o_), view(n_)
+        blob[f"{tag_dt}/draws"] = np.stack([view(d) for d in draws])
+        net = lambda xx, t, sg, al: xx * (0.3 - 0.1 * sg + 0.05 * al)  # noqa: E731
+        for k, (stext, mtext, sched, steps_n) in enumerate(loops):
+            pool = list(draws)
+            res = eval(stext, names).sample_model(s_.clone(), net, eval(mtext, names), eval(sched, names), steps_n, rng=lambda *_: pool.pop(0))
+            assert res.dtype == dt
+            blob[f"{tag_dt}/loop{k}"] = view(res)
+            meta.append({"key": f"{tag_dt}/loop{k}", "kind": "loop", "dtype": tag_dt, "sampler": stext, "model": mtext, "schedule": sched, "steps": steps_n, "draws_used": len(draws) - len(pool)})
+        for k, text in enumerate(calls):
+            res = eval(text, {**names, "s": s_, "o": o_, "n": n_})
+            assert res.dtype == dt
+            blob[f"{tag_dt}/call{k}"] = view(res)
+            meta.append({"key": f"{tag_dt}/call{k}", "kind": "call", "dtype": tag_dt, "text": text})
+    blob["meta"] = np.asarray(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "native_api16.npz"), **blob)
+
+
 # ---------------------------------------------------------------------------------------------------
 class _RecGen:
     "torch.Generator stand-in is impossible (C++ type); instead patch torch.randn/rand inside the noise module"
@@ -887,6 +938,7 @@ if __name__ == "__main__":
     steps()
     sweep()
     sweep_native()
+    native_api16()
     noise()
     wrapper_api()
     functional_api()
