@@ -89,3 +89,93 @@ def driver(text: str, steps: int):
     d = made(steps)
     d.set_timesteps(steps)
     return d
+
+
+# ---- tests/golden/native_api16.npz: functional loops and direct calls as oracle calls -----------------------------------------------------------
+def _pt(t, s, a):
+    from skr_oracle.scalars import Pt
+
+    return Pt(t, s, a)
+
+
+class _Model:
+    "M.<Model>() in a `call` text: the methods forward to the oracle's predictor functions"
+
+    def __init__(self, pred):
+        self.pred = pred
+
+    def to_x(self, s, o, p):
+        from skr_oracle import predictors as P
+
+        return P.to_x(self.pred, s, o, p)
+
+    def from_x(self, s, x, p):
+        from skr_oracle import predictors as P
+
+        return P.from_x(self.pred, s, x, p)
+
+    def forward(self, s, o, d, n=None, eta=0):
+        from skr_oracle import predictors as P
+
+        return P.forward(self.pred, s, o, d[0], d[1], n, eta)
+
+    def backward(self, s, r, d, n=None, eta=0):
+        from skr_oracle import predictors as P
+
+        return P.backward(self.pred, s, r, d[0], d[1], n, eta)
+
+
+class _Convert:
+    def __init__(self, a: _Model, b: _Model):
+        self.a, self.b = a, b
+
+    def output_to(self, s, o, p):
+        from skr_oracle import predictors as P
+
+        return P.convert(self.a.pred, self.b.pred, s, o, p, identical=self.a is self.b)
+
+    def output_from(self, s, o, p):
+        from skr_oracle import predictors as P
+
+        return P.convert(self.b.pred, self.a.pred, s, o, p, identical=self.a is self.b)
+
+
+from skr_oracle.scalars import Pt as _Pt  # noqa: E402
+
+
+class _PointCalls(_Pt):
+    def add_noise(self, s, n):
+        from skr_oracle.scalars import pt_add_noise
+
+        return pt_add_noise(self, s, n)
+
+    def remove_noise(self, s, n):
+        from skr_oracle.scalars import pt_remove_noise
+
+        return pt_remove_noise(self, s, n)
+
+
+CALL_NAMES = {
+    "M": types.SimpleNamespace(
+        DataModel=lambda: _Model("data"), NoiseModel=lambda: _Model("eps"), FlowModel=lambda: _Model("flow"), VelocityModel=lambda: _Model("v"), ScaleX=lambda bias=3: _Model(("scalex", bias)),
+        ModelConvert=_Convert,
+    ),  # fmt: skip
+    "Point": lambda t, s, a: _PointCalls(t, s, a),
+    "DeltaPoint": lambda a, b: (a, b),
+}
+
+
+def loop(sampler_text: str, model_text: str, schedule_text: str, steps: int, x, net, rng):
+    "a functional sampler loop of the fixture through the oracle's loops (rk_loop / adapter_loop)"
+    pred = eval(model_text, {"M": M})
+    sched = eval(schedule_text, {"S": S}).build(None)  # (no wrapper here: a Karras / Exponential ramp keeps its constructor's `steps`)
+
+    def rk(order=2, stochasticity=0, derivative_transform="data", **kw):
+        tab = OK.pick_tableau(order)
+        return lambda: OK.rk_loop(lambda st: tab, x, net, pred, sched, steps, rng=rng, deriv=derivative_transform, eta=stochasticity)
+
+    def dyn(order=2, stochasticity=0, derivative_transform="data", **kw):
+        return lambda: OK.rk_loop(lambda st: OK.dynasaur_tableau(st, order, **kw), x, net, pred, sched, steps, rng=rng, deriv=derivative_transform, eta=stochasticity)
+
+    run = eval(sampler_text, {"F": types.SimpleNamespace(RKUltra=rk, DynasauRK=dyn), "I": types.SimpleNamespace(StructuredFunctionalAdapter=lambda cfg: lambda: OA.adapter_loop(cfg, x, net, pred, sched, steps, rng=rng)), "T": T, "M": M})
+    return run()

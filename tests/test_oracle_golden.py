@@ -399,3 +399,26 @@ def test_oracle_replays_the_reference_recorded_sweeps(fname):
             x = from_bits(fx["prev"][i], dt)
         replayed += 1
     assert replayed >= (58 if not native else 30)
+
+
+def test_oracle_replays_the_16_bit_functional_loops_and_transforms():
+    "tests/golden/native_api16.npz through the oracle's loops and predictor functions: generic tensor operators on bf16 / fp16 tensors, the reference's bits"
+    import json
+
+    import oracle_sweep as OSW
+
+    blob = load_npz("native_api16.npz")
+    net = lambda xx, t, sg, al: xx * (0.3 - 0.1 * sg + 0.05 * al)  # noqa: E731
+    checked = 0
+    for m in json.loads(str(blob["meta"])):
+        dt = torch.bfloat16 if m["dtype"] == "bf16" else torch.float16
+        get = lambda key: torch.from_numpy(blob[f"{m['dtype']}/{key}"].copy()).view(dt)  # noqa: E731
+        want = torch.from_numpy(blob[m["key"]].copy()).view(dt)
+        if m["kind"] == "loop":
+            pool = list(get("draws"))
+            got = OSW.loop(m["sampler"], m["model"], m["schedule"], m["steps"], get("s").clone(), net, lambda *_: pool.pop(0))
+        else:
+            got = eval(m["text"], {**OSW.CALL_NAMES, "s": get("s"), "o": get("o"), "n": get("n")})
+        assert got.dtype == dt and torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)), m
+        checked += 1
+    assert checked == 40
