@@ -177,8 +177,10 @@ def dynasaur_tableau(step, order: int = 2, per_step_decay=math.log(0.5) / -2, to
 
 
 # ---- inside-out stage machine (diffusers.py:602-873) -------------------------------------------------
-def rk_all_points(tab, sched: Sched, steps: int) -> list[Pt]:
-    "diffusers.py:943-963: every point the model is evaluated at (t=0 stages included)"
+def rk_all_points(tab, sched: Sched, steps: int, epsilon: float = -math.inf) -> list[Pt]:
+    """diffusers.py:943-963: every point the model is evaluated at (t=0 stages included).  `tab` may be a function of the step (DynasauRK,
+    diffusers.py:1029-1042: there the table comes out of a scalar run of the functional sampler itself, default epsilon -- stages on the clean
+    end are not recorded and the count assertion fires for schedules that put one there)."""
     seen: list[Pt] = []
 
     def rec(x, t, s, a):
@@ -186,7 +188,8 @@ def rk_all_points(tab, sched: Sched, steps: int) -> list[Pt]:
         return x
 
     for n in range(steps):
-        step_tableau(tab, 1, rec, "data", sched, stp_from_int(n, steps), epsilon=-math.inf)
+        step = stp_from_int(n, steps)
+        step_tableau(tab(step) if callable(tab) else tab, 1, rec, "data", sched, step, epsilon=epsilon)
     return seen
 
 
@@ -196,8 +199,12 @@ class InsideOutRK:
 
     def __init__(self, tab, sched: Sched, steps: int, pred, deriv="data", eta: float = 0):
         self.tab, self.sched, self.steps, self.pred, self.deriv, self.eta = tab, sched, steps, pred, deriv, eta
-        self.all_points = rk_all_points(tab, sched, steps)
-        self.order = len(tab[0])
+        self.order = len((tab(stp_from_int(0, 1)) if callable(tab) else tab)[0])
+        if callable(tab):  # DynasauRK: a tableau per step (diffusers.py:1023-1042)
+            self.all_points = rk_all_points(tab, sched, steps, epsilon=1e-8)
+            assert len(self.all_points) == self.order * steps
+        else:
+            self.all_points = rk_all_points(tab, sched, steps)
         self.index = 0
         self.ders: list = []
         self.base = None
@@ -205,7 +212,7 @@ class InsideOutRK:
 
     def _stage(self, sample, output, space, s0, s1, sn, noise_fn):
         "diffusers.py:746-796"
-        nodes, weights = self.tab
+        nodes, weights = self.tab(stp_from_int(self.index // self.order, self.steps)) if callable(self.tab) else self.tab
         self.ders.append(output)
         if self.base is None:
             self.base = sample

@@ -1,6 +1,6 @@
 """The sweep fixtures' constructor texts (tests/sweep_grammar.py: W = wrappers, T = samplers, S = schedules, M = models) evaluated into ORACLE objects:
 a namespace of small shims that turn each constructor call into the oracle's own description (skr_oracle dict configs / Sched objects / drivers), so that
-the oracle replays the reference-recorded sweeps like every other fixture.  Returns None for what the oracle does not drive (DynasauRK's per-step tableau)."""
+the oracle replays the reference-recorded sweeps like every other fixture.  (driver() still returns None for a wrapper class without a shim.)"""
 
 from __future__ import annotations
 
@@ -77,7 +77,12 @@ def _rk(schedule: _Pending, sampler_order=2, stochasticity=0, model="eps", inver
     return lambda steps: OW.RKDriver(OK.pick_tableau(sampler_order), schedule.build(steps), model, derivative_transform, stochasticity, compute=compute_scale, invert=invert_prediction)
 
 
-W = types.SimpleNamespace(SkrampleWrapperScheduler=_wrapper, RKUltraWrapperScheduler=_rk, DynasauRKWrapperScheduler=lambda *a, **k: None)
+def _dyn(schedule: _Pending, sampler_order=2, stochasticity=0, model="eps", invert_prediction=False, compute_scale=torch.float32, derivative_transform="data"):
+    # (the DynasauRK wrapper reads its stage points off the PRISTINE schedule: diffusers.py:1029-1042 runs functional_interface()'s)
+    return lambda steps: OW.RKDriver(lambda st: OK.dynasaur_tableau(st, sampler_order), schedule.build(None), model, derivative_transform, stochasticity, compute=compute_scale, invert=invert_prediction)
+
+
+W = types.SimpleNamespace(SkrampleWrapperScheduler=_wrapper, RKUltraWrapperScheduler=_rk, DynasauRKWrapperScheduler=_dyn)
 NAMES = {"W": W, "T": T, "S": S, "M": M, "torch": torch}
 
 

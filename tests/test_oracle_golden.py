@@ -367,8 +367,7 @@ def test_colorize_with_up_to_six_axes_fixtures():
 # ---- the two reference-recorded sweeps (tests/golden/steps_sweep.npz, steps_sweep_native.npz) through the oracle --------------------------------
 @pytest.mark.parametrize("fname", ["steps_sweep.npz", "steps_sweep_native.npz"])
 def test_oracle_replays_the_reference_recorded_sweeps(fname):
-    """every drawn configuration the oracle models (tests/oracle_sweep.py turns the constructor text into skr_oracle objects; DynasauRK's per-step tableau is
-    not driven) -- teacher-forced, the reference's recorded outputs come back bit for bit: nested predictors, every schedule modifier, invert_prediction,
+    """every drawn configuration the oracle models (tests/oracle_sweep.py turns the constructor text into skr_oracle objects) -- teacher-forced, the reference's recorded outputs come back bit for bit: nested predictors, every schedule modifier, invert_prediction,
     compute_scale fp32 / fp64 / None on bf16 / fp16 / fp32 / fp64 tensors, the Runge-Kutta wrapper stage by stage"""
     import json
 
@@ -398,7 +397,7 @@ def test_oracle_replays_the_reference_recorded_sweeps(fname):
             assert torch.equal(prev, from_bits(fx["prev"][i], dt)), (m["tag"], i, "prev_sample", m["text"])
             x = from_bits(fx["prev"][i], dt)
         replayed += 1
-    assert replayed >= (58 if not native else 30)
+    assert replayed == (64 if not native else 32)
 
 
 def test_oracle_replays_the_16_bit_functional_loops_and_transforms():
