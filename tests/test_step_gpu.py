@@ -272,7 +272,10 @@ def replay_native_api16(dev):
 
     blob = load_npz("native_api16.npz")
     names = {"F": PF, "I": PI, "T": PT, "S": PS, "M": PM, "Point": Point, "DeltaPoint": DeltaPoint}
-    net = lambda xx, t, sg, al: xx * (0.3 - 0.1 * sg + 0.05 * al)  # noqa: E731
+    # the recording's network is `xx * factor` on CPU tensors: fp32 product, rounded to fp32, then to the tensor dtype.  torch's DEVICE kernel for an fp16
+    # tensor times a Python number rounds once (the compiler folds the product and the conversion into v_fma_mixlo_f16), so a product that lands on a tie
+    # in fp32 comes out one ulp away from the CPU's: spelled in fp32 steps the network is the same function on either side
+    net = lambda xx, t, sg, al: (xx.float() * (0.3 - 0.1 * sg + 0.05 * al)).to(xx.dtype)  # noqa: E731
     checked = 0
     for m in json.loads(str(blob["meta"])):
         dt = torch.bfloat16 if m["dtype"] == "bf16" else torch.float16
@@ -804,8 +807,9 @@ def test_functional_samplers_on_16_bit_device_tensors_equal_the_host_run(dtype, 
     x = torch.randn(2, 4, 16, 16, generator=g).to(dtype)
     draws = [torch.randn(2, 4, 16, 16, generator=g).to(dtype) for _ in range(40)]
     # (the network is torch's own code on either side: a product with a host-computed factor -- torch adds / subtracts a Python number to a 16-bit tensor
-    #  differently on the CPU, where it rounds the number to the tensor dtype first, and on the device)
-    net = lambda xx, t, s, a: xx * (0.3 - 0.1 * s + 0.05 * a)  # noqa: E731
+    #  differently on the CPU, where it rounds the number to the tensor dtype first, and on the device; and its device kernel for fp16 * number rounds once
+    #  where the CPU rounds to fp32 and then to fp16 -- hence the product in explicit fp32 steps)
+    net = lambda xx, t, s, a: (xx.float() * (0.3 - 0.1 * s + 0.05 * a)).to(xx.dtype)  # noqa: E731
     for sampler, model, schedule in (
         (PF.RKUltra(order=4), PM.NoiseModel(), PS.Scaled()),
         (PF.RKUltra(order=3, stochasticity=1, derivative_transform=PM.VelocityModel()), PM.FlowModel(), PS.Linear()),
