@@ -317,13 +317,14 @@ const char* skr_build_info(void);
  *   "rk_uv"    0|1|2|4  vectors per lane of the grid-stride Runge-Kutta stage kernel (0 = default)
  *   "rk_blk"   0|128|256  threads per workgroup of the one-trip Runge-Kutta stage kernel (0 = by operand count, the default:
  *                   128 for 4-6 operands, 256 otherwise)
+ *   "tape_words" 0|1|2  skr_tape_launch: 16-byte words a lane carries per trip (0 = by tensor size, the default: two from 2 Mi elements up)
  *   "fft_rank" 0|1|2  skr_noise_colored_any / skr_colorize: trailing axes handed to the N-D transform (0 = up to three, the
  *                   default); the other axes run on the direct-DFT kernels (results agree to rounding, not bit for bit)
  *   "hipfft"   -1|0|1  the N-D transform of those axes: 0 the library's own kernels (skr_noise_colored_any's comment lists the lengths;
  *                   anything else is SKR_ERR_UNSUPPORTED), 1 hipFFT (dlopen'ed; any length), -1 = by the environment, the default: own
  *                   kernels unless SKR_FFT_HIPFFT is set
  *   "reset"    (value ignored) back to the defaults
- * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_NO_TWO_OUT, SKR_RK_UV=n, SKR_RK_BLK=n. */
+ * Initial values can also be set by the environment: SKR_ONE_TRIP=0, SKR_XMAP=n, SKR_NO_TILE, SKR_NO_TWO_OUT, SKR_RK_UV=n, SKR_RK_BLK=n, SKR_TAPE_WORDS=n. */
 int skr_set_tuning(const char* key, int32_t value);
 
 #ifdef __cplusplus

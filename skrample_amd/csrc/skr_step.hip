@@ -643,6 +643,7 @@ extern "C" int skr_set_tuning(const char* key, int32_t value) {
   else if (!strcmp(key, "two_out")) skr::g_tune.two_out = value;
   else if (!strcmp(key, "pace")) skr::g_tune.pace = value;
   else if (!strcmp(key, "two_nt")) skr::g_tune.two_nt = value;
+  else if (!strcmp(key, "tape_words")) skr::g_tune.tape_words = (value == 1 || value == 2) ? value : 0;
   else if (!strcmp(key, "rk_blk")) skr::g_tune.rk_blk = (value == 128 || value == 256) ? value : 0;
   else return SKR_ERR_UNSUPPORTED;
   return SKR_OK;

@@ -13,7 +13,7 @@ namespace skr {
 
 // tuning switches (defaults = the measured best; initialised from the environment, changed with skr_set_tuning)
 struct Tuning {
-  int one_trip, xmap, tile, rk_uv, two_out, pace, rk_blk, two_nt;
+  int one_trip, xmap, tile, rk_uv, two_out, pace, rk_blk, two_nt, tape_words;
   Tuning() {
     const char* e;
     one_trip = !((e = getenv("SKR_ONE_TRIP")) && e[0] == '0');
@@ -24,6 +24,7 @@ struct Tuning {
     pace = getenv("SKR_NO_PACE") == nullptr;
     two_nt = (e = getenv("SKR_TWO_NT")) ? atoi(e) : -1;  // two-output launches without in-kernel noise: non-temporal stores (1), write-through (0), by operand count (-1)
     rk_blk = (e = getenv("SKR_RK_BLK")) ? atoi(e) : 0;  // threads per workgroup of the one-trip Runge-Kutta stage kernel: 0 = by operand count, 128, 256
+    tape_words = (e = getenv("SKR_TAPE_WORDS")) ? atoi(e) : 0;  // 16-byte words per lane and trip of the op-tape kernel: 0 = by tensor size, 1, 2
   }
 };
 extern Tuning g_tune;  // defined in skr_step.hip

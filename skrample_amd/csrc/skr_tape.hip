@@ -84,124 +84,162 @@ template <typename M> __device__ __forceinline__ M tape_add(M a, M b) {
   return a + b;
 }
 
-template <typename T, typename M>
+// one op over a thread's NW words; each case of the dispatch below is a complete read - compute - round - write of its own, so that no value has to be
+// merged across cases (the merged form cost the compiler a register copy per element and a flag per case, and this kernel lives on instruction issue)
+template <typename T, typename M, int NW, typename F>
+__device__ __forceinline__ void tape_binary(typename TapeWord<T>::type* file, int dst, int ia, int ib, F f) {
+  constexpr int WE = TapeElems<T>::value;
+#pragma unroll
+  for (int h = 0; h < NW; ++h) {
+    M x[WE], z[WE], y[WE];
+    tape_unpack<T, M>(file[(ia * NW + h) * TAPE_THREADS], x);
+    tape_unpack<T, M>(file[(ib * NW + h) * TAPE_THREADS], z);
+#pragma unroll
+    for (int i = 0; i < WE; ++i) y[i] = f(x[i], z[i]);
+    file[(dst * NW + h) * TAPE_THREADS] = tape_pack<T, M>(y);
+  }
+}
+template <typename T, typename M, int NW, typename F>
+__device__ __forceinline__ void tape_scalar(typename TapeWord<T>::type* file, int dst, int ia, M k, F f) {
+  constexpr int WE = TapeElems<T>::value;
+#pragma unroll
+  for (int h = 0; h < NW; ++h) {
+    M x[WE], y[WE];
+    tape_unpack<T, M>(file[(ia * NW + h) * TAPE_THREADS], x);
+#pragma unroll
+    for (int i = 0; i < WE; ++i) y[i] = f(x[i], k);
+    file[(dst * NW + h) * TAPE_THREADS] = tape_pack<T, M>(y);
+  }
+}
+
+// NW 16-byte (fp64: 32-byte) words per lane and trip: the decode of an op -- scalar loads, compares, branches, on the CU's one scalar unit -- is paid
+// per wave and op whatever the wave then computes, and with one word per lane it was what bounded the kernel.  Word h of a trip's chunk sits a whole
+// block apart from word h - 1 (consecutive lanes, consecutive words: every access coalesced).
+template <typename T, typename M, int NW>
 __global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
   typedef typename TapeWord<T>::type Word;
-  constexpr int TAPE_ELEMS = TapeElems<T>::value;
+  constexpr int WE = TapeElems<T>::value;
   extern __shared__ __attribute__((aligned(16))) unsigned char tape_lds[];
-  Word* const file = reinterpret_cast<Word*>(tape_lds) + threadIdx.x;  // register g of this thread: file[g * TAPE_THREADS]
+  Word* const file = reinterpret_cast<Word*>(tape_lds) + threadIdx.x;  // word h of register g of this thread: file[(g * NW + h) * TAPE_THREADS]
   const int n_ops = a.tape.n_ops;
-  const int64_t n_vec = (a.numel + TAPE_ELEMS - 1) / TAPE_ELEMS;
-  for (int64_t v = (int64_t)blockIdx.x * TAPE_THREADS + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * TAPE_THREADS) {
-    const int64_t e0 = v * TAPE_ELEMS;
-    const bool whole = e0 + TAPE_ELEMS <= a.numel;
+  const int64_t n_words = (a.numel + WE - 1) / WE;
+  const int64_t n_chunks = (n_words + (int64_t)TAPE_THREADS * NW - 1) / ((int64_t)TAPE_THREADS * NW);
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    int64_t w[NW];
+    bool whole[NW], some[NW];
+#pragma unroll
+    for (int h = 0; h < NW; ++h) {
+      w[h] = (c * NW + h) * TAPE_THREADS + threadIdx.x;
+      whole[h] = (w[h] + 1) * WE <= a.numel;
+      some[h] = w[h] * WE < a.numel;
+    }
     skr_tape_op ahead = a.tape.ops[0];  // uniform: scalar loads from the kernel argument block, one op ahead of its use (the load's latency
     for (int o = 0; o < n_ops; ++o) {   // then runs under the current op's LDS round trip instead of in front of it)
       const skr_tape_op op = ahead;
       ahead = a.tape.ops[o + 1 < SKR_TAPE_MAX_OPS ? o + 1 : o];
       const int code = op.code, dst = op.dst, ia = op.a, ib = op.b;
-      if (code == SKR_TAPE_LOAD) {
+      switch (code) {
+      case SKR_TAPE_LOAD: {
         // A run of consecutive LOADs (the recorder opens a tape with its leaves) is issued as ONE batch: every global load first, the LDS
         // writes behind them -- one memory latency per run instead of one per input.
-        constexpr int RUN = sizeof(T) == 8 ? 2 : (sizeof(T) == 4 ? 4 : 6);  // (batch registers: 8, 16, 24)
+        constexpr int RUN = (sizeof(T) == 8 ? 2 : (sizeof(T) == 4 ? 4 : 6)) / (NW > 1 ? 2 : 1) + (NW > 1 && sizeof(T) != 8 ? 1 : 0);  // (batch registers: 8 / 16 / 24 with one word, 16 / 24 / 32 with two)
         int run = 1;
         while (run < RUN && o + run < n_ops && a.tape.ops[o + run].code == SKR_TAPE_LOAD) ++run;
-        Word q[RUN];
-        if (whole) {
+        Word q[RUN][NW];
 #pragma unroll
-          for (int j = 0; j < RUN; ++j)
-            if (j < run) q[j] = *(reinterpret_cast<const Word*>(a.in[a.tape.ops[o + j].a]) + v);
-        } else {
-          for (int j = 0; j < run; ++j) {
+        for (int j = 0; j < RUN; ++j) {
+          if (j < run) {
             const void* src = a.in[a.tape.ops[o + j].a];
-            M x[TAPE_ELEMS];
 #pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) {
-              if constexpr (std::is_same<M, double>::value) x[i] = e0 + i < a.numel ? load_scalar_d<T>(src, e0 + i) : 0.0;
-              else x[i] = e0 + i < a.numel ? load_scalar<T>(src, e0 + i) : 0.f;
+            for (int h = 0; h < NW; ++h) {
+              if (whole[h]) q[j][h] = *(reinterpret_cast<const Word*>(src) + w[h]);
+              else {
+                M x[WE];
+#pragma unroll
+                for (int i = 0; i < WE; ++i) {
+                  const int64_t e = w[h] * WE + i;
+                  if constexpr (std::is_same<M, double>::value) x[i] = e < a.numel ? load_scalar_d<T>(src, e) : 0.0;
+                  else x[i] = e < a.numel ? load_scalar<T>(src, e) : 0.f;
+                }
+                q[j][h] = tape_pack<T, M>(x);  // (exact: the values come from the tensor dtype)
+              }
             }
-            const Word w = tape_pack<T, M>(x);  // (exact: the values come from the tensor dtype)
-#pragma unroll
-            for (int jj = 0; jj < RUN; ++jj)
-              if (jj == j) q[jj] = w;
           }
         }
 #pragma unroll
-        for (int j = 0; j < RUN; ++j)
-          if (j < run) file[a.tape.ops[o + j].dst * TAPE_THREADS] = q[j];
+        for (int j = 0; j < RUN; ++j) {
+          if (j < run) {
+            const int d = a.tape.ops[o + j].dst;
+#pragma unroll
+            for (int h = 0; h < NW; ++h) file[(d * NW + h) * TAPE_THREADS] = q[j][h];
+          }
+        }
         if (run > 1) { o += run - 1; ahead = a.tape.ops[o + 1 < SKR_TAPE_MAX_OPS ? o + 1 : o]; }
-      } else if (code == SKR_TAPE_STORE) {
-        const Word w = file[ia * TAPE_THREADS];
+        break;
+      }
+      case SKR_TAPE_STORE: {
         void* dstp = a.out[ib];
-        if (whole) {
-          if constexpr (sizeof(T) == 8) { f64x2_t* p = reinterpret_cast<f64x2_t*>(dstp) + 2 * v; p[0] = w.lo; p[1] = w.hi; }
-          else __builtin_nontemporal_store(w, reinterpret_cast<Word*>(dstp) + v);
-        } else {
-          M x[TAPE_ELEMS];
-          tape_unpack<T, M>(w, x);
 #pragma unroll
-          for (int i = 0; i < TAPE_ELEMS; ++i) if (e0 + i < a.numel) store_scalar<T, M>(dstp, e0 + i, x[i]);
-        }
-      } else {
-        // both operand numbers are valid for every code (the host checks them); a scalar op replaces the second operand by the Python
-        // scalar, converted to the op-math type as torch does
-        M x[TAPE_ELEMS], z[TAPE_ELEMS], y[TAPE_ELEMS];
-        tape_unpack<T, M>(file[ia * TAPE_THREADS], x);
-        if (code >= SKR_TAPE_ADD && code != SKR_TAPE_NEG) tape_unpack<T, M>(file[ib * TAPE_THREADS], z);
-        else {
-          // the Python scalar: converted to the op-math type for x k, / k, k / (torch's mul / div keep it there) -- but torch's add / sub /
-          // rsub round it to the TENSOR dtype first (`bf16_tensor + 7.7` adds 7.6875; found by the tape fuzz of tests/test_step_gpu.py)
-          M k = (M)op.k;
-          if constexpr (!std::is_same<M, double>::value) {
-            if (code == SKR_TAPE_ADD_S || code == SKR_TAPE_RSUB_S) k = rnd<T>(k);
+        for (int h = 0; h < NW; ++h) {
+          const Word v = file[(ia * NW + h) * TAPE_THREADS];
+          if (whole[h]) {
+            if constexpr (sizeof(T) == 8) { f64x2_t* p = reinterpret_cast<f64x2_t*>(dstp) + 2 * w[h]; p[0] = v.lo; p[1] = v.hi; }
+            else __builtin_nontemporal_store(v, reinterpret_cast<Word*>(dstp) + w[h]);
+          } else if (some[h]) {
+            M x[WE];
+            tape_unpack<T, M>(v, x);
+#pragma unroll
+            for (int i = 0; i < WE; ++i) if (w[h] * WE + i < a.numel) store_scalar<T, M>(dstp, w[h] * WE + i, x[i]);
           }
-#pragma unroll
-          for (int i = 0; i < TAPE_ELEMS; ++i) z[i] = k;
+        }
+        break;
+      }
+      default: {
+        // both operand numbers are valid for every code (the host checks them).  The Python scalar: converted to the op-math type for x k, / k, k /
+        // (torch's mul / div keep it there) -- but torch's add / sub / rsub round it to the TENSOR dtype first (`bf16_tensor + 7.7` adds 7.6875; found
+        // by the tape fuzz of tests/test_step_gpu.py)
+        M k = (M)op.k;
+        if constexpr (!std::is_same<M, double>::value) {
+          if (code == SKR_TAPE_ADD_S || code == SKR_TAPE_RSUB_S) k = rnd<T>(k);
         }
         switch (code) {
-          case SKR_TAPE_MUL_S: case SKR_TAPE_MUL:
-#pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = mul_(x[i], z[i]);
-            break;
-          case SKR_TAPE_DIV_S: case SKR_TAPE_DIV:
-#pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = div_(x[i], z[i]);
-            break;
-          case SKR_TAPE_ADD_S: case SKR_TAPE_ADD:
-#pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = tape_add(x[i], z[i]);
-            break;
-          case SKR_TAPE_RSUB_S:
-#pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = sub_(z[i], x[i]);
-            break;
-          case SKR_TAPE_SUB:
-#pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = sub_(x[i], z[i]);
-            break;
-          case SKR_TAPE_RDIV_S:
-#pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = div_(z[i], x[i]);
-            break;
-          default:  // SKR_TAPE_NEG
-#pragma unroll
-            for (int i = 0; i < TAPE_ELEMS; ++i) y[i] = -x[i];
-            break;
+          case SKR_TAPE_MUL_S: tape_scalar<T, M, NW>(file, dst, ia, k, [](M x, M kk) { return mul_(x, kk); }); break;
+          case SKR_TAPE_DIV_S: tape_scalar<T, M, NW>(file, dst, ia, k, [](M x, M kk) { return div_(x, kk); }); break;
+          case SKR_TAPE_ADD_S: tape_scalar<T, M, NW>(file, dst, ia, k, [](M x, M kk) { return tape_add(x, kk); }); break;
+          case SKR_TAPE_RSUB_S: tape_scalar<T, M, NW>(file, dst, ia, k, [](M x, M kk) { return sub_(kk, x); }); break;
+          case SKR_TAPE_RDIV_S: tape_scalar<T, M, NW>(file, dst, ia, k, [](M x, M kk) { return div_(kk, x); }); break;
+          case SKR_TAPE_ADD: tape_binary<T, M, NW>(file, dst, ia, ib, [](M x, M z) { return tape_add(x, z); }); break;
+          case SKR_TAPE_SUB: tape_binary<T, M, NW>(file, dst, ia, ib, [](M x, M z) { return sub_(x, z); }); break;
+          case SKR_TAPE_MUL: tape_binary<T, M, NW>(file, dst, ia, ib, [](M x, M z) { return mul_(x, z); }); break;
+          case SKR_TAPE_DIV: tape_binary<T, M, NW>(file, dst, ia, ib, [](M x, M z) { return div_(x, z); }); break;
+          default: tape_scalar<T, M, NW>(file, dst, ia, k, [](M x, M) { return -x; }); break;  // SKR_TAPE_NEG
         }
-        file[dst * TAPE_THREADS] = tape_pack<T, M>(y);
+        break;
+      }
       }
     }
   }
 }
 
+template <typename T, typename M, int NW>
+static int launch_tape_words(const TapeArgs& a, int regs, hipStream_t s) {
+  constexpr int WE = TapeElems<T>::value;
+  const int64_t n_words = (a.numel + WE - 1) / WE;
+  int64_t blocks = (n_words + (int64_t)TAPE_THREADS * NW - 1) / ((int64_t)TAPE_THREADS * NW);
+  if (blocks > 256 * 32) blocks = 256 * 32;  // chunk-stride beyond 32 blocks per CU
+  const size_t lds = sizeof(typename TapeWord<T>::type) * (size_t)regs * NW * TAPE_THREADS;  // per register and word: 4 KiB (16-bit, fp32), 8 KiB (fp64)
+  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(tape_kernel<T, M, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return SKR_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL((tape_kernel<T, M, NW>), dim3((unsigned)blocks), dim3(TAPE_THREADS), lds, s, a);
+  return finish_launch();
+}
+
 template <typename T, typename M>
 static int launch_tape(const TapeArgs& a, hipStream_t s) {
-  constexpr int TAPE_ELEMS = TapeElems<T>::value;
-  const int64_t n_vec = (a.numel + TAPE_ELEMS - 1) / TAPE_ELEMS;
-  int64_t blocks = (n_vec + TAPE_THREADS - 1) / TAPE_THREADS;
-  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 blocks per CU
   // the file holds the registers the tape names, not all SKR_TAPE_REGS: the elements in flight on a CU are what its LDS can give a register
-  // file to, and the loads of those elements are the memory parallelism of this kernel (a 4-register Euler tape: 8 KiB per block, 32 waves per CU)
+  // file to, and the loads of those elements are the memory parallelism of this kernel (a 4-register Euler tape: 8 KiB per block and word)
   int regs = 1;
   for (int o = 0; o < a.tape.n_ops; ++o) {
     const skr_tape_op& op = a.tape.ops[o];
@@ -210,13 +248,14 @@ static int launch_tape(const TapeArgs& a, hipStream_t s) {
     if (two && op.b > hi) hi = op.b;
     if (hi + 1 > regs) regs = hi + 1;
   }
-  const size_t lds = sizeof(typename TapeWord<T>::type) * (size_t)regs * TAPE_THREADS;  // per register: 4 KiB (16-bit, fp32), 8 KiB (fp64)
-  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(tape_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-    (void)hipGetLastError();
-    return SKR_ERR_UNSUPPORTED;
-  }
-  hipLaunchKernelGGL((tape_kernel<T, M>), dim3((unsigned)blocks), dim3(TAPE_THREADS), lds, s, a);
-  return finish_launch();
+  const int forced = g_tune.tape_words;  // tuning switch (skr_set_tuning "tape_words"): 1 or 2 words per lane
+  constexpr int WE = TapeElems<T>::value;
+  // two words per lane halve the decode work per element, and pay while four blocks of the doubled file still fit a CU (measured at 256 x 4 x 128 x 128
+  // bf16, kernel time under rocprofv3: Euler, 2 registers, 26.2 -> 22.4 us; DPM-2, 5 registers, 61.6 -> 58.0; UniPC-3, 8 registers, 137.6 -> 148.6);
+  // one word where the tensor is too small to give every CU two blocks that way
+  const size_t doubled = sizeof(typename TapeWord<T>::type) * (size_t)regs * 2 * TAPE_THREADS;
+  const bool two_words = forced ? (forced == 2 && doubled <= 64 * 1024) : (doubled <= 40 * 1024 && a.numel >= (int64_t)WE * 2 * TAPE_THREADS * 512);
+  return two_words ? launch_tape_words<T, M, 2>(a, regs, s) : launch_tape_words<T, M, 1>(a, regs, s);
 }
 
 }  // namespace skr

@@ -311,10 +311,9 @@ def _noise_leaf(tape: Tape, noise):
 
 
 # ---- execution ----------------------------------------------------------------------------------------------------------------------
-def _run(tape: Tape, results: list) -> list[torch.Tensor]:
-    """Allocate registers (one pass over the straight-line tape: a value holds its register from its definition to its last read),
-    fill a skr_tape and launch it.  `results` are the values to return: a leaf comes back as the caller's own tensor, anything else
-    is stored by the launch right behind its definition."""
+def _allocate(tape: Tape, results: list) -> tuple[list[tuple[int, int, int, int, float]], list[int], dict[int, int]]:
+    """Registers for the straight-line tape, one pass: a value holds its register from its definition to its last read.  Returns the skr_tape
+    ops (code, dst, a, b, k), the leaves they load (indices into tape.leaves, in input order) and the output slot of every stored value."""
     n = len(tape.ops)
     two = (_hip.TAPE_ADD, _hip.TAPE_SUB, _hip.TAPE_MUL, _hip.TAPE_DIV)
     reads = [() if code == _hip.TAPE_LOAD else ((a, b) if code in two else (a,)) for code, a, b, _k in tape.ops]
@@ -358,18 +357,97 @@ def _run(tape: Tape, results: list) -> list[torch.Tensor]:
             reg_of[i] = dst
     if len(out_ops) > _hip.TAPE_MAX_OPS or not used_leaves:
         raise _Refused
+    return out_ops, used_leaves, stores
+
+
+def _compile(tape: Tape, results: list):
+    "the launch form of a tape: (skr_tape, indices into tape.leaves of its inputs, output slot of every stored value)"
+    out_ops, used_leaves, stores = _allocate(tape, results)
     # the whole skr_tape in one pack (field-by-field ctypes stores were half of this function's time): header, then (code, dst, a, b, k) per op
     flat = [len(out_ops), len(used_leaves), len(stores), _hip.DTYPE_CODE[tape.dtype]]
     for entry in out_ops:
         flat.extend(entry)
     c = _hip.TapeC.from_buffer_copy(struct.pack("<4i" + "4id" * len(out_ops), *flat).ljust(ctypes.sizeof(_hip.TapeC), b"\0"))
-    leaves = [tape.leaves[i] for i in used_leaves]
-    outs = [lazy.empty_output(tape.shape, tape.dtype, tape.device) for _ in stores]
+    return c, used_leaves, stores
+
+
+def _launch(c, leaves: list[torch.Tensor], n_outputs: int) -> list[torch.Tensor]:
+    first = leaves[0]
+    outs = [lazy.empty_output(first.shape, first.dtype, first.device) for _ in range(n_outputs)]
     ins = (ctypes.c_void_p * len(leaves))(*[t.data_ptr() for t in leaves])
-    ous = (ctypes.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
-    _hip.check(_hip.load().skr_tape_launch(ctypes.byref(c), ins, ous, leaves[0].numel(), _hip.current_stream_ptr(tape.device)), "skr_tape_launch")
+    ous = (ctypes.c_void_p * n_outputs)(*[t.data_ptr() for t in outs])
+    _hip.check(_hip.load().skr_tape_launch(ctypes.byref(c), ins, ous, first.numel(), _hip.current_stream_ptr(first.device)), "skr_tape_launch")
     global launches
     launches += 1
+    return outs
+
+
+def _run(tape: Tape, results: list) -> list[torch.Tensor]:
+    """Fill a skr_tape and launch it.  `results` are the values to return: a leaf comes back as the caller's own tensor, anything else
+    is stored by the launch right behind its definition."""
+    c, used_leaves, stores = _compile(tape, results)
+    outs = _launch(c, [tape.leaves[i] for i in used_leaves], len(stores))
+    return [tape.leaves[tape.ops[v.n][1]] if tape.ops[v.n][0] == _hip.TAPE_LOAD else outs[stores[v.n]] for v in results]
+
+
+# ---- remembered steps ---------------------------------------------------------------------------------------------------------------
+# Everything a sampler step's tape holds besides the tensors -- op order, register numbers, the scalars -- is a function of (sampler, model,
+# schedule, step, the steps of the history, which optional tensors are present, dtype, which arguments are one and the same tensor).  Recording
+# is 20-150 us of host work per step (profiles/r05_bench_tape.txt), more than the launch takes up to a few million elements: a step seen before
+# binds today's tensors to the remembered skr_tape instead.  Configuration objects the reference leaves unhashable are not remembered.
+_remembered: dict = {}
+REMEMBER_AT_MOST = 4096  # (3 KiB apiece)
+remembered_hits = 0  # (diagnostics / tests)
+
+
+def _settled(t, dtype):
+    "what Tape.leaf turns an argument into"
+    if isinstance(t, lazy.PhiloxNoise):
+        return t.realize(dtype)
+    if isinstance(t, lazy.LazyTensor):
+        return t.materialize()
+    return t
+
+
+def _step_key(kind: str, sampler, model, schedule, packed, previous, arguments: list):
+    first_seen: dict[int, int] = {}
+    same = tuple(-1 if t is None else first_seen.setdefault(id(t), i) for i, t in enumerate(arguments))
+    key = (kind, sampler, model, schedule, tuple(packed.step), tuple(tuple(p.step) for p in previous), packed.sample.dtype, same)
+    try:
+        hash(key)
+    except TypeError:
+        return None
+    return key
+
+
+def _remembered_step(kind: str, recorder, sampler, packed, model, schedule, previous, arguments: list) -> list:
+    """`recorder(...) -> (tape, results)` run through the launch, or -- for a step remembered from an earlier call -- today's `arguments` (the
+    tensors the recorder may read, in a fixed order) bound to the skr_tape recorded then.  Device tensors only; returns the tensors of `results`."""
+    global remembered_hits
+    like = packed.sample
+    key = _step_key(kind, sampler, model, schedule, packed, previous, arguments) if like.is_cuda else None
+    entry = _remembered.get(key) if key is not None else None
+    if entry is not None:
+        c, used, n_outputs, answer = entry
+        settled = [None if t is None else _settled(t, like.dtype) for t in arguments]
+        # (Tape.leaf's own conditions, on every argument the recorder would have made a leaf of -- read by the tape or not)
+        if all(t is None or (isinstance(t, torch.Tensor) and t.dtype == like.dtype and t.shape == like.shape and t.device == like.device and t.is_contiguous()) for t in settled):
+            outs = _launch(c, [settled[i] for i in used], n_outputs)
+            remembered_hits += 1
+            return [outs[n] if stored else settled[n] for stored, n in answer]
+    tape, results = recorder(sampler, packed, model, schedule, previous, require_device=False)
+    if tape.device.type != "cuda":
+        return _run_host(tape, results)
+    c, used_leaves, stores = _compile(tape, results)
+    outs = _launch(c, [tape.leaves[i] for i in used_leaves], len(stores))
+    if key is not None:
+        where = {id(_settled(t, like.dtype)): i for i, t in reversed(list(enumerate(arguments))) if t is not None}
+        used = [where.get(id(tape.leaves[i])) for i in used_leaves]
+        answer = [(False, where.get(id(tape.leaves[tape.ops[v.n][1]]))) if tape.ops[v.n][0] == _hip.TAPE_LOAD else (True, stores[v.n]) for v in results]
+        if None not in used and all(n is not None for _stored, n in answer):
+            if len(_remembered) >= REMEMBER_AT_MOST:
+                _remembered.clear()
+            _remembered[key] = (c, used, len(stores), answer)
     return [tape.leaves[tape.ops[v.n][1]] if tape.ops[v.n][0] == _hip.TAPE_LOAD else outs[stores[v.n]] for v in results]
 
 
@@ -458,8 +536,11 @@ def try_stated(sampler, packed, model, schedule, previous):
         return None
     from .structured import SKSamples
 
+    arguments = [packed.sample, packed.prediction, packed.noise]
+    for p in previous:
+        arguments += (p.sample, p.prediction)
     try:
-        (final,) = _execute(*record_stated(sampler, packed, model, schedule, previous, require_device=False))
+        (final,) = _remembered_step("stated", record_stated, sampler, packed, model, schedule, previous, arguments)
     except _Refused:
         return None
     return SKSamples(packed.sample, packed.prediction, packed.step, packed.noise, final)
@@ -471,8 +552,13 @@ def try_unipc(sampler, packed, model, schedule, previous):
 
     if type(sampler) is not S.UniPC or not _eligible(packed.sample, packed.prediction):
         return None
+    arguments = [packed.sample, packed.prediction, packed.noise]
+    for p in previous:
+        arguments += (p.sample, p.prediction)
+    if previous:
+        arguments.append(previous[-1].noise)
     try:
-        sample, prediction, final = _execute(*record_unipc(sampler, packed, model, schedule, previous, require_device=False))
+        sample, prediction, final = _remembered_step("unipc", record_unipc, sampler, packed, model, schedule, previous, arguments)
     except _Refused:
         return None
     return S.SKSamples(sample, prediction, packed.step, packed.noise, final)

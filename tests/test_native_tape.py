@@ -53,14 +53,45 @@ def interpret(tape: native.Tape, results):
     return [vals[v.n] for v in results]
 
 
+def launch_form(tape: native.Tape, results):
+    """The skr_tape native._allocate builds for the launch, run on the CPU as the kernel runs it: a file of SKR_TAPE_REGS registers, every operand
+    number under skr_tape_launch's own checks, reads of defined registers only.  Returns the tensors `results` name."""
+    ops, used_leaves, stores = native._allocate(tape, results)
+    assert len(ops) <= _hip.TAPE_MAX_OPS and len(used_leaves) <= _hip.TAPE_MAX_INPUTS and 1 <= len(stores) <= _hip.TAPE_MAX_OUTPUTS
+    file, outs = {}, {}
+    scalar = {_hip.TAPE_MUL_S: lambda x, k: x * k, _hip.TAPE_DIV_S: lambda x, k: x / k, _hip.TAPE_ADD_S: lambda x, k: x + k, _hip.TAPE_RSUB_S: lambda x, k: k - x,
+              _hip.TAPE_RDIV_S: lambda x, k: x.reciprocal(), _hip.TAPE_NEG: lambda x, k: -x}
+    binary = {_hip.TAPE_ADD: lambda x, y: x + y, _hip.TAPE_SUB: lambda x, y: x - y, _hip.TAPE_MUL: lambda x, y: x * y, _hip.TAPE_DIV: lambda x, y: x / y}
+    for code, dst, a, b, k in ops:
+        assert 0 <= dst < _hip.TAPE_REGS
+        if code == _hip.TAPE_LOAD:
+            assert 0 <= a < len(used_leaves)
+            file[dst] = tape.leaves[used_leaves[a]]
+        elif code == _hip.TAPE_STORE:
+            assert 0 <= b < len(stores) and b not in outs
+            outs[b] = file[a]
+        else:
+            assert code != _hip.TAPE_RDIV_S or k == 1.0
+            file[dst] = scalar[code](file[a], k) if code in scalar else binary[code](file[a], file[b])
+    return [tape.leaves[tape.ops[v.n][1]] if tape.ops[v.n][0] == _hip.TAPE_LOAD else outs[stores[v.n]] for v in results]
+
+
+def interpret_both(tape: native.Tape, results):
+    "the op list as recorded, and the launch form of it (registers allocated): same tensors, bit for bit"
+    plain = interpret(tape, results)
+    for want, got in zip(plain, launch_form(tape, results)):
+        assert got.dtype == want.dtype and torch.equal(torch.nan_to_num(got.double()), torch.nan_to_num(want.double())) and torch.equal(torch.isnan(got), torch.isnan(want))
+    return plain
+
+
 def record(sampler, x, out, step, model, sched, noise, previous):
     packed = PT.SampleInput(x, out, step, noise)
     if type(sampler) is PT.UniPC:
         tape, res = native.record_unipc(sampler, packed, model, sched, previous, require_device=False)
-        s, p, f = interpret(tape, res)
+        s, p, f = interpret_both(tape, res)
         return PT.SKSamples(s, p, step, noise, f), tape
     tape, res = native.record_stated(sampler, packed, model, sched, previous, require_device=False)
-    return PT.SKSamples(x, out, step, noise, interpret(tape, res)[0]), tape
+    return PT.SKSamples(x, out, step, noise, interpret_both(tape, res)[0]), tape
 
 
 @pytest.mark.parametrize("tag", NATIVE16_TAGS)

