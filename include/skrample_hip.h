@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SKR_ABI_VERSION 12
+#define SKR_ABI_VERSION 13
 #define SKR_MAX_TERMS 80 /* 2 x 35-stage tableau pairs + base + noise, see skr_step_plan */
 
 /* Devices and streams: every entry point launches on the device that owns its output buffer (queried from the pointer when
@@ -150,6 +150,8 @@ void skr_program_destroy(skr_program* prog);
  *     LOAD   r[dst] = inputs[a][e]                        STORE  outputs[b][e] = r[a]
  *     MUL_S  r[dst] = rnd(r[a] * k)    DIV_S  rnd(r[a] / k)    ADD_S  rnd(r[a] + k)    RSUB_S  rnd(k - r[a])    RDIV_S  rnd(k / r[a])
  *     ADD    r[dst] = rnd(r[a] + r[b]) SUB    rnd(r[a] - r[b]) MUL    rnd(r[a] * r[b]) DIV     rnd(r[a] / r[b]) NEG     -r[a]
+ *     ADD_MS r[dst] = rnd(r[a] + rnd(r[b] * k))   SUB_MS  rnd(r[a] - rnd(r[b] * k))   RSUB_MS  rnd(rnd(r[b] * k) - r[a])   MULZ_S  rnd(rnd(r[a] * k) + 0)
+ *       (two ops of the lines above in one visit, for a product nothing else reads: `total + p * q`, `s - sigma * o`, `0 + p * q` -- same roundings)
  *
  * (IEEE operations, no contraction; rnd = round-to-nearest-even to `dtype`.  The scalar k: converted to the op-math type for MUL_S / DIV_S /
  * RDIV_S, but rounded to `dtype` FIRST for ADD_S / RSUB_S -- torch's add / sub / rsub of a Python number to a 16-bit CPU tensor do that, its
@@ -162,7 +164,8 @@ void skr_program_destroy(skr_program* prog);
 #define SKR_TAPE_MAX_OUTPUTS 4
 enum skr_tape_code {
   SKR_TAPE_LOAD = 0, SKR_TAPE_STORE = 1, SKR_TAPE_MUL_S = 2, SKR_TAPE_DIV_S = 3, SKR_TAPE_ADD_S = 4, SKR_TAPE_RSUB_S = 5, SKR_TAPE_RDIV_S = 6,
-  SKR_TAPE_ADD = 7, SKR_TAPE_SUB = 8, SKR_TAPE_MUL = 9, SKR_TAPE_DIV = 10, SKR_TAPE_NEG = 11
+  SKR_TAPE_ADD = 7, SKR_TAPE_SUB = 8, SKR_TAPE_MUL = 9, SKR_TAPE_DIV = 10, SKR_TAPE_NEG = 11,
+  SKR_TAPE_ADD_MS = 12, SKR_TAPE_SUB_MS = 13, SKR_TAPE_RSUB_MS = 14, SKR_TAPE_MULZ_S = 15
 };
 typedef struct skr_tape_op {
   int32_t code; /* skr_tape_code */

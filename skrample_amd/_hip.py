@@ -14,7 +14,7 @@ import threading
 import torch
 
 MAX_TERMS = 80
-ABI_VERSION = 12
+ABI_VERSION = 13
 SKR_ERR_UNSUPPORTED = 7  # include/skrample_hip.h: valid request outside what the fast kernels cover
 
 BF16, F16, F32, F64, NONE = 0, 1, 2, 3, -1
@@ -84,7 +84,8 @@ class StepPlanC(ctypes.Structure):
 
 
 TAPE_MAX_OPS, TAPE_REGS, TAPE_MAX_INPUTS, TAPE_MAX_OUTPUTS = 96, 16, 24, 4  # include/skrample_hip.h SKR_TAPE_*
-(TAPE_LOAD, TAPE_STORE, TAPE_MUL_S, TAPE_DIV_S, TAPE_ADD_S, TAPE_RSUB_S, TAPE_RDIV_S, TAPE_ADD, TAPE_SUB, TAPE_MUL, TAPE_DIV, TAPE_NEG) = range(12)
+(TAPE_LOAD, TAPE_STORE, TAPE_MUL_S, TAPE_DIV_S, TAPE_ADD_S, TAPE_RSUB_S, TAPE_RDIV_S, TAPE_ADD, TAPE_SUB, TAPE_MUL, TAPE_DIV, TAPE_NEG,
+ TAPE_ADD_MS, TAPE_SUB_MS, TAPE_RSUB_MS, TAPE_MULZ_S) = range(16)  # fmt: skip
 
 
 class TapeOpC(ctypes.Structure):

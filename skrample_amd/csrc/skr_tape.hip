@@ -84,6 +84,12 @@ template <typename M> __device__ __forceinline__ M tape_add(M a, M b) {
   return a + b;
 }
 
+// an op result on its way into another op of the same visit: rounded to the tensor dtype, kept in the op-math type
+template <typename T, typename M> __device__ __forceinline__ M tape_round(M v) {
+  if constexpr (std::is_same<M, double>::value || std::is_same<T, float>::value) return v;
+  else return rnd<T>(v);
+}
+
 // one op over a thread's NW words; each case of the dispatch below is a complete read - compute - round - write of its own, so that no value has to be
 // merged across cases (the merged form cost the compiler a register copy per element and a flag per case, and this kernel lives on instruction issue)
 template <typename T, typename M, int NW, typename F>
@@ -212,6 +218,11 @@ __global__ __launch_bounds__(TAPE_THREADS) void tape_kernel(const TapeArgs a) {
           case SKR_TAPE_SUB: tape_binary<T, M, NW>(file, dst, ia, ib, [](M x, M z) { return sub_(x, z); }); break;
           case SKR_TAPE_MUL: tape_binary<T, M, NW>(file, dst, ia, ib, [](M x, M z) { return mul_(x, z); }); break;
           case SKR_TAPE_DIV: tape_binary<T, M, NW>(file, dst, ia, ib, [](M x, M z) { return div_(x, z); }); break;
+          // a product by a scalar read by one sum or difference only, in the same visit (the product rounded to the tensor dtype on its way, as the op it stands for)
+          case SKR_TAPE_ADD_MS: tape_binary<T, M, NW>(file, dst, ia, ib, [k](M x, M z) { return tape_add(x, tape_round<T, M>(mul_(z, k))); }); break;
+          case SKR_TAPE_SUB_MS: tape_binary<T, M, NW>(file, dst, ia, ib, [k](M x, M z) { return sub_(x, tape_round<T, M>(mul_(z, k))); }); break;
+          case SKR_TAPE_RSUB_MS: tape_binary<T, M, NW>(file, dst, ia, ib, [k](M x, M z) { return sub_(tape_round<T, M>(mul_(z, k)), x); }); break;
+          case SKR_TAPE_MULZ_S: tape_scalar<T, M, NW>(file, dst, ia, k, [](M x, M kk) { return tape_add(tape_round<T, M>(mul_(x, kk)), (M)0); }); break;
           default: tape_scalar<T, M, NW>(file, dst, ia, k, [](M x, M) { return -x; }); break;  // SKR_TAPE_NEG
         }
         break;
@@ -243,7 +254,7 @@ static int launch_tape(const TapeArgs& a, hipStream_t s) {
   int regs = 1;
   for (int o = 0; o < a.tape.n_ops; ++o) {
     const skr_tape_op& op = a.tape.ops[o];
-    const bool two = op.code >= SKR_TAPE_ADD && op.code != SKR_TAPE_NEG;  // (the second operand number means a register for the tensor-tensor ops only)
+    const bool two = op.code >= SKR_TAPE_ADD && op.code != SKR_TAPE_NEG && op.code != SKR_TAPE_MULZ_S;  // (the second operand number means a register for the tensor-tensor ops only)
     int hi = op.code == SKR_TAPE_LOAD ? op.dst : (op.code == SKR_TAPE_STORE ? op.a : (op.dst > op.a ? op.dst : op.a));
     if (two && op.b > hi) hi = op.b;
     if (hi + 1 > regs) regs = hi + 1;
@@ -289,9 +300,9 @@ extern "C" int skr_tape_launch(const skr_tape* tape, const void* const* inputs, 
     switch (op.code) {
       case SKR_TAPE_LOAD: if (!reg_d || op.a < 0 || op.a >= t.n_inputs) return SKR_ERR_TERMS; break;
       case SKR_TAPE_STORE: if (!reg_a || op.b < 0 || op.b >= t.n_outputs) return SKR_ERR_TERMS; break;
-      case SKR_TAPE_MUL_S: case SKR_TAPE_DIV_S: case SKR_TAPE_ADD_S: case SKR_TAPE_RSUB_S: case SKR_TAPE_RDIV_S: case SKR_TAPE_NEG:
+      case SKR_TAPE_MUL_S: case SKR_TAPE_DIV_S: case SKR_TAPE_ADD_S: case SKR_TAPE_RSUB_S: case SKR_TAPE_RDIV_S: case SKR_TAPE_NEG: case SKR_TAPE_MULZ_S:
         if (!reg_a || !reg_d) return SKR_ERR_TERMS; break;
-      case SKR_TAPE_ADD: case SKR_TAPE_SUB: case SKR_TAPE_MUL: case SKR_TAPE_DIV:
+      case SKR_TAPE_ADD: case SKR_TAPE_SUB: case SKR_TAPE_MUL: case SKR_TAPE_DIV: case SKR_TAPE_ADD_MS: case SKR_TAPE_SUB_MS: case SKR_TAPE_RSUB_MS:
         if (!reg_a || !reg_b || !reg_d) return SKR_ERR_TERMS; break;
       default: return SKR_ERR_UNSUPPORTED;
     }

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 import struct
 from typing import Sequence
 
@@ -311,31 +312,69 @@ def _noise_leaf(tape: Tape, noise):
 
 
 # ---- execution ----------------------------------------------------------------------------------------------------------------------
+_TWO_REGISTERS = (_hip.TAPE_ADD, _hip.TAPE_SUB, _hip.TAPE_MUL, _hip.TAPE_DIV, _hip.TAPE_ADD_MS, _hip.TAPE_SUB_MS, _hip.TAPE_RSUB_MS)
+fuse = os.environ.get("SKR_TAPE_NO_FUSE") is None  # (tuning / test switch: the launch form op for op as recorded)
+
+
+def _fused(recorded: list, stored) -> list:
+    """The recorded ops with every product by a scalar that one sum or difference reads -- and nothing else, no result either -- folded into its reader:
+    `total + p * k` -> ADD_MS, `s - o * k` -> SUB_MS, `o * k - s` -> RSUB_MS, `0 + p * k` -> MULZ_S (the first term of a sumprod; `+ 0` turns -0 into +0,
+    so it stays).  Same operations, same roundings, one visit of the kernel's dispatch and one trip through its register file fewer per pair; positions
+    keep their meaning (a folded product leaves a None behind)."""
+    T = _hip
+    uses = [0] * len(recorded)
+    for code, a, b, _k in recorded:
+        if code != T.TAPE_LOAD:
+            uses[a] += 1
+            if code in _TWO_REGISTERS:
+                uses[b] += 1
+    ops: list = list(recorded)
+
+    def product(v: int):
+        "(operand, scalar) of value v if it is such a product"
+        op = ops[v]
+        return (op[1], op[3]) if op is not None and op[0] == T.TAPE_MUL_S and uses[v] == 1 and v not in stored else None
+
+    for i, (code, a, b, k) in enumerate(recorded):
+        if code == T.TAPE_ADD or code == T.TAPE_SUB:
+            for mine, other, folded in ((b, a, T.TAPE_ADD_MS if code == T.TAPE_ADD else T.TAPE_SUB_MS), (a, b, T.TAPE_ADD_MS if code == T.TAPE_ADD else T.TAPE_RSUB_MS)):
+                found = product(mine)
+                if found is not None:
+                    ops[i], ops[mine] = (folded, other, found[0], found[1]), None
+                    break
+        elif code == T.TAPE_ADD_S and k == 0.0 and math.copysign(1.0, k) > 0:
+            found = product(a)
+            if found is not None:
+                ops[i], ops[a] = (T.TAPE_MULZ_S, found[0], 0, found[1]), None
+    return ops
+
+
 def _allocate(tape: Tape, results: list) -> tuple[list[tuple[int, int, int, int, float]], list[int], dict[int, int]]:
     """Registers for the straight-line tape, one pass: a value holds its register from its definition to its last read.  Returns the skr_tape
     ops (code, dst, a, b, k), the leaves they load (indices into tape.leaves, in input order) and the output slot of every stored value."""
-    n = len(tape.ops)
-    two = (_hip.TAPE_ADD, _hip.TAPE_SUB, _hip.TAPE_MUL, _hip.TAPE_DIV)
-    reads = [() if code == _hip.TAPE_LOAD else ((a, b) if code in two else (a,)) for code, a, b, _k in tape.ops]
-    last_read = [-1] * n
-    for i, rd in enumerate(reads):
-        for r in rd:
-            last_read[r] = i
     stores: dict[int, int] = {}  # value -> output slot
     for v in results:
         if tape.ops[v.n][0] != _hip.TAPE_LOAD and v.n not in stores:
             stores[v.n] = len(stores)
     if not stores or len(stores) > _hip.TAPE_MAX_OUTPUTS:
         raise _Refused
+    ops = _fused(tape.ops, stores) if fuse else list(tape.ops)
+    n = len(ops)
+    reads = [() if op is None or op[0] == _hip.TAPE_LOAD else ((op[1], op[2]) if op[0] in _TWO_REGISTERS else (op[1],)) for op in ops]
+    last_read = [-1] * n
+    for i, rd in enumerate(reads):
+        for r in rd:
+            last_read[r] = i
     # (a value nothing reads -- e.g. a difference the reference computes for a term of weight zero -- stays on the tape: it costs no
     #  memory traffic; only the LOAD of a leaf nothing reads is dropped)
     free = list(range(_hip.TAPE_REGS - 1, -1, -1))
     reg_of: dict[int, int] = {}
     out_ops: list[tuple[int, int, int, int, float]] = []
     used_leaves: list[int] = []
-    for i, (code, a, b, k) in enumerate(tape.ops):
-        if code == _hip.TAPE_LOAD and last_read[i] < 0:
+    for i, op in enumerate(ops):
+        if op is None or (op[0] == _hip.TAPE_LOAD and last_read[i] < 0):
             continue
+        code, a, _b, k = op
         srcs = [reg_of[r] for r in reads[i]]
         for r in set(reads[i]):  # an operand read here for the last time hands its register on (the kernel reads before it writes)
             if last_read[r] == i:

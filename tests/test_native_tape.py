@@ -60,8 +60,9 @@ def launch_form(tape: native.Tape, results):
     assert len(ops) <= _hip.TAPE_MAX_OPS and len(used_leaves) <= _hip.TAPE_MAX_INPUTS and 1 <= len(stores) <= _hip.TAPE_MAX_OUTPUTS
     file, outs = {}, {}
     scalar = {_hip.TAPE_MUL_S: lambda x, k: x * k, _hip.TAPE_DIV_S: lambda x, k: x / k, _hip.TAPE_ADD_S: lambda x, k: x + k, _hip.TAPE_RSUB_S: lambda x, k: k - x,
-              _hip.TAPE_RDIV_S: lambda x, k: x.reciprocal(), _hip.TAPE_NEG: lambda x, k: -x}
-    binary = {_hip.TAPE_ADD: lambda x, y: x + y, _hip.TAPE_SUB: lambda x, y: x - y, _hip.TAPE_MUL: lambda x, y: x * y, _hip.TAPE_DIV: lambda x, y: x / y}
+              _hip.TAPE_RDIV_S: lambda x, k: x.reciprocal(), _hip.TAPE_NEG: lambda x, k: -x, _hip.TAPE_MULZ_S: lambda x, k: x * k + 0}
+    binary = {_hip.TAPE_ADD: lambda x, y, k: x + y, _hip.TAPE_SUB: lambda x, y, k: x - y, _hip.TAPE_MUL: lambda x, y, k: x * y, _hip.TAPE_DIV: lambda x, y, k: x / y,
+              _hip.TAPE_ADD_MS: lambda x, y, k: x + y * k, _hip.TAPE_SUB_MS: lambda x, y, k: x - y * k, _hip.TAPE_RSUB_MS: lambda x, y, k: y * k - x}
     for code, dst, a, b, k in ops:
         assert 0 <= dst < _hip.TAPE_REGS
         if code == _hip.TAPE_LOAD:
@@ -72,7 +73,7 @@ def launch_form(tape: native.Tape, results):
             outs[b] = file[a]
         else:
             assert code != _hip.TAPE_RDIV_S or k == 1.0
-            file[dst] = scalar[code](file[a], k) if code in scalar else binary[code](file[a], file[b])
+            file[dst] = scalar[code](file[a], k) if code in scalar else binary[code](file[a], file[b], k)
     return [tape.leaves[tape.ops[v.n][1]] if tape.ops[v.n][0] == _hip.TAPE_LOAD else outs[stores[v.n]] for v in results]
 
 
