@@ -644,6 +644,10 @@ def test_tape_ops_through_the_c_abi(dtype, dev):
             ([(T.TAPE_LOAD, 3, 0, 0, 0.0), (T.TAPE_LOAD, 4, 1, 0, 0.0), (T.TAPE_ADD_S, 0, 3, 0, 7.7), (T.TAPE_STORE, 0, 0, 0, 0.0), (T.TAPE_RSUB_S, 1, 4, 0, 0.001), (T.TAPE_STORE, 0, 1, 1, 0.0),
               (T.TAPE_MUL_S, 2, 3, 0, 7.7), (T.TAPE_STORE, 0, 2, 2, 0.0), (T.TAPE_ADD_S, 2, 4, 0, -3.3), (T.TAPE_STORE, 0, 2, 3, 0.0)],
              lambda: [a + 7.7, 0.001 - b, a * 7.7, b - 3.3]),
+            # the two-op forms: a product by a scalar inside the sum / difference that reads it, rounded on its way as the op it stands for
+            ([(T.TAPE_LOAD, 0, 0, 0, 0.0), (T.TAPE_LOAD, 1, 1, 0, 0.0), (T.TAPE_ADD_MS, 2, 0, 1, 0.3), (T.TAPE_STORE, 0, 2, 0, 0.0), (T.TAPE_SUB_MS, 2, 0, 1, 7.7), (T.TAPE_STORE, 0, 2, 1, 0.0),
+              (T.TAPE_RSUB_MS, 3, 0, 1, -1.7), (T.TAPE_STORE, 0, 3, 2, 0.0), (T.TAPE_MULZ_S, 3, 0, 0, 0.0), (T.TAPE_STORE, 0, 3, 3, 0.0)],
+             lambda: [a + b * 0.3, a - b * 7.7, b * -1.7 - a, 0 + a * 0.0]),  # (the last: -0 products come out +0, `0 + x`)
         ]
         for ops, ref in programs:
             want = ref()
@@ -656,14 +660,19 @@ def test_tape_ops_through_the_c_abi(dtype, dev):
             ins = (ctypes.c_void_p * 2)(ad.data_ptr(), bd.data_ptr())
             ous = (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
             assert lib.skr_tape_launch(ctypes.byref(tape), ins, ous, numel, _hip.current_stream_ptr(dev)) == 0
+            bits = {2: torch.int16, 4: torch.int32, 8: torch.int64}[a.element_size()]  # (bit patterns: the sign of a zero counts)
             for got, w in zip(outs, want):
-                assert torch.equal(got.cpu(), w), (dtype, numel, (got.cpu().double() - w.double()).abs().max())
+                assert torch.equal(got.cpu().view(bits), w.view(bits)), (dtype, numel, (got.cpu().double() - w.double()).abs().max())
     bad = _hip.TapeC()
     bad.n_ops, bad.n_inputs, bad.n_outputs, bad.dtype = 1, 1, 1, _hip.BF16
     bad.ops[0].code, bad.ops[0].dst, bad.ops[0].a = _hip.TAPE_MUL_S, 16, 0  # register out of range
     x = torch.zeros(8, dtype=torch.bfloat16, device=dev)
     one = (ctypes.c_void_p * 1)(x.data_ptr())
     assert lib.skr_tape_launch(ctypes.byref(bad), one, one, 8, _hip.current_stream_ptr(dev)) == 3  # SKR_ERR_TERMS
+    bad.ops[0].code, bad.ops[0].dst, bad.ops[0].a, bad.ops[0].b = _hip.TAPE_ADD_MS, 0, 0, 16  # second register of a two-op form out of range
+    assert lib.skr_tape_launch(ctypes.byref(bad), one, one, 8, _hip.current_stream_ptr(dev)) == 3
+    bad.ops[0].code, bad.ops[0].b = 16, 0  # no such op code
+    assert lib.skr_tape_launch(ctypes.byref(bad), one, one, 8, _hip.current_stream_ptr(dev)) != 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
