@@ -19,6 +19,7 @@ place while they are still within `require_previous` steps of use.
 from __future__ import annotations
 
 import dataclasses
+import functools
 import math
 from abc import ABC, abstractmethod
 from dataclasses import dataclass, replace
@@ -226,6 +227,40 @@ class Adams(StructuredUnified, StatedSampler):
         return space.update_form(packed.sample, q, delta, packed.noise, self.stochasticity)
 
 
+@functools.lru_cache(maxsize=8192)  # (a function of its numbers alone, and a 20 us linear solve; a run meets every step's system again in its next run)
+def _unisolve_weights(fast_solve: bool, order: int, lam: float, lam_next: float, lam_history: tuple[float, ...], corrector: bool) -> tuple[tuple[float, ...], float]:
+    """(weights over [q_0, q_1..q_{order-1}], weight of q_next).
+    q = q0 + sum_k rho_k (q_k - q0)/r_k  [+ rho_c (q_next - q0)],  R rho = b with
+    R_nk = r_k^(n-1), b_n = n! h_phi_n / B(h)."""
+    h = abs(lam_next - lam)
+    hh = -h
+    phi_1 = math.expm1(hh)
+    ratios: list[float] = []  # r_k as used in the linear system (non-finite -> 0)
+    raw: list[float] = []  # r_k as used to divide the differences
+    for lam_k in lam_history[: order - 1]:
+        rk = (lam_k - lam) / h
+        raw.append(rk)
+        ratios.append(rk if math.isfinite(rk) else 0)
+    if corrector:
+        ratios.append(1.0)
+    threshold = 1 if corrector else 2
+    if not ratios or (order == threshold and fast_solve):
+        rhos = [0.5]
+    else:
+        phi_k = phi_1 / hh - 1
+        rows, rhs = [], []
+        for n in range(1, len(ratios) + 1):
+            rows.append([math.pow(v, n - 1) for v in ratios])
+            rhs.append(phi_k * math.factorial(n) / phi_1)
+            phi_k = phi_k / hh - 1 / math.factorial(n + 1)
+        rhos = np.linalg.solve(rows, rhs).tolist()
+    n_terms = len(raw) + (1 if corrector else 0)
+    rhos = rhos[:n_terms]
+    hist = [rho / rk for rho, rk in zip(rhos, raw)]  # rho/inf = 0: an infinitely distant point drops out
+    w_next = rhos[len(raw)] if corrector and len(rhos) > len(raw) else 0.0
+    return (1.0 - math.fsum(hist) - w_next, *hist), w_next
+
+
 @dataclass(frozen=True)
 class UniP(StructuredUnified, StatedSampler):
     "the UniPC predictor on its own (arXiv 2302.04867)"
@@ -238,36 +273,8 @@ class UniP(StructuredUnified, StatedSampler):
         return 9
 
     def _unisolve_weights(self, order: int, lam: float, lam_next: float, lam_history: Sequence[float], corrector: bool) -> tuple[list[float], float]:
-        """(weights over [q_0, q_1..q_{order-1}], weight of q_next).
-        q = q0 + sum_k rho_k (q_k - q0)/r_k  [+ rho_c (q_next - q0)],  R rho = b with
-        R_nk = r_k^(n-1), b_n = n! h_phi_n / B(h)."""
-        h = abs(lam_next - lam)
-        hh = -h
-        phi_1 = math.expm1(hh)
-        ratios: list[float] = []  # r_k as used in the linear system (non-finite -> 0)
-        raw: list[float] = []  # r_k as used to divide the differences
-        for lam_k in lam_history[: order - 1]:
-            rk = (lam_k - lam) / h
-            raw.append(rk)
-            ratios.append(rk if math.isfinite(rk) else 0)
-        if corrector:
-            ratios.append(1.0)
-        threshold = 1 if corrector else 2
-        if not ratios or (order == threshold and self.fast_solve):
-            rhos = [0.5]
-        else:
-            phi_k = phi_1 / hh - 1
-            rows, rhs = [], []
-            for n in range(1, len(ratios) + 1):
-                rows.append([math.pow(v, n - 1) for v in ratios])
-                rhs.append(phi_k * math.factorial(n) / phi_1)
-                phi_k = phi_k / hh - 1 / math.factorial(n + 1)
-            rhos = np.linalg.solve(rows, rhs).tolist()
-        n_terms = len(raw) + (1 if corrector else 0)
-        rhos = rhos[:n_terms]
-        hist = [rho / rk for rho, rk in zip(rhos, raw)]  # rho/inf = 0: an infinitely distant point drops out
-        w_next = rhos[len(raw)] if corrector and len(rhos) > len(raw) else 0.0
-        return [1.0 - math.fsum(hist) - w_next, *hist], w_next
+        weights, w_next = _unisolve_weights(self.fast_solve, order, lam, lam_next, tuple(lam_history), corrector)
+        return list(weights), w_next
 
     def _unisolve_form(self, packed, model_transform, schedule, previous, prediction_next=None):
         "UniP (prediction_next is None) or UniC (prediction_next given, already in derivative space)"
