@@ -464,11 +464,13 @@ def _remembered_step(kind: str, recorder, sampler, packed, model, schedule, prev
     tensors the recorder may read, in a fixed order) bound to the skr_tape recorded then.  Device tensors only; returns the tensors of `results`."""
     global remembered_hits
     like = packed.sample
-    key = _step_key(kind, sampler, model, schedule, packed, previous, arguments) if like.is_cuda else None
-    entry = _remembered.get(key) if key is not None else None
+    key = entry = None
+    if like.is_cuda:
+        settled = [None if t is None else _settled(t, like.dtype) for t in arguments]  # (what the recorder's leaves would be: sameness is judged on these)
+        key = _step_key(kind, sampler, model, schedule, packed, previous, settled)
+        entry = _remembered.get(key) if key is not None else None
     if entry is not None:
         c, used, n_outputs, answer = entry
-        settled = [None if t is None else _settled(t, like.dtype) for t in arguments]
         # (Tape.leaf's own conditions, on every argument the recorder would have made a leaf of -- read by the tape or not)
         if all(t is None or (isinstance(t, torch.Tensor) and t.dtype == like.dtype and t.shape == like.shape and t.device == like.device and t.is_contiguous()) for t in settled):
             outs = _launch(c, [settled[i] for i in used], n_outputs)
@@ -480,7 +482,7 @@ def _remembered_step(kind: str, recorder, sampler, packed, model, schedule, prev
     c, used_leaves, stores = _compile(tape, results)
     outs = _launch(c, [tape.leaves[i] for i in used_leaves], len(stores))
     if key is not None:
-        where = {id(_settled(t, like.dtype)): i for i, t in reversed(list(enumerate(arguments))) if t is not None}
+        where = {id(t): i for i, t in reversed(list(enumerate(settled))) if t is not None}
         used = [where.get(id(tape.leaves[i])) for i in used_leaves]
         answer = [(False, where.get(id(tape.leaves[tape.ops[v.n][1]]))) if tape.ops[v.n][0] == _hip.TAPE_LOAD else (True, stores[v.n]) for v in results]
         if None not in used and all(n is not None for _stored, n in answer):
