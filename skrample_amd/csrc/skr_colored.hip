@@ -57,6 +57,11 @@ struct ColoredArgs {
 #endif
 };
 
+#ifdef SKR_INV_STEP_MODEL  // experiment (tools/tune/tune_inverse128_step.hip); compiled out of the library
+struct StepModel { const void* narrow[7]; const void* wide[2]; float* state; };
+__device__ StepModel g_step_model;
+#endif
+
 // Phase stamps for the timeline harness (tools/tune/tune_colored.hip); compiled out of the library.
 #ifdef SKR_COLORED_TRACE
 uint64_t* g_colored_trace = nullptr;
@@ -990,6 +995,45 @@ __global__ __launch_bounds__(512, 4) void colored_inverse128(const ColoredArgs a
       T* da = reinterpret_cast<T*>(dst + (uint32_t)((2 * line * W + 4 * j) * (int)sizeof(T)));
 #ifdef SKR_INV_NOSTORE  // experiment: results stay on the chip (one store per block keeps the arithmetic alive)
       if (z0.x != 12345.678f) continue;
+#endif
+#ifdef SKR_INV_STEP_MODEL  // experiment (tools/tune/tune_inverse128_step.hip): the traffic and arithmetic of BASELINE config 3's two-output
+      // step as this plane's epilogue -- seven 16-bit and two fp32 operands read at the plane's own offsets beside the noise in registers, an fp32 state
+      // and a 16-bit result written; the values are a model (fixed coefficients), the bytes per element (22 read, 6 written, noise never stored) are the step's
+      if constexpr (sizeof(T) == 2) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const int64_t e = pl(p) * (int64_t)(H * W) + (2 * line * W + 4 * j);
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          float nz[4] = {row ? z0.y * f : z0.x * f, row ? z1.y * f : z1.x * f, row ? z2.y * f : z2.x * f, row ? z3.y * f : z3.x * f};
+          const u32x2 nq = u32x2{pack_pair<T>(nz[0], nz[1]), pack_pair<T>(nz[2], nz[3])};  // the noise as the tensor dtype holds it
+          float s0[4], s1[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = __uint_as_float(i & 1 ? nq[i >> 1] & 0xFFFF0000u : nq[i >> 1] << 16);
+            s0[i] = 0.37f * v; s1[i] = -0.11f * v;
+          }
+#pragma unroll
+          for (int k = 0; k < 7; ++k) {
+            const u32x2 w = *(reinterpret_cast<const u32x2*>(g_step_model.narrow[k]) + ((e + row * W) >> 2));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float v = __uint_as_float(i & 1 ? w[i >> 1] & 0xFFFF0000u : w[i >> 1] << 16);
+              s0[i] = fmaf(0.05f * (float)(k + 1), v, s0[i]); s1[i] = fmaf(-0.03f * (float)(k + 2), v, s1[i]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const pk_f32x4 w = *(reinterpret_cast<const pk_f32x4*>(g_step_model.wide[k]) + ((e + row * W) >> 2));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0[i] = fmaf(0.4f, w[i], s0[i]); s1[i] = fmaf(0.2f, w[i], s1[i]); }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s1[i] = fmaf(0.9f, s0[i], s1[i]);  // (the chained second output)
+          __builtin_nontemporal_store(pk_f32x4{s0[0], s0[1], s0[2], s0[3]}, reinterpret_cast<pk_f32x4*>(g_step_model.state) + ((e + row * W) >> 2));
+          __builtin_nontemporal_store(u32x2{pack_pair<T>(s1[0], s1[1]), pack_pair<T>(s1[2], s1[3])}, reinterpret_cast<u32x2*>(da + row * W));
+        }
+        continue;
+      }
 #endif
       if constexpr (sizeof(T) == 2) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

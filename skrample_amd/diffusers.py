@@ -830,9 +830,14 @@ class SkrampleWrapperScheduler(SkrampleWrapperCore):
             self._fast = {}
         self._fast_ids = (self.sampler, self.model, self.schedule, self.compute_scale, self.noise_type, self.noise_props, self._steps)
         roles = program.Roles(sample, model_output, noise, self._previous, self._raw_outputs, self._raw_samples)
+        # (a record's `sample` is the caller's own tensor for the first step of a run and a state tensor -- UniPC's corrected, SPC's blended sample, in
+        #  the compute dtype -- afterwards: a program lowered where the two coincide has ONE operand for both, so which records coincide is part of the
+        #  key.  The step index alone does not say: a run may start anywhere, and a schedule may hand out one timestep several times -- Exponential over
+        #  ZSNR repeats 1000.0, and a repeated value resolves to its first index, here as in the reference)
         key = (
             idx, tuple(rec.step for rec in self._previous), sample.dtype, model_output.dtype, tuple(sample.shape),
             type(noise), getattr(noise, "dtype", None), tuple(type(rec.noise) for rec in self._previous),
+            tuple((rec.sample is raw, getattr(rec.sample, "dtype", None)) for rec, raw in zip(self._previous, self._raw_samples)),
         )  # fmt: skip
         record = None
         prog = self._programs.get(key)

@@ -876,6 +876,47 @@ def test_functional_samplers_on_16_bit_device_tensors_equal_the_host_run(dtype, 
         assert native.launches > before and card.is_cuda and card.dtype == dtype and torch.equal(card.cpu(), host), sampler
 
 
+def test_step_programs_tell_a_runs_first_record_from_a_state(dev):
+    """A history record's `sample` is the caller's tensor after the first step of a run and a state tensor (UniPC's corrected, SPC's blended sample) later;
+    the lowered step programs are kept per (index, history steps, ...) and must not be replayed across that difference.  Two ways there: a schedule that
+    hands out one timestep several times (Exponential over ZSNR: 1000.0 six times, every one resolving to index 0 as in the reference; found by
+    tests/soak_sweep.py seed 851552), and one scheduler object used for a run from the middle of the schedule and then for a full run."""
+    shape = (3, 3, 7, 8)
+    g = torch.Generator().manual_seed(851552)
+    for dt in (torch.float16, torch.bfloat16):
+        mk = lambda: PD.SkrampleWrapperScheduler(PT.SPC(predictor=PT.Euler(stochasticity=0.5), corrector=PT.Euler(stochasticity=0.5), invert=True), PS.Exponential(PS.ZSNR()), PM.VelocityModel())  # noqa: E731
+        host, card = mk(), mk()
+        host.set_timesteps(8)
+        card.set_timesteps(8)
+        assert host.timesteps.tolist().count(host.timesteps[0].item()) > 2  # (the premise: repeated timesteps)
+        x = torch.randn(shape, generator=g).to(dt)
+        outs = [torch.randn(shape, generator=g).to(dt) for _ in range(8)]
+        noises = [torch.randn(shape, generator=g) for _ in range(8)]
+        host._noise_generator, card._noise_generator = Injected(noises, "cpu"), Injected(noises, dev)
+        for i, t in enumerate(host.timesteps):
+            want = host.step(outs[i], t, x, return_dict=False)[0]
+            got = card.step(outs[i].to(dev), t, x.to(dev), return_dict=False)[0]
+            want, got = (torch.as_tensor(v.materialize() if isinstance(v, lazy.LazyTensor) else v) for v in (want, got))
+            assert_close(got, want, dt, f"repeated timesteps {dt} step {i}", flips=0.2)
+            x = want
+    # one scheduler object: a run over the last steps of the schedule, then a full run -- index 5 follows a first record in the one, a state in the other
+    host, card = (PD.SkrampleWrapperScheduler(PT.UniPC(order=2), PS.Scaled()) for _ in range(2))
+    steps, dt = 8, torch.bfloat16
+    outs = [torch.randn(shape, generator=g).to(dt) for _ in range(steps)]
+    x0 = torch.randn(shape, generator=g).to(dt)
+    for first in (4, 0, 3):
+        host.set_timesteps(steps)
+        card.set_timesteps(steps)
+        x = x0
+        for i in range(first, steps):
+            t = host.timesteps[i]
+            want = host.step(outs[i], t, x, return_dict=False)[0]
+            got = card.step(outs[i].to(dev), t, x.to(dev), return_dict=False)[0]
+            want, got = (torch.as_tensor(v.materialize() if isinstance(v, lazy.LazyTensor) else v) for v in (want, got))
+            assert_close(got, want, dt, f"run from {first}, step {i}", flips=0.2)
+            x = want
+
+
 def test_wrappers_keep_their_compute_scale(dev):
     "the scheduler wrappers widen to compute_scale before the sampler runs (reference diffusers.py:575-599): fused kernel; compute_scale=None: the tape"
     from skrample_amd.sampling import native
