@@ -460,7 +460,14 @@ class SkrampleWrapperCore(abc.ABC):
             noise = gen.generate_lazy(step) if lazy_ok else gen.generate(step)
             if self._noise_side is not None and isinstance(gen, BatchTensorNoise) and isinstance(sample, Tensor) and sample.is_cuda:
                 gen.used_on(torch.cuda.current_stream(sample.device))  # (workspaces may have been allocated under the side stream)
-        return noise if lazy_ok else lazy.cast(noise, dtype or sample.dtype)
+        if not lazy_ok:
+            return lazy.cast(noise, dtype or sample.dtype)
+        # The reference casts whatever its generator returns to the compute scale (diffusers.py:346).  The step kernel widens a tensor of the SAMPLE's dtype
+        # in registers (exact, so the same values: the built-in generators draw in that dtype) and symbolic white noise is drawn inside it; only a generator
+        # object that returns some third dtype -- fp32 noise beside fp16 latents under a float64 compute scale -- is cast here, as there
+        if isinstance(noise, Tensor) and noise.dtype not in (sample.dtype, dtype or sample.dtype):
+            return lazy.cast(noise, dtype or sample.dtype)
+        return noise
 
     # ---- next step's noise, drawn ahead on a side stream ----------------------------------------------------------------
     # Pyramid / Offset noise is a chain of VALU-bound kernels that depends on nothing but (seeds, draw counter, step);

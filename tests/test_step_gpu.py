@@ -917,6 +917,26 @@ def test_step_programs_tell_a_runs_first_record_from_a_state(dev):
             x = want
 
 
+def test_a_generator_of_a_third_dtype_is_cast_to_the_compute_scale(dev):
+    """fp16 latents, compute_scale=float64 and a noise generator object that returns fp32 tensors: the reference casts what the generator returns to the compute
+    scale (diffusers.py:346); here that used to hand the step kernel three operand dtypes (found by tests/soak_sweep.py seed 860587)"""
+    shape, steps, dt = (1, 2, 8, 8), 9, torch.float16
+    g = torch.Generator().manual_seed(860587)
+    host, card = (PD.SkrampleWrapperScheduler(PT.UniPC(order=2, stochasticity=-1.5), PS.Beta(PS.Linear()), PM.DataModel(), compute_scale=torch.float64) for _ in range(2))
+    host.set_timesteps(steps)
+    card.set_timesteps(steps)
+    x = torch.randn(shape, generator=g).to(dt)
+    outs = [torch.randn(shape, generator=g).to(dt) for _ in range(steps)]
+    noises = [torch.randn(shape, generator=g) for _ in range(steps)]
+    host._noise_generator, card._noise_generator = Injected(noises, "cpu"), Injected(noises, dev)
+    for i, t in enumerate(host.timesteps):
+        want = host.step(outs[i], t, x, return_dict=False)[0]
+        got = card.step(outs[i].to(dev), t, x.to(dev), return_dict=False)[0]
+        want, got = (torch.as_tensor(v.materialize() if isinstance(v, lazy.LazyTensor) else v) for v in (want, got))
+        assert_close(got, want, dt, f"step {i}", flips=0.2)
+        x = want
+
+
 def test_wrappers_keep_their_compute_scale(dev):
     "the scheduler wrappers widen to compute_scale before the sampler runs (reference diffusers.py:575-599): fused kernel; compute_scale=None: the tape"
     from skrample_amd.sampling import native
