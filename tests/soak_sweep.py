@@ -1,5 +1,5 @@
 """GPU box: the device path against the package's own host executor over the sweep grammar (tests/sweep_grammar.py) -- usage:
-python tests/soak_sweep.py [first_seed last_seed [native]].  The host side of every case is what tools/sweep_vs_reference.py compares with the imported
+python tests/soak_sweep.py [first_seed last_seed [native | reuse]].  The host side of every case is what tools/sweep_vs_reference.py compares with the imported
 reference in the build container (1500 configurations, 0 differences), so device == host here carries the reference's answer to seeds
 the fixture (tests/golden/steps_sweep.npz, 64 cases) does not hold.  Teacher-forced: each step sees the host run's inputs."""
 import os
@@ -26,6 +26,7 @@ def settle(v):
 
 
 NATIVE = len(sys.argv) > 3 and sys.argv[3] == "native"  # compute_scale=None on 16-bit tensors: the tape on the device against torch's own ops on the host, bit for bit
+REUSE = len(sys.argv) > 3 and sys.argv[3] == "reuse"  # one scheduler object over three runs: from a random later index, from the start, from the start with float timesteps
 
 
 def one(seed: int) -> str:
@@ -43,6 +44,33 @@ def one(seed: int) -> str:
         return "non-finite"  # (a Karras / Exponential ramp over one step: nan timesteps, in the reference too)
     assert torch.equal(times, card.timesteps.cpu())
     n = len(times)
+    if REUSE:
+        # what the replayed steps (step programs, _fast_step) remember must hold for the next run of the same object whatever that run looks like
+        first = 0 if "RK" in text else random.Random(seed ^ 0x5eed).randrange(n)  # (the Runge-Kutta wrappers insist on the schedule's order, as the reference's do)
+        for lap, (start, as_float) in enumerate(((first, False), (0, False), (0, True))):
+            host.set_timesteps(steps_n)
+            card.set_timesteps(steps_n)
+            x = torch.randn(shape, generator=g).to(dt)
+            outs = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]
+            noises = [torch.randn(shape, generator=g) for _ in range(n)]
+            host._noise_generator, card._noise_generator = T.Injected(noises[start:], "cpu"), T.Injected(noises[start:], dev)
+            for i in range(start, n):
+                t = float(times[i]) if as_float else times[i]
+                try:
+                    ref = [settle(v) for v in host.step(outs[i], t, x, return_dict=False)]
+                except (ZeroDivisionError, np.linalg.LinAlgError):
+                    try:
+                        card.step(outs[i].to(dev), t, x.to(dev), return_dict=False)
+                    except (ZeroDivisionError, np.linalg.LinAlgError):
+                        return "singular"
+                    raise AssertionError(f"lap {lap} step {i}: the host path refuses a singular point, the device path does not")
+                got = [settle(v) for v in card.step(outs[i].to(dev), t, x.to(dev), return_dict=False)]
+                if not all(torch.isfinite(v.float()).all() for v in ref):
+                    return "non-finite"
+                for name, a, b in zip(("prev_sample", "pred_original_sample"), got, ref):
+                    T.assert_close(a, b, dt, f"lap {lap} (from {start}{', float timesteps' if as_float else ''}) step {i} {name}", flips=0.2)
+                x = ref[0]
+        return "ok"
     x = torch.randn(shape, generator=g).to(dt)
     outs = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]
     noises = [torch.randn(shape, generator=g).to(dt if NATIVE else torch.float32) for _ in range(n)]
