@@ -102,6 +102,24 @@ def one(seed: int) -> str | None:
         exact = dt in (torch.bfloat16, torch.float16)  # (16-bit: the reference's own rounded ops, bit for bit)
         if a.shape != b.shape or not (torch.equal(a, b) if exact else torch.allclose(a, b, rtol=1e-5, atol=1e-6, equal_nan=True)):
             return f"{name} at timestep index {start} differs: max diff {(a - b).abs().max().item():.3g}"
+    for lap in range(LAPS):
+        if lap:  # the same two objects again (SWEEP_LAPS=2): a full run on fresh inputs behind the first one, whatever state that left
+            r.set_timesteps(steps_n)
+            p.set_timesteps(steps_n)
+            start = 0
+            x = torch.randn(shape, generator=g).to(dt)
+            outs = [torch.randn(shape, generator=g).to(dt) for _ in range(n)]
+            noises = [torch.randn(shape, generator=g).to(dt if NOISE_LIKE_SAMPLE else torch.float32) for _ in range(n)]
+        found = _steps(r, p, r_times, p_times, start, x, outs, noises, dt)
+        if found:
+            return found if not lap else f"second run: {found}"
+    return None
+
+
+LAPS = int(os.environ.get("SWEEP_LAPS", "1"))
+
+
+def _steps(r, p, r_times, p_times, start, x, outs, noises, dt) -> str | None:
     r._noise_generator, p._noise_generator = MG._Injected(noises[start:]), _Replay(noises[start:])
     for i, (tr, tp) in enumerate(zip(r_times, p_times)):
         if i < start:
