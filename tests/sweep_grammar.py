@@ -65,3 +65,36 @@ def native_spec(rng) -> tuple[str, str, tuple[int, ...], int]:
     if dtype in ("float32", "float64"):
         dtype = rng.choice(("bfloat16", "float16"))
     return text, dtype, shape, steps_n
+
+
+def functional_spec(rng):
+    "a functional sampler (RKUltra, DynasauRK, adaptive RKMoire, the structured adapter), schedule, model, run length and step window -- texts over F / I / T / S / M"
+    eta = lambda: rng.choice(("0", "0", "0.5", "1", "-1.5"))  # noqa: E731
+    deriv = lambda: rng.choice(("", "", ", derivative_transform=None", ", derivative_transform=M.VelocityModel()", ", derivative_transform=M.FlowModel()"))  # noqa: E731
+    roll = rng.random()
+    if roll < 0.3:
+        text = f"F.RKUltra(order={rng.randint(1, 9)}, stochasticity={eta()}{deriv()})"
+    elif roll < 0.5:
+        opts = rng.choice(("", ", invert=True", ", per_step_decay=0.1, total_step_decay=-0.02", ", per_step_decay=0.0", ", total_step_decay=0.3"))
+        text = f"F.DynasauRK(order={rng.randint(2, 4)}, stochasticity={eta()}{opts}{deriv()})"
+    elif roll < 0.8:
+        opts = "".join(
+            rng.sample(
+                (", threshold=1e-3", ", initial=1 / 20", ", maximum=1 / 3", ", adaption=0.5", ", discard=2.0", ", rescale_init=False", ", rescale_max=True", ", evaluator=F.FunctionalAdaptive.mae"),
+                rng.randint(0, 3),
+            )
+        )
+        text = f"F.RKMoire(order={rng.randint(2, 7)}{opts}{deriv()})"
+    else:
+        kind = rng.choice(("T.Euler(stochasticity={e})", "T.DPM(order={o3}, stochasticity={e})", "T.Adams(order={o9})", "T.UniP(order={o9})", "T.UniPC(order={o6}, stochasticity={e})", "T.SPC()"))
+        text = "I.StructuredFunctionalAdapter(" + kind.format(e=eta(), o3=rng.randint(1, 3), o9=rng.randint(1, 9), o6=rng.randint(1, 6)) + ")"
+    if rng.random() < 0.4:
+        schedule = rng.choice(("S.Linear()", "S.FlowShift(S.Linear())", "S.Sinner(S.Linear())", "S.Beta(S.Linear())"))
+        model = rng.choice(("M.FlowModel()", "M.DataModel()", "M.VelocityModel()"))
+    else:
+        schedule = rng.choice(("S.Scaled()", "S.ZSNR()", "S.Karras(S.Scaled())", "S.Exponential(S.Scaled())", "S.Hyper(S.Scaled())", "S.Scaled(beta_scale=1)"))
+        model = rng.choice(("M.DataModel()", "M.VelocityModel()") if "ZSNR" in schedule else ("M.NoiseModel()", "M.DataModel()", "M.VelocityModel()", "M.ScaleX()"))
+    steps_n = rng.randint(1, 9)
+    lo = rng.choice((None, None, 0, 1, 2))
+    hi = rng.choice((None, None, steps_n, max(steps_n - 1, 1), 5))
+    return text, schedule, model, steps_n, (lo, hi)
