@@ -111,10 +111,11 @@ def colorize(white: torch.Tensor, exponent: float, energy: float | None) -> torc
     body = white.squeeze()
     if body.dtype not in (torch.float32, torch.float64):
         body = body.to(torch.float32)
+    spectrum = torch.fft.rfftn(body)  # (first, as in noise.py:377: a unit whose axes are all 1 long is refused by torch, with torch's error)
     mean_side = sum(body.shape) / len(body.shape) if body.shape else 1.0
     floor = 0.5 / max(mean_side, 4.0)  # half a bin: DC would diverge
     gain = torch.clamp(_radial_frequencies(tuple(body.shape), body.device), min=floor) ** (-exponent / 2.0)
-    shaped = torch.fft.irfftn(torch.fft.rfftn(body) * gain, s=body.shape)
+    shaped = torch.fft.irfftn(spectrum * gain, s=body.shape)
     shaped_std = shaped.std()
     if shaped_std > 1e-8:
         shaped *= (white_std if energy is None else energy) / shaped_std

@@ -132,3 +132,9 @@ def test_brownian_on_host_tensors_says_what_is_missing():
     x = torch.randn(1, 4, 8, 8)
     with pytest.raises(Exception, match="torchsde"):
         w.step(x, w.timesteps[0], x, generator=torch.Generator().manual_seed(1))
+
+
+def test_a_unit_of_unit_axes_is_refused_with_torchs_own_error():
+    "noise.py:371-377: squeeze() leaves no axis and torch.fft.rfftn refuses -- the same error here (live sweep, noise mode, seed 3000165)"
+    with pytest.raises(RuntimeError, match="rfftn must transform at least one axis"):
+        one(PN.Colored, (1, 1, 1), 3, PN.ColoredProps(energy=0.5, color_start=-1, color_end=-2, color_curve=2), Step(0.3, 0.9))

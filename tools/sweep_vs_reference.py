@@ -509,25 +509,36 @@ def one_generator(seed: int) -> str | None:
     g = torch.Generator().manual_seed(seed)
     x0 = torch.randn(shape, generator=g).to(dt)
     outs = [torch.randn(shape, generator=g).to(dt) for _ in range(16)]
-    sides = []
+    def gens():
+        return {"none": None, "single": torch.Generator().manual_seed(5), "list": [torch.Generator().manual_seed(7 + i) for i in range(shape[0])], "shortlist": [torch.Generator().manual_seed(9)]}[mode]
+
+    # Teacher-forced on the reference's state, like the other modes: a free-running bf16 loop turns one last-place difference of step i
+    # (fp32 registers rounded once, against the reference's rounded fp32 chain) into several of them at step i + 1 (seeds 3001965, 3002873).
+    made = []
     for names, N in ((REF, MG.RN), (OWN, ON)):
-        gens = {"none": None, "single": torch.Generator().manual_seed(5), "list": [torch.Generator().manual_seed(7 + i) for i in range(shape[0])], "shortlist": [torch.Generator().manual_seed(9)]}[mode]
         try:
             w = eval(text, {**names, "N": N})
             w.set_timesteps(3)
-            x, got = x0, []
-            for i, t in enumerate(w.timesteps):
-                x = torch.as_tensor(w.step(outs[i], t, x, generator=gens, return_dict=False)[0])
-                got.append(x)
-            sides.append(got)
+            made.append((w, gens()))
         except Exception as err:  # noqa: BLE001
-            sides.append(err)
-    r, p = sides
-    if isinstance(r, Exception) or isinstance(p, Exception):
-        return None if type(r) is type(p) else f"reference {r!r}, here {p!r}"
-    for i, (a, b) in enumerate(zip(p, r)):
+            made.append(err)
+    if any(isinstance(m, Exception) for m in made):
+        return None if type(made[0]) is type(made[1]) else f"reference {made[0]!r}, here {made[1]!r}"
+    (wr, gr), (wp, gp) = made
+    x = x0
+    for i, t in enumerate(wr.timesteps):
+        got = []
+        for w, gen in ((wr, gr), (wp, gp)):
+            try:
+                got.append(torch.as_tensor(w.step(outs[i], t, x, generator=gen, return_dict=False)[0]))
+            except Exception as err:  # noqa: BLE001
+                got.append(err)
+        b, a = got
+        if isinstance(a, Exception) or isinstance(b, Exception):
+            return None if type(a) is type(b) else f"step {i}: reference {b!r}, here {a!r}"
         if a.dtype != b.dtype or not torch.allclose(a.double(), b.double(), rtol=1e-5 if dt == torch.float32 else 2.0**-7, atol=1e-5):
             return f"step {i}: max diff {(a.double() - b.double()).abs().max().item():.3g} (the draws differ, or the step)"
+        x = b
     return None
 
 
@@ -600,21 +611,22 @@ def one_array(seed: int) -> str | None:
     g = np.random.default_rng(seed)
     mk = (lambda: float(g.standard_normal())) if kind == "float" else (lambda: g.standard_normal(shape).astype(np.float64 if kind == "f64" else np.float32))
     x0, outs, nzs = mk(), [mk() for _ in range(steps_n)], [mk() for _ in range(steps_n)]
-    sides = []
-    for names, StepT in ((REF, RStep), (OWN, OStep)):
+    def run(names, StepT, cast=lambda v: v):
         try:
             sampler, schedule, model = eval(text, names)
-            x, prev, got = x0, [], []
+            x, prev, got = cast(x0), [], []
             for i in range(steps_n):
-                rec = sampler.sample(x, outs[i], StepT.from_int(i, steps_n), model, schedule, nzs[i] if sampler.require_noise else None, tuple(prev))
+                rec = sampler.sample(x, cast(outs[i]), StepT.from_int(i, steps_n), model, schedule, cast(nzs[i]) if sampler.require_noise else None, tuple(prev))
                 pred = rec.prediction.materialize() if hasattr(rec.prediction, "materialize") else rec.prediction
                 got.append((rec.final, pred))
                 prev.append(rec)
                 x = rec.final
-            sides.append(got)
+            return got
         except Exception as err:  # noqa: BLE001
-            sides.append(err)
-    r, p = sides
+            return err
+
+    r, p = run(REF, RStep), run(OWN, OStep)
+    yardstick = None  # the reference's own run on the same inputs widened to float64, made when a float32 comparison fails
     if isinstance(r, Exception) or isinstance(p, Exception):
         if isinstance(r, Exception) and isinstance(p, Exception):
             return None
@@ -632,6 +644,15 @@ def one_array(seed: int) -> str | None:
                 return None
             tol = 1e-5 if kind == "f32" else 1e-9  # (float32 inputs: float32 arithmetic somewhere upstream even where numpy promoted the result)
             if not np.allclose(a, b, rtol=tol, atol=tol * max(1.0, float(np.abs(b).max()))):
+                # A free-running float32 loop of a high-order solver where the result is a small difference of large terms (seed 3000401: UniPC-6,
+                # prediction 5.5 out of operands near 90): the reference's float32 run is itself 1.5e-4 from its float64 run there.  Ours
+                # may be as far from that float64 run as the reference's own float32 run is (and a little more), no further.
+                if kind == "f32":
+                    yardstick = yardstick or run(REF, RStep, lambda v: v.astype(np.float64))
+                    if not isinstance(yardstick, Exception):
+                        y = np.asarray(yardstick[i][0 if name == "final" else 1])
+                        if float(np.abs(a - y).max()) <= 1.5 * float(np.abs(b - y).max()) + tol * max(1.0, float(np.abs(b).max())):
+                            continue
                 return f"step {i} {name}: max diff {float(np.abs(a - b).max()):.3g}"
     return None
 
